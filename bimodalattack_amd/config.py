@@ -1,0 +1,126 @@
+"""API types of the attack engine.
+
+Field-for-field compatible with the reference's dataclasses so that callers
+(`experiments.py:86-112` in the reference) can switch packages unchanged:
+
+* ``BimodalAttackConfig``  <- reference bimodalattack/bimodal_attack.py:42-70 (27 fields)
+* ``BimodalAttackResult``  <- reference bimodalattack/bimodal_attack.py:73-85 (11 fields)
+* ``GCGConfig``            alias; nanoGCG's name for the same config.
+
+Engine-only knobs (backend, sharding, RNG placement) deliberately live OUTSIDE
+the dataclass -- see ``EngineOptions`` -- so the dataclass stays drop-in.
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Union
+
+
+@dataclass
+class BimodalAttackConfig:
+    # -- GCG side ---------------------------------------------------------
+    num_steps: int = 250
+    optim_str_init: Union[str, List[str]] = "x x x x x x x x x x x x x x x x x x x"
+    search_width: int = 512
+    batch_size: Optional[int] = None
+    topk: int = 256
+    n_replace: int = 1
+    buffer_size: int = 0
+    use_mellowmax: bool = False          # declared by the reference, never read
+    mellowmax_alpha: float = 1.0         # declared by the reference, never read
+    early_stop: bool = False
+    allow_non_ascii: bool = False
+    filter_ids: bool = True
+    add_space_before_target: bool = False  # declared by the reference, never read
+    seed: Optional[int] = None
+    verbosity: str = "INFO"
+    dynamic_search: bool = False
+    min_search_width: int = 32
+    # -- PGD side ---------------------------------------------------------
+    alpha: float = 0.01
+    eps: float = 0.1
+    pgd_attack: bool = False
+    gcg_attack: bool = True
+    debug_output: bool = False
+    joint_eval: bool = False
+    experiment_folder: str = "experiments/missing_folder"  # never read
+    images_folder: str = "experiments/missing_folder/images"
+    pgd_after_gcg: bool = False
+    model: str = "llava"                 # declared by the reference, never read
+
+
+# nanoGCG spelling, named in BASELINE.json's north_star.
+GCGConfig = BimodalAttackConfig
+
+
+@dataclass
+class BimodalAttackResult:
+    best_loss: float
+    best_string: str
+    losses: List[float]
+    strings: List[str]
+    adversarial_suffixes: List[str]
+    model_outputs: List[str]
+    gradient_times: List[float]
+    sampling_times: List[float]
+    loss_times: List[float]
+    pgd_times: List[float]
+    total_times: List[float] = None
+
+
+@dataclass
+class EngineOptions:
+    """Knobs of the MI355X engine that the reference has no field for.
+
+    Read from keyword arguments of :func:`bimodalattack_amd.run` or from the
+    environment (``BMA_*``), never from ``BimodalAttackConfig``.
+    """
+
+    # "model": draw the sampling randoms on the model's device exactly where the
+    # reference draws them (bimodal_attack.py:151,159).  "cpu": draw them from the
+    # CPU generator and upload -- reproduces the reference's CPU path bit for bit
+    # ("RNG").
+    rng_device: str = "model"
+    # Re-use the keys/values of the segments in front of the suffix across all
+    # candidates of a step (identical maths under causal attention).
+    prefix_reuse: bool = True
+    # Ask the model for logits on the target rows only (`logits_to_keep`).
+    target_rows_only: bool = True
+    # Candidates per forward chunk; None = size analytically from free HBM.
+    chunk: Optional[int] = None
+    # Write images_folder/{i}.png every step (reference side effect, :744).
+    save_images: bool = True
+    # Record per-step internals (sampled ids, N after filter, best_idx, ...).
+    trace: Optional[list] = None
+    # torch.distributed process group used to shard candidate scoring; None =
+    # the default group when initialised, else single process.
+    group: object = None
+    # Round per-candidate losses to the model dtype before the argmin, as the
+    # reference's model-dtype cross-entropy does ("quirks").
+    loss_in_model_dtype: bool = True
+
+    @classmethod
+    def from_env(cls, **overrides) -> "EngineOptions":
+        opts = cls()
+        env = os.environ
+        if "BMA_RNG_DEVICE" in env:
+            opts.rng_device = env["BMA_RNG_DEVICE"]
+        if "BMA_PREFIX_REUSE" in env:
+            opts.prefix_reuse = env["BMA_PREFIX_REUSE"] not in ("0", "false", "False")
+        if "BMA_TARGET_ROWS_ONLY" in env:
+            opts.target_rows_only = env["BMA_TARGET_ROWS_ONLY"] not in ("0", "false", "False")
+        if "BMA_CHUNK" in env:
+            opts.chunk = int(env["BMA_CHUNK"])
+        if "BMA_SAVE_IMAGES" in env:
+            opts.save_images = env["BMA_SAVE_IMAGES"] not in ("0", "false", "False")
+        for k, v in overrides.items():
+            if v is None:
+                continue
+            if not hasattr(opts, k):
+                raise TypeError(f"unknown engine option {k!r}")
+            setattr(opts, k, v)
+        if opts.rng_device not in ("model", "cpu"):
+            raise ValueError(f"rng_device must be 'model' or 'cpu', got {opts.rng_device!r}")
+        return opts
