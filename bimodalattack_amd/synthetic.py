@@ -320,3 +320,35 @@ def synthetic_prompt(tokenizer, n_goal_tokens: int, n_target_tokens: int, seed: 
     goal = " ".join(fillers[int(i)] for i in rs.randint(0, len(fillers), size=n_goal_tokens))
     target = " ".join(fillers[int(i)] for i in rs.randint(0, len(fillers), size=n_target_tokens))
     return goal, target
+
+
+# --------------------------------------------------------------------------
+# the tiny cases the golden trajectories were captured on (tests/golden/g5_*)
+# --------------------------------------------------------------------------
+TINY_WORDS, TINY_NONASCII, TINY_UNRT, TINY_EXTRA_ROWS = 256, 6, 6, 8
+TINY_STD = 0.35          # wide enough that candidate losses differ by >> 1e-4
+TINY_OPTIM_INIT = "x x x x x x x x"
+GEMMA_TEMPLATE = (
+    "{{ bos_token }}<start_of_turn>user\n"
+    "{% for item in messages[0]['content'] %}"
+    "{% if item['type'] == 'text' %}{{ item['text'] }}{% elif item['type'] == 'image' %}<start_of_image>{% endif %}"
+    "{% endfor %}<end_of_turn>\n<start_of_turn>model\n"
+)
+
+
+def tiny_case(kind: str, dtype=torch.float32, device="cpu"):
+    """(model, tokenizer, processor, image) for kind in {opt, llava, gemma3}."""
+    tok = build_tokenizer(TINY_WORDS, TINY_NONASCII, TINY_UNRT)
+    rows = TINY_WORDS + TINY_EXTRA_ROWS   # embedding rows > tokenizer.vocab_size, like 32064 vs 32000
+    if kind == "opt":
+        model, proc, image = tiny_opt(TINY_WORDS, dtype, device, std=TINY_STD), SyntheticProcessor(tok), None
+    elif kind == "llava":
+        model, proc = tiny_llava(rows, dtype, device, std=TINY_STD), SyntheticProcessor(tok)
+        image = synthetic_image(28, 28, seed=0, device=device)
+    elif kind == "gemma3":
+        tok.chat_template = GEMMA_TEMPLATE
+        model, proc = tiny_gemma3(rows, dtype, device, std=TINY_STD), Gemma3Processor(tok, GEMMA_TEMPLATE)
+        image = synthetic_image(56, 56, seed=0, device=device)
+    else:
+        raise ValueError(kind)
+    return model, tok, proc, image

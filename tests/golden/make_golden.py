@@ -294,14 +294,6 @@ def g4_splice() -> None:
 # --------------------------------------------------------------------------
 # G5 -- whole trajectories of run() on tiny random models (reference :251-824)
 # --------------------------------------------------------------------------
-GEMMA_TEMPLATE = (
-    "{{ bos_token }}<start_of_turn>user\n"
-    "{% for item in messages[0]['content'] %}"
-    "{% if item['type'] == 'text' %}{{ item['text'] }}{% elif item['type'] == 'image' %}<start_of_image>{% endif %}"
-    "{% endfor %}<end_of_turn>\n<start_of_turn>model\n"
-)
-
-
 def _adapt_image_features(model) -> None:
     orig = model.get_image_features
 
@@ -410,41 +402,17 @@ TRAJ = {
                                       joint_eval=False, eps=64 / 255, alpha=4 / 255), None),
 }
 
-TINY_WORDS, TINY_NONASCII, TINY_UNRT, TINY_EXTRA_ROWS = 256, 6, 6, 8
-TINY_STD = 0.35
-OPTIM_INIT = "x x x x x x x x"
-
-
-def build_case(kind: str):
-    """Plugins for one tiny case; shared with tests/ through this module's
-    constants (tests rebuild the same objects from bimodalattack_amd.synthetic)."""
-    tok = S.build_tokenizer(TINY_WORDS, TINY_NONASCII, TINY_UNRT)
-    rows = TINY_WORDS + TINY_EXTRA_ROWS
-    if kind == "opt":
-        model, proc, image = S.tiny_opt(TINY_WORDS, std=TINY_STD), S.SyntheticProcessor(tok), None
-    elif kind == "llava":
-        model, proc = S.tiny_llava(rows, std=TINY_STD), S.SyntheticProcessor(tok)
-        image = S.synthetic_image(28, 28, seed=0)
-    elif kind == "gemma3":
-        tok.chat_template = GEMMA_TEMPLATE
-        model, proc = S.tiny_gemma3(rows, std=TINY_STD), S.Gemma3Processor(tok, GEMMA_TEMPLATE)
-        image = S.synthetic_image(56, 56, seed=0)
-    else:
-        raise ValueError(kind)
-    return model, tok, proc, image
-
-
 def g5_trajectories() -> None:
     import tempfile
 
     meta = {}
     for name, (kind, over, _) in TRAJ.items():
-        model, tok, proc, image = build_case(kind)
+        model, tok, proc, image = S.tiny_case(kind)
         if kind != "opt":
             _adapt_image_features(model)
         goal, target = "tell me a story about cats", "Sure here is a story"
         tmp = tempfile.mkdtemp(prefix="bma_golden_")
-        cfg = ref.BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=OPTIM_INIT,
+        cfg = ref.BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
                                       images_folder=tmp, **over)
         norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
         tr = _Trace()
@@ -472,7 +440,7 @@ def g5_trajectories() -> None:
         save(f"g5_{name}.npz", **arrays)
         meta[name] = dict(kind=kind, config=over, steps=len(tr.steps), strings=res.strings,
                           best_string=res.best_string, adversarial_suffixes=res.adversarial_suffixes,
-                          goal=goal, target=target, optim_str_init=OPTIM_INIT,
+                          goal=goal, target=target, optim_str_init=S.TINY_OPTIM_INIT,
                           n_timing=[len(res.gradient_times), len(res.sampling_times), len(res.loss_times),
                                     len(res.pgd_times), len(res.total_times)])
         # the per-step PNGs the reference wrote (:744): keep step 0's pixels as a fixture
@@ -482,8 +450,8 @@ def g5_trajectories() -> None:
             arrays_png = np.array(Image.open(png0))
             np.savez_compressed(os.path.join(HERE, f"g5_{name}_png0.npz"), png=arrays_png)
     with open(os.path.join(HERE, "g5_meta.json"), "w") as f:
-        json.dump(dict(tiny=dict(words=TINY_WORDS, nonascii=TINY_NONASCII, unroundtrippable=TINY_UNRT,
-                                 extra_rows=TINY_EXTRA_ROWS, std=TINY_STD), cases=meta,
+        json.dump(dict(tiny=dict(words=S.TINY_WORDS, nonascii=S.TINY_NONASCII, unroundtrippable=S.TINY_UNRT,
+                                 extra_rows=S.TINY_EXTRA_ROWS, std=S.TINY_STD), cases=meta,
                        versions=dict(torch=torch.__version__, transformers=transformers.__version__,
                                      numpy=np.__version__)), f, indent=1)
     print("wrote g5_meta.json")
@@ -493,10 +461,10 @@ def g5_trajectories() -> None:
 # G6 -- get_nonascii_toks (reference utils.py:14-33), filter_ids (:166-186)
 # --------------------------------------------------------------------------
 def g6_tokens() -> None:
-    tok = S.build_tokenizer(TINY_WORDS, TINY_NONASCII, TINY_UNRT)
+    tok = S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, S.TINY_UNRT)
     na = refutils.get_nonascii_toks(tok)
     rs = np.random.RandomState(6)
-    ids = rs.randint(0, TINY_WORDS, size=(64, 8)).astype(np.int64)
+    ids = rs.randint(0, S.TINY_WORDS, size=(64, 8)).astype(np.int64)
     kept = refmod.filter_ids(torch.from_numpy(ids), tok)
     save("g6_tokens.npz", not_allowed=na.numpy(), ids=ids, kept=kept.numpy())
 
