@@ -1,0 +1,240 @@
+"""Torch-facing wrappers over the C ABI (``include/bma.h``).
+
+torch supplies device memory and the current HIP stream; every computation below
+happens inside ``libbma_hip.so``.  Each wrapper checks on the host that operand
+shapes, dtypes, devices and strides are what the kernel and its grid assume before
+anything is launched.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import native
+from .native import BMA_BF16, BMA_F16, BMA_F32, BMA_SEG_GATHER, BMA_SEG_PERCAND, BMA_SEG_SHARED, BmaSegment, check, lib
+
+_DT = {torch.float32: BMA_F32, torch.bfloat16: BMA_BF16, torch.float16: BMA_F16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}; the kernels take float32, bfloat16, float16") from None
+
+
+def _need_gpu(*ts: torch.Tensor) -> torch.device:
+    dev = ts[0].device
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "bimodalattack_amd kernels run on an AMD GPU only (tensor on %s); there is no CPU path" % t.device)
+        if t.device != dev:
+            raise RuntimeError("tensors on different devices")
+    return dev
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+# ---------------------------------------------------------------------------
+def linf_step(x: torch.Tensor, g: torch.Tensor, x0: torch.Tensor, eps: float, alpha: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """clamp(clamp(x - (alpha*eps)*sign(g), x0-eps, x0+eps), 0, 1)  -- reference :1030-1037."""
+    dev = _need_gpu(x, g, x0)
+    for t in (x, g, x0):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != x.shape:
+            raise ValueError("linf_step wants three contiguous float32 tensors of one shape")
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.shape != x.shape or out.device != dev:
+        raise ValueError("bad out tensor")
+    step = float(alpha * eps)  # the reference multiplies the two Python floats first (:1033)
+    check("bma_linf_step", lib.bma_linf_step(x.data_ptr(), g.data_ptr(), x0.data_ptr(), x.numel(), float(eps), step,
+                                             out.data_ptr(), _stream(dev)))
+    return out
+
+
+# ---------------------------------------------------------------------------
+def ce_target(logits: torch.Tensor, labels: torch.Tensor, want_match: bool = False, want_dlogits: bool = False,
+              grad_scale: float = 1.0):
+    """Mean target cross-entropy per candidate.
+
+    logits (B,T,V) in the model dtype, last dim contiguous (a strided view of a
+    bigger tensor is fine); labels (T,) int64.  Returns
+    ``(loss fp32 (B,), match int32 (B,) | None, dlogits (B,T,V) | None, row_loss fp32 (B,T))``.
+    """
+    if logits.dim() != 3:
+        raise ValueError("logits must be (B,T,V)")
+    dev = _need_gpu(logits, labels)
+    B, T, V = logits.shape
+    if labels.dtype != torch.int64 or labels.numel() != T or not labels.is_contiguous():
+        raise ValueError("labels must be T contiguous int64 values")
+    if B == 0:
+        z = torch.empty(0, dtype=torch.float32, device=dev)
+        return z, (torch.empty(0, dtype=torch.int32, device=dev) if want_match else None), \
+            (torch.empty_like(logits) if want_dlogits else None), torch.empty(0, T, dtype=torch.float32, device=dev)
+    if logits.stride(2) != 1 or logits.stride(1) < V or (B > 1 and logits.stride(0) < 0):
+        logits = logits.contiguous()
+    ws = torch.empty(3 * B * T, dtype=torch.float32, device=dev)
+    assert ws.numel() * 4 == lib.bma_ce_target_ws_bytes(B, T)
+    loss = torch.empty(B, dtype=torch.float32, device=dev)
+    match = torch.empty(B, dtype=torch.int32, device=dev) if want_match else None
+    dlog = torch.empty((B, T, V), dtype=logits.dtype, device=dev) if want_dlogits else None
+    check("bma_ce_target", lib.bma_ce_target(
+        logits.data_ptr(), logits.stride(0) if B > 1 else T * logits.stride(1), logits.stride(1), labels.data_ptr(),
+        B, T, V, _dt(logits), ws.data_ptr(), loss.data_ptr(), match.data_ptr() if want_match else None,
+        dlog.data_ptr() if want_dlogits else None, float(grad_scale), _stream(dev)))
+    return loss, match, dlog, ws[: B * T].view(B, T)
+
+
+class TargetCrossEntropy(torch.autograd.Function):
+    """mean CE over the target rows with the backward produced by the same kernel
+    launch sequence (the gradient pass, reference :1006-1028)."""
+
+    @staticmethod
+    def forward(ctx, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        x = logits.detach()
+        if x.dim() == 2:
+            x = x.unsqueeze(0)
+        loss, _, dlog, _ = ce_target(x, labels, want_dlogits=True)
+        ctx.save_for_backward(dlog)
+        ctx.in_shape = logits.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (dlog,) = ctx.saved_tensors
+        return (dlog * grad_out.to(dlog.dtype)).view(ctx.in_shape), None
+
+
+# ---------------------------------------------------------------------------
+def build_mask_bits(not_allowed_ids: Optional[torch.Tensor], V: int, device) -> Optional[torch.Tensor]:
+    """ceil(V/32) words, bit set = token not allowed.  Built once per attack."""
+    if not_allowed_ids is None:
+        return None
+    import numpy as np
+
+    idn = not_allowed_ids.to("cpu", torch.int64).numpy()
+    idn = idn[(idn >= 0) & (idn < V)]      # the list covers range(tokenizer.vocab_size) <= V
+    w = np.zeros((V + 31) // 32, dtype=np.uint32)
+    np.bitwise_or.at(w, idn >> 5, np.uint32(1) << (idn & 31).astype(np.uint32))   # several ids share a word
+    return torch.from_numpy(w.view(np.int32)).to(device)
+
+
+def mask_topk(grad: torch.Tensor, mask_bits: Optional[torch.Tensor], k: int) -> torch.Tensor:
+    """topk(-grad with not-allowed = +inf, k).indices, ordered (grad asc, id asc) -- reference :144-147."""
+    if grad.dim() != 2:
+        raise ValueError("grad must be (rows, V)")
+    dev = _need_gpu(grad)
+    rows, V = grad.shape
+    if grad.stride(1) != 1 or grad.stride(0) < V:
+        grad = grad.contiguous()
+    if not (1 <= k <= V):
+        raise ValueError(f"topk={k} out of range for vocabulary {V}")
+    if mask_bits is not None:
+        if mask_bits.device != dev or mask_bits.dtype != torch.int32 or mask_bits.numel() != (V + 31) // 32 \
+                or not mask_bits.is_contiguous():
+            raise ValueError("mask_bits must be ceil(V/32) contiguous int32 words on the gradient's device")
+    out = torch.empty((rows, k), dtype=torch.int64, device=dev)
+    check("bma_mask_topk", lib.bma_mask_topk(grad.data_ptr(), grad.stride(0), rows, V, _dt(grad),
+                                             mask_bits.data_ptr() if mask_bits is not None else None, k,
+                                             out.data_ptr(), _stream(dev)))
+    return out
+
+
+def rand_positions(rnd: torch.Tensor, n_replace: int) -> torch.Tensor:
+    """argsort(rnd)[..., :n_replace] -- reference :150-154."""
+    dev = _need_gpu(rnd)
+    if rnd.dim() != 2 or rnd.dtype != torch.float32 or not rnd.is_contiguous():
+        raise ValueError("rnd must be a contiguous float32 (B, n_opt) tensor")
+    B, n_opt = rnd.shape
+    out = torch.empty((B, n_replace), dtype=torch.int64, device=dev)
+    check("bma_rand_positions", lib.bma_rand_positions(rnd.data_ptr(), B, n_opt, n_replace, out.data_ptr(), _stream(dev)))
+    return out
+
+
+def sample_scatter(ids: torch.Tensor, topk_idx: torch.Tensor, pos: torch.Tensor, rank: torch.Tensor) -> torch.Tensor:
+    """ids.repeat(B,1).scatter_(1, pos, topk_idx[pos, rank]) -- reference :142, :156-162."""
+    dev = _need_gpu(ids, topk_idx, pos, rank)
+    n_opt = ids.numel()
+    if topk_idx.dim() != 2 or topk_idx.shape[0] != n_opt or pos.shape != rank.shape or pos.dim() != 2:
+        raise ValueError("shape mismatch")
+    for t in (ids, topk_idx, pos, rank):
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("index tensors must be contiguous int64")
+    B, n_rep = pos.shape
+    k = topk_idx.shape[1]
+    out = torch.empty((B, n_opt), dtype=torch.int64, device=dev)
+    check("bma_sample_scatter", lib.bma_sample_scatter(ids.data_ptr(), topk_idx.data_ptr(), pos.data_ptr(),
+                                                       rank.data_ptr(), B, n_opt, n_rep, k, out.data_ptr(),
+                                                       _stream(dev)))
+    return out
+
+
+# ---------------------------------------------------------------------------
+Segment = Tuple[str, Optional[torch.Tensor]]   # ("shared"|"percand"|"gather", tensor or None)
+
+
+def splice(segments: Sequence[Segment], B: int, emb_weight: Optional[torch.Tensor] = None,
+           ids: Optional[torch.Tensor] = None, emb_scale: float = 1.0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Build (B,S,D) candidate embeddings -- reference :1112-1225.
+
+    ``("shared", t)``: t is (L,D) or (1,L,D), broadcast to every candidate;
+    ``("percand", t)``: t is (B,L,D); ``("gather", None)``: rows emb_weight[ids[b]] * emb_scale.
+    """
+    if not segments or len(segments) > native.BMA_MAX_SEGS:
+        raise ValueError(f"1..{native.BMA_MAX_SEGS} segments")
+    ref = next((t for _, t in segments if t is not None), emb_weight)
+    if ref is None:
+        raise ValueError("nothing to splice")
+    dev, dtype, D = _need_gpu(ref), ref.dtype, ref.shape[-1]
+    arr = (BmaSegment * len(segments))()
+    keep: List[torch.Tensor] = []
+    S, n_opt, V = 0, 0, 0
+    for i, (kind, t) in enumerate(segments):
+        if kind == "gather":
+            if emb_weight is None or ids is None:
+                raise ValueError("gather segment needs emb_weight and ids")
+            if emb_weight.dim() != 2 or emb_weight.shape[1] != D or emb_weight.dtype != dtype or \
+                    not emb_weight.is_contiguous() or emb_weight.device != dev:
+                raise ValueError("emb_weight must be a contiguous (V,D) table of the segments' dtype")
+            if ids.dim() != 2 or ids.shape[0] != B or ids.dtype != torch.int64 or not ids.is_contiguous() \
+                    or ids.device != dev:
+                raise ValueError("ids must be contiguous int64 (B, n_opt) on the table's device")
+            n_opt, V = ids.shape[1], emb_weight.shape[0]
+            arr[i] = BmaSegment(None, n_opt, BMA_SEG_GATHER)
+            S += n_opt
+            continue
+        if t.device != dev or t.dtype != dtype or t.shape[-1] != D:
+            raise ValueError("segments must share device, dtype and width")
+        if kind == "shared":
+            if t.dim() == 3:
+                if t.shape[0] != 1:
+                    raise ValueError("shared segment must have batch 1")
+                t = t[0]
+            code = BMA_SEG_SHARED
+            L = t.shape[0]
+        elif kind == "percand":
+            if t.dim() != 3 or t.shape[0] != B:
+                raise ValueError("percand segment must be (B,L,D)")
+            code = BMA_SEG_PERCAND
+            L = t.shape[1]
+        else:
+            raise ValueError(f"unknown segment kind {kind!r}")
+        t = t.contiguous()
+        keep.append(t)
+        arr[i] = BmaSegment(t.data_ptr() if L else None, L, code)
+        S += L
+    if out is None:
+        out = torch.empty((B, S, D), dtype=dtype, device=dev)
+    elif out.shape != (B, S, D) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+        raise ValueError("bad out tensor")
+    check("bma_splice", lib.bma_splice(arr, len(segments), emb_weight.data_ptr() if emb_weight is not None else None,
+                                       V, ids.data_ptr() if ids is not None else None, B, n_opt, D, _DT[dtype],
+                                       float(emb_scale), out.data_ptr(), _stream(dev)))
+    return out

@@ -1,0 +1,142 @@
+/*
+ * bma.h -- C ABI of libbma_hip.so: the per-step kernels of the joint GCG+PGD
+ * attack loop, hand-written for gfx950 (MI355X).
+ *
+ * Drop-in boundary.  The reference is pure Python and has no FFI;
+ * each entry point below replaces the PyTorch op sequence cited next to it
+ * (file:line into /root/reference/bimodalattack/bimodal_attack.py).  A host
+ * binds these with ctypes (INTEGRATION.md shows the stub) and passes raw device
+ * pointers plus the HIP stream to launch on -- no torch types cross this line.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t (NULL = the default stream); every call only
+ *     enqueues work on it and returns -- no allocation, no synchronisation, so
+ *     calls can be captured into a hipGraph;
+ *   - the caller owns every buffer, including scratch (`ws`), whose size the
+ *     matching *_ws_bytes() function returns;
+ *   - return value: 0 on success, a negative BMA_E* code otherwise; nothing is
+ *     launched when a negative code is returned; no exceptions cross the line.
+ */
+#ifndef BMA_H
+#define BMA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMA_VERSION 100 /* 0.1.0 */
+
+/* element types of model-dtype tensors */
+enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
+
+/* error codes */
+enum {
+  BMA_OK = 0,
+  BMA_EINVAL = -1,   /* bad argument (null pointer, negative size, k > V, ...) */
+  BMA_EDTYPE = -2,   /* unsupported dtype code */
+  BMA_EALIGN = -3,   /* pointer / stride not aligned as the kernel requires */
+  BMA_ELAUNCH = -4,  /* hipLaunchKernel reported an error */
+  BMA_ELIMIT = -5    /* size beyond what the kernel was built for */
+};
+
+int bma_version(void);
+const char* bma_strerror(int code);
+
+/* ---------------------------------------------------------------------------
+ * a5  perform_pgd_step  (:1030-1037)
+ *   out[i] = clamp(clamp(x[i] - step*sign(g[i]), x0[i]-eps, x0[i]+eps), 0, 1)
+ * fp32, exact arithmetic (bit-comparable with the reference's three torch ops).
+ * `step` is the reference's alpha*eps already multiplied by the caller in double
+ * and rounded to fp32.  out may alias x.  Pointers 4-byte aligned; the 16-byte
+ * vector path is used when all four are 16-byte aligned.
+ * ------------------------------------------------------------------------- */
+int bma_linf_step(const float* x, const float* g, const float* x0, int64_t n,
+                  float eps, float step, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a2  cross-entropy over the target slice
+ *     (:1006-1012 gradient pass, :1289-1306 candidate scoring)
+ * logits: B candidates x T rows x V columns of `dtype`; element (b,t,v) lives at
+ *   logits + b*ld_cand + t*ld_row + v   (strides in ELEMENTS; rows contiguous).
+ * labels: T int64 target token ids, shared by all candidates (the reference
+ *   `.repeat`s them, :1291).
+ * Outputs (fp32 accumulation throughout):
+ *   loss      [B]    mean over the T rows of a candidate, summed in row order
+ *   match     [B]    1 if argmax(row) == label for all T rows (first maximum
+ *                    wins, as torch.argmax) -- the early-stop test (:1300-1306);
+ *                    may be NULL
+ *   dlogits   [B*T*V] of `dtype`, contiguous: (softmax(row) - onehot(label)) *
+ *                    grad_scale / T -- the backward of the mean CE; may be NULL
+ *   ws        scratch of bma_ce_target_ws_bytes(B,T) bytes = 3*B*T 4-byte words,
+ *                    left holding: [0,BT) per-row loss f32 (logsumexp - x[label]),
+ *                    [BT,2BT) per-row argmax==label i32, [2BT,3BT) logsumexp f32
+ * ------------------------------------------------------------------------- */
+size_t bma_ce_target_ws_bytes(int B, int T);
+int bma_ce_target(const void* logits, int64_t ld_cand, int64_t ld_row,
+                  const int64_t* labels, int B, int T, int V, int dtype,
+                  float* ws, float* loss, int32_t* match,
+                  void* dlogits, float grad_scale, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a3  sample_ids_from_grad, first half  (:144-147)
+ *   grad[:, not_allowed] = +inf ; topk(-grad, k).indices
+ * grad: rows x V of `dtype`, row r at grad + r*ld_row (elements).
+ * mask_bits: ceil(V/32) uint32 words, bit (v & 31) of word (v >> 5) set = token
+ *   v is not allowed (counts as +inf); NULL = nothing masked.
+ * idx_out [rows*k] int64: per row the k allowed tokens with the most negative
+ *   gradient, ordered by gradient ascending, ties by token id ascending; NaN
+ *   gradients rank first (torch.topk ranks NaN highest in -grad); -0.0 == +0.0.
+ *   The gradient itself is not modified.
+ * Limits: 1 <= k <= 2048, k <= V, V < 2^31.
+ * ------------------------------------------------------------------------- */
+int bma_mask_topk(const void* grad, int64_t ld_row, int rows, int V, int dtype,
+                  const uint32_t* mask_bits, int k, int64_t* idx_out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a3  sample_ids_from_grad, second half  (:150-162)
+ * bma_rand_positions: pos[b, 0:n_rep] = the n_rep positions of row b of `rnd`
+ *   (B x n_opt uniform floats) with the smallest values, in ascending order of
+ *   value (ties by position) == argsort(rnd)[..., :n_rep].  n_opt <= 64.
+ * bma_sample_scatter: out[b,:] = ids; out[b, pos[b,j]] = topk_idx[pos[b,j]*k +
+ *   rank[b,j]] for j < n_rep.   ids [n_opt], topk_idx [n_opt*k], pos/rank
+ *   [B*n_rep], out [B*n_opt], all int64.
+ * ------------------------------------------------------------------------- */
+int bma_rand_positions(const float* rnd, int B, int n_opt, int n_rep,
+                       int64_t* pos_out, void* stream);
+int bma_sample_scatter(const int64_t* ids, const int64_t* topk_idx,
+                       const int64_t* pos, const int64_t* rank, int B, int n_opt,
+                       int n_rep, int k, int64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * a7  _build_input_embeds  (:1112-1225): emb(sampled_ids) gather + repeat + cat
+ * Builds out[B][S][D] (contiguous, `dtype`) from up to BMA_MAX_SEGS segments laid
+ * end to end along the sequence axis.  Segment kinds:
+ *   BMA_SEG_SHARED  ptr -> [len][D], the same rows for every candidate
+ *   BMA_SEG_PERCAND ptr -> [B][len][D], candidate-major
+ *   BMA_SEG_GATHER  rows emb[ids[b][j]] * emb_scale for j < len (len == n_opt);
+ *                   ptr unused.  emb_scale == 1.0f copies bits; otherwise the
+ *                   product is formed in fp32 and rounded to `dtype` (Gemma's
+ *                   scaled embedding, :1142).
+ * S is the sum of the segment lengths.  D*sizeof(elem) must be a multiple of 16
+ * and every pointer 16-byte aligned.  ids are int64 in [0, V).
+ * ------------------------------------------------------------------------- */
+#define BMA_MAX_SEGS 8
+enum { BMA_SEG_SHARED = 0, BMA_SEG_PERCAND = 1, BMA_SEG_GATHER = 2 };
+typedef struct bma_segment {
+  const void* ptr;
+  int32_t len;
+  int32_t kind;
+} bma_segment;
+
+int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
+               const int64_t* ids, int B, int n_opt, int D, int dtype,
+               float emb_scale, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMA_H */

@@ -33,7 +33,8 @@ def linf_step(x: np.ndarray, g: np.ndarray, x0: np.ndarray, eps: float, alpha: f
     x0 = np.asarray(x0, np.float32)
     step = np.float32(alpha * eps)
     e = np.float32(eps)
-    y = (x - step * np.sign(g)).astype(np.float32)
+    sgn = (g > 0).astype(np.float32) - (g < 0).astype(np.float32)   # torch.sign: 0 for NaN and for -0.0
+    y = (x - step * sgn).astype(np.float32)
     lo = (x0 - e).astype(np.float32)
     hi = (x0 + e).astype(np.float32)
     y = np.where(y < lo, lo, y)

@@ -220,6 +220,9 @@ def g3_pgd() -> None:
         g = rs.standard_normal(shape).astype(np.float32)
         g.reshape(-1)[::7] = 0.0
         g.reshape(-1)[3::29] = -0.0
+        if name == "b":
+            g.reshape(-1)[1::31] = np.nan       # torch.sign(nan) == 0: the pixel only gets re-projected
+            g.reshape(-1)[2::37] = np.inf
         y = refmod.BimodalAttack.perform_pgd_step(
             None, torch.from_numpy(x.copy()), eps, alpha, torch.from_numpy(g), torch.from_numpy(x0)
         )

@@ -1,0 +1,84 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every
+symbol include/bma.h declares, validates arguments without launching, and the
+product refuses to run on CPU tensors (no fallback)."""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "bma.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bma_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bimodalattack_amd import native
+    syms = declared_symbols()
+    assert len(syms) >= 9
+    raw = ctypes.CDLL(native.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/bma.h but not exported"
+    assert sorted(native.PROTOTYPES) == syms, "native.PROTOTYPES and include/bma.h disagree"
+    assert native.lib.bma_version() == native.ABI_VERSION
+    assert native.strerror(0) == "ok" and "align" in native.strerror(-3)
+
+
+def test_argument_validation_launches_nothing():
+    """Every entry point rejects bad arguments before touching the device."""
+    from bimodalattack_amd.native import BmaSegment, lib
+    assert lib.bma_linf_step(None, None, None, -1, 0.1, 0.1, None, None) == -1
+    assert lib.bma_linf_step(None, None, None, 0, 0.1, 0.1, None, None) == 0
+    assert lib.bma_linf_step(2, 4, 4, 8, 0.1, 0.1, 4, None) == -3          # misaligned pointer
+    assert lib.bma_ce_target(None, 0, 0, None, 1, 0, 10, 0, None, None, None, None, 1.0, None) == -1
+    assert lib.bma_ce_target(16, 40, 10, 16, 4, 4, 10, 7, 16, 16, None, None, 1.0, None) == -2   # dtype
+    assert lib.bma_ce_target(None, 0, 10, None, 0, 4, 10, 0, None, None, None, None, 1.0, None) == 0
+    assert lib.bma_ce_target_ws_bytes(512, 20) == 3 * 512 * 20 * 4
+    assert lib.bma_mask_topk(16, 100, 1, 100, 0, None, 101, 16, None) == -1   # k > V
+    assert lib.bma_mask_topk(16, 5000, 1, 5000, 0, None, 4096, 16, None) == -5  # k > 2048
+    assert lib.bma_mask_topk(16, 100, 0, 100, 0, None, 5, 16, None) == 0
+    assert lib.bma_rand_positions(16, 4, 65, 1, 16, None) == -5
+    assert lib.bma_rand_positions(16, 4, 8, 9, 16, None) == -1
+    assert lib.bma_sample_scatter(16, 16, 16, 16, 0, 8, 1, 4, 16, None) == 0
+    segs = (BmaSegment * 1)(BmaSegment(16, 4, 0))
+    assert lib.bma_splice(segs, 1, None, 0, None, 2, 0, 6, 1, 1.0, 16, None) == -3   # D*2 not a multiple of 16
+    assert lib.bma_splice(segs, 9, None, 0, None, 2, 0, 8, 1, 1.0, 16, None) == -1
+    assert lib.bma_splice(segs, 1, None, 0, None, 0, 0, 8, 1, 1.0, None, None) == 0
+    bad = (BmaSegment * 1)(BmaSegment(16, 4, 7))
+    assert lib.bma_splice(bad, 1, None, 0, None, 2, 0, 8, 1, 1.0, 16, None) == -1
+
+
+def test_no_cpu_fallback():
+    from bimodalattack_amd import ops
+    x = torch.zeros(8)
+    with pytest.raises(RuntimeError, match="AMD GPU only"):
+        ops.linf_step(x, x, x, 0.1, 0.1)
+    with pytest.raises(RuntimeError, match="AMD GPU only"):
+        ops.ce_target(torch.zeros(1, 2, 8), torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="AMD GPU only"):
+        ops.mask_topk(torch.zeros(2, 8), None, 2)
+    with pytest.raises(RuntimeError, match="AMD GPU only"):
+        ops.splice([("shared", torch.zeros(2, 8))], 2)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import subprocess, sys
+    env = dict(os.environ, BMA_LIB=str(tmp_path / "nope.so"), PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-c", "import bimodalattack_amd.native"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "HIP library not found" in r.stderr and "no CPU or PyTorch fallback" in r.stderr
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(REPO, "bimodalattack_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "from oracle" not in src and "import oracle" not in src, f

@@ -1,0 +1,334 @@
+"""Parity of the HIP kernels (called through the C ABI) with the oracle and with the
+golden vectors captured from the reference.  Run on the MI355X box: pytest -m gpu.
+
+Bars: indices / ids / copied bytes / PGD pixels bit-exact; fp32 losses <= 1e-4 rel
+(BASELINE.json north_star), tolerances written at each assert.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernels as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bimodalattack_amd import native, ops as _ops
+    native.check_single_hip_runtime()
+    return _ops
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+# ------------------------------------------------------------------ a5 L-inf step
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_linf_golden(ops, golden_dir, case):
+    z = load(golden_dir, "g3_pgd.npz")
+    eps, alpha = (float(v) for v in z[f"{case}_eps_alpha"])
+    y = ops.linf_step(dev(z[f"{case}_x"]), dev(z[f"{case}_g"]), dev(z[f"{case}_x0"]), eps, alpha)
+    assert np.array_equal(bits(y.cpu().numpy()), bits(z[f"{case}_y"]))
+
+
+def test_linf_chain_golden_inplace(ops, golden_dir):
+    z = load(golden_dir, "g3_pgd.npz")
+    eps, alpha = (float(v) for v in z["chain_eps_alpha"])
+    x0 = dev(z["chain_x0"])
+    x = x0.clone()
+    for g, want in zip(z["chain_g"], z["chain_x"]):
+        ops.linf_step(x, dev(g), x0, eps, alpha, out=x)          # out aliases x
+        assert np.array_equal(bits(x.cpu().numpy()), bits(want))
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 1023, 4099, 3 * 336 * 336, 3 * 896 * 896])
+def test_linf_sizes_vs_oracle(ops, n):
+    rs = np.random.RandomState(n % 9973)
+    x0 = rs.uniform(0, 1, n).astype(np.float32)
+    x = np.clip(x0 + rs.uniform(-0.3, 0.3, n), 0, 1).astype(np.float32)
+    g = rs.standard_normal(n).astype(np.float32)
+    g[::5] = 0
+    g[1::17] = np.nan
+    g[2::19] = -np.inf
+    eps, alpha = 64 / 255, 4 / 255
+    want = K.linf_step(x, g, x0, eps, alpha)
+    got = ops.linf_step(dev(x), dev(g), dev(x0), eps, alpha).cpu().numpy()
+    assert np.array_equal(bits(got), bits(want))
+    assert np.abs(got - x0).max() <= np.float32(eps) + 1e-7 and got.min() >= 0 and got.max() <= 1
+    # idempotent projection: a zero gradient leaves a feasible point untouched
+    again = ops.linf_step(dev(got), torch.zeros(n, device=DEV), dev(x0), eps, alpha).cpu().numpy()
+    assert np.array_equal(bits(again), bits(got))
+
+
+def test_linf_unaligned_and_empty(ops):
+    rs = np.random.RandomState(0)
+    n = 1001
+    buf = [dev(rs.uniform(0, 1, n + 1).astype(np.float32)) for _ in range(3)]
+    x, g, x0 = (b[1:] for b in buf)                     # 4-byte aligned only -> scalar path
+    g = g - 0.5
+    want = K.linf_step(x.cpu().numpy(), g.cpu().numpy(), x0.cpu().numpy(), 0.1, 0.5)
+    out = torch.empty(n + 1, device=DEV)[1:]
+    from bimodalattack_amd.native import lib, check
+    check("bma_linf_step", lib.bma_linf_step(x.data_ptr(), g.contiguous().data_ptr() if False else g.data_ptr(),
+                                             x0.data_ptr(), n, 0.1, float(0.5 * 0.1), out.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+    assert np.array_equal(bits(out.cpu().numpy()), bits(want))
+    e = torch.empty(0, device=DEV)
+    assert ops.linf_step(e, e, e, 0.1, 0.1).numel() == 0
+
+
+# ------------------------------------------------------------------ a2 CE target
+def test_ce_golden(ops, golden_dir):
+    z = load(golden_dir, "g2_ce.npz")
+    logits, T = z["logits"], z["target"].shape[1]
+    full = dev(logits)
+    sl = full[:, logits.shape[1] - T - 1:-1]                    # strided view, as the engine passes it
+    loss, match, dlog, rows = ops.ce_target(sl, dev(z["target"][0]), want_match=True, want_dlogits=True)
+    np.testing.assert_allclose(loss.cpu().numpy(), z["loss"], rtol=1e-4)
+    np.testing.assert_allclose(rows.cpu().numpy(), z["row_loss"], rtol=1e-4)
+    assert not match.any()
+    np.testing.assert_allclose(dlog[0].cpu().numpy(), z["dlogits0"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(loss[0].item(), float(z["mean0"]), rtol=1e-4)
+    loss_hit, match_hit, _, _ = ops.ce_target(sl, dev(z["target_hit"][0]), want_match=True)
+    np.testing.assert_allclose(loss_hit.cpu().numpy(), z["loss_hit"], rtol=1e-4)
+    assert match_hit.cpu().tolist() == [int(i == 5) for i in range(8)]
+    # the oracle itself (float64) is a tighter reference than the fp32 golden
+    want, _ = K.ce_target(logits[:, logits.shape[1] - T - 1:-1], z["target"][0])
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("V", [1000, 1003, 32064, 7])
+def test_ce_dtypes_vs_oracle(ops, dtype, V):
+    rs = np.random.RandomState(V)
+    B, T = 5, 4
+    x = (rs.standard_normal((B, T + 2, V)) * 3).astype(np.float32)
+    xt = dev(x, dtype)
+    lab = rs.randint(0, V, size=T).astype(np.int64)
+    sl = xt[:, 1:1 + T]
+    xr = sl.float().cpu().numpy()                                # the rounded inputs the kernel saw
+    want, wmatch = K.ce_target(xr, lab)
+    loss, match, dlog, rows = ops.ce_target(sl, dev(lab), want_match=True, want_dlogits=True, grad_scale=0.5)
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=1e-5)
+    np.testing.assert_allclose(rows.cpu().numpy(), K.ce_rows(xr, lab), rtol=1e-5, atol=1e-6)
+    assert match.cpu().numpy().astype(bool).tolist() == wmatch.tolist()
+    tol = dict(rtol=1e-5, atol=1e-8) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-6)
+    for b in range(B):
+        np.testing.assert_allclose(dlog[b].float().cpu().numpy(), K.ce_target_grad(xr[b], lab, 0.5), **tol)
+
+
+def test_ce_argmax_first_maximum_and_extremes(ops):
+    V, T = 520, 3
+    x = np.full((2, T, V), -5.0, np.float32)
+    x[0, :, 100] = 7.0
+    x[0, :, 300] = 7.0            # tie: argmax is the FIRST maximum (index 100)
+    x[1, :, 300] = 7.0
+    x[1, 2, 10] = 80.0            # large logit: no overflow in the online sum
+    loss, match, _, _ = ops.ce_target(dev(x), dev(np.array([300, 300, 300])), want_match=True)
+    assert match.cpu().tolist() == [0, 0]
+    loss2, match2, _, _ = ops.ce_target(dev(x), dev(np.array([100, 100, 100])), want_match=True)
+    assert match2.cpu().tolist() == [1, 0]
+    want, _ = K.ce_target(x, np.array([300, 300, 300]))
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=1e-5)
+    assert torch.isfinite(loss).all()
+
+
+def test_ce_autograd_function(ops):
+    rs = np.random.RandomState(1)
+    T, V = 6, 264
+    x = dev(rs.standard_normal((T, V)).astype(np.float32)).requires_grad_()
+    lab = dev(rs.randint(0, V, T))
+    loss = ops.TargetCrossEntropy.apply(x, lab)
+    (g,) = torch.autograd.grad(loss * 2.0, x)
+    xr = x.detach().cpu().numpy()
+    np.testing.assert_allclose(loss.item(), K.ce_rows(xr, lab.cpu().numpy()).mean(), rtol=1e-5)
+    np.testing.assert_allclose(g.cpu().numpy(), K.ce_target_grad(xr, lab.cpu().numpy(), 2.0), rtol=1e-4, atol=1e-8)
+
+
+def test_ce_baseline_size(ops):
+    """B=512, T=20, V=32064, bf16 (657 MB): a sample of candidates against the
+    oracle; size-independent properties for the rest."""
+    B, T, V = 512, 20, 32064
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = (torch.randn((B, T + 1, V), generator=g, device=DEV, dtype=torch.float32) * 2).to(torch.bfloat16)
+    lab = torch.randint(0, V, (T,), generator=g, device=DEV)
+    sl = x[:, :T]
+    loss, match, _, rows = ops.ce_target(sl, lab, want_match=True)
+    pick = [0, 1, 255, 256, 511]
+    want, _ = K.ce_target(sl[pick].float().cpu().numpy(), lab.cpu().numpy())
+    np.testing.assert_allclose(loss[pick].cpu().numpy(), want, rtol=1e-5)
+    assert torch.isfinite(loss).all() and not match.any()
+    # permutation of candidates permutes the losses, bit for bit
+    perm = torch.randperm(B, generator=g, device=DEV)
+    loss_p, _, _, _ = ops.ce_target(sl[perm].contiguous(), lab)
+    assert torch.equal(loss_p, loss[perm])
+    # mean of rows in fixed order
+    np.testing.assert_allclose(loss.cpu().numpy(), rows.cpu().numpy().astype(np.float64).mean(1), rtol=1e-6)
+    # against torch's own fp32 log-softmax on the device (a second opinion, not the oracle)
+    ref = torch.nn.functional.cross_entropy(sl.float().reshape(-1, V), lab.repeat(B), reduction="none").view(B, T).mean(1)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ a3 sampling
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_sampling_golden(ops, golden_dir, case):
+    z = load(golden_dir, "g1_sampling.npz")
+    n_opt, V, sw, topk, n_rep = (int(v) for v in z[f"{case}_meta"])
+    na = z[f"{case}_not_allowed"]
+    mask = ops.build_mask_bits(torch.from_numpy(na), V, DEV) if na.size else None
+    tk = ops.mask_topk(dev(z[f"{case}_grad"]), mask, topk)
+    assert np.array_equal(tk.cpu().numpy(), z[f"{case}_topk_ids"])
+    pos = ops.rand_positions(dev(z[f"{case}_rand"]), n_rep)
+    assert np.array_equal(pos.cpu().numpy(), z[f"{case}_pos"])
+    new = ops.sample_scatter(dev(z[f"{case}_ids"]), tk, pos, dev(z[f"{case}_rank"]))
+    assert np.array_equal(new.cpu().numpy(), z[f"{case}_new_ids"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("V,k,rows", [(32064, 256, 19), (32003, 256, 3), (262208, 256, 19), (300, 300, 2),
+                                      (5000, 2048, 2), (64, 1, 5)])
+def test_topk_vs_oracle_with_ties(ops, dtype, V, k, rows):
+    """bf16 gradients over a 32k vocabulary have ~2k distinct values: heavy ties at
+    the k-th boundary.  Policy (value asc, id asc) must hold exactly."""
+    rs = np.random.RandomState(V + k)
+    g = (rs.standard_normal((rows, V)) * 0.01).astype(np.float32)
+    g[:, ::97] = 0.0
+    g[:, 5::101] = -0.0
+    if V > 1000:
+        g[0, 11] = np.nan
+        g[1, 13] = -np.inf
+        g[0, 17] = np.inf
+    gt = dev(g, dtype)
+    gr = gt.float().cpu().numpy()
+    na = np.unique(rs.randint(0, V, size=max(1, V // 50)))
+    if k >= V:
+        na = np.zeros(0, np.int64)
+    mask = ops.build_mask_bits(torch.from_numpy(na), V, DEV)
+    got = ops.mask_topk(gt, mask, k).cpu().numpy()
+    want = K.mask_topk(gr, na, k)
+    assert np.array_equal(got, want)
+    # no forbidden token is ever selected; rows hold k distinct ids
+    assert not np.isin(got, na).any()
+    assert all(len(set(r.tolist())) == k for r in got)
+    # unmasked variant
+    assert np.array_equal(ops.mask_topk(gt, None, k).cpu().numpy(), K.mask_topk(gr, None, k))
+
+
+def test_topk_strided_rows_and_grad_untouched(ops):
+    rs = np.random.RandomState(5)
+    big = dev(rs.standard_normal((4, 2, 1024)).astype(np.float32))
+    view = big[:, 1]                                            # row stride 2048 elements
+    before = view.clone()
+    na = np.arange(0, 1024, 3)
+    got = ops.mask_topk(view, ops.build_mask_bits(torch.from_numpy(na), 1024, DEV), 32).cpu().numpy()
+    assert np.array_equal(got, K.mask_topk(before.cpu().numpy(), na, 32))
+    assert torch.equal(view, before)
+
+
+def test_rand_positions_and_scatter_vs_oracle(ops):
+    rs = np.random.RandomState(9)
+    for B, n_opt, n_rep, k in [(512, 19, 1, 256), (128, 19, 3, 64), (1, 1, 1, 4), (77, 64, 64, 8)]:
+        rnd = rs.uniform(size=(B, n_opt)).astype(np.float32)
+        rnd[0, :] = 0.5 if n_opt > 1 else rnd[0, :]              # ties: lowest position first
+        pos = ops.rand_positions(dev(rnd), n_rep)
+        assert np.array_equal(pos.cpu().numpy(), K.rand_positions(rnd, n_rep))
+        ids = rs.randint(0, 32000, n_opt).astype(np.int64)
+        tk = rs.randint(0, 32000, (n_opt, k)).astype(np.int64)
+        rank = rs.randint(0, k, (B, n_rep)).astype(np.int64)
+        new = ops.sample_scatter(dev(ids), dev(tk), pos, dev(rank))
+        assert np.array_equal(new.cpu().numpy(), K.sample_scatter(ids, tk, pos.cpu().numpy(), rank))
+        # every candidate differs from the parent in at most n_rep positions
+        assert ((new.cpu().numpy() != ids[None]).sum(1) <= n_rep).all()
+
+
+# ------------------------------------------------------------------ a7 splice
+COMBOS = {
+    "pgd_single": dict(mode="pgd", single=True), "gcg_single": dict(mode="gcg", single=True),
+    "gcg_nojoint": dict(mode="gcg", no_joint_eval=True), "gcg_notarget": dict(mode="gcg", no_target=True),
+    "gcgpgd_single": dict(mode="gcg_pgd", single=True), "gcgpgd_notarget": dict(mode="gcg_pgd", no_target=True),
+    "gcgpgd_full": dict(mode="gcg_pgd"),
+}
+
+
+@pytest.mark.parametrize("mt", ["llava", "gemma3"])
+def test_splice_golden(ops, golden_dir, mt):
+    from bimodalattack_amd.layout import segment_order
+    z = load(golden_dir, "g4_splice.npz")
+    seg = {k[4:]: dev(z[k]) for k in z.files if k.startswith("seg_")}
+    seg["image"] = dev(z["image"])
+    table, ids = dev(z["table"]), dev(z["ids"])
+    scale = float(np.float32(8 ** 0.5)) if mt == "gemma3" else 1.0
+    for name, kw in COMBOS.items():
+        order = segment_order(kw["mode"], mt, **{k: v for k, v in kw.items() if k != "mode"})
+        segs = [("gather", None) if n == "optim" else ("shared", seg[n]) for n in order]
+        y = ops.splice(segs, ids.shape[0], table, ids, scale)
+        assert np.array_equal(bits(y.cpu().numpy()), bits(z[f"{mt}_{name}"])), name
+    order = segment_order("gcg_pgd", mt)
+    segs = [("gather", None) if n == "optim" else ("shared", seg[n]) for n in order]
+    y1 = ops.splice(segs, 1, table, ids[2:3].contiguous(), scale)
+    assert np.array_equal(bits(y1.cpu().numpy()), bits(z[f"{mt}_gcgpgd_one"]))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,lens,D", [(512, (21, 19, 6, 19), 4096), (64, (5, 576, 18, 19, 6, 20), 4096),
+                                      (3, (2, 19, 1), 8), (33, (0, 19, 0, 7), 2560)])
+def test_splice_sizes_bitwise(ops, dtype, B, lens, D):
+    """Copy semantics: every output byte equals its source byte (checked with torch
+    indexing on the device as the independent reference)."""
+    g = torch.Generator(device=DEV).manual_seed(B)
+    V, n_opt = 1000, 19
+    table = torch.randn((V, D), generator=g, device=DEV).to(dtype)
+    ids = torch.randint(0, V, (B, n_opt), generator=g, device=DEV)
+    segs, parts = [], []
+    for i, L in enumerate(lens):
+        if L == n_opt and not any(k == "gather" for k, _ in segs):
+            segs.append(("gather", None))
+            parts.append(table[ids])
+        elif i % 2 == 0:
+            t = torch.randn((1, L, D), generator=g, device=DEV).to(dtype)
+            segs.append(("shared", t))
+            parts.append(t.expand(B, L, D))
+        else:
+            t = torch.randn((B, L, D), generator=g, device=DEV).to(dtype)
+            segs.append(("percand", t))
+            parts.append(t)
+    y = ops.splice(segs, B, table, ids)
+    want = torch.cat(parts, dim=1)
+    assert y.shape == want.shape and torch.equal(y.view(torch.uint8), want.contiguous().view(torch.uint8))
+
+
+def test_splice_gemma_scale_matches_hf_embedding(ops):
+    from transformers.models.gemma3.modeling_gemma3 import Gemma3TextScaledWordEmbedding
+    V, D, B, n = 512, 2560, 16, 19
+    for dtype in (torch.bfloat16, torch.float32):
+        emb = Gemma3TextScaledWordEmbedding(V, D, padding_idx=0, embed_scale=D ** 0.5).to(DEV, dtype)
+        with torch.no_grad():
+            emb.weight.copy_(torch.randn(V, D, device=DEV) * 0.02)
+        ids = torch.randint(0, V, (B, n), device=DEV)
+        with torch.no_grad():
+            want = emb(ids)
+        scale = float(emb.embed_scale.to(dtype).float())
+        y = ops.splice([("gather", None)], B, emb.weight.detach(), ids, scale)
+        assert torch.equal(y.view(torch.uint8), want.contiguous().view(torch.uint8))
+
+
+def test_splice_clamps_bad_ids(ops):
+    table = torch.randn(10, 8, device=DEV)
+    ids = torch.tensor([[-3, 99]], device=DEV)
+    y = ops.splice([("gather", None)], 1, table, ids)
+    assert torch.equal(y[0, 0], table[0]) and torch.equal(y[0, 1], table[9])
