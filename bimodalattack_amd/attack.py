@@ -1,0 +1,608 @@
+"""The attack engine: the per-step loop of joint GCG (token suffix) + PGD (image
+pixels) optimisation, MI355X-native, behind the reference's ``run()`` API.
+
+Mirrors /root/reference/bimodalattack/bimodal_attack.py:
+  ``BimodalAttack.__init__`` :193-249      chat-template defaults, forbidden tokens
+  ``BimodalAttack.run``      :251-824      prompt split, step loop, bookkeeping
+  ``init_buffer``            :826-906      ``candidate_sampling`` :908-951
+  ``compute_gradient``       :953-1028     ``perform_pgd_step``   :1030-1037
+  ``_build_input_embeds``    :1112-1225    ``_compute_candidates_loss_original`` :1278-1310
+  ``_save_image``            :1312-1317    ``run``                :1323-1338
+
+What runs where.  torch supplies device memory, streams, autograd through the
+HuggingFace model (whose GEMMs are rocBLAS/hipBLASLt) and torch.distributed (RCCL).
+Everything the loop itself computes goes through hand-written gfx950 kernels in
+libbma_hip.so: the target-slice cross-entropy and its gradient, forbidden-token mask +
+top-k, candidate scatter, the embedding gather/splice and the L-inf projection
+(``ops``).  There is no fallback path: on a CPU model the engine raises.
+
+Differences from the reference that do NOT change results:
+logits only on the T target rows; shared-prefix keys/values computed once per step;
+analytic chunk sizing; one batched tokenizer round trip; PNG encoding off the
+critical path; candidate scoring sharded over ranks with one all-gather of losses.
+Reference quirks that are kept: step = alpha*eps; second BOS in the PGD prompt; the
+gradient pass uses the llava segment order and the UNSCALED embedding table for every
+model; greedy acceptance of the step winner; losses rounded to the model dtype.
+"""
+
+from __future__ import annotations
+
+import copy
+import logging
+import os
+import queue
+import threading
+import time
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import ops
+from .config import BimodalAttackConfig, BimodalAttackResult, EngineOptions
+from .dist import CandidateSharder
+from .hf_adapter import HFAdapter
+from .layout import dynamic_width, segment_order, split_at_suffix
+from .utils import INIT_CHARS, filter_ids, get_nonascii_toks, is_oom, plan_chunk
+
+logger = logging.getLogger("gcg")
+if not logger.hasHandlers():
+    _h = logging.StreamHandler()
+    _h.setFormatter(logging.Formatter("%(asctime)s [%(filename)s:%(lineno)d] %(message)s", datefmt="%Y-%m-%d %H:%M:%S"))
+    logger.addHandler(_h)
+    logger.setLevel(logging.INFO)
+logger.propagate = False
+
+TEMPLATE_PGD = "USER: <image>\n{{ messages[0]['content'][0]['text'] }} \nASSISTANT: "
+TEMPLATE_GCG = "{% for message in messages %}{{ message['content'] }}{% endfor %}"
+
+
+class AttackBuffer:
+    """Best-so-far suffixes, ascending by loss (reference :91-124)."""
+
+    def __init__(self, size: int):
+        self.size = size
+        self.buffer: List[tuple] = []
+
+    def add(self, loss: float, optim_ids: Tensor) -> None:
+        if self.size == 0:
+            self.buffer = [(loss, optim_ids)]
+            return
+        if len(self.buffer) < self.size:
+            self.buffer.append((loss, optim_ids))
+        else:
+            self.buffer[-1] = (loss, optim_ids)
+        self.buffer.sort(key=lambda e: e[0])
+
+    def get_best_ids(self) -> Tensor:
+        return self.buffer[0][1]
+
+    def get_lowest_loss(self) -> float:
+        return self.buffer[0][0]
+
+    def get_highest_loss(self) -> float:
+        return self.buffer[-1][0]
+
+    def log_buffer(self, tokenizer) -> None:
+        if not logger.isEnabledFor(logging.INFO):
+            return
+        lines = ["buffer:"]
+        for loss, ids in self.buffer:
+            s = tokenizer.batch_decode(ids)[0].replace("\\", "\\\\").replace("\n", "\\n")
+            lines.append(f"loss: {loss} | string: {s}")
+        logger.info("\n".join(lines))
+
+
+class _PngWriter:
+    """images_folder/{i}.png every step (reference :744, :1312-1317) with the same
+    truncating *255 -> uint8 quantisation, done on the device; the 8-bit pixels are
+    copied to the host and a worker thread does the encoding."""
+
+    def __init__(self):
+        self.q: "queue.Queue" = queue.Queue()
+        self.t = threading.Thread(target=self._work, daemon=True)
+        self.err: Optional[BaseException] = None
+        self.t.start()
+
+    def _work(self) -> None:
+        from PIL import Image
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            arr, path = item
+            try:
+                Image.fromarray(arr).save(path)
+            except BaseException as e:  # surfaced by close()
+                self.err = e
+
+    def submit(self, image: Tensor, path: str) -> None:
+        px = (image.detach().squeeze(0) * 255).to(torch.uint8).permute(1, 2, 0).contiguous()
+        self.q.put((px.cpu().numpy(), path))
+
+    def close(self) -> None:
+        self.q.put(None)
+        self.t.join()
+        if self.err is not None:
+            raise self.err
+
+
+class BimodalAttack:
+    def __init__(self, model, tokenizer, processor, config: BimodalAttackConfig, normalize=None,
+                 options: Optional[EngineOptions] = None):
+        self.model, self.tokenizer, self.processor = model, tokenizer, processor
+        self.config, self.normalize = config, normalize
+        self.opt = options or EngineOptions.from_env()
+        if model.device.type != "cuda":
+            raise RuntimeError(
+                f"bimodalattack_amd runs on an AMD GPU only (model is on {model.device}); there is no CPU path. "
+                "Move the model to the device first.")
+        self.hf = HFAdapter(model, processor, normalize)
+        self.embedding_layer = self.hf.embedding
+        self.not_allowed_ids = None if config.allow_non_ascii else get_nonascii_toks(tokenizer, device=model.device)
+        self.mask_bits = ops.build_mask_bits(self.not_allowed_ids, self.embedding_layer.num_embeddings, model.device)
+        self.stop_flag = False
+        self.shard = CandidateSharder(self.opt.group)
+        self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
+        self._rng = None
+        if hasattr(model.config, "model_type"):
+            logger.info(f"Model type: {model.config.model_type}")
+        if model.dtype in (torch.float32, torch.float64):
+            logger.warning(f"Model is in {model.dtype}. Use a lower precision data type for faster optimization.")
+        if not getattr(tokenizer, "chat_template", None):                      # :233-249
+            tpl = TEMPLATE_PGD if config.pgd_attack else TEMPLATE_GCG
+            logger.warning("Tokenizer does not have a chat template. Using custom chat template for "
+                           + ("GCG+PGD attack." if config.pgd_attack else "GCG only attack."))
+            tokenizer.chat_template = tpl
+            self.processor.chat_template = tpl
+
+    # ------------------------------------------------------------------ setup
+    def _encode(self, text, special: bool) -> Tensor:
+        kw = {} if special else {"add_special_tokens": False}
+        ids = self.tokenizer(text, padding=False, return_tensors="pt", **kw)["input_ids"]
+        return ids.to(self.model.device, torch.int64)
+
+    def _prepare_prompt(self, messages, target: str) -> None:
+        cfg, tok = self.config, self.tokenizer
+        msgs = [{"role": "user", "content": messages}] if isinstance(messages, str) else copy.deepcopy(messages)
+        tail = msgs[-1]
+        if isinstance(tail["content"], str) and "{optim_str}" not in tail["content"]:
+            tail["content"] = tail["content"] + " {optim_str}"
+        if cfg.pgd_attack:
+            if isinstance(tail["content"], str):
+                tail["content"] = [{"type": "text", "text": tail["content"]}, {"type": "image"}]
+            elif isinstance(tail["content"], list) and not any(it.get("type") == "image" for it in tail["content"]):
+                tail["content"].append({"type": "image"})
+        prompt = self.processor.apply_chat_template(msgs, add_generation_prompt=True)
+        if tok.bos_token and prompt.startswith(tok.bos_token):
+            prompt = prompt.replace(tok.bos_token, "")
+        logger.info(f"Prompt after removing BOS token: {prompt}")
+
+        ids: Dict[str, Tensor] = {}
+        if cfg.pgd_attack:
+            if self.hf.is_gemma_processor:
+                head, rest = prompt.split("{optim_str}", 1)
+                if "<start_of_image>" not in rest:
+                    raise ValueError("Expected <start_of_image> token in Gemma PGD prompt.")
+                mid, marker, after = rest.partition("<start_of_image>")
+                texts = dict(before_img=head.strip(), before_suffix=(mid + marker).strip(), after=after.strip())
+            else:
+                marker = next((m for m in ("<start_of_image>", "<image>") if m in prompt), None)
+                if marker is None:
+                    raise ValueError("No image token found in prompt for PGD attack")
+                head, rest = prompt.split(marker, 1)
+                mid, after = rest.split("{optim_str}", 1)
+                texts = dict(before_img=head, before_suffix=mid, after=after)
+            # both "before" pieces go through the tokenizer's default special-token
+            # handling, so the PGD layout carries a second BOS mid-sequence (:346-351)
+            ids["before_img"] = self._encode(texts["before_img"], True)
+            ids["before_suffix"] = self._encode(texts["before_suffix"], True)
+            ids["after"] = self._encode(texts["after"], False)
+        else:
+            head, after = prompt.split("{optim_str}")
+            ids["before"] = self._encode(head, True)
+            ids["after"] = self._encode(after, False)
+        ids["target"] = self._encode(target, False)
+        self.target_ids = ids["target"]
+        self.labels = self.target_ids[0].contiguous()
+        self.T = int(self.labels.numel())
+        with torch.no_grad():
+            self.seg: Dict[str, Tensor] = {k: self.embedding_layer(v).detach() for k, v in ids.items()}
+        self.seg_ids = ids
+        # the target without its last token: what the candidate forward is fed
+        self.seg["target_in"] = self.seg["target"][:, :-1, :].contiguous()
+
+    # ------------------------------------------------------------ random draws
+    def _draw(self, width: int, n_opt: int):
+        """The two draws of sample_ids_from_grad (:150-160), in the reference's order."""
+        cfg, dev = self.config, self.model.device
+        if self.opt.rng_device == "cpu":
+            rnd = torch.rand((width, n_opt)).to(dev)
+            rank = torch.randint(0, cfg.topk, (width, cfg.n_replace, 1)).squeeze(2).to(dev)
+        else:
+            rnd = torch.rand((width, n_opt), device=dev)
+            rank = torch.randint(0, cfg.topk, (width, cfg.n_replace, 1), device=dev).squeeze(2)
+        return rnd.contiguous(), rank.contiguous()
+
+    # ------------------------------------------------------------ gradient pass
+    def compute_gradient(self, optim_ids: Tensor, image: Optional[Tensor] = None):
+        """One forward/backward at batch 1 (:953-1028): d(mean target CE)/d(one-hot
+        suffix) and /d(image).  The one-hot is never built: its gradient is
+        (dL/d suffix embeddings) @ E^T, the same product autograd would form."""
+        cfg = self.config
+        E = self.embedding_layer.weight
+        emb = E[optim_ids[0]].unsqueeze(0).detach()
+        if cfg.gcg_attack:
+            emb.requires_grad_()
+        if cfg.pgd_attack:
+            feats = self.hf.image_features(image)
+            parts = [self.seg["before_img"], feats.to(emb.dtype), self.seg["before_suffix"], emb, self.seg["after"],
+                     self.seg["target"]]
+        else:
+            parts = [self.seg["before"], emb, self.seg["after"], self.seg["target"]]
+        x = torch.cat(parts, dim=1)
+        if self.opt.target_rows_only:
+            logits = self.hf.target_logits(x[:, :-1], self.T, rows_only=True)
+        else:
+            logits = self.hf.target_logits(x, self.T, rows_only=False)
+        loss = ops.TargetCrossEntropy.apply(logits[0], self.labels)
+        wanted = ([emb] if cfg.gcg_attack else []) + ([image] if cfg.pgd_attack else [])
+        grads = list(torch.autograd.grad(loss, wanted))
+        g_tok = None
+        if cfg.gcg_attack:
+            g_emb = grads.pop(0)[0]                       # (n_opt, D), model dtype
+            with torch.no_grad():
+                g_tok = (g_emb @ E.t()).unsqueeze(0)      # (1, n_opt, V), model dtype
+        g_img = grads.pop(0) if cfg.pgd_attack else None
+        return g_tok, g_img
+
+    def perform_pgd_step(self, image: Tensor, eps: float, alpha: float, image_grad: Tensor,
+                         image_original: Tensor) -> Tensor:
+        """x <- clamp(clamp(x - alpha*eps*sign(g), x0-eps, x0+eps), 0, 1) (:1030-1037)."""
+        x = image.detach()
+        if x.dtype != torch.float32:
+            raise TypeError("the PGD image must be float32 (the reference feeds ToTensor() output)")
+        out = ops.linf_step(x.contiguous(), image_grad.to(torch.float32).contiguous(),
+                            image_original.detach().contiguous(), eps, alpha)
+        return out.requires_grad_()
+
+    # ------------------------------------------------------------ sampling
+    def candidate_sampling(self, step: int, optim_ids: Tensor, g_tok: Optional[Tensor]):
+        cfg = self.config
+        width = dynamic_width(step, cfg.search_width, cfg.num_steps, cfg.min_search_width, cfg.dynamic_search)
+        if not cfg.gcg_attack:
+            return optim_ids, 1
+        ids = optim_ids[0].contiguous()
+        rnd, rank = self._draw(width, ids.numel())
+        topk_idx = ops.mask_topk(g_tok[0], self.mask_bits, cfg.topk)
+        pos = ops.rand_positions(rnd, cfg.n_replace)
+        sampled = ops.sample_scatter(ids, topk_idx, pos, rank)
+        self._last = dict(topk_idx=topk_idx, pos=pos, rank=rank, sampled=sampled)
+        if cfg.filter_ids:
+            sampled = filter_ids(sampled, self.tokenizer)
+        sampled = self.shard.broadcast_ids(sampled)
+        return sampled, sampled.shape[0]
+
+    # ------------------------------------------------------------ scoring
+    def _segments(self, order, feats):
+        out = []
+        for name in order:
+            if name == "optim":
+                out.append(("gather", None))
+            elif name == "image":
+                out.append(("shared", feats))
+            else:
+                out.append(("shared", self.seg[name]))
+        return out
+
+    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
+        """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
+        all-gathered to the full vector.  `order` ends in "target"."""
+        cfg, hf = self.config, self.hf
+        n = sampled.shape[0]
+        lo, hi = self.shard.bounds(n)
+        mine = sampled[lo:hi].contiguous()
+        m = mine.shape[0]
+        E = self.embedding_layer.weight
+        feats = None if feats is None else feats.to(E.dtype)
+        rows_only = self.opt.target_rows_only
+        prefix_names, tail_names = split_at_suffix(order)
+        tail_names = [("target_in" if (t == "target" and rows_only) else t) for t in tail_names]
+        use_prefix = self.opt.prefix_reuse and rows_only and prefix_names and hf.prefix_ok is not False and m > 0
+
+        cache, P = None, 0
+        if use_prefix:
+            prefix = torch.cat([feats if p == "image" else self.seg[p] for p in prefix_names], dim=1)
+            P = prefix.shape[1]
+            if P == 0:
+                use_prefix = False
+            else:
+                try:
+                    cache = hf.build_prefix(prefix)
+                except Exception as e:  # a model without cache support: remember, fall back to the full sequence
+                    logger.warning(f"prefix reuse disabled: {type(e).__name__}: {e}")
+                    cache = None
+                if cache is None:
+                    hf.prefix_ok, use_prefix = False, False
+                else:
+                    hf.prefix_ok = True
+        if not use_prefix:
+            seq_names = [("target_in" if (t == "target" and rows_only) else t) for t in order]
+        else:
+            seq_names = tail_names
+        segs = self._segments(seq_names, feats)
+        L = sum((mine.shape[1] if k == "gather" else (t.shape[-2])) for k, t in segs)
+
+        free = torch.cuda.mem_get_info(self.model.device)[0]
+        chunk = plan_chunk(max(m, 1), L, P, hf.kv_bytes_per_token, hf.act_bytes_per_token, free,
+                           cfg.batch_size if cfg.batch_size is not None else self.opt.chunk)
+        if self._chunk_cap is not None:
+            chunk = min(chunk, self._chunk_cap)
+
+        losses = torch.empty(m, dtype=torch.float32, device=self.model.device)
+        stop = False
+        s = 0
+        while s < m:
+            b = min(chunk, m - s)
+            try:
+                x = ops.splice(segs, b, E, mine[s:s + b].contiguous(), hf.emb_scale)
+                kv = hf.expand_prefix(cache, b) if use_prefix else None
+                logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
+                loss, match, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
+                losses[s:s + b] = loss
+                if cfg.early_stop and bool(match.any().item()):
+                    stop = True
+                del x, kv, logits
+                s += b
+            except Exception as e:
+                if not is_oom(e) or chunk == 1:
+                    raise
+                chunk = max(1, chunk // 2)
+                self._chunk_cap = chunk
+                logger.warning(f"Decreasing batch size to: {chunk}")
+                torch.cuda.empty_cache()
+        full, any_stop = self.shard.gather_losses(losses, n, stop, want_flag=cfg.early_stop)
+        if any_stop:
+            self.stop_flag = True
+        if self.opt.loss_in_model_dtype:
+            full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
+        return full
+
+    # ------------------------------------------------------------ buffer init
+    def init_buffer(self, image) -> AttackBuffer:
+        cfg, tok, dev = self.config, self.tokenizer, self.model.device
+        buffer = AttackBuffer(cfg.buffer_size)
+        if isinstance(cfg.optim_str_init, str):
+            first = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+            if cfg.buffer_size > 1:
+                pool = tok(INIT_CHARS, add_special_tokens=False, return_tensors="pt")["input_ids"].squeeze().to(dev)
+                pick = torch.randint(0, pool.shape[0], (cfg.buffer_size - 1, first.shape[1]))   # CPU draw, as :847
+                ids = torch.cat([first, pool[pick.to(dev)]], dim=0)
+            else:
+                ids = first
+        else:
+            if len(cfg.optim_str_init) != cfg.buffer_size:
+                logger.warning(f"Using {len(cfg.optim_str_init)} initializations but buffer size is set to {cfg.buffer_size}")
+            ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+        ids = ids.to(torch.int64).contiguous()
+        n = max(1, cfg.buffer_size)
+        mt = self.hf.model_type
+        with torch.no_grad():
+            if cfg.pgd_attack:
+                feats = self.hf.image_features(image)
+                losses = self.score_candidates(ids[:n], segment_order("gcg_pgd", mt, single=True), feats)
+            else:
+                losses = self.score_candidates(ids[:n], segment_order("gcg", mt, no_joint_eval=True), None)
+        self.init_losses = losses.float().clone()
+        host = losses.float().cpu().tolist()
+        for i in range(n):
+            buffer.add(host[i], ids[[i]])
+        buffer.log_buffer(tok)
+        return buffer
+
+    # ------------------------------------------------------------------- run
+    def _sync(self) -> float:
+        torch.cuda.synchronize(self.model.device)
+        return time.perf_counter()
+
+    def run(self, messages: Union[str, List[dict]], goal: str, target: str,
+            image: Optional[Tensor] = None) -> BimodalAttackResult:
+        from transformers import set_seed
+
+        cfg, tok, mt = self.config, self.tokenizer, self.hf.model_type
+        self.initial_prompt = goal
+        os.makedirs(cfg.images_folder, exist_ok=True)
+        if cfg.seed is not None:
+            set_seed(cfg.seed)
+            torch.use_deterministic_algorithms(True, warn_only=True)
+        if cfg.pgd_after_gcg:
+            # the reference's pgd_after_gcg branch dies on iteration 0 (:661, current_loss is None)
+            raise TypeError("unsupported format string passed to NoneType.__format__")
+        if cfg.pgd_attack and image is None:
+            raise ValueError("pgd_attack=True needs an image")
+
+        self._prepare_prompt(messages, target)
+        buffer = self.init_buffer(image)
+        optim_ids = buffer.get_best_ids()
+
+        losses: List[float] = []
+        strings: List[str] = []
+        suffixes: List[str] = []
+        outputs: List[str] = []
+        t_grad: List[float] = []
+        t_samp: List[float] = []
+        t_loss: List[float] = []
+        t_pgd: List[float] = []
+        t_total: List[float] = []
+        trace = self.opt.trace
+        writer = _PngWriter() if (cfg.pgd_attack and self.opt.save_images and self.shard.rank == 0) else None
+
+        if cfg.pgd_attack:
+            logger.warning(f"Using alpha: {cfg.alpha}, eps: {cfg.eps}")
+            image.requires_grad = True            # the caller's tensor, as the reference (:425)
+            image_original = image.clone()
+
+        try:
+            for i in range(cfg.num_steps):
+                st: Optional[dict] = {} if trace is not None else None
+                if st is not None:
+                    trace.append(st)
+                    st.update(optim_ids_in=optim_ids.cpu().numpy(), n_grad=0, grad_tok=[], grad_img=[], losses=[])
+
+                # ---- phase A: gradients --------------------------------------------------
+                def grad_pass():
+                    t0 = self._sync()
+                    g = self.compute_gradient(optim_ids, image if cfg.pgd_attack else None)
+                    dt = self._sync() - t0
+                    t_grad.append(dt)
+                    if st is not None:
+                        st["n_grad"] += 1
+                        if g[0] is not None:
+                            st["grad_tok"].append(g[0][0].float().cpu().numpy())
+                        if g[1] is not None:
+                            st["grad_img"].append(g[1].cpu().numpy())
+                    return g, dt
+
+                (g_tok, g_img), grad_time = grad_pass()
+
+                # ---- phase B: PGD update; phase C: second gradient pass -------------------
+                pgd_time = 0.0
+                if cfg.pgd_attack:
+                    t0 = self._sync()
+                    image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
+                    if self.shard.enabled:
+                        with torch.no_grad():
+                            self.shard.broadcast_(image)
+                    pgd_time = self._sync() - t0
+                    t_pgd.append(pgd_time)
+                    if st is not None:
+                        st["image_after_pgd"] = image.detach().cpu().numpy()
+                    if cfg.gcg_attack and not cfg.joint_eval:
+                        (g_tok, g_img), grad_time = grad_pass()
+
+                # ---- phase D: sampling ----------------------------------------------------
+                samp_time = 0.0
+                if cfg.gcg_attack:
+                    t0 = self._sync()
+                    sampled, n = self.candidate_sampling(i, optim_ids, g_tok)
+                    samp_time = self._sync() - t0
+                    t_samp.append(samp_time)
+                    if st is not None:
+                        st["sampled"] = self._last["sampled"].cpu().numpy()
+                        st["topk_idx"] = self._last["topk_idx"].cpu().numpy()
+                        if cfg.filter_ids:
+                            st["filtered"] = sampled.cpu().numpy()
+                else:
+                    sampled, n = optim_ids, 1
+
+                # ---- phase D: scoring -----------------------------------------------------
+                t0 = self._sync()
+                with torch.no_grad():
+                    if cfg.pgd_attack:
+                        feats = self.hf.image_features(image)
+                        if cfg.joint_eval:
+                            loss = self.score_candidates(sampled, segment_order("pgd", mt, single=True), feats)
+                        elif cfg.gcg_attack:
+                            loss = self.score_candidates(sampled, segment_order("gcg", mt, single=True), None)
+                        else:
+                            loss = None
+                        best_idx = int(loss.argmin().item()) if loss is not None else 0
+                        if st is not None and loss is not None:
+                            st["losses"].append(loss.float().cpu().numpy())
+                        winner = sampled[best_idx:best_idx + 1].contiguous()
+                        # re-score the winner with the image (:605-612); on every rank, unsharded
+                        keep, self.shard = self.shard, _SOLO
+                        try:
+                            full = self.score_candidates(winner, segment_order("gcg_pgd", mt), feats)
+                        finally:
+                            self.shard = keep
+                        if self.shard.enabled:
+                            self.shard.broadcast_(full)
+                        current_loss = full.item()
+                        if st is not None:
+                            st["losses"].append(full.float().cpu().numpy())
+                    else:
+                        loss = self.score_candidates(sampled, segment_order("gcg", mt, no_joint_eval=True), None)
+                        if st is not None:
+                            st["losses"].append(loss.float().cpu().numpy())
+                        best_idx = int(loss.argmin().item())
+                        current_loss = loss[best_idx].item()
+                        winner = sampled[best_idx:best_idx + 1].contiguous()
+                    optim_ids = winner                      # greedy: accepted even when worse (:613, :638)
+                    losses.append(current_loss)
+                    strings.append(tok.batch_decode(optim_ids)[0])
+                    if buffer.size == 0 or current_loss < buffer.get_highest_loss():
+                        buffer.add(current_loss, optim_ids)
+                    if st is not None:
+                        st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
+                loss_time = self._sync() - t0
+                t_loss.append(loss_time)
+                logger.info(f"[Iteration {i}] Current loss: {current_loss:.4f} | Best loss: {buffer.get_lowest_loss():.4f} | ")
+
+                if writer is not None:
+                    writer.submit(image, os.path.join(cfg.images_folder, f"{i}.png"))
+                if cfg.debug_output and i % 10 == 0:
+                    outputs.append(self._debug_generate(sampled, image if cfg.pgd_attack else None, n))
+                else:
+                    outputs.append("")
+                suffixes.append(tok.batch_decode(optim_ids)[0])
+                buffer.log_buffer(tok)
+                if self.stop_flag:
+                    logger.info("Early stopping due to finding a perfect match.")
+                    break
+                t_total.append(grad_time + samp_time + pgd_time + loss_time)
+        finally:
+            if writer is not None:
+                writer.close()
+
+        self.final_image = image
+        k = losses.index(min(losses))
+        return BimodalAttackResult(
+            best_loss=losses[k], best_string=strings[k], losses=losses, strings=strings,
+            adversarial_suffixes=suffixes, model_outputs=outputs, gradient_times=t_grad, sampling_times=t_samp,
+            loss_times=t_loss, pgd_times=t_pgd, total_times=t_total)
+
+    # ------------------------------------------------------------ debug output
+    def _debug_generate(self, sampled: Tensor, image: Optional[Tensor], n: int) -> str:
+        """debug_output (:745-777): greedy generation from the first candidate's prompt."""
+        mt, E = self.hf.model_type, self.embedding_layer.weight
+        with torch.no_grad():
+            if image is not None:
+                feats = self.hf.image_features(image).to(E.dtype)
+                order = segment_order("gcg_pgd", mt, no_target=True)
+            else:
+                feats, order = None, segment_order("gcg", mt, no_target=True)
+            x = ops.splice(self._segments(order, feats), n, E, sampled.contiguous(), self.hf.emb_scale)
+            out = self.model.generate(inputs_embeds=x, max_new_tokens=120)
+        text = self.tokenizer.decode(out[0], skip_special_tokens=True)
+        logger.info(f"Output generated: {text}")
+        return text
+
+
+class _Solo:
+    """A sharder that does nothing: used while every rank re-scores the winner."""
+    enabled, world, rank = False, 1, 0
+
+    @staticmethod
+    def bounds(n, rank=None):
+        return 0, n
+
+    @staticmethod
+    def gather_losses(local, n, flag=False, want_flag=False):
+        return local, bool(flag)
+
+
+_SOLO = _Solo()
+
+
+def run(model, tokenizer, processor, messages: Union[str, List[dict]], goal: str, target: str,
+        image: Optional[Tensor] = None, config: Optional[BimodalAttackConfig] = None, normalize=None,
+        **engine_options) -> BimodalAttackResult:
+    """Drop-in for the reference's ``bimodalattack.run`` (:1323-1338).  Extra keyword
+    arguments are engine options (``EngineOptions``), never config fields."""
+    if config is None:
+        config = BimodalAttackConfig()
+    logger.setLevel(getattr(logging, config.verbosity))
+    attack = BimodalAttack(model, tokenizer, processor, config, normalize, EngineOptions.from_env(**engine_options))
+    return attack.run(messages, goal, target, image)

@@ -1,0 +1,83 @@
+"""Candidate sharding across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Weights
+are replicated; the candidates of a step are independent given (sampled_ids,
+image features), so rank r scores the contiguous slice [r*per, (r+1)*per) and the
+only data-path exchange is one all-gather of `per` fp32 losses per rank (<= 2 KiB
+in total at search_width 512) -- latency-bound, so a single one-shot collective,
+never a ring of point-to-point hops.  N varies per step (filter, dynamic width):
+slices are padded to `per` slots with +inf, which can never win the argmin.
+
+Rank 0's sampled ids, PGD image and winner loss are broadcast so that ranks cannot
+drift apart through last-bit differences in redundantly computed gradients.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class CandidateSharder:
+    def __init__(self, group=None):
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.group = group
+        if self.enabled:
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        self.enabled = self.enabled and self.world > 1
+
+    # -- partition ---------------------------------------------------------
+    def per_rank(self, n: int) -> int:
+        return -(-n // self.world)
+
+    def bounds(self, n: int, rank: Optional[int] = None) -> Tuple[int, int]:
+        r = self.rank if rank is None else rank
+        per = self.per_rank(n)
+        lo = min(n, r * per)
+        return lo, min(n, lo + per)
+
+    # -- exchange ----------------------------------------------------------
+    def gather_losses(self, local: torch.Tensor, n: int, flag: bool = False,
+                      want_flag: bool = False) -> Tuple[torch.Tensor, bool]:
+        """local: fp32 losses of this rank's slice (length hi-lo).  Returns the n losses
+        in candidate order on every rank, and the OR of `flag` over ranks."""
+        if not self.enabled:
+            return local, bool(flag)
+        per = self.per_rank(n)
+        send = torch.full((per + 1,), float("inf"), dtype=torch.float32, device=local.device)
+        send[: local.numel()] = local.to(torch.float32)
+        send[per] = 1.0 if flag else 0.0
+        recv = torch.empty((self.world, per + 1), dtype=torch.float32, device=local.device)
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+        else:
+            parts = [torch.empty_like(send) for _ in range(self.world)]
+            dist.all_gather(parts, send, group=self.group)
+            recv = torch.stack(parts)
+        # the flag is only read (one host sync) when the caller asked for early stopping
+        any_flag = bool((recv[:, per] > 0).any().item()) if want_flag else False
+        return recv[:, :per].reshape(-1)[:n].contiguous(), any_flag
+
+    def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        if self.enabled:
+            dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src,
+                           group=self.group)
+        return t
+
+    def broadcast_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        """Rank 0's (N, n_opt) candidate ids to everyone; N itself may differ per rank
+        only if ranks have drifted, so it is sent first."""
+        if not self.enabled:
+            return ids
+        shape = torch.tensor(list(ids.shape), dtype=torch.int64, device=ids.device)
+        self.broadcast_(shape)
+        n, w = (int(v) for v in shape.tolist())
+        if tuple(ids.shape) != (n, w):
+            ids = torch.empty((n, w), dtype=torch.int64, device=ids.device)
+        return self.broadcast_(ids.contiguous())

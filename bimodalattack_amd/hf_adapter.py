@@ -1,0 +1,113 @@
+"""The HuggingFace plugin points the engine calls, and the two
+mathematically-identical restructurings of the candidate forward:
+
+* logits on the T target rows only (``logits_to_keep``) with the last input token
+  dropped -- the reference materialises (B,S,V) logits and reads T rows of them
+  (bimodal_attack.py:1287-1290);
+* the keys/values of everything in front of the suffix computed ONCE per step and
+  shared by all candidates -- under causal attention those positions cannot see the
+  suffix, so their keys/values are the same in every candidate.
+
+No kernel is launched from here and nothing depends on the device, so this file is
+exercised by CPU tests as well.
+"""
+
+from __future__ import annotations
+
+import copy
+import inspect
+from typing import Optional
+
+import torch
+
+
+def features_tensor(out) -> torch.Tensor:
+    """``get_image_features`` returned a (1,N,D) tensor in transformers 4.50 (reference
+    pins 4.50.2) and returns an output object in 5.x whose ``pooler_output`` is a
+    tensor (Gemma-3) or a per-image list of (N,D) (LLaVA)."""
+    if torch.is_tensor(out):
+        return out
+    p = getattr(out, "pooler_output", None)
+    if p is None:
+        raise TypeError(f"cannot find image features in {type(out).__name__}")
+    return p if torch.is_tensor(p) else torch.stack(list(p))
+
+
+class HFAdapter:
+    def __init__(self, model, processor, normalize=None):
+        self.model = model
+        self.processor = processor
+        self.normalize = normalize
+        self.embedding = model.get_input_embeddings()
+        self.device = model.device
+        self.dtype = model.dtype
+        self.model_type = getattr(model.config, "model_type", "")
+        self.is_gemma_processor = processor.__class__.__name__ == "Gemma3Processor"
+        params = inspect.signature(model.forward).parameters
+        self.has_logits_to_keep = "logits_to_keep" in params
+        scale = getattr(self.embedding, "embed_scale", None)
+        # Gemma's embedding multiplies by sqrt(D) held in the weight dtype (:1142 via HF)
+        self.emb_scale = 1.0 if scale is None else float(torch.as_tensor(scale).to(self.embedding.weight.dtype).float())
+        tc = getattr(model.config, "text_config", None) or model.config
+        self.n_layers = int(getattr(tc, "num_hidden_layers", 0) or 0)
+        heads = int(getattr(tc, "num_attention_heads", 1) or 1)
+        kv_heads = int(getattr(tc, "num_key_value_heads", None) or heads)
+        hidden = int(getattr(tc, "hidden_size", 0) or 0)
+        head_dim = int(getattr(tc, "head_dim", None) or (hidden // heads if heads else 0))
+        inter = int(getattr(tc, "intermediate_size", None) or getattr(tc, "ffn_dim", None) or 4 * hidden)
+        es = torch.empty((), dtype=self.dtype).element_size()
+        self.kv_bytes_per_token = 2 * self.n_layers * kv_heads * head_dim * es
+        self.act_bytes_per_token = (16 * hidden + 4 * inter) * es
+        self.prefix_ok: Optional[bool] = None   # learnt on first use
+
+    # ------------------------------------------------------------ vision
+    def image_features(self, image: torch.Tensor) -> torch.Tensor:
+        px = self.normalize(image)
+        if self.is_gemma_processor:
+            out = self.model.get_image_features(pixel_values=px)
+        else:
+            out = self.model.get_image_features(pixel_values=px, vision_feature_layer=-2,
+                                                vision_feature_select_strategy="default")
+        return features_tensor(out)
+
+    # ------------------------------------------------------------ language model
+    def target_logits(self, embeds: torch.Tensor, T: int, rows_only: bool = True, cache=None) -> torch.Tensor:
+        """Logits (B,T,V) of the T positions that predict the target tokens.
+
+        ``embeds`` is the whole sequence (B,S,D) -- or, with ``cache``, only the part
+        behind the cached prefix -- INCLUDING the last target token when
+        ``rows_only`` is False (reference call shape) and EXCLUDING it otherwise."""
+        kw = {}
+        if cache is not None:
+            kw["past_key_values"] = cache
+        else:
+            kw["use_cache"] = False
+        if rows_only and self.has_logits_to_keep:
+            return self.model(inputs_embeds=embeds, logits_to_keep=T, **kw).logits
+        if rows_only:
+            return self.model(inputs_embeds=embeds, **kw).logits[:, -T:, :]
+        logits = self.model(inputs_embeds=embeds, **kw).logits
+        return logits[:, -T - 1:-1, :]
+
+    def build_prefix(self, prefix_embeds: torch.Tensor):
+        """Keys/values of the shared prefix (1,P,D) -> an HF cache object, or None when
+        the model does not hand one back."""
+        kw = {"logits_to_keep": 1} if self.has_logits_to_keep else {}
+        out = self.model(inputs_embeds=prefix_embeds, use_cache=True, **kw)
+        return getattr(out, "past_key_values", None)
+
+    @staticmethod
+    def expand_prefix(cache, batch: int):
+        """A per-chunk copy of the prefix cache with batch dimension `batch`.  The
+        model's own cache update appends the candidates' keys/values to it."""
+        c = copy.deepcopy(cache)
+        layers = getattr(c, "layers", None)
+        if layers is not None and all(hasattr(l, "keys") and hasattr(l, "values") for l in layers):
+            for l in layers:
+                if torch.is_tensor(l.keys) and l.keys.shape[0] == 1:
+                    # stride-0 view: the one real copy happens in the cache's own concat
+                    l.keys = l.keys.expand(batch, *l.keys.shape[1:])
+                    l.values = l.values.expand(batch, *l.values.shape[1:])
+            return c
+        c.batch_repeat_interleave(batch)
+        return c

@@ -1,0 +1,82 @@
+"""Tokenizer-side helpers of the attack loop (reference bimodalattack/utils.py).
+
+* ``get_nonascii_toks``  <- utils.py:14-33   forbidden-token list, built once
+* ``filter_ids``         <- bimodal_attack.py:166-186   retokenisation filter
+* ``INIT_CHARS``         <- utils.py:8-12
+* ``plan_chunk``         replaces utils.py:57-115 (OOM-halving retry, restarted from the
+                         full batch on every step) with analytic sizing; the halving
+                         survives only as a safety net that REMEMBERS what it learnt.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import List, Optional
+
+import torch
+
+logger = logging.getLogger("gcg")
+
+INIT_CHARS = [
+    ".", ",", "!", "?", ";", ":", "(", ")", "[", "]", "{", "}",
+    "@", "#", "$", "%", "&", "*",
+    "w", "x", "y", "z",
+]
+
+
+def get_nonascii_toks(tokenizer, device="cpu") -> torch.Tensor:
+    """Token ids that must never be sampled: every id in range(vocab_size) whose decoded
+    text is not printable ASCII, then bos/eos/pad/unk (appended even if already listed).
+    One batched decode instead of vocab_size single calls; same strings, same result."""
+    n = tokenizer.vocab_size
+    texts = tokenizer.batch_decode([[i] for i in range(n)])
+    bad: List[int] = [i for i, s in enumerate(texts) if not (s.isascii() and s.isprintable())]
+    for name in ("bos_token_id", "eos_token_id", "pad_token_id", "unk_token_id"):
+        tid = getattr(tokenizer, name, None)
+        if tid is not None:
+            bad.append(tid)
+    return torch.tensor(bad, device=device)
+
+
+def filter_ids(ids: torch.Tensor, tokenizer) -> torch.Tensor:
+    """Keep the candidates whose decode -> encode round trip reproduces them exactly.
+
+    The reference tokenises one string per call and compares on the device (512 syncs
+    per step, 0.18 s at sw=512: SURVEY.md 8 f1).  Here: one device->host copy, one
+    batched decode, one batched encode, a host-side list comparison, one gather."""
+    rows = ids.tolist()
+    texts = tokenizer.batch_decode(rows)
+    again = tokenizer(texts, add_special_tokens=False, padding=False)["input_ids"]
+    keep = [i for i, (a, b) in enumerate(zip(rows, again)) if a == list(b)]
+    if not keep:
+        raise RuntimeError(
+            "No token sequences are the same after decoding and re-encoding. "
+            "Consider setting filter_ids=False or trying a different optim_str_init"
+        )
+    if len(keep) == len(rows):
+        return ids
+    return ids[torch.tensor(keep, device=ids.device)]
+
+
+def is_oom(exc: BaseException) -> bool:
+    """The messages the reference matches (utils.py:39-54) plus HIP's spelling."""
+    if not (isinstance(exc, RuntimeError) and len(exc.args) == 1 and isinstance(exc.args[0], str)):
+        return isinstance(exc, torch.OutOfMemoryError) if hasattr(torch, "OutOfMemoryError") else False
+    msg = exc.args[0]
+    return any(s in msg for s in ("CUDA out of memory.", "HIP out of memory.", "out of memory",
+                                  "DefaultCPUAllocator: can't allocate memory"))
+
+
+def plan_chunk(n_candidates: int, new_tokens: int, prefix_tokens: int, kv_bytes_per_token: int,
+               act_bytes_per_token: int, free_bytes: int, user_batch: Optional[int] = None,
+               token_budget: int = 49152) -> int:
+    """Candidates per forward.  ``user_batch`` (config.batch_size) wins when given, as in
+    the reference (:521-523).  Otherwise bound (a) the new tokens in flight and (b) the
+    memory of activations plus the per-candidate copy of the shared-prefix keys/values,
+    using at most half of the free HBM."""
+    if user_batch is not None:
+        return max(1, min(n_candidates, int(user_batch)))
+    per_cand = new_tokens * act_bytes_per_token + (prefix_tokens + new_tokens) * kv_bytes_per_token
+    by_mem = max(1, int(free_bytes * 0.5) // max(per_cand, 1))
+    by_tok = max(1, token_budget // max(new_tokens, 1))
+    return max(1, min(n_candidates, by_mem, by_tok))

@@ -1,0 +1,78 @@
+"""world_size-2 (and 3) sharding of candidate scoring over gloo on CPU: slices are
+contiguous and cover every candidate, ragged N pads with +inf, the gathered vector and
+its argmin are identical on every rank and equal to the unsharded result."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bimodalattack_amd.dist import CandidateSharder
+        sh = CandidateSharder()
+        assert sh.enabled and sh.world == world and sh.rank == rank
+        res = {}
+        for n in (1, 2, 5, 64, 511, 512):
+            truth = torch.arange(n, dtype=torch.float32).mul(0.37).sin() + 3.0     # every rank knows all
+            lo, hi = sh.bounds(n)
+            full, flag = sh.gather_losses(truth[lo:hi].clone(), n, flag=(rank == world - 1 and n == 5),
+                                          want_flag=True)
+            assert full.shape == (n,) and torch.equal(full, truth), (n, rank)
+            assert flag == (n == 5)
+            res[n] = int(full.argmin())
+        # rank 0's ids win the broadcast even when another rank drifted (different N)
+        ids = torch.arange(12, dtype=torch.int64).view(4, 3) if rank == 0 else torch.zeros((6, 3), dtype=torch.int64)
+        got = sh.broadcast_ids(ids)
+        assert got.shape == (4, 3) and torch.equal(got, torch.arange(12).view(4, 3))
+        img = torch.full((1, 3, 4, 4), float(rank))
+        sh.broadcast_(img)
+        assert float(img.sum()) == 0.0
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_scoring_gloo(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    first = results[0][1]
+    assert all(r[1] == first for r in results)                                     # same argmin everywhere
+    for n, idx in first.items():
+        assert idx == int((torch.arange(n, dtype=torch.float32).mul(0.37).sin() + 3.0).argmin())
+
+
+def test_bounds_cover_everything():
+    from bimodalattack_amd.dist import CandidateSharder
+    sh = CandidateSharder()
+    assert (sh.world, sh.rank, sh.enabled) == (1, 0, False) and sh.bounds(7) == (0, 7)
+    sh.world = 8
+    for n in (0, 1, 7, 8, 9, 64, 500, 512):
+        spans = [sh.bounds(n, r) for r in range(8)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) <= sh.per_rank(n)
