@@ -491,6 +491,8 @@ class BimodalAttack:
                     if st is not None:
                         st["sampled"] = self._last["sampled"].cpu().numpy()
                         st["topk_idx"] = self._last["topk_idx"].cpu().numpy()
+                        st["pos"] = self._last["pos"].cpu().numpy()
+                        st["rank"] = self._last["rank"].cpu().numpy()
                         if cfg.filter_ids:
                             st["filtered"] = sampled.cpu().numpy()
                 else:
