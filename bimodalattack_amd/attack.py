@@ -422,6 +422,7 @@ class BimodalAttack:
         if cfg.pgd_attack and image is None:
             raise ValueError("pgd_attack=True needs an image")
 
+        self.n_scored: List[int] = []          # candidates scored at each step
         self._prepare_prompt(messages, target)
         buffer = self.init_buffer(image)
         optim_ids = buffer.get_best_ids()
@@ -444,7 +445,12 @@ class BimodalAttack:
             image_original = image.clone()
 
         try:
+            hook = self.opt.step_hook
+            n_done = 0
             for i in range(cfg.num_steps):
+                if hook is not None:
+                    hook(i)
+                n_done = i + 1
                 st: Optional[dict] = {} if trace is not None else None
                 if st is not None:
                     trace.append(st)
@@ -536,6 +542,7 @@ class BimodalAttack:
                     strings.append(tok.batch_decode(optim_ids)[0])
                     if buffer.size == 0 or current_loss < buffer.get_highest_loss():
                         buffer.add(current_loss, optim_ids)
+                    self.n_scored.append(n)
                     if st is not None:
                         st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
                 loss_time = self._sync() - t0
@@ -554,6 +561,8 @@ class BimodalAttack:
                     logger.info("Early stopping due to finding a perfect match.")
                     break
                 t_total.append(grad_time + samp_time + pgd_time + loss_time)
+            if hook is not None:
+                hook(n_done)
         finally:
             if writer is not None:
                 writer.close()

@@ -97,6 +97,9 @@ class EngineOptions:
     # torch.distributed process group used to shard candidate scoring; None =
     # the default group when initialised, else single process.
     group: object = None
+    # Called as step_hook(i) at the start of step i and once more, with i = the number
+    # of steps run, after the last one (bench.py brackets its timed region with it).
+    step_hook: object = None
     # Round per-candidate losses to the model dtype before the argmin, as the
     # reference's model-dtype cross-entropy does ("quirks").
     loss_in_model_dtype: bool = True

@@ -18,6 +18,7 @@
 // argmax==label i32 | [2BT,3BT) row logsumexp f32 (consumed by the dlogits pass).
 
 #include "bma_common.h"
+#include "bma_profile.h"
 
 namespace {
 
@@ -232,21 +233,25 @@ int launch(const void* logits, int64_t ld_cand, int64_t ld_row, const int64_t* l
   const bool am = match != nullptr;
 #define BMA_CE_GO(VEC_, AM_) \
   hipLaunchKernelGGL((ce_rows_kernel<DT, VEC_, AM_>), grid, block, 0, st, logits, ld_cand, ld_row, labels, T, V, ws, BT)
+  BMA_PROF_BEGIN(BMA_K_CE_ROWS, st, static_cast<double>(BT) * V * ES);
   if (vec) { if (am) BMA_CE_GO(true, true); else BMA_CE_GO(true, false); }
   else     { if (am) BMA_CE_GO(false, true); else BMA_CE_GO(false, false); }
 #undef BMA_CE_GO
+  BMA_PROF_END(BMA_K_CE_ROWS, st);
   BMA_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_fold_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, T, BT, loss, match);
   BMA_LAUNCH_CHECK();
   if (dlogits) {
     const bool ovec = vec && (reinterpret_cast<uintptr_t>(dlogits) % 16 == 0);
     const float scale = grad_scale / static_cast<float>(T);
+    BMA_PROF_BEGIN(BMA_K_CE_DLOGITS, st, 2.0 * static_cast<double>(BT) * V * ES);
     if (ovec)
       hipLaunchKernelGGL((ce_dlogits_kernel<DT, true>), grid, block, 0, st, logits, ld_cand, ld_row, labels, T, V,
                          ws, BT, dlogits, scale);
     else
       hipLaunchKernelGGL((ce_dlogits_kernel<DT, false>), grid, block, 0, st, logits, ld_cand, ld_row, labels, T, V,
                          ws, BT, dlogits, scale);
+    BMA_PROF_END(BMA_K_CE_DLOGITS, st);
     BMA_LAUNCH_CHECK();
   }
   return BMA_OK;

@@ -14,6 +14,7 @@
 // as torch.clamp propagates them.
 
 #include "bma_common.h"
+#include "bma_profile.h"
 
 namespace {
 
@@ -68,10 +69,12 @@ extern "C" int bma_linf_step(const float* x, const float* g, const float* x0, in
     const int64_t n4 = n / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    BMA_PROF_BEGIN(BMA_K_LINF, st, 16.0 * static_cast<double>(n4) * 4.0);
     hipLaunchKernelGGL(linf_step_vec4, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
                        reinterpret_cast<const bma::float4_t*>(x), reinterpret_cast<const bma::float4_t*>(g),
                        reinterpret_cast<const bma::float4_t*>(x0), reinterpret_cast<bma::float4_t*>(out), n4,
                        eps, step);
+    BMA_PROF_END(BMA_K_LINF, st);
     BMA_LAUNCH_CHECK();
     done = n4 * 4;
   }

@@ -19,6 +19,7 @@
 // reads it afterwards.
 
 #include "bma_common.h"
+#include "bma_profile.h"
 
 namespace {
 
@@ -183,12 +184,14 @@ int launch(const void* grad, int64_t ld_row, int rows, int V, const uint32_t* ma
   while (npow2 < k) npow2 <<= 1;
   const bool vec = (reinterpret_cast<uintptr_t>(grad) % 16 == 0) && ((ld_row * ES) % 16 == 0) &&
                    ((static_cast<int64_t>(V) * ES) % 16 == 0);
+  BMA_PROF_BEGIN(BMA_K_TOPK, st, static_cast<double>(rows) * V * ES + static_cast<double>(rows) * k * 8.0);
   if (vec)
     hipLaunchKernelGGL((mask_topk_kernel<DT, true>), dim3(rows), dim3(kTPB), 0, st, grad, ld_row, V, mask, k, npow2,
                        idx_out);
   else
     hipLaunchKernelGGL((mask_topk_kernel<DT, false>), dim3(rows), dim3(kTPB), 0, st, grad, ld_row, V, mask, k,
                        npow2, idx_out);
+  BMA_PROF_END(BMA_K_TOPK, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }

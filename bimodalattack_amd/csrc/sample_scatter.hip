@@ -9,6 +9,7 @@
 // is what a stable argsort yields.
 
 #include "bma_common.h"
+#include "bma_profile.h"
 
 namespace {
 
@@ -78,8 +79,10 @@ extern "C" int bma_sample_scatter(const int64_t* ids, const int64_t* topk_idx, c
   if (B == 0) return BMA_OK;
   if (!ids || !topk_idx || !pos || !rank || !out) return BMA_EINVAL;
   const int64_t n = static_cast<int64_t>(B) * n_opt;
+  BMA_PROF_BEGIN(BMA_K_SCATTER, static_cast<hipStream_t>(stream), 8.0 * n + 16.0 * B * n_rep);
   hipLaunchKernelGGL(sample_scatter_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), ids, topk_idx, pos, rank, B, n_opt, n_rep, k, out);
+  BMA_PROF_END(BMA_K_SCATTER, static_cast<hipStream_t>(stream));
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }

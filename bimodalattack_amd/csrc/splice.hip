@@ -15,6 +15,7 @@
 // (thousands), so every CU streams.
 
 #include "bma_common.h"
+#include "bma_profile.h"
 
 namespace {
 
@@ -135,6 +136,17 @@ extern "C" int bma_splice(const bma_segment* segs_host, int n_segs, const void* 
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(S), gy), block(256);
   uint4_t* o = static_cast<uint4_t*>(out);
+  {
+    double gathered = 0.0, shared = 0.0, percand = 0.0;
+    for (int i = 0; i < n_segs; ++i) {
+      const double rows = static_cast<double>(segs_host[i].len);
+      if (segs_host[i].kind == BMA_SEG_GATHER) gathered += rows * B;
+      else if (segs_host[i].kind == BMA_SEG_PERCAND) percand += rows * B;
+      else shared += rows;
+    }
+    // written once + every source row read once
+    BMA_PROF_BEGIN(BMA_K_SPLICE, st, (static_cast<double>(B) * S + gathered + percand + shared) * D * es);
+  }
   switch (dtype) {
     case BMA_F32:
       hipLaunchKernelGGL((splice_kernel<BMA_F32>), grid, block, 0, st, a, emb, V, ids, B, n_opt, S, cpr, cb,
@@ -149,6 +161,7 @@ extern "C" int bma_splice(const bma_segment* segs_host, int n_segs, const void* 
                          emb_scale, o);
       break;
   }
+  BMA_PROF_END(BMA_K_SPLICE, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }

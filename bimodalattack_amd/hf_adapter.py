@@ -83,11 +83,24 @@ class HFAdapter:
         else:
             kw["use_cache"] = False
         if rows_only and self.has_logits_to_keep:
-            return self.model(inputs_embeds=embeds, logits_to_keep=T, **kw).logits
+            # An index TENSOR, not the int: HF then gathers the T rows into a contiguous
+            # (B,T,D) block and the lm_head runs as ONE (B*T, D) x (D, V) GEMM.  With the int
+            # it slices a strided view and the head degenerates into B small batched GEMMs
+            # (16 ms instead of ~3 ms per step at B=512 on MI355X).
+            L = embeds.shape[1]
+            keep = self._keep_index(L, T, embeds.device)
+            return self.model(inputs_embeds=embeds, logits_to_keep=keep, **kw).logits
         if rows_only:
             return self.model(inputs_embeds=embeds, **kw).logits[:, -T:, :]
         logits = self.model(inputs_embeds=embeds, **kw).logits
         return logits[:, -T - 1:-1, :]
+
+    def _keep_index(self, L: int, T: int, device) -> torch.Tensor:
+        key = (L, T, str(device))
+        cached = getattr(self, "_keep_cache", None)
+        if cached is None or cached[0] != key:
+            self._keep_cache = (key, torch.arange(L - T, L, device=device))
+        return self._keep_cache[1]
 
     def build_prefix(self, prefix_embeds: torch.Tensor):
         """Keys/values of the shared prefix (1,P,D) -> an HF cache object, or None when

@@ -52,7 +52,26 @@ PROTOTYPES = {
                                    c_void_p, c_void_p]),
     "bma_splice": (c_int, [POINTER(BmaSegment), c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                            c_float, c_void_p, c_void_p]),
+    "bma_profile_enable": (c_int, [c_int]),
+    "bma_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "bma_profile_kernel_name": (c_char_p, [c_int]),
 }
+
+KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5}
+
+
+def profile_enable(on: bool) -> None:
+    check("bma_profile_enable", lib.bma_profile_enable(1 if on else 0))
+
+
+def profile_read() -> dict:
+    """{kernel: dict(symbol, launches, ms, bytes)} for every kernel launched since profile_enable(True)."""
+    out = {}
+    for name, k in KERNEL_IDS.items():
+        n, ms, by = c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check("bma_profile_read", lib.bma_profile_read(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+        out[name] = dict(symbol=lib.bma_profile_kernel_name(k).decode(), launches=n.value, ms=ms.value, bytes=by.value)
+    return out
 
 
 def _load() -> ctypes.CDLL:

@@ -136,6 +136,22 @@ int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
                const int64_t* ids, int B, int n_opt, int D, int dtype,
                float emb_scale, void* out, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Measurement aid (bench.py).  When enabled, the dominant kernel of
+ * each entry point is bracketed by HIP events on the launch stream and the launch's
+ * ALGORITHMIC bytes (the figures DESIGN.md states per unit) are tallied.  Disabled
+ * by default -- nothing is recorded and calls stay graph-capturable.
+ * bma_profile_enable(on) resets all tallies; bma_profile_read() waits for the
+ * recorded events and returns launches, summed device milliseconds, summed bytes.
+ * ------------------------------------------------------------------------- */
+enum {
+  BMA_K_LINF = 0, BMA_K_CE_ROWS = 1, BMA_K_CE_DLOGITS = 2, BMA_K_TOPK = 3,
+  BMA_K_SCATTER = 4, BMA_K_SPLICE = 5, BMA_K_COUNT = 6
+};
+int bma_profile_enable(int on);
+int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);
+const char* bma_profile_kernel_name(int kernel);
+
 #ifdef __cplusplus
 }
 #endif

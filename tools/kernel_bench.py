@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Standalone driver for the hand-written kernels at BASELINE shapes.
+
+    python tools/kernel_bench.py [--iters 20] [--only ce_rows,splice] [--json out.json]
+
+Launches ONLY the libbma_hip kernels (no model), so it can run under
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) to collect HBM
+traffic for the roofline, and it times each kernel with the in-library HIP events.
+Shapes: LLaVA-1.5-7B V=32064 D=4096 T=20 n_opt=19 sw=512; Gemma-3-4b
+V=262208 D=2560.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+from bimodalattack_amd import native, ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def cases():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    bf = torch.bfloat16
+
+    def ce(B, T, V):
+        x = (torch.randn((B, T, V), generator=g, device=DEV) * 2).to(bf)
+        lab = torch.randint(0, V, (T,), generator=g, device=DEV)
+        return lambda: ops.ce_target(x, lab)
+
+    def ce_grad(T, V):
+        x = (torch.randn((1, T, V), generator=g, device=DEV) * 2).to(bf)
+        lab = torch.randint(0, V, (T,), generator=g, device=DEV)
+        return lambda: ops.ce_target(x, lab, want_dlogits=True)
+
+    def splice(B, lens, D, V=32064, n_opt=19):
+        table = torch.randn((V, D), generator=g, device=DEV).to(bf)
+        ids = torch.randint(0, V, (B, n_opt), generator=g, device=DEV)
+        segs = []
+        for L in lens:
+            segs.append(("gather", None) if L == "g" else ("shared", torch.randn((1, L, D), generator=g, device=DEV).to(bf)))
+        out = torch.empty((B, sum(n_opt if L == "g" else L for L in lens), D), dtype=bf, device=DEV)
+        return lambda: ops.splice(segs, B, table, ids, 1.0, out=out)
+
+    def topk(rows, V, k=256, dtype=bf):
+        gr = (torch.randn((rows, V), generator=g, device=DEV) * 0.01).to(dtype)
+        mask = ops.build_mask_bits(torch.arange(0, 5), V, DEV)
+        return lambda: ops.mask_topk(gr, mask, k)
+
+    def linf(n):
+        x0 = torch.rand(n, generator=g, device=DEV)
+        x = x0.clone()
+        gr = torch.randn(n, generator=g, device=DEV)
+        return lambda: ops.linf_step(x, gr, x0, 64 / 255, 4 / 255, out=x)
+
+    def scatter(B, n_opt=19, k=256):
+        ids = torch.randint(0, 32000, (n_opt,), generator=g, device=DEV)
+        tk = torch.randint(0, 32000, (n_opt, k), generator=g, device=DEV)
+        rnd = torch.rand((B, n_opt), generator=g, device=DEV)
+        rank = torch.randint(0, k, (B, 1), generator=g, device=DEV)
+
+        def go():
+            pos = ops.rand_positions(rnd, 1)
+            return ops.sample_scatter(ids, tk, pos, rank)
+        return go
+
+    return {
+        # name: (kernel id in the profiler, thunk factory)
+        "ce_rows/llava_B512_T20_V32064": ("ce_rows", lambda: ce(512, 20, 32064)),
+        "ce_rows/llava_B64_T20_V32064": ("ce_rows", lambda: ce(64, 20, 32064)),
+        "ce_rows/gemma_B64_T20_V262208": ("ce_rows", lambda: ce(64, 20, 262208)),
+        "ce_dlogits/llava_T20_V32064": ("ce_dlogits", lambda: ce_grad(20, 32064)),
+        "splice/c3_tail_B512_S44_D4096": ("splice", lambda: splice(512, ["g", 6, 19], 4096)),
+        "splice/c3_full_B512_S65_D4096": ("splice", lambda: splice(512, [21, "g", 6, 19], 4096)),
+        "splice/c4_full_B64_S643_D4096": ("splice", lambda: splice(64, [5, 576, 18, "g", 6, 19], 4096)),
+        "splice/c4_full_B512_S643_D4096": ("splice", lambda: splice(512, [5, 576, 18, "g", 6, 19], 4096)),
+        "mask_topk/llava_19x32064_bf16": ("mask_topk", lambda: topk(19, 32064)),
+        "mask_topk/gemma_19x262208_bf16": ("mask_topk", lambda: topk(19, 262208)),
+        "mask_topk/llava_19x32064_f32": ("mask_topk", lambda: topk(19, 32064, dtype=torch.float32)),
+        "linf/llava_3x336x336": ("linf", lambda: linf(3 * 336 * 336)),
+        "linf/gemma_3x896x896": ("linf", lambda: linf(3 * 896 * 896)),
+        "sample_scatter/B512": ("sample_scatter", lambda: scatter(512)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+    native.check_single_hip_runtime()
+    want = [w for w in args.only.split(",") if w]
+    results = {}
+    for name, (kid, make) in cases().items():
+        if want and not any(w in name for w in want):
+            continue
+        fn = make()
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        native.profile_enable(True)
+        for _ in range(args.iters):
+            fn()
+        torch.cuda.synchronize()
+        p = native.profile_read()[kid]
+        native.profile_enable(False)
+        us = 1e3 * p["ms"] / max(1, p["launches"])
+        mb = p["bytes"] / max(1, p["launches"]) / 1e6
+        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] else 0.0
+        results[name] = dict(symbol=p["symbol"], launches=p["launches"], avg_us=us, algorithmic_MB=mb,
+                             achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0)
+        print(f"{name:40s} {us:9.1f} us  {mb:9.2f} MB  {gbs:8.0f} GB/s  {100 * gbs / 8000.0:5.1f}% of 8 TB/s", flush=True)
+        del fn
+        torch.cuda.empty_cache()
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, csv) of
+tools/kernel_bench.py into per-kernel HBM bytes per launch.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> out.json
+
+Corrections (MI355X_MICROARCH.md, HBM): counters are in KiB; on gfx950 FETCH_SIZE
+reports exactly half of the bytes of a wide coalesced streaming read, so it is
+doubled; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def fold(path, counter):
+    by = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") != counter:
+                continue
+            m = re.search(r"\b(ce_rows_kernel|ce_dlogits_kernel|ce_fold_kernel|splice_kernel|mask_topk_kernel|"
+                          r"linf_step_vec4|linf_step_scalar|sample_scatter_kernel|rand_positions_kernel)\b(<[^>]*>)?",
+                          r["Kernel_Name"])
+            if not m:
+                continue
+            key = (m.group(1) + (m.group(2) or ""), r.get("Grid_Size", ""))
+            by[key].append(float(r["Counter_Value"]))
+    return by
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = fold(fetch, "FETCH_SIZE"), fold(write, "WRITE_SIZE")
+    res = {}
+    for key in sorted(set(f) | set(w)):
+        kern, grid = key
+        fv, wv = f.get(key, []), w.get(key, [])
+        fetch_b = 2.0 * 1024.0 * (sum(fv) / len(fv)) if fv else None
+        write_b = 1024.0 * (sum(wv) / len(wv)) if wv else None
+        res[f"{kern}/threads{grid}"] = dict(launches=max(len(fv), len(wv)), fetch_bytes_per_launch_corrected=fetch_b,
+                                         write_bytes_per_launch=write_b,
+                                         hbm_bytes_per_launch=(fetch_b or 0) + (write_b or 0))
+    json.dump(dict(corrections="FETCH_SIZE KiB x2 (gfx950 half-count), WRITE_SIZE KiB x1", kernels=res), open(out, "w"), indent=1)
+    for k, v in res.items():
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
