@@ -100,6 +100,7 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
   switch (kernel) {
     case BMA_K_LINF: return "linf_step_vec4";
     case BMA_K_CE_ROWS: return "ce_rows_kernel";
+    case BMA_K_CE_ROWS_B1: return "ce_rows_kernel";
     case BMA_K_CE_DLOGITS: return "ce_dlogits_kernel";
     case BMA_K_TOPK: return "mask_topk_kernel";
     case BMA_K_SCATTER: return "sample_scatter_kernel";

@@ -233,11 +233,12 @@ int launch(const void* logits, int64_t ld_cand, int64_t ld_row, const int64_t* l
   const bool am = match != nullptr;
 #define BMA_CE_GO(VEC_, AM_) \
   hipLaunchKernelGGL((ce_rows_kernel<DT, VEC_, AM_>), grid, block, 0, st, logits, ld_cand, ld_row, labels, T, V, ws, BT)
-  BMA_PROF_BEGIN(BMA_K_CE_ROWS, st, static_cast<double>(BT) * V * ES);
+  const int prof_slot = B > 1 ? BMA_K_CE_ROWS : BMA_K_CE_ROWS_B1;
+  BMA_PROF_BEGIN(prof_slot, st, static_cast<double>(BT) * V * ES);
   if (vec) { if (am) BMA_CE_GO(true, true); else BMA_CE_GO(true, false); }
   else     { if (am) BMA_CE_GO(false, true); else BMA_CE_GO(false, false); }
 #undef BMA_CE_GO
-  BMA_PROF_END(BMA_K_CE_ROWS, st);
+  BMA_PROF_END(prof_slot, st);
   BMA_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_fold_kernel, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, T, BT, loss, match);
   BMA_LAUNCH_CHECK();

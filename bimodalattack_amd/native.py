@@ -57,7 +57,8 @@ PROTOTYPES = {
     "bma_profile_kernel_name": (c_char_p, [c_int]),
 }
 
-KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5}
+KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5,
+              "ce_rows_grad": 6}
 
 
 def profile_enable(on: bool) -> None:

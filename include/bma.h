@@ -145,8 +145,9 @@ int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
  * recorded events and returns launches, summed device milliseconds, summed bytes.
  * ------------------------------------------------------------------------- */
 enum {
-  BMA_K_LINF = 0, BMA_K_CE_ROWS = 1, BMA_K_CE_DLOGITS = 2, BMA_K_TOPK = 3,
-  BMA_K_SCATTER = 4, BMA_K_SPLICE = 5, BMA_K_COUNT = 6
+  BMA_K_LINF = 0, BMA_K_CE_ROWS = 1 /* B > 1: candidate scoring */, BMA_K_CE_DLOGITS = 2,
+  BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
+  BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_COUNT = 7
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);
