@@ -174,11 +174,17 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if os.environ.get("BMA_DIST_BACKEND", "nccl") != "nccl":
+        local = 0                                               # rehearsal: every rank on the one GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("BMA_DIST_BACKEND", "nccl")     # "gloo" only to rehearse ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from bimodalattack_amd import BimodalAttackConfig, native
     from bimodalattack_amd.attack import BimodalAttack, logger as gcg_logger

@@ -187,3 +187,46 @@ def test_early_stop_and_errors():
     res = run(model, tok, proc, "tell me", "tell me", "Sure here", None,
               BimodalAttackConfig(num_steps=3, search_width=8, topk=8, early_stop=True, **base), rng_device="cpu")
     assert 1 <= len(res.losses) <= 3
+
+
+# ------------------------------------------------------------------ sharded engine, 2 ranks on one GPU
+def _sharded_worker(rank, world, port, name, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves the GPU tensors through the host
+    try:
+        torch.cuda.set_device(0)
+        m, res, trace, tmp = run_case(name)
+        out.put((rank, res.losses, res.strings, [st["n_scored"] for st in trace],
+                 [st["losses"][0].tolist() for st in trace if st["losses"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["llava_joint", "llava_joint_dyn", "opt_gcg"])
+def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
+    """Candidate scoring sharded over 2 ranks (rehearsed with gloo, both ranks on cuda:0 --
+    the driver's 8-GPU run uses RCCL): every rank returns the single-process result."""
+    import socket
+    import torch.multiprocessing as mp
+    m, res1, trace1, _ = run_case(name)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, losses, strings, n_scored, cand_losses in got:
+        assert strings == res1.strings, f"rank {rank}"
+        np.testing.assert_allclose(losses, res1.losses, rtol=1e-5)
+        assert n_scored == [st["n_scored"] for st in trace1]
+        for a, b in zip(cand_losses, [st["losses"][0] for st in trace1 if st["losses"]]):
+            np.testing.assert_allclose(a, b, rtol=1e-5)
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2]          # ranks agree bit for bit
