@@ -305,6 +305,7 @@ def main() -> None:
                              "sampling_incl_filter": samp_s / args.steps, "scoring": loss_s / args.steps},
         "roofline": roofline, "kernels": kernels, "forward_roofline": fwd,
         "final_loss": res.losses[-1],
+        "gradient_pass_ms_each": [round(1e3 * t, 2) for t in res.gradient_times],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -145,7 +145,7 @@ class BimodalAttack:
         self.stop_flag = False
         self.shard = CandidateSharder(self.opt.group)
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
-        self._rng = None
+        self._grad_graph = None                    # None: not tried yet; False: eager for good
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
         if model.dtype in (torch.float32, torch.float64):
@@ -227,8 +227,24 @@ class BimodalAttack:
 
     # ------------------------------------------------------------ gradient pass
     def compute_gradient(self, optim_ids: Tensor, image: Optional[Tensor] = None):
-        """One forward/backward at batch 1 (:953-1028): d(mean target CE)/d(one-hot
-        suffix) and /d(image).  The one-hot is never built: its gradient is
+        """d(mean target CE)/d(one-hot suffix) and /d(image) (:953-1028).  Shapes never
+        change during an attack, so the whole forward+backward is captured into a hipGraph
+        on the first call (after one eager run) and replayed afterwards; results are the
+        eager ones (same kernels, same order)."""
+        if not self.opt.graph_gradient or self._grad_graph is False:
+            return self._gradient_eager(optim_ids, image)
+        if self._grad_graph is None:           # first call of the attack: warm up eagerly, capture, replay
+            try:
+                self._grad_graph = _GradientGraph(self, optim_ids, image)
+            except Exception as e:            # not capturable with this model: stay eager
+                logger.warning(f"gradient pass not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._grad_graph = False
+                torch.cuda.synchronize(self.model.device)
+                return self._gradient_eager(optim_ids, image)
+        return self._grad_graph(optim_ids, image)
+
+    def _gradient_eager(self, optim_ids: Tensor, image: Optional[Tensor] = None):
+        """One forward/backward at batch 1.  The one-hot is never built: its gradient is
         (dL/d suffix embeddings) @ E^T, the same product autograd would form."""
         cfg = self.config
         E = self.embedding_layer.weight
@@ -589,6 +605,34 @@ class BimodalAttack:
         text = self.tokenizer.decode(out[0], skip_special_tokens=True)
         logger.info(f"Output generated: {text}")
         return text
+
+
+class _GradientGraph:
+    """The batch-1 gradient pass as one hipGraph.  Inputs live in static buffers that are
+    overwritten before each replay; outputs are static too and stay valid until the next
+    replay (the loop consumes them at once)."""
+
+    def __init__(self, attack: "BimodalAttack", optim_ids: Tensor, image: Optional[Tensor]):
+        dev = attack.model.device
+        self.ids = optim_ids.detach().clone()
+        self.image = None if image is None else image.detach().clone().requires_grad_()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # lazy initialisations must not land in the capture
+            attack._gradient_eager(self.ids, self.image)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = attack._gradient_eager(self.ids, self.image)
+
+    def __call__(self, optim_ids: Tensor, image: Optional[Tensor]):
+        with torch.no_grad():
+            self.ids.copy_(optim_ids)
+            if self.image is not None:
+                self.image.copy_(image)
+        self.graph.replay()
+        return self.out
 
 
 class _Solo:

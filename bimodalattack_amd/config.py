@@ -88,6 +88,11 @@ class EngineOptions:
     prefix_reuse: bool = True
     # Ask the model for logits on the target rows only (`logits_to_keep`).
     target_rows_only: bool = True
+    # Capture the fixed-shape batch-1 gradient pass (forward + backward) into a hipGraph
+    # on its first call (after one eager run) and replay it every step: the pass is launch-bound
+    # (~1500 small kernels around 7 ms of weight streaming).  Falls back to eager, once and
+    # for good, if the model's forward cannot be captured.
+    graph_gradient: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
     # Write images_folder/{i}.png every step (reference side effect, :744).
@@ -114,6 +119,8 @@ class EngineOptions:
             opts.prefix_reuse = env["BMA_PREFIX_REUSE"] not in ("0", "false", "False")
         if "BMA_TARGET_ROWS_ONLY" in env:
             opts.target_rows_only = env["BMA_TARGET_ROWS_ONLY"] not in ("0", "false", "False")
+        if "BMA_GRAPH_GRADIENT" in env:
+            opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_CHUNK" in env:
             opts.chunk = int(env["BMA_CHUNK"])
         if "BMA_SAVE_IMAGES" in env:
