@@ -42,6 +42,7 @@ from torch import Tensor
 from . import ops
 from .config import BimodalAttackConfig, BimodalAttackResult, EngineOptions
 from .dist import CandidateSharder
+from .fused import FusedInference
 from .hf_adapter import HFAdapter
 from .layout import dynamic_width, segment_order, split_at_suffix
 from .utils import INIT_CHARS, filter_ids, get_nonascii_toks, is_oom, plan_chunk
@@ -146,6 +147,7 @@ class BimodalAttack:
         self.shard = CandidateSharder(self.opt.group)
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
         self._grad_graph = None                    # None: not tried yet; False: eager for good
+        self.fused = FusedInference(model, self.opt.fused_elementwise)
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
         if model.dtype in (torch.float32, torch.float64):
@@ -315,6 +317,10 @@ class BimodalAttack:
     def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
         """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
         all-gathered to the full vector.  `order` ends in "target"."""
+        with self.fused:
+            return self._score_candidates(sampled, order, feats)
+
+    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         lo, hi = self.shard.bounds(n)

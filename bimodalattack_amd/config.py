@@ -93,6 +93,9 @@ class EngineOptions:
     # (~1500 small kernels around 7 ms of weight streaming).  Falls back to eager, once and
     # for good, if the model's forward cannot be captured.
     graph_gradient: bool = True
+    # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
+    # one-pass kernels while scoring candidates (no autograd there); see fused.py.
+    fused_elementwise: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
     # Write images_folder/{i}.png every step (reference side effect, :744).
@@ -121,6 +124,8 @@ class EngineOptions:
             opts.target_rows_only = env["BMA_TARGET_ROWS_ONLY"] not in ("0", "false", "False")
         if "BMA_GRAPH_GRADIENT" in env:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
+        if "BMA_FUSED_ELEMENTWISE" in env:
+            opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
         if "BMA_CHUNK" in env:
             opts.chunk = int(env["BMA_CHUNK"])
         if "BMA_SAVE_IMAGES" in env:

@@ -105,6 +105,9 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_TOPK: return "mask_topk_kernel";
     case BMA_K_SCATTER: return "sample_scatter_kernel";
     case BMA_K_SPLICE: return "splice_kernel";
+    case BMA_K_RMSNORM: return "rmsnorm_kernel";
+    case BMA_K_SWIGLU: return "swiglu_kernel";
+    case BMA_K_ROPE: return "rope_kernel";
     default: return "?";
   }
 }

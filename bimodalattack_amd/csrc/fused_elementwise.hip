@@ -1,0 +1,286 @@
+// a6 (candidate scoring) -- the elementwise tail of a Llama-family decoder layer, fused.
+//
+// The reference scores candidates with `self.model(inputs_embeds=...)` (bimodal_attack.py:1287);
+// inside the HuggingFace model every RMSNorm, rotary embedding and SwiGLU gate is a
+// chain of 5-8 eager elementwise launches that re-read and re-write the whole activation
+// (B*L x D, 184 MB at B=512, L=44, D=4096): ~40 % of the scoring phase on MI355X
+// (profiles/r1_bench_gcg_kernel_stats.csv).  These three kernels do each chain in ONE
+// pass over HBM.  They reproduce the eager chain's ROUNDING POINTS (every intermediate the
+// eager code materialises in the model dtype is rounded to the model dtype here too), so
+// SwiGLU and RoPE are bit-identical to the eager modules and RMSNorm differs only through
+// the summation order of the mean (<= 1 ulp of the model dtype, rarely).
+//
+//   rmsnorm : y = w * dt(x * rsqrt(mean(x^2) + eps))         (Llama; HF LlamaRMSNorm.forward)
+//             y = dt(x * rsqrt(mean(x^2) + eps) * (1 + w))   (Gemma; HF Gemma3RMSNorm.forward)
+//   swiglu  : y = dt(dt(silu(g)) * u)                        (HF LlamaMLP: act_fn(gate_proj(x)) * up_proj(x))
+//   rope    : q <- dt(dt(q*cos) + dt(rotate_half(q)*sin))    (HF apply_rotary_pos_emb), in place
+//
+// All HBM-bound: 2 (rmsnorm, rope) or 3 (swiglu) x rows x D x es algorithmic bytes.
+
+#include "bma_common.h"
+#include "bma_profile.h"
+
+// The eager chains round every intermediate to the model dtype.  With contraction on,
+// LLVM narrows (half)((float)a*(float)b) + ... into half-precision mul+add and then fuses
+// them into an FMA, silently dropping one of those roundings (seen as 1-ulp product
+// differences amplified by cancellation in fp16 RoPE).  No contraction in this file.
+#pragma clang fp contract(off)
+
+namespace {
+
+using bma::uint4_t;
+
+template <int DT>
+__device__ __forceinline__ float rnd(float v) {  // round to the model dtype and back
+  if (DT == BMA_F32) return v;
+  if (DT == BMA_BF16) return bma::bf16_bits_to_f32(bma::f32_to_bf16_bits(v));
+  return bma::f16_bits_to_f32(bma::f32_to_f16_bits(v));
+}
+
+template <int DT>
+struct Chunk {  // one 16-byte chunk = NE elements
+  static constexpr int NE = 16 / bma::elem_bytes<DT>::value;
+  __device__ static __forceinline__ void unpack(const uint4_t& w, float* f) {
+    if (DT == BMA_F32) {
+      f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y);
+      f[2 % NE] = __uint_as_float(w.z); f[3 % NE] = __uint_as_float(w.w);
+    } else {
+      f[0] = bma::unpack16<DT>(w.x, 0); f[1] = bma::unpack16<DT>(w.x, 1);
+      f[2] = bma::unpack16<DT>(w.y, 0); f[3] = bma::unpack16<DT>(w.y, 1);
+      f[4 % NE] = bma::unpack16<DT>(w.z, 0); f[5 % NE] = bma::unpack16<DT>(w.z, 1);
+      f[6 % NE] = bma::unpack16<DT>(w.w, 0); f[7 % NE] = bma::unpack16<DT>(w.w, 1);
+    }
+  }
+  __device__ static __forceinline__ uint4_t pack(const float* f) {
+    uint4_t w;
+    if (DT == BMA_F32) {
+      w.x = __float_as_uint(f[0]); w.y = __float_as_uint(f[1]);
+      w.z = __float_as_uint(f[2 % NE]); w.w = __float_as_uint(f[3 % NE]);
+    } else {
+      w.x = bma::pack16<DT>(f[0], f[1]); w.y = bma::pack16<DT>(f[2], f[3]);
+      w.z = bma::pack16<DT>(f[4 % NE], f[5 % NE]); w.w = bma::pack16<DT>(f[6 % NE], f[7 % NE]);
+    }
+    return w;
+  }
+};
+
+// ---------------------------------------------------------------------------- rmsnorm
+// One 256-thread workgroup per row; the row (<= 4 chunks per lane) stays in registers
+// between the sum of squares and the scaling, so it is read once and written once.
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxChunks = 4;
+
+template <int DT, int NCH, bool GEMMA>
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4_t* __restrict__ x,
+                                                               const uint4_t* __restrict__ w, float eps, int cpr,
+                                                               int D, uint4_t* __restrict__ y) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint4_t* xr = x + row * cpr;
+  float v[NCH][NE];
+  float ss = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      Chunk<DT>::unpack(xr[i], v[c]);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) ss += v[c][j] * v[c][j];
+    }
+  }
+  ss = bma::wave_sum(ss);
+  __shared__ float part[kNormThreads / 64];
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  float tot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kNormThreads / 64; ++i) tot += part[i];
+  const float rstd = 1.0f / sqrtf(tot / static_cast<float>(D) + eps);
+  uint4_t* yr = y + row * cpr;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float wf[NE], o[NE];
+      Chunk<DT>::unpack(w[i], wf);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (GEMMA) o[j] = v[c][j] * rstd * (1.0f + wf[j]);   // fp32 throughout, one rounding at the end
+        else o[j] = wf[j] * rnd<DT>(v[c][j] * rstd);         // normalised x is rounded before the weight
+      }
+      yr[i] = Chunk<DT>::pack(o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- swiglu
+template <int DT>
+__global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
+                                                     int64_t n_chunks, uint4_t* __restrict__ y) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_chunks; i += stride) {
+    float gf[NE], uf[NE], o[NE];
+    Chunk<DT>::unpack(g[i], gf);
+    Chunk<DT>::unpack(u[i], uf);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const float s = gf[j] / (1.0f + expf(-gf[j]));     // silu in fp32 with the accurate exp, as aten's silu kernel
+      o[j] = rnd<DT>(s) * uf[j];
+    }
+    y[i] = Chunk<DT>::pack(o);
+  }
+}
+
+// ---------------------------------------------------------------------------- rope
+// q is addressed through strides (elements): element (b,h,l,d) at q + b*sb + h*sh + l*sl + d.
+// One lane owns one 16-byte chunk of the FIRST half of a head vector and its partner chunk in
+// the second half, so the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
+template <int DT>
+__global__ __launch_bounds__(256) void rope_kernel(void* __restrict__ q, int64_t sb, int64_t sh, int64_t sl, int B,
+                                                   int H, int L, int Dh, const void* __restrict__ cosp,
+                                                   const void* __restrict__ sinp, int cos_batch) {
+  constexpr int NE = Chunk<DT>::NE;
+  constexpr int ES = bma::elem_bytes<DT>::value;
+  const int half_chunks = Dh / 2 / NE;
+  const int64_t total = static_cast<int64_t>(B) * H * L * half_chunks;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    // order (b, l, h, c): consecutive lanes walk the Dh axis, then heads -- contiguous in a
+    // (B,L,H,Dh) projection output
+    const int c = static_cast<int>(i % half_chunks);
+    int64_t r = i / half_chunks;
+    const int h = static_cast<int>(r % H);
+    r /= H;
+    const int l = static_cast<int>(r % L);
+    const int b = static_cast<int>(r / L);
+    char* base = static_cast<char*>(q) + (static_cast<int64_t>(b) * sb + static_cast<int64_t>(h) * sh +
+                                          static_cast<int64_t>(l) * sl) * ES;
+    uint4_t* lo = reinterpret_cast<uint4_t*>(base) + c;
+    uint4_t* hi = reinterpret_cast<uint4_t*>(base + static_cast<int64_t>(Dh / 2) * ES) + c;
+    const int64_t cs = (static_cast<int64_t>(cos_batch > 1 ? b : 0) * L + l) * Dh;
+    const uint4_t* c_lo = reinterpret_cast<const uint4_t*>(static_cast<const char*>(cosp) + cs * ES) + c;
+    const uint4_t* c_hi = reinterpret_cast<const uint4_t*>(static_cast<const char*>(cosp) + (cs + Dh / 2) * ES) + c;
+    const uint4_t* s_lo = reinterpret_cast<const uint4_t*>(static_cast<const char*>(sinp) + cs * ES) + c;
+    const uint4_t* s_hi = reinterpret_cast<const uint4_t*>(static_cast<const char*>(sinp) + (cs + Dh / 2) * ES) + c;
+    float x1[NE], x2[NE], cl[NE], ch[NE], sl_[NE], sh_[NE], o1[NE], o2[NE];
+    Chunk<DT>::unpack(*lo, x1);
+    Chunk<DT>::unpack(*hi, x2);
+    Chunk<DT>::unpack(*c_lo, cl);
+    Chunk<DT>::unpack(*c_hi, ch);
+    Chunk<DT>::unpack(*s_lo, sl_);
+    Chunk<DT>::unpack(*s_hi, sh_);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      // rotate_half(x) = cat(-x2, x1)
+      o1[j] = rnd<DT>(rnd<DT>(x1[j] * cl[j]) + rnd<DT>(-x2[j] * sl_[j]));
+      o2[j] = rnd<DT>(rnd<DT>(x2[j] * ch[j]) + rnd<DT>(x1[j] * sh_[j]));
+    }
+    *lo = Chunk<DT>::pack(o1);
+    *hi = Chunk<DT>::pack(o2);
+  }
+}
+
+template <int DT>
+int launch_rmsnorm(const void* x, const void* w, float eps, int64_t rows, int D, int gemma, void* y, hipStream_t st) {
+  constexpr int ES = bma::elem_bytes<DT>::value;
+  const int cpr = static_cast<int>(static_cast<int64_t>(D) * ES / 16);
+  const int nch = (cpr + kNormThreads - 1) / kNormThreads;
+  if (nch > kNormMaxChunks) return BMA_ELIMIT;
+  const dim3 grid(static_cast<unsigned>(rows)), block(kNormThreads);
+  const uint4_t* xp = static_cast<const uint4_t*>(x);
+  const uint4_t* wp = static_cast<const uint4_t*>(w);
+  uint4_t* yp = static_cast<uint4_t*>(y);
+  BMA_PROF_BEGIN(BMA_K_RMSNORM, st, 2.0 * static_cast<double>(rows) * D * ES);
+#define BMA_NORM_GO(N)                                                                                          \
+  do {                                                                                                          \
+    if (gemma) hipLaunchKernelGGL((rmsnorm_kernel<DT, N, true>), grid, block, 0, st, xp, wp, eps, cpr, D, yp);   \
+    else hipLaunchKernelGGL((rmsnorm_kernel<DT, N, false>), grid, block, 0, st, xp, wp, eps, cpr, D, yp);        \
+  } while (0)
+  switch (nch) {
+    case 1: BMA_NORM_GO(1); break;
+    case 2: BMA_NORM_GO(2); break;
+    case 3: BMA_NORM_GO(3); break;
+    default: BMA_NORM_GO(4); break;
+  }
+#undef BMA_NORM_GO
+  BMA_PROF_END(BMA_K_RMSNORM, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+}  // namespace
+
+extern "C" int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t rows, int D, int dtype,
+                           int gemma_style, void* out, void* stream) {
+  if (rows < 0 || D <= 0 || rows > 0x7fffffffLL) return BMA_EINVAL;
+  if (rows == 0) return BMA_OK;
+  if (!x || !weight || !out) return BMA_EINVAL;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((static_cast<int64_t>(D) * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(out)) % 16)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BMA_F32: return launch_rmsnorm<BMA_F32>(x, weight, eps, rows, D, gemma_style, out, st);
+    case BMA_BF16: return launch_rmsnorm<BMA_BF16>(x, weight, eps, rows, D, gemma_style, out, st);
+    case BMA_F16: return launch_rmsnorm<BMA_F16>(x, weight, eps, rows, D, gemma_style, out, st);
+    default: return BMA_EDTYPE;
+  }
+}
+
+extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream) {
+  if (n < 0) return BMA_EINVAL;
+  if (n == 0) return BMA_OK;
+  if (!gate || !up || !out) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((n * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(up) | reinterpret_cast<uintptr_t>(out)) % 16)
+    return BMA_EALIGN;
+  const int64_t chunks = n * es / 16;
+  int64_t blocks = (chunks + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const uint4_t* g = static_cast<const uint4_t*>(gate);
+  const uint4_t* u = static_cast<const uint4_t*>(up);
+  uint4_t* y = static_cast<uint4_t*>(out);
+  BMA_PROF_BEGIN(BMA_K_SWIGLU, st, 3.0 * static_cast<double>(n) * es);
+  if (dtype == BMA_F32) hipLaunchKernelGGL((swiglu_kernel<BMA_F32>), grid, block, 0, st, g, u, chunks, y);
+  else if (dtype == BMA_BF16) hipLaunchKernelGGL((swiglu_kernel<BMA_BF16>), grid, block, 0, st, g, u, chunks, y);
+  else hipLaunchKernelGGL((swiglu_kernel<BMA_F16>), grid, block, 0, st, g, u, chunks, y);
+  BMA_PROF_END(BMA_K_SWIGLU, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, int B, int H, int L,
+                                int Dh, const void* cos, const void* sin, int cos_batch, int dtype, void* stream) {
+  if (B < 0 || H <= 0 || L < 0 || Dh <= 0 || (cos_batch != 1 && cos_batch != B)) return BMA_EINVAL;
+  if (B == 0 || L == 0) return BMA_OK;
+  if (!q || !cos || !sin) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  const int ne = 16 / es;
+  if (Dh % (2 * ne)) return BMA_EALIGN;                       // half a head must be whole 16-byte chunks
+  if ((stride_b * es) % 16 || (stride_h * es) % 16 || (stride_l * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin)) % 16)
+    return BMA_EALIGN;
+  const int64_t total = static_cast<int64_t>(B) * H * L * (Dh / 2 / ne);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  BMA_PROF_BEGIN(BMA_K_ROPE, st, 2.0 * static_cast<double>(B) * H * L * Dh * es);
+  if (dtype == BMA_F32)
+    hipLaunchKernelGGL((rope_kernel<BMA_F32>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch);
+  else if (dtype == BMA_BF16)
+    hipLaunchKernelGGL((rope_kernel<BMA_BF16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch);
+  else
+    hipLaunchKernelGGL((rope_kernel<BMA_F16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch);
+  BMA_PROF_END(BMA_K_ROPE, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}

@@ -1,0 +1,128 @@
+"""Fused inference path for the elementwise tail of Llama-family decoder layers.
+
+While a :class:`FusedInference` context is active AND autograd is off, the RMSNorm
+modules, SiLU-gated MLPs and rotary-embedding function of the given HuggingFace model run
+the one-pass kernels of ``csrc/fused_elementwise.hip`` instead of their eager op chains.
+Outside the context -- and whenever gradients are recorded (the gradient pass), the input
+is not on the GPU, or a shape is beyond the kernels' limits -- the original code runs.
+Nothing is left on the user's model afterwards: patches are instance attributes removed
+on exit.
+
+What qualifies (checked structurally, not by model name):
+  * a module whose class name ends in ``RMSNorm`` with a 1-D ``weight`` and an epsilon
+    (``variance_epsilon`` / ``eps``); classes named ``Gemma*`` use the (1 + w) form;
+  * a module with ``gate_proj``, ``up_proj``, ``down_proj`` and a SiLU ``act_fn``;
+  * ``apply_rotary_pos_emb`` of the modelling file of known rotary families (full-head
+    rotary, ``rotate_half`` convention): llama, mistral, qwen2, gemma3.
+"""
+
+from __future__ import annotations
+
+import sys
+from typing import List, Tuple
+
+import torch
+
+from . import ops
+
+_ROPE_FILES = ("modeling_llama", "modeling_mistral", "modeling_qwen2", "modeling_gemma3")
+_DTYPES = (torch.bfloat16, torch.float16, torch.float32)
+
+
+def _eps_of(m):
+    for name in ("variance_epsilon", "eps"):
+        v = getattr(m, name, None)
+        if isinstance(v, float):
+            return v
+    return None
+
+
+class FusedInference:
+    def __init__(self, model: torch.nn.Module, enabled: bool = True):
+        self.enabled = enabled
+        self.norms: List[Tuple[torch.nn.Module, float, bool]] = []
+        self.mlps: List[torch.nn.Module] = []
+        self.rope_modules = []
+        self._saved_rope = {}
+        self.depth = 0
+        if not enabled:
+            return
+        files = set()
+        for m in model.modules():
+            cls = type(m).__name__
+            w = getattr(m, "weight", None)
+            if cls.endswith("RMSNorm") and torch.is_tensor(w) and w.dim() == 1 and _eps_of(m) is not None:
+                self.norms.append((m, _eps_of(m), cls.startswith("Gemma")))
+            elif all(hasattr(m, a) for a in ("gate_proj", "up_proj", "down_proj", "act_fn")) and \
+                    type(m.act_fn).__name__ in ("SiLU", "SiLUActivation"):
+                self.mlps.append(m)
+            files.add(type(m).__module__)
+        for f in files:
+            mod = sys.modules.get(f)
+            if mod is not None and f.rsplit(".", 1)[-1] in _ROPE_FILES and hasattr(mod, "apply_rotary_pos_emb"):
+                self.rope_modules.append(mod)
+
+    # -- the replacements ----------------------------------------------------------------
+    @staticmethod
+    def _usable(x: torch.Tensor) -> bool:
+        return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype in _DTYPES
+
+    def _norm_forward(self, m, eps, gemma, orig):
+        def forward(x):
+            D = x.shape[-1]
+            if not self._usable(x) or (D * x.element_size()) % 16 or D * x.element_size() > 16384 \
+                    or m.weight.dtype != x.dtype:
+                return orig(x)
+            return ops.rmsnorm(x, m.weight, eps, gemma)
+        return forward
+
+    def _mlp_forward(self, m, orig):
+        def forward(x):
+            if not self._usable(x):
+                return orig(x)
+            g, u = m.gate_proj(x), m.up_proj(x)
+            if (g.numel() * g.element_size()) % 16:
+                return m.down_proj(m.act_fn(g) * u)
+            return m.down_proj(ops.swiglu(g, u))
+        return forward
+
+    def _rope(self, orig):
+        def apply_rotary_pos_emb(q, k, cos, sin, *args, unsqueeze_dim=1, **kw):
+            ok = (self._usable(q) and not args and not kw and unsqueeze_dim == 1 and q.dim() == 4 and k.dim() == 4
+                  and cos.dim() == 3 and cos.dtype == q.dtype and k.dtype == q.dtype and q.stride(3) == 1
+                  and k.stride(3) == 1 and cos.shape[-1] == q.shape[-1]
+                  and q.shape[-1] % (32 // q.element_size()) == 0
+                  and all((s * q.element_size()) % 16 == 0 for s in q.stride()[:3] + k.stride()[:3]))
+            if not ok:
+                return orig(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kw)
+            ops.rope_(q, cos, sin)
+            ops.rope_(k, cos, sin)
+            return q, k
+        return apply_rotary_pos_emb
+
+    # -- install / remove ------------------------------------------------------------------
+    def __enter__(self):
+        self.depth += 1
+        if not self.enabled or self.depth > 1:
+            return self
+        for m, eps, gemma in self.norms:
+            m.forward = self._norm_forward(m, eps, gemma, type(m).forward.__get__(m))
+        for m in self.mlps:
+            m.forward = self._mlp_forward(m, type(m).forward.__get__(m))
+        for mod in self.rope_modules:
+            self._saved_rope[mod] = mod.apply_rotary_pos_emb
+            mod.apply_rotary_pos_emb = self._rope(mod.apply_rotary_pos_emb)
+        return self
+
+    def __exit__(self, *exc):
+        self.depth -= 1
+        if not self.enabled or self.depth > 0:
+            return False
+        for m, _, _ in self.norms:
+            m.__dict__.pop("forward", None)
+        for m in self.mlps:
+            m.__dict__.pop("forward", None)
+        for mod, fn in self._saved_rope.items():
+            mod.apply_rotary_pos_emb = fn
+        self._saved_rope.clear()
+        return False

@@ -238,3 +238,43 @@ def splice(segments: Sequence[Segment], B: int, emb_weight: Optional[torch.Tenso
                                        V, ids.data_ptr() if ids is not None else None, B, n_opt, D, _DT[dtype],
                                        float(emb_scale), out.data_ptr(), _stream(dev)))
     return out
+
+
+# ---------------------------------------------------------------------------
+# fused elementwise tail of a Llama-family layer (candidate scoring only, no autograd)
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, gemma_style: bool = False) -> torch.Tensor:
+    dev = _need_gpu(x, weight)
+    D = x.shape[-1]
+    if weight.shape != (D,) or weight.dtype != x.dtype or not weight.is_contiguous():
+        raise ValueError("weight must be a contiguous (D,) tensor of x's dtype")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check("bma_rmsnorm", lib.bma_rmsnorm(x.data_ptr(), weight.data_ptr(), float(eps), x.numel() // D, D, _dt(x),
+                                         1 if gemma_style else 0, out.data_ptr(), _stream(dev)))
+    return out
+
+
+def swiglu(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    dev = _need_gpu(gate, up)
+    if gate.shape != up.shape or gate.dtype != up.dtype:
+        raise ValueError("gate and up must agree in shape and dtype")
+    gate, up = gate.contiguous(), up.contiguous()
+    out = torch.empty_like(gate)
+    check("bma_swiglu", lib.bma_swiglu(gate.data_ptr(), up.data_ptr(), gate.numel(), _dt(gate), out.data_ptr(),
+                                       _stream(dev)))
+    return out
+
+
+def rope_(q: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """In-place rotary embedding of q (B,H,L,Dh; any strides with a contiguous last dim);
+    cos/sin (1|B, L, Dh)."""
+    dev = _need_gpu(q, cos, sin)
+    if q.dim() != 4 or q.stride(3) != 1 or cos.shape != sin.shape or cos.dim() != 3:
+        raise ValueError("q must be (B,H,L,Dh) with a contiguous last dim; cos/sin (1|B,L,Dh)")
+    B, H, L, Dh = q.shape
+    if cos.shape[1] != L or cos.shape[2] != Dh or cos.shape[0] not in (1, B) or cos.dtype != q.dtype:
+        raise ValueError("cos/sin do not match q")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    check("bma_rope_inplace", lib.bma_rope_inplace(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), B, H, L, Dh,
+                                                   cos.data_ptr(), sin.data_ptr(), cos.shape[0], _dt(q), _stream(dev)))
+    return q

@@ -137,6 +137,25 @@ int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
                float emb_scale, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * a6  the elementwise tail of a Llama-family decoder layer during candidate scoring
+ *     (the model forward of :1287).  Each replaces a chain of eager HuggingFace ops with
+ *     one pass over HBM and keeps the chain's rounding points (see fused_elementwise.hip).
+ * bma_rmsnorm:      out[r,:] = weight * dt(x[r,:] * rsqrt(mean(x[r,:]^2) + eps))   (gemma_style=0)
+ *                   out[r,:] = dt(x[r,:] * rsqrt(mean(..)+eps) * (1 + weight))     (gemma_style=1)
+ *                   x, out: rows x D contiguous; D*es a multiple of 16 and <= 16 KiB.
+ * bma_swiglu:       out = dt(dt(silu(gate)) * up), n contiguous elements each.
+ * bma_rope_inplace: q <- dt(dt(q*cos) + dt(rotate_half(q)*sin)) in place; element (b,h,l,d) of q
+ *                   at q + b*stride_b + h*stride_h + l*stride_l + d (elements, d contiguous);
+ *                   cos/sin: [cos_batch][L][Dh] contiguous, cos_batch = 1 or B.
+ * ------------------------------------------------------------------------- */
+int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t rows, int D,
+                int dtype, int gemma_style, void* out, void* stream);
+int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream);
+int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l,
+                     int B, int H, int L, int Dh, const void* cos, const void* sin,
+                     int cos_batch, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Measurement aid (bench.py).  When enabled, the dominant kernel of
  * each entry point is bracketed by HIP events on the launch stream and the launch's
  * ALGORITHMIC bytes (the figures DESIGN.md states per unit) are tallied.  Disabled
@@ -147,7 +166,8 @@ int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
 enum {
   BMA_K_LINF = 0, BMA_K_CE_ROWS = 1 /* B > 1: candidate scoring */, BMA_K_CE_DLOGITS = 2,
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
-  BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_COUNT = 7
+  BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
+  BMA_K_ROPE = 9, BMA_K_COUNT = 10
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);
