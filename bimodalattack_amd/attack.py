@@ -43,6 +43,7 @@ from . import ops
 from .config import BimodalAttackConfig, BimodalAttackResult, EngineOptions
 from .dist import CandidateSharder
 from .fused import FusedInference
+from . import gemm_tuning
 from .hf_adapter import HFAdapter
 from .layout import dynamic_width, segment_order, split_at_suffix
 from .utils import INIT_CHARS, filter_ids, get_nonascii_toks, is_oom, plan_chunk
@@ -147,7 +148,9 @@ class BimodalAttack:
         self.shard = CandidateSharder(self.opt.group)
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
         self._grad_graph = None                    # None: not tried yet; False: eager for good
+        self._width: Optional[int] = None
         self.fused = FusedInference(model, self.opt.fused_elementwise)
+        self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
         if model.dtype in (torch.float32, torch.float64):
@@ -300,6 +303,7 @@ class BimodalAttack:
         if cfg.filter_ids:
             sampled = filter_ids(sampled, self.tokenizer)
         sampled = self.shard.broadcast_ids(sampled)
+        self._width = width                       # candidates sampled before the filter
         return sampled, sampled.shape[0]
 
     # ------------------------------------------------------------ scoring
@@ -314,17 +318,26 @@ class BimodalAttack:
                 out.append(("shared", self.seg[name]))
         return out
 
-    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
+    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
+                         width: Optional[int] = None) -> Tensor:
         """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
-        all-gathered to the full vector.  `order` ends in "target"."""
+        all-gathered to the full vector.  `order` ends in "target".  `width` is the number
+        of candidates sampled before the filter (static per step); when given, the slice is
+        padded to this rank's share of it so the forward sees the same shapes every step."""
         with self.fused:
-            return self._score_candidates(sampled, order, feats)
+            return self._score_candidates(sampled, order, feats, width)
 
-    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
+    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
+                          width: Optional[int]) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         lo, hi = self.shard.bounds(n)
         mine = sampled[lo:hi].contiguous()
+        m_real = mine.shape[0]
+        if self.opt.pad_candidates and width is not None and m_real > 0:
+            want = self.shard.per_rank(width)
+            if want > m_real:
+                mine = torch.cat([mine, mine[-1:].expand(want - m_real, -1)], dim=0).contiguous()
         m = mine.shape[0]
         E = self.embedding_layer.weight
         feats = None if feats is None else feats.to(E.dtype)
@@ -373,7 +386,7 @@ class BimodalAttack:
                 logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
                 loss, match, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
                 losses[s:s + b] = loss
-                if cfg.early_stop and bool(match.any().item()):
+                if cfg.early_stop and bool(match[: max(0, min(b, m_real - s))].any().item()):
                     stop = True
                 del x, kv, logits
                 s += b
@@ -384,7 +397,7 @@ class BimodalAttack:
                 self._chunk_cap = chunk
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
-        full, any_stop = self.shard.gather_losses(losses, n, stop, want_flag=cfg.early_stop)
+        full, any_stop = self.shard.gather_losses(losses[:m_real], n, stop, want_flag=cfg.early_stop)
         if any_stop:
             self.stop_flag = True
         if self.opt.loss_in_model_dtype:
@@ -532,9 +545,11 @@ class BimodalAttack:
                     if cfg.pgd_attack:
                         feats = self.hf.image_features(image)
                         if cfg.joint_eval:
-                            loss = self.score_candidates(sampled, segment_order("pgd", mt, single=True), feats)
+                            loss = self.score_candidates(sampled, segment_order("pgd", mt, single=True), feats,
+                                                         self._width if cfg.gcg_attack else None)
                         elif cfg.gcg_attack:
-                            loss = self.score_candidates(sampled, segment_order("gcg", mt, single=True), None)
+                            loss = self.score_candidates(sampled, segment_order("gcg", mt, single=True), None,
+                                                         self._width)
                         else:
                             loss = None
                         best_idx = int(loss.argmin().item()) if loss is not None else 0
@@ -553,7 +568,8 @@ class BimodalAttack:
                         if st is not None:
                             st["losses"].append(full.float().cpu().numpy())
                     else:
-                        loss = self.score_candidates(sampled, segment_order("gcg", mt, no_joint_eval=True), None)
+                        loss = self.score_candidates(sampled, segment_order("gcg", mt, no_joint_eval=True), None,
+                                                     self._width)
                         if st is not None:
                             st["losses"].append(loss.float().cpu().numpy())
                         best_idx = int(loss.argmin().item())
