@@ -46,7 +46,7 @@ from .fused import FusedInference
 from . import gemm_tuning
 from .hf_adapter import HFAdapter
 from .layout import dynamic_width, segment_order, split_at_suffix
-from .utils import INIT_CHARS, filter_ids, get_nonascii_toks, is_oom, plan_chunk
+from .utils import INIT_CHARS, FilterJob, get_nonascii_toks, is_oom, plan_chunk
 
 logger = logging.getLogger("gcg")
 if not logger.hasHandlers():
@@ -148,7 +148,8 @@ class BimodalAttack:
         self.shard = CandidateSharder(self.opt.group)
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
         self._grad_graph = None                    # None: not tried yet; False: eager for good
-        self._width: Optional[int] = None
+        self._prefix_cache: Dict[tuple, tuple] = {}
+        self._match: Optional[Tensor] = None
         self.fused = FusedInference(model, self.opt.fused_elementwise)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         if hasattr(model.config, "model_type"):
@@ -290,21 +291,21 @@ class BimodalAttack:
 
     # ------------------------------------------------------------ sampling
     def candidate_sampling(self, step: int, optim_ids: Tensor, g_tok: Optional[Tensor]):
+        """mask -> top-k -> random position/rank -> scatter (:130-163).  Returns every sampled
+        candidate and a FilterJob: the retokenisation filter (:166-186) runs on the host while
+        the GPU scores, and is applied to the losses afterwards."""
         cfg = self.config
         width = dynamic_width(step, cfg.search_width, cfg.num_steps, cfg.min_search_width, cfg.dynamic_search)
         if not cfg.gcg_attack:
-            return optim_ids, 1
+            return optim_ids, FilterJob(optim_ids, self.tokenizer, False)
         ids = optim_ids[0].contiguous()
         rnd, rank = self._draw(width, ids.numel())
         topk_idx = ops.mask_topk(g_tok[0], self.mask_bits, cfg.topk)
         pos = ops.rand_positions(rnd, cfg.n_replace)
         sampled = ops.sample_scatter(ids, topk_idx, pos, rank)
+        sampled = self.shard.broadcast_ids(sampled)          # rank 0's candidates everywhere
         self._last = dict(topk_idx=topk_idx, pos=pos, rank=rank, sampled=sampled)
-        if cfg.filter_ids:
-            sampled = filter_ids(sampled, self.tokenizer)
-        sampled = self.shard.broadcast_ids(sampled)
-        self._width = width                       # candidates sampled before the filter
-        return sampled, sampled.shape[0]
+        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids)
 
     # ------------------------------------------------------------ scoring
     def _segments(self, order, feats):
@@ -318,65 +319,64 @@ class BimodalAttack:
                 out.append(("shared", self.seg[name]))
         return out
 
-    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
-                         width: Optional[int] = None) -> Tensor:
+    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
         """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
-        all-gathered to the full vector.  `order` ends in "target".  `width` is the number
-        of candidates sampled before the filter (static per step); when given, the slice is
-        padded to this rank's share of it so the forward sees the same shapes every step."""
+        all-gathered to the full vector.  `order` ends in "target".  Only enqueues work: the
+        host does not wait for the device here (unless an OOM forces a retry)."""
         with self.fused:
-            return self._score_candidates(sampled, order, feats, width)
+            return self._score_candidates(sampled, order, feats)
 
-    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
-                          width: Optional[int]) -> Tensor:
+    def _prefix(self, prefix_names: List[str], feats: Optional[Tensor]):
+        """Keys/values of the segments in front of the suffix.  They depend on nothing but
+        the prompt -- and on the image when it is part of the prefix -- so a text-only prefix
+        is computed once per attack and an image prefix once per call."""
+        hf = self.hf
+        key = tuple(prefix_names)
+        if "image" not in prefix_names and key in self._prefix_cache:
+            return self._prefix_cache[key]
+        prefix = torch.cat([feats if p == "image" else self.seg[p] for p in prefix_names], dim=1)
+        P = prefix.shape[1]
+        cache = None
+        if P > 0:
+            try:
+                cache = hf.build_prefix(prefix)
+            except Exception as e:  # a model without cache support: remember, use the full sequence
+                logger.warning(f"prefix reuse disabled: {type(e).__name__}: {e}")
+            hf.prefix_ok = cache is not None
+        out = (cache, P)
+        if "image" not in prefix_names:
+            self._prefix_cache[key] = out
+        return out
+
+    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         lo, hi = self.shard.bounds(n)
         mine = sampled[lo:hi].contiguous()
-        m_real = mine.shape[0]
-        if self.opt.pad_candidates and width is not None and m_real > 0:
-            want = self.shard.per_rank(width)
-            if want > m_real:
-                mine = torch.cat([mine, mine[-1:].expand(want - m_real, -1)], dim=0).contiguous()
         m = mine.shape[0]
         E = self.embedding_layer.weight
         feats = None if feats is None else feats.to(E.dtype)
         rows_only = self.opt.target_rows_only
         prefix_names, tail_names = split_at_suffix(order)
-        tail_names = [("target_in" if (t == "target" and rows_only) else t) for t in tail_names]
-        use_prefix = self.opt.prefix_reuse and rows_only and prefix_names and hf.prefix_ok is not False and m > 0
+        use_prefix = bool(self.opt.prefix_reuse and rows_only and prefix_names and hf.prefix_ok is not False and m > 0)
 
         cache, P = None, 0
         if use_prefix:
-            prefix = torch.cat([feats if p == "image" else self.seg[p] for p in prefix_names], dim=1)
-            P = prefix.shape[1]
-            if P == 0:
-                use_prefix = False
-            else:
-                try:
-                    cache = hf.build_prefix(prefix)
-                except Exception as e:  # a model without cache support: remember, fall back to the full sequence
-                    logger.warning(f"prefix reuse disabled: {type(e).__name__}: {e}")
-                    cache = None
-                if cache is None:
-                    hf.prefix_ok, use_prefix = False, False
-                else:
-                    hf.prefix_ok = True
-        if not use_prefix:
-            seq_names = [("target_in" if (t == "target" and rows_only) else t) for t in order]
-        else:
-            seq_names = tail_names
-        segs = self._segments(seq_names, feats)
-        L = sum((mine.shape[1] if k == "gather" else (t.shape[-2])) for k, t in segs)
+            cache, P = self._prefix(prefix_names, feats)
+            use_prefix = cache is not None
+        names = tail_names if use_prefix else list(order)
+        names = [("target_in" if (t == "target" and rows_only) else t) for t in names]
+        segs = self._segments(names, feats)
+        L = sum((mine.shape[1] if k == "gather" else t.shape[-2]) for k, t in segs)
 
         free = torch.cuda.mem_get_info(self.model.device)[0]
-        chunk = plan_chunk(max(m, 1), L, P, hf.kv_bytes_per_token, hf.act_bytes_per_token, free,
+        chunk = plan_chunk(max(m, 1), L, P if use_prefix else 0, hf.kv_bytes_per_token, hf.act_bytes_per_token, free,
                            cfg.batch_size if cfg.batch_size is not None else self.opt.chunk)
         if self._chunk_cap is not None:
             chunk = min(chunk, self._chunk_cap)
 
         losses = torch.empty(m, dtype=torch.float32, device=self.model.device)
-        stop = False
+        match = torch.zeros(m, dtype=torch.float32, device=self.model.device) if cfg.early_stop else None
         s = 0
         while s < m:
             b = min(chunk, m - s)
@@ -384,10 +384,10 @@ class BimodalAttack:
                 x = ops.splice(segs, b, E, mine[s:s + b].contiguous(), hf.emb_scale)
                 kv = hf.expand_prefix(cache, b) if use_prefix else None
                 logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
-                loss, match, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
+                loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
                 losses[s:s + b] = loss
-                if cfg.early_stop and bool(match[: max(0, min(b, m_real - s))].any().item()):
-                    stop = True
+                if match is not None:
+                    match[s:s + b] = hit.to(torch.float32)
                 del x, kv, logits
                 s += b
             except Exception as e:
@@ -397,9 +397,8 @@ class BimodalAttack:
                 self._chunk_cap = chunk
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
-        full, any_stop = self.shard.gather_losses(losses[:m_real], n, stop, want_flag=cfg.early_stop)
-        if any_stop:
-            self.stop_flag = True
+        full = self.shard.gather(losses, n)
+        self._match = self.shard.gather(match, n, pad=0.0) if match is not None else None
         if self.opt.loss_in_model_dtype:
             full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
         return full
@@ -429,6 +428,8 @@ class BimodalAttack:
                 losses = self.score_candidates(ids[:n], segment_order("gcg_pgd", mt, single=True), feats)
             else:
                 losses = self.score_candidates(ids[:n], segment_order("gcg", mt, no_joint_eval=True), None)
+        if cfg.early_stop and self._match is not None and bool(self._match.any().item()):
+            self.stop_flag = True
         self.init_losses = losses.float().clone()
         host = losses.float().cpu().tolist()
         for i in range(n):
@@ -522,59 +523,73 @@ class BimodalAttack:
                     if cfg.gcg_attack and not cfg.joint_eval:
                         (g_tok, g_img), grad_time = grad_pass()
 
-                # ---- phase D: sampling ----------------------------------------------------
+                # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
+                t0 = self._sync()
+                sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok)
                 if cfg.gcg_attack:
-                    t0 = self._sync()
-                    sampled, n = self.candidate_sampling(i, optim_ids, g_tok)
                     samp_time = self._sync() - t0
-                    t_samp.append(samp_time)
                     if st is not None:
                         st["sampled"] = self._last["sampled"].cpu().numpy()
                         st["topk_idx"] = self._last["topk_idx"].cpu().numpy()
                         st["pos"] = self._last["pos"].cpu().numpy()
                         st["rank"] = self._last["rank"].cpu().numpy()
-                        if cfg.filter_ids:
-                            st["filtered"] = sampled.cpu().numpy()
-                else:
-                    sampled, n = optim_ids, 1
 
                 # ---- phase D: scoring -----------------------------------------------------
                 t0 = self._sync()
                 with torch.no_grad():
+                    def survivors(loss_all: Tensor):
+                        """Apply the retokenisation filter, computed on the host while the GPU
+                        scored, to the losses: the reference's filtered vector, in order."""
+                        keep = job.result()
+                        if len(keep) == loss_all.shape[0]:
+                            idx = None
+                            out = loss_all, sampled_all
+                        else:
+                            idx = torch.tensor(keep, device=loss_all.device)
+                            out = loss_all[idx], sampled_all[idx]
+                        if cfg.early_stop and self._match is not None:
+                            hit = self._match if idx is None else self._match[idx]
+                            if bool(hit.any().item()):
+                                self.stop_flag = True
+                        if st is not None:
+                            if cfg.filter_ids:
+                                st["filtered"] = out[1].cpu().numpy()
+                            st["losses"].append(out[0].float().cpu().numpy())
+                        return out
+
                     if cfg.pgd_attack:
                         feats = self.hf.image_features(image)
                         if cfg.joint_eval:
-                            loss = self.score_candidates(sampled, segment_order("pgd", mt, single=True), feats,
-                                                         self._width if cfg.gcg_attack else None)
+                            loss, sampled = survivors(self.score_candidates(
+                                sampled_all, segment_order("pgd", mt, single=True), feats))
                         elif cfg.gcg_attack:
-                            loss = self.score_candidates(sampled, segment_order("gcg", mt, single=True), None,
-                                                         self._width)
+                            loss, sampled = survivors(self.score_candidates(
+                                sampled_all, segment_order("gcg", mt, single=True), None))
                         else:
-                            loss = None
+                            loss, sampled = None, sampled_all
                         best_idx = int(loss.argmin().item()) if loss is not None else 0
-                        if st is not None and loss is not None:
-                            st["losses"].append(loss.float().cpu().numpy())
                         winner = sampled[best_idx:best_idx + 1].contiguous()
                         # re-score the winner with the image (:605-612); on every rank, unsharded
-                        keep, self.shard = self.shard, _SOLO
+                        keep_shard, self.shard = self.shard, _SOLO
                         try:
                             full = self.score_candidates(winner, segment_order("gcg_pgd", mt), feats)
                         finally:
-                            self.shard = keep
+                            self.shard = keep_shard
+                        if cfg.early_stop and self._match is not None and bool(self._match.any().item()):
+                            self.stop_flag = True
                         if self.shard.enabled:
                             self.shard.broadcast_(full)
                         current_loss = full.item()
                         if st is not None:
                             st["losses"].append(full.float().cpu().numpy())
                     else:
-                        loss = self.score_candidates(sampled, segment_order("gcg", mt, no_joint_eval=True), None,
-                                                     self._width)
-                        if st is not None:
-                            st["losses"].append(loss.float().cpu().numpy())
+                        loss, sampled = survivors(self.score_candidates(
+                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None))
                         best_idx = int(loss.argmin().item())
                         current_loss = loss[best_idx].item()
                         winner = sampled[best_idx:best_idx + 1].contiguous()
+                    n = sampled.shape[0]
                     optim_ids = winner                      # greedy: accepted even when worse (:613, :638)
                     losses.append(current_loss)
                     strings.append(tok.batch_decode(optim_ids)[0])
@@ -584,6 +599,11 @@ class BimodalAttack:
                     if st is not None:
                         st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
                 loss_time = self._sync() - t0
+                if cfg.gcg_attack:
+                    # the reference books the filter under "sampling"; it ran inside this section
+                    samp_time += job.seconds
+                    loss_time = max(loss_time - job.seconds, 0.0)
+                    t_samp.append(samp_time)
                 t_loss.append(loss_time)
                 logger.info(f"[Iteration {i}] Current loss: {current_loss:.4f} | Best loss: {buffer.get_lowest_loss():.4f} | ")
 
@@ -664,6 +684,10 @@ class _Solo:
     @staticmethod
     def bounds(n, rank=None):
         return 0, n
+
+    @staticmethod
+    def gather(local, n, pad=float("inf")):
+        return local
 
     @staticmethod
     def gather_losses(local, n, flag=False, want_flag=False):

@@ -96,11 +96,6 @@ class EngineOptions:
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
-    # Pad this rank's candidate slice up to its share of the SAMPLED width (the filter drops
-    # a few candidates per step) by repeating the last candidate; pad rows are scored and
-    # dropped.  <= 0.4 % extra work buys static GEMM shapes: stable library kernel
-    # selection (and a usable tuned-selection file) instead of a new M every step.
-    pad_candidates: bool = True
     # GEMM selection: "auto" loads bimodalattack_amd/tuning/<arch>.csv into PyTorch's
     # TunableOp in lookup-only mode when its validators (torch / hipBLASLt / rocBLAS versions,
     # arch) match this process; "off" leaves the library heuristics alone.
@@ -135,8 +130,6 @@ class EngineOptions:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
-        if "BMA_PAD_CANDIDATES" in env:
-            opts.pad_candidates = env["BMA_PAD_CANDIDATES"] not in ("0", "false", "False")
         if "BMA_GEMM_TUNING" in env:
             opts.gemm_tuning = env["BMA_GEMM_TUNING"]
         if "BMA_CHUNK" in env:

@@ -42,27 +42,35 @@ class CandidateSharder:
         return lo, min(n, lo + per)
 
     # -- exchange ----------------------------------------------------------
-    def gather_losses(self, local: torch.Tensor, n: int, flag: bool = False,
-                      want_flag: bool = False) -> Tuple[torch.Tensor, bool]:
-        """local: fp32 losses of this rank's slice (length hi-lo).  Returns the n losses
-        in candidate order on every rank, and the OR of `flag` over ranks."""
+    def gather(self, local: torch.Tensor, n: int, pad: float = float("inf")) -> torch.Tensor:
+        """local: this rank's slice (length hi-lo) of a per-candidate fp32 vector.  Returns the
+        n values in candidate order on every rank.  One collective of per_rank(n) floats per
+        rank; short slices are padded with `pad` (+inf can never win an argmin)."""
         if not self.enabled:
-            return local, bool(flag)
+            return local
         per = self.per_rank(n)
-        send = torch.full((per + 1,), float("inf"), dtype=torch.float32, device=local.device)
+        send = torch.full((per,), pad, dtype=torch.float32, device=local.device)
         send[: local.numel()] = local.to(torch.float32)
-        send[per] = 1.0 if flag else 0.0
-        recv = torch.empty((self.world, per + 1), dtype=torch.float32, device=local.device)
-        backend = dist.get_backend(self.group)
-        if backend == "nccl":
-            dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+        if dist.get_backend(self.group) == "nccl":
+            recv = torch.empty((self.world * per,), dtype=torch.float32, device=local.device)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
         else:
             parts = [torch.empty_like(send) for _ in range(self.world)]
             dist.all_gather(parts, send, group=self.group)
-            recv = torch.stack(parts)
-        # the flag is only read (one host sync) when the caller asked for early stopping
-        any_flag = bool((recv[:, per] > 0).any().item()) if want_flag else False
-        return recv[:, :per].reshape(-1)[:n].contiguous(), any_flag
+            recv = torch.cat(parts)
+        return recv[:n].contiguous()
+
+    def gather_losses(self, local: torch.Tensor, n: int, flag: bool = False,
+                      want_flag: bool = False) -> Tuple[torch.Tensor, bool]:
+        """Losses plus the OR of a per-rank flag (kept for callers that stop per rank)."""
+        full = self.gather(local, n)
+        if not self.enabled:
+            return full, bool(flag)
+        any_flag = False
+        if want_flag:
+            f = self.gather(torch.tensor([1.0 if flag else 0.0], device=local.device), self.world, pad=0.0)
+            any_flag = bool((f > 0).any().item())
+        return full, any_flag
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.enabled:

@@ -38,13 +38,10 @@ def get_nonascii_toks(tokenizer, device="cpu") -> torch.Tensor:
     return torch.tensor(bad, device=device)
 
 
-def filter_ids(ids: torch.Tensor, tokenizer) -> torch.Tensor:
-    """Keep the candidates whose decode -> encode round trip reproduces them exactly.
-
-    The reference tokenises one string per call and compares on the device (512 syncs
-    per step, 0.18 s at sw=512: SURVEY.md 8 f1).  Here: one device->host copy, one
-    batched decode, one batched encode, a host-side list comparison, one gather."""
-    rows = ids.tolist()
+def roundtrip_keep(rows: List[List[int]], tokenizer) -> List[int]:
+    """Indices of the candidates whose decode -> encode round trip reproduces them exactly
+    (reference :166-186), from ids already on the host.  One batched decode, one batched
+    encode, a list comparison; raises like the reference when nothing survives."""
     texts = tokenizer.batch_decode(rows)
     again = tokenizer(texts, add_special_tokens=False, padding=False)["input_ids"]
     keep = [i for i, (a, b) in enumerate(zip(rows, again)) if a == list(b)]
@@ -53,9 +50,52 @@ def filter_ids(ids: torch.Tensor, tokenizer) -> torch.Tensor:
             "No token sequences are the same after decoding and re-encoding. "
             "Consider setting filter_ids=False or trying a different optim_str_init"
         )
+    return keep
+
+
+def filter_ids(ids: torch.Tensor, tokenizer) -> torch.Tensor:
+    """Keep the candidates whose decode -> encode round trip reproduces them exactly.
+
+    The reference tokenises one string per call and compares on the device (512 syncs
+    per step, 0.18 s at sw=512: SURVEY.md 8 f1).  Here: one device->host copy, one
+    batched decode, one batched encode, a host-side list comparison, one gather."""
+    rows = ids.tolist()
+    keep = roundtrip_keep(rows, tokenizer)
     if len(keep) == len(rows):
         return ids
     return ids[torch.tensor(keep, device=ids.device)]
+
+
+class FilterJob:
+    """The retokenisation filter taken off the critical path: the candidate ids start
+    their way to the host (pinned buffer, non-blocking copy) right after sampling, the
+    GPU goes on to score EVERY sampled candidate, and the host runs the tokenizer round
+    trip meanwhile.  ``result()`` returns the surviving indices; the caller masks the
+    losses with them -- the same candidates win as if they had been filtered first."""
+
+    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool):
+        self.n = ids.shape[0]
+        self.tokenizer = tokenizer
+        self.enabled = enabled
+        self.seconds = 0.0
+        self._keep: Optional[List[int]] = None
+        if enabled:
+            self.host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
+            self.host.copy_(ids, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(ids.device))
+
+    def result(self) -> List[int]:
+        if self._keep is None:
+            if not self.enabled:
+                self._keep = list(range(self.n))
+            else:
+                import time
+                self.event.synchronize()
+                t0 = time.perf_counter()
+                self._keep = roundtrip_keep(self.host.tolist(), self.tokenizer)
+                self.seconds = time.perf_counter() - t0
+        return self._keep
 
 
 def is_oom(exc: BaseException) -> bool:
