@@ -55,6 +55,8 @@ WORKLOADS = {
                     name="PGD+GCG non-joint, LLaVA-1.5-7B-shaped bf16, search_width=512"),
     "pgd": dict(pgd_attack=True, gcg_attack=False, joint_eval=False,
                 name="PGD-only, LLaVA-1.5-7B-shaped bf16 (BASELINE configs[1])"),
+    "gemma_joint": dict(pgd_attack=True, gcg_attack=True, joint_eval=True, gemma=True,
+                        name="Joint GCG+PGD, Gemma-3-4b-it-shaped bf16, dynamic_search 512->128 (BASELINE configs[4])"),
 }
 
 
@@ -62,6 +64,17 @@ def build_plugins(workload: str, device, dtype, layers: int):
     """Synthetic tokenizer (32000 printable-ASCII words; embedding table has 32064 rows),
     LLaVA-1.5-7B-shaped random-weight model, prompt strings of the fixed segment lengths."""
     from bimodalattack_amd import synthetic as S
+    if workload == "gemma_joint":
+        # Gemma-3 layout 20|19|3|256|6|20 (SURVEY.md 8): suffix in FRONT of the image
+        tok = S.build_tokenizer(262144, 0, 0)
+        tok.chat_template = S.GEMMA_TEMPLATE
+        proc = S.Gemma3Processor(tok, S.GEMMA_TEMPLATE)
+        log("tokenizer built; building Gemma-3-4b-shaped model on the device")
+        model = S.gemma3_4b_shaped(dtype=dtype, device=device, seed=0)
+        log(f"model ready on {model.device} ({sum(p.numel() for p in model.parameters()) / 1e9:.2f} B parameters)")
+        goal, target = S.synthetic_prompt(tok, 18, 20, seed=0)        # <start_of_turn>user + 18 + BOS = 20
+        image = S.synthetic_image(896, 896, seed=0, device=device)
+        return model, tok, proc, goal, goal, target, image, S.Normalize((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
     tok = S.build_tokenizer(32000, 0, 0)
     proc = S.SyntheticProcessor(tok)
     log("tokenizer built; building LLaVA-1.5-7B-shaped model on the device")
@@ -197,6 +210,8 @@ def main() -> None:
     cfg_kw = dict(search_width=args.search_width, topk=256, n_replace=1, seed=1, verbosity="ERROR",
                   pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
                   eps=64 / 255, alpha=4 / 255)
+    if wl.get("gemma"):
+        cfg_kw.update(dynamic_search=True, min_search_width=128)
     total = args.warmup + args.steps
     cfg = BimodalAttackConfig(num_steps=total, images_folder=tempfile.mkdtemp(prefix="bma_bench_"), **cfg_kw)
 
@@ -278,7 +293,9 @@ def main() -> None:
     p_layer = 4 * tc.hidden_size ** 2 + 3 * tc.hidden_size * tc.intermediate_size
     p_lm = tc.num_hidden_layers * p_layer
     seg = SEG["gcg" if args.workload == "gcg" else "joint"]
-    new_tok = seg["optim"] + seg["after"] + seg["target"] - 1
+    if wl.get("gemma"):   # everything behind before_img is per candidate in the Gemma layout
+        seg = dict(before_img=20, optim=19, before_suffix=3, n_img=256, after=6, target=20)
+    new_tok = (sum(seg.values()) - seg["before_img"] - 1) if wl.get("gemma") else (seg["optim"] + seg["after"] + seg["target"] - 1)
     full_tok = sum(v for k_, v in seg.items())
     flops_cand = 2 * p_lm * new_tok + 2 * tc.hidden_size * tc.vocab_size * seg["target"]
     fwd = None

@@ -96,6 +96,10 @@ class EngineOptions:
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
+    # Attend to the shared prefix without copying its keys/values into every candidate
+    # (two flash launches + a merge kernel; llama-family text models).  See prefix_attention.py.
+    shared_prefix_attention: bool = True
+    shared_prefix_min_tokens: int = 64
     # GEMM selection: "auto" loads bimodalattack_amd/tuning/<arch>.csv into PyTorch's
     # TunableOp in lookup-only mode when its validators (torch / hipBLASLt / rocBLAS versions,
     # arch) match this process; "off" leaves the library heuristics alone.
@@ -130,6 +134,8 @@ class EngineOptions:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
+        if "BMA_SHARED_PREFIX_ATTENTION" in env:
+            opts.shared_prefix_attention = env["BMA_SHARED_PREFIX_ATTENTION"] not in ("0", "false", "False")
         if "BMA_GEMM_TUNING" in env:
             opts.gemm_tuning = env["BMA_GEMM_TUNING"]
         if "BMA_CHUNK" in env:

@@ -108,6 +108,7 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_RMSNORM: return "rmsnorm_kernel";
     case BMA_K_SWIGLU: return "swiglu_kernel";
     case BMA_K_ROPE: return "rope_kernel";
+    case BMA_K_ATTN_MERGE: return "attn_merge_kernel";
     default: return "?";
   }
 }

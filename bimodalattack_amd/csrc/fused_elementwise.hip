@@ -284,3 +284,67 @@ extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }
+
+// ---------------------------------------------------------------------------- attention merge
+// Shared-prefix attention (hf_adapter / prefix_attention.py): a candidate's new tokens attend
+// (1) to the prompt prefix, whose keys/values are THE SAME for every candidate, and (2) causally
+// to themselves.  The two partial softmaxes come from two flash-attention launches with their
+// log-sum-exps; this kernel merges them,  out = w*o1 + (1-w)*o2,  w = 1/(1+exp(l2-l1)),
+// in one pass.  o1, o2, out: [B][L][H][Dh] contiguous; lse1: [H][B*L] (the prefix launch runs
+// with batch 1 and B*L queries), lse2: [B][H][L]; both fp32.
+namespace {
+
+template <int DT>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const uint4_t* __restrict__ o1, const uint4_t* __restrict__ o2,
+                                                         const float* __restrict__ lse1, const float* __restrict__ lse2,
+                                                         int B, int L, int H, int cph, uint4_t* __restrict__ out) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t total = static_cast<int64_t>(B) * L * H * cph;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t r = i / cph;                       // (b, l, h)
+    const int h = static_cast<int>(r % H);
+    r /= H;
+    const int l = static_cast<int>(r % L);
+    const int b = static_cast<int>(r / L);
+    const float l1 = lse1[static_cast<int64_t>(h) * B * L + static_cast<int64_t>(b) * L + l];
+    const float l2 = lse2[(static_cast<int64_t>(b) * H + h) * L + l];
+    const float w = 1.0f / (1.0f + expf(l2 - l1));
+    float a[NE], c[NE], o[NE];
+    Chunk<DT>::unpack(o1[i], a);
+    Chunk<DT>::unpack(o2[i], c);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) o[j] = c[j] + w * (a[j] - c[j]);
+    out[i] = Chunk<DT>::pack(o);
+  }
+}
+
+}  // namespace
+
+extern "C" int bma_attn_merge(const void* o1, const void* o2, const float* lse1, const float* lse2, int B, int L,
+                              int H, int Dh, int dtype, void* out, void* stream) {
+  if (B < 0 || L < 0 || H <= 0 || Dh <= 0) return BMA_EINVAL;
+  if (B == 0 || L == 0) return BMA_OK;
+  if (!o1 || !o2 || !lse1 || !lse2 || !out) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((Dh * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(o1) | reinterpret_cast<uintptr_t>(o2) | reinterpret_cast<uintptr_t>(out)) % 16)
+    return BMA_EALIGN;
+  const int cph = Dh * es / 16;
+  const int64_t total = static_cast<int64_t>(B) * L * H * cph;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const uint4_t* a = static_cast<const uint4_t*>(o1);
+  const uint4_t* c = static_cast<const uint4_t*>(o2);
+  uint4_t* y = static_cast<uint4_t*>(out);
+  BMA_PROF_BEGIN(BMA_K_ATTN_MERGE, st, 3.0 * static_cast<double>(B) * L * H * Dh * es);
+  if (dtype == BMA_F32) hipLaunchKernelGGL((attn_merge_kernel<BMA_F32>), grid, block, 0, st, a, c, lse1, lse2, B, L, H, cph, y);
+  else if (dtype == BMA_BF16) hipLaunchKernelGGL((attn_merge_kernel<BMA_BF16>), grid, block, 0, st, a, c, lse1, lse2, B, L, H, cph, y);
+  else hipLaunchKernelGGL((attn_merge_kernel<BMA_F16>), grid, block, 0, st, a, c, lse1, lse2, B, L, H, cph, y);
+  BMA_PROF_END(BMA_K_ATTN_MERGE, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}

@@ -59,6 +59,9 @@ class HFAdapter:
         self.kv_bytes_per_token = 2 * self.n_layers * kv_heads * head_dim * es
         self.act_bytes_per_token = (16 * hidden + 4 * inter) * es
         self.prefix_ok: Optional[bool] = None   # learnt on first use
+        # shared-prefix attention (prefix_attention.py): None = not probed, [] = not applicable
+        self._shared_cfgs = None
+        self.shared_ok: Optional[bool] = None
 
     # ------------------------------------------------------------ vision
     def image_features(self, image: torch.Tensor) -> torch.Tensor:
@@ -108,6 +111,23 @@ class HFAdapter:
         kw = {"logits_to_keep": 1} if self.has_logits_to_keep else {}
         out = self.model(inputs_embeds=prefix_embeds, use_cache=True, **kw)
         return getattr(out, "past_key_values", None)
+
+    def shared_prefix_configs(self) -> list:
+        if self._shared_cfgs is None:
+            from . import prefix_attention as pa
+            ok = self.device.type == "cuda" and self.has_logits_to_keep and pa.register()
+            self._shared_cfgs = pa.eligible_configs(self.model) if ok else []
+        return self._shared_cfgs
+
+    def target_logits_shared_prefix(self, embeds: torch.Tensor, T: int, cache) -> torch.Tensor:
+        """Like ``target_logits(..., cache=expand_prefix(cache, B))`` but the prefix keys/values
+        are never copied per candidate (prefix_attention.py).  embeds: (B,L,D), the part behind
+        the prefix, without the last target token."""
+        from . import prefix_attention as pa
+        kv = pa.SharedPrefixKV(cache)
+        keep = self._keep_index(embeds.shape[1], T, embeds.device)
+        with pa.active(self.shared_prefix_configs(), kv):
+            return self.model(inputs_embeds=embeds, past_key_values=kv, logits_to_keep=keep).logits
 
     @staticmethod
     def expand_prefix(cache, batch: int):

@@ -278,3 +278,19 @@ def rope_(q: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor
     check("bma_rope_inplace", lib.bma_rope_inplace(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), B, H, L, Dh,
                                                    cos.data_ptr(), sin.data_ptr(), cos.shape[0], _dt(q), _stream(dev)))
     return q
+
+
+def attn_merge(o1: torch.Tensor, o2: torch.Tensor, lse1: torch.Tensor, lse2: torch.Tensor) -> torch.Tensor:
+    """Merge prefix-attention (o1, lse1) and self-attention (o2, lse2) partial results.
+    o1, o2: (B,L,H,Dh) contiguous; lse1: (H, B*L) fp32; lse2: (B,H,L) fp32."""
+    dev = _need_gpu(o1, o2, lse1, lse2)
+    B, L, H, Dh = o2.shape
+    if o1.shape != o2.shape or o1.dtype != o2.dtype or not o1.is_contiguous() or not o2.is_contiguous():
+        raise ValueError("o1/o2 must be contiguous (B,L,H,Dh) tensors of one dtype")
+    if lse1.dtype != torch.float32 or lse2.dtype != torch.float32 or lse1.numel() != B * L * H or \
+            lse2.shape != (B, H, L) or not lse1.is_contiguous() or not lse2.is_contiguous():
+        raise ValueError("lse1 must be (H, B*L) and lse2 (B,H,L), contiguous fp32")
+    out = torch.empty_like(o2)
+    check("bma_attn_merge", lib.bma_attn_merge(o1.data_ptr(), o2.data_ptr(), lse1.data_ptr(), lse2.data_ptr(), B, L, H, Dh,
+                                               _dt(o2), out.data_ptr(), _stream(dev)))
+    return out

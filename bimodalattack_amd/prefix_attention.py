@@ -1,0 +1,174 @@
+"""Shared-prefix attention for candidate scoring.
+
+Every candidate of a step shares the prompt in front of the suffix (and, in joint mode,
+the 576 image tokens): under causal attention those positions' keys/values are identical
+in all candidates.  ``hf_adapter.build_prefix`` computes them once.  The stock HuggingFace
+cache then COPIES them into every candidate's key/value tensors (``torch.cat`` per layer:
+5.4 GB per layer at 512 candidates x 644 tokens) -- which is what this module removes.
+
+A candidate's new tokens attend to
+  (1) the shared prefix: ONE flash-attention launch with batch 1 and B*L queries against
+      the (1,H,P,Dh) prefix keys/values (no mask: every prefix position is visible), and
+  (2) themselves, causally: one flash launch with batch B,
+and the two partial softmaxes are merged from their log-sum-exps by ``bma_attn_merge``.
+Identical maths to attention over the concatenated sequence; nothing is copied per
+candidate, so joint-mode scoring no longer needs small chunks.
+
+Plumbing (transformers >= 4.48 attention interface): a registered attention function
+``bma_shared_prefix`` + a no-op mask function, switched on for the duration of one forward;
+a cache object that hands the new keys/values back untouched and reports the prefix length
+so rotary positions are right.  Used only for model families whose text layers are all
+full causal attention (llama / mistral / qwen2 modelling files); anything else keeps the
+generic path.
+"""
+
+from __future__ import annotations
+
+import contextlib
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+NAME = "bma_shared_prefix"
+_FAMILIES = ("modeling_llama", "modeling_mistral", "modeling_qwen2")
+_ACTIVE: List["SharedPrefixKV"] = []
+_REGISTERED = {"done": False}
+
+try:
+    from transformers.cache_utils import Cache as _CacheBase
+except Exception:  # pragma: no cover
+    _CacheBase = object
+
+
+class SharedPrefixKV(_CacheBase):
+    """Duck-typed HF cache holding the prefix keys/values of every layer, batch 1."""
+
+    def __init__(self, base_cache):
+        try:
+            super().__init__(layers=[])
+        except Exception:
+            pass
+        layers = base_cache.layers
+        self.k = [l.keys for l in layers]
+        self.v = [l.values for l in layers]
+        self.P = int(self.k[0].shape[2])
+        self._sliding = [False] * len(layers)
+        self._rep = {}
+
+    @property
+    def is_sliding(self):                          # read-only property on the HF base class
+        return self._sliding
+
+    # -- what the HF forward asks of a cache --------------------------------------------
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        return key_states, value_states            # the new tokens only: nothing is concatenated
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.P
+
+    def get_mask_sizes(self, q, layer_idx: int = 0):
+        q_len = int(q) if isinstance(q, int) else int(q.shape[0])
+        return self.P + q_len, 0
+
+    def get_max_cache_shape(self, layer_idx: int = 0) -> int:
+        return -1
+
+    def __len__(self):
+        return len(self.k)
+
+    def prefix(self, layer_idx: int, n_rep: int):
+        """(K, V) of one layer, with kv heads repeated to the query heads when grouped."""
+        if n_rep == 1:
+            return self.k[layer_idx], self.v[layer_idx]
+        hit = self._rep.get(layer_idx)
+        if hit is None:
+            hit = (self.k[layer_idx].repeat_interleave(n_rep, dim=1), self.v[layer_idx].repeat_interleave(n_rep, dim=1))
+            self._rep[layer_idx] = hit
+        return hit
+
+
+def _partial_attention(q, k, v, causal: bool, scale: float):
+    """(out (B,H,L,Dh), lse (B,H,L) fp32) of softmax(q k^T * scale) v."""
+    if q.dtype in (torch.bfloat16, torch.float16):
+        out, lse = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, causal, False, scale=scale)[:2]
+    else:
+        out, lse = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, None, True, 0.0, causal, scale=scale)[:2]
+    return out, lse[..., : q.shape[2]]
+
+
+def shared_prefix_attention(module, query, key, value, attention_mask=None, dropout: float = 0.0,
+                            scaling: Optional[float] = None, **kwargs):
+    """HF attention-interface function: returns (attn_output (B,L,H,Dh), None)."""
+    kv = _ACTIVE[-1]
+    B, H, L, Dh = query.shape
+    n_rep = H // key.shape[1]
+    if n_rep > 1:
+        key, value = key.repeat_interleave(n_rep, dim=1), value.repeat_interleave(n_rep, dim=1)
+    Kp, Vp = kv.prefix(module.layer_idx, n_rep)
+    scale = float(scaling) if scaling is not None else Dh ** -0.5
+    qm = query.transpose(1, 2)                      # (B,L,H,Dh): the projection's own memory order
+    if not qm.is_contiguous():
+        qm = qm.contiguous()
+    q1 = qm.view(1, B * L, H, Dh).transpose(1, 2)   # (1,H,B*L,Dh) view, no copy
+    o1, l1 = _partial_attention(q1, Kp, Vp, False, scale)
+    o2, l2 = _partial_attention(qm.transpose(1, 2), key, value, True, scale)
+    o1 = o1.transpose(1, 2).reshape(B, L, H, Dh).contiguous()
+    o2 = o2.transpose(1, 2).contiguous()
+    out = ops.attn_merge(o1, o2, l1.reshape(H, B * L).contiguous(), l2.contiguous())
+    return out, None
+
+
+def _no_mask(*args, **kwargs):
+    return None
+
+
+def register() -> bool:
+    if _REGISTERED["done"]:
+        return True
+    try:
+        from transformers.masking_utils import AttentionMaskInterface
+        from transformers.modeling_utils import AttentionInterface
+        AttentionInterface.register(NAME, shared_prefix_attention)
+        AttentionMaskInterface.register(NAME, _no_mask)
+        _REGISTERED["done"] = True
+    except Exception:
+        return False
+    return True
+
+
+def eligible_configs(model) -> list:
+    """Config objects of the text attention layers when EVERY text layer is full causal
+    attention from a known modelling file; [] otherwise."""
+    cfgs, ok = {}, False
+    for m in model.modules():
+        if type(m).__name__.endswith("Attention") and hasattr(m, "layer_idx") and hasattr(m, "q_proj"):
+            f = type(m).__module__.rsplit(".", 1)[-1]
+            if f not in _FAMILIES or getattr(m, "sliding_window", None):
+                return []
+            cfgs[id(m.config)] = m.config
+            ok = True
+    if not ok:
+        return []
+    for c in cfgs.values():
+        types = getattr(c, "layer_types", None)
+        if types and any(t != "full_attention" for t in types):
+            return []
+    # the decoder stack's own config object drives mask creation: same object as the layers'
+    return list(cfgs.values())
+
+
+@contextlib.contextmanager
+def active(configs: list, kv: SharedPrefixKV):
+    """Switch the text layers to the shared-prefix attention for one forward."""
+    old = [getattr(c, "_attn_implementation", None) for c in configs]
+    _ACTIVE.append(kv)
+    try:
+        for c in configs:
+            c._attn_implementation = NAME
+        yield
+    finally:
+        _ACTIVE.pop()
+        for c, o in zip(configs, old):
+            c._attn_implementation = o

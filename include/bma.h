@@ -154,6 +154,12 @@ int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out
 int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l,
                      int B, int H, int L, int Dh, const void* cos, const void* sin,
                      int cos_batch, int dtype, void* stream);
+/* bma_attn_merge: merges the two partial attentions of the shared-prefix scheme (new tokens
+ *   vs the prompt prefix shared by all candidates; new tokens vs themselves, causal):
+ *   out = w*o1 + (1-w)*o2 with w = 1/(1+exp(lse2-lse1)).  o1, o2, out: [B][L][H][Dh] contiguous
+ *   of `dtype`; lse1: [H][B*L] fp32 (prefix launch: batch 1, B*L queries); lse2: [B][H][L] fp32. */
+int bma_attn_merge(const void* o1, const void* o2, const float* lse1, const float* lse2,
+                   int B, int L, int H, int Dh, int dtype, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Measurement aid (bench.py).  When enabled, the dominant kernel of
@@ -167,7 +173,7 @@ enum {
   BMA_K_LINF = 0, BMA_K_CE_ROWS = 1 /* B > 1: candidate scoring */, BMA_K_CE_DLOGITS = 2,
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
-  BMA_K_ROPE = 9, BMA_K_COUNT = 10
+  BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_COUNT = 11
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

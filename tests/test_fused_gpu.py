@@ -129,3 +129,62 @@ def test_fused_context_patches_and_restores(kind, dtype):
     with fused:
         y = model(inputs_embeds=x.clone().requires_grad_(), use_cache=False).logits
     assert y.requires_grad
+
+
+# ------------------------------------------------------------------ shared-prefix attention
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_attn_merge_and_shared_prefix_equal_full_attention(dtype):
+    """Two partial attentions + merge == attention over [prefix | own tokens] with a causal
+    mask on the own part, to the dtype's rounding."""
+    from bimodalattack_amd import prefix_attention as pa
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for B, H, Hkv, L, P, Dh in [(16, 8, 8, 44, 21, 128), (3, 4, 2, 7, 50, 64), (1, 2, 2, 5, 1, 32)]:
+        q = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2)
+        k = torch.randn((B, L, Hkv, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2)
+        v = torch.randn((B, L, Hkv, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2)
+        kp = torch.randn((1, Hkv, P, Dh), generator=g, device=DEV).to(dtype)
+        vp = torch.randn((1, Hkv, P, Dh), generator=g, device=DEV).to(dtype)
+
+        class Layer:
+            keys, values = kp, vp
+
+        kv = pa.SharedPrefixKV(type("C", (), {"layers": [Layer]})())
+        mod = type("M", (), {"layer_idx": 0})()
+        pa._ACTIVE.append(kv)
+        try:
+            out, _ = pa.shared_prefix_attention(mod, q, k, v, None, scaling=Dh ** -0.5)
+        finally:
+            pa._ACTIVE.pop()
+        rep = H // Hkv
+        fk = torch.cat([kp.expand(B, -1, -1, -1), k], 2).repeat_interleave(rep, 1).float()
+        fv = torch.cat([vp.expand(B, -1, -1, -1), v], 2).repeat_interleave(rep, 1).float()
+        mask = torch.ones(L, P + L, dtype=torch.bool, device=DEV)
+        mask[:, P:] = torch.tril(torch.ones(L, L, dtype=torch.bool, device=DEV))
+        ref = torch.nn.functional.scaled_dot_product_attention(q.float(), fk, fv, attn_mask=mask, scale=Dh ** -0.5)
+        tol = 2e-5 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
+        assert out.shape == (B, L, H, Dh)
+        assert float((out.float() - ref.transpose(1, 2)).abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_prefix_forward_equals_cache_forward(dtype):
+    """Whole-model check on a small Llama: logits through the shared-prefix attention equal
+    logits through the stock HF cache path."""
+    from bimodalattack_amd.hf_adapter import HFAdapter
+    from bimodalattack_amd import synthetic as S
+    model = _small_llama(dtype)
+    ad = HFAdapter(model, S.SyntheticProcessor(None), None)
+    assert ad.shared_prefix_configs()
+    D = model.get_input_embeddings().weight.shape[1]
+    B, P, L, T = 6, 9, 12, 4
+    g = torch.Generator(device=DEV).manual_seed(2)
+    prefix = (torch.randn((1, P, D), generator=g, device=DEV) * 0.5).to(dtype)
+    tail = (torch.randn((B, L, D), generator=g, device=DEV) * 0.5).to(dtype)
+    with torch.no_grad():
+        cache = ad.build_prefix(prefix)
+        want = ad.target_logits(tail, T, cache=ad.expand_prefix(cache, B)).float()
+        got = ad.target_logits_shared_prefix(tail, T, cache).float()
+        again = ad.target_logits(tail, T, cache=ad.expand_prefix(cache, B)).float()
+    assert torch.equal(again, want)                                   # attention implementation restored
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
