@@ -115,70 +115,87 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4_t* __
 }
 
 // ---------------------------------------------------------------------------- swiglu
+#ifdef BMA_FAST_SILU
+#define BMA_SILU(x) __fdividef((x), 1.0f + __expf(-(x)))
+#else
+#define BMA_SILU(x) ((x) / (1.0f + expf(-(x))))   // accurate exp + IEEE division, as aten's silu kernel
+#endif
+
+template <int DT>
+__device__ __forceinline__ uint4_t swiglu_chunk(const uint4_t& gw, const uint4_t& uw) {
+  constexpr int NE = Chunk<DT>::NE;
+  float gf[NE], uf[NE], o[NE];
+  Chunk<DT>::unpack(gw, gf);
+  Chunk<DT>::unpack(uw, uf);
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    const float s = BMA_SILU(gf[j]);
+    o[j] = rnd<DT>(s) * uf[j];
+  }
+  return Chunk<DT>::pack(o);
+}
+
+// Four chunks per lane per trip: eight 16-byte loads in flight before the first use.
 template <int DT>
 __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
                                                      int64_t n_chunks, uint4_t* __restrict__ y) {
-  constexpr int NE = Chunk<DT>::NE;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_chunks; i += stride) {
-    float gf[NE], uf[NE], o[NE];
-    Chunk<DT>::unpack(g[i], gf);
-    Chunk<DT>::unpack(u[i], uf);
-#pragma unroll
-    for (int j = 0; j < NE; ++j) {
-      const float s = gf[j] / (1.0f + expf(-gf[j]));     // silu in fp32 with the accurate exp, as aten's silu kernel
-      o[j] = rnd<DT>(s) * uf[j];
-    }
-    y[i] = Chunk<DT>::pack(o);
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n_chunks; i += 4 * stride) {
+    const uint4_t g0 = g[i], g1 = g[i + stride], g2 = g[i + 2 * stride], g3 = g[i + 3 * stride];
+    const uint4_t u0 = u[i], u1 = u[i + stride], u2 = u[i + 2 * stride], u3 = u[i + 3 * stride];
+    y[i] = swiglu_chunk<DT>(g0, u0);
+    y[i + stride] = swiglu_chunk<DT>(g1, u1);
+    y[i + 2 * stride] = swiglu_chunk<DT>(g2, u2);
+    y[i + 3 * stride] = swiglu_chunk<DT>(g3, u3);
   }
+  for (; i < n_chunks; i += stride) y[i] = swiglu_chunk<DT>(g[i], u[i]);
 }
 
 // ---------------------------------------------------------------------------- rope
 // q is addressed through strides (elements): element (b,h,l,d) at q + b*sb + h*sh + l*sl + d.
-// One lane owns one 16-byte chunk of the FIRST half of a head vector and its partner chunk in
-// the second half, so the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
+// One lane owns ONE 16-byte chunk of a head vector; the chunk of the other half of the head
+// (its rotate_half partner) lives in the lane `cph/2` lanes away, and the two exchange their
+// values with one shuffle.  Consecutive lanes therefore walk whole head vectors: every wave
+// instruction loads/stores 1 KiB of contiguous memory when heads are adjacent (a projection
+// output), and the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
+// Requires cph = Dh*es/16 to be a power of two <= 64 (Dh = 64..512 for 16-bit dtypes).
 template <int DT>
 __global__ __launch_bounds__(256) void rope_kernel(void* __restrict__ q, int64_t sb, int64_t sh, int64_t sl, int B,
                                                    int H, int L, int Dh, const void* __restrict__ cosp,
-                                                   const void* __restrict__ sinp, int cos_batch) {
+                                                   const void* __restrict__ sinp, int cos_batch, int cph_log2) {
   constexpr int NE = Chunk<DT>::NE;
   constexpr int ES = bma::elem_bytes<DT>::value;
-  const int half_chunks = Dh / 2 / NE;
-  const int64_t total = static_cast<int64_t>(B) * H * L * half_chunks;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
-    // order (b, l, h, c): consecutive lanes walk the Dh axis, then heads -- contiguous in a
-    // (B,L,H,Dh) projection output
-    const int c = static_cast<int>(i % half_chunks);
-    int64_t r = i / half_chunks;
-    const int h = static_cast<int>(r % H);
-    r /= H;
-    const int l = static_cast<int>(r % L);
-    const int b = static_cast<int>(r / L);
-    char* base = static_cast<char*>(q) + (static_cast<int64_t>(b) * sb + static_cast<int64_t>(h) * sh +
-                                          static_cast<int64_t>(l) * sl) * ES;
-    uint4_t* lo = reinterpret_cast<uint4_t*>(base) + c;
-    uint4_t* hi = reinterpret_cast<uint4_t*>(base + static_cast<int64_t>(Dh / 2) * ES) + c;
-    const int64_t cs = (static_cast<int64_t>(cos_batch > 1 ? b : 0) * L + l) * Dh;
-    const uint4_t* c_lo = reinterpret_cast<const uint4_t*>(static_cast<const char*>(cosp) + cs * ES) + c;
-    const uint4_t* c_hi = reinterpret_cast<const uint4_t*>(static_cast<const char*>(cosp) + (cs + Dh / 2) * ES) + c;
-    const uint4_t* s_lo = reinterpret_cast<const uint4_t*>(static_cast<const char*>(sinp) + cs * ES) + c;
-    const uint4_t* s_hi = reinterpret_cast<const uint4_t*>(static_cast<const char*>(sinp) + (cs + Dh / 2) * ES) + c;
-    float x1[NE], x2[NE], cl[NE], ch[NE], sl_[NE], sh_[NE], o1[NE], o2[NE];
-    Chunk<DT>::unpack(*lo, x1);
-    Chunk<DT>::unpack(*hi, x2);
-    Chunk<DT>::unpack(*c_lo, cl);
-    Chunk<DT>::unpack(*c_hi, ch);
-    Chunk<DT>::unpack(*s_lo, sl_);
-    Chunk<DT>::unpack(*s_hi, sh_);
+  const int cph = 1 << cph_log2;               // chunks per head vector
+  const int half = cph >> 1;
+  // one workgroup per (b, l): no per-chunk division, only shifts and masks
+  const int row = blockIdx.x;
+  const int b = row / L, l = row - b * L;
+  char* qrow = static_cast<char*>(q) + (static_cast<int64_t>(b) * sb + static_cast<int64_t>(l) * sl) * ES;
+  const int64_t cs = (static_cast<int64_t>(cos_batch > 1 ? b : 0) * L + l) * Dh;
+  const uint4_t* crow = reinterpret_cast<const uint4_t*>(static_cast<const char*>(cosp) + cs * ES);
+  const uint4_t* srow = reinterpret_cast<const uint4_t*>(static_cast<const char*>(sinp) + cs * ES);
+  const int n = H << cph_log2;                 // chunks in this row (a multiple of cph: whole heads per wave)
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i & (cph - 1);
+    const int h = i >> cph_log2;
+    uint4_t* px = reinterpret_cast<uint4_t*>(qrow + static_cast<int64_t>(h) * sh * ES) + c;
+    const uint4_t cw = crow[c], sw = srow[c];
+    const uint4_t xw = *px;
+    uint4_t pw;                                 // the partner half's chunk
+    pw.x = __shfl_xor(xw.x, half, BMA_WAVE);
+    pw.y = __shfl_xor(xw.y, half, BMA_WAVE);
+    pw.z = __shfl_xor(xw.z, half, BMA_WAVE);
+    pw.w = __shfl_xor(xw.w, half, BMA_WAVE);
+    float x[NE], p[NE], cf[NE], sf[NE], o[NE];
+    Chunk<DT>::unpack(xw, x);
+    Chunk<DT>::unpack(pw, p);
+    Chunk<DT>::unpack(cw, cf);
+    Chunk<DT>::unpack(sw, sf);
+    const float sign = (c < half) ? -1.0f : 1.0f;   // rotate_half(x) = cat(-x2, x1)
 #pragma unroll
-    for (int j = 0; j < NE; ++j) {
-      // rotate_half(x) = cat(-x2, x1)
-      o1[j] = rnd<DT>(rnd<DT>(x1[j] * cl[j]) + rnd<DT>(-x2[j] * sl_[j]));
-      o2[j] = rnd<DT>(rnd<DT>(x2[j] * ch[j]) + rnd<DT>(x1[j] * sh_[j]));
-    }
-    *lo = Chunk<DT>::pack(o1);
-    *hi = Chunk<DT>::pack(o2);
+    for (int j = 0; j < NE; ++j) o[j] = rnd<DT>(rnd<DT>(x[j] * cf[j]) + rnd<DT>(sign * p[j] * sf[j]));
+    *px = Chunk<DT>::pack(o);
   }
 }
 
@@ -265,21 +282,26 @@ extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int
   const int es = dtype == BMA_F32 ? 4 : 2;
   const int ne = 16 / es;
   if (Dh % (2 * ne)) return BMA_EALIGN;                       // half a head must be whole 16-byte chunks
+  const int cph_host = Dh / ne;
+  if (cph_host > 64 || (cph_host & (cph_host - 1))) return BMA_ELIMIT;   // partner exchange stays inside a wave
   if ((stride_b * es) % 16 || (stride_h * es) % 16 || (stride_l * es) % 16) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin)) % 16)
     return BMA_EALIGN;
-  const int64_t total = static_cast<int64_t>(B) * H * L * (Dh / 2 / ne);
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  int cph_log2 = 0;
+  while ((1 << cph_log2) < cph_host) ++cph_log2;
+  // every lane of a wave must be active while partners exchange values: H*cph is a multiple of
+  // cph and 256 % cph == 0, so a head vector never straddles the loop's tail
+  const int64_t rows = static_cast<int64_t>(B) * L;
+  if (rows > 0x7fffffffLL) return BMA_ELIMIT;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const dim3 grid(static_cast<unsigned>(rows)), block(256);
   BMA_PROF_BEGIN(BMA_K_ROPE, st, 2.0 * static_cast<double>(B) * H * L * Dh * es);
   if (dtype == BMA_F32)
-    hipLaunchKernelGGL((rope_kernel<BMA_F32>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch);
+    hipLaunchKernelGGL((rope_kernel<BMA_F32>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch, cph_log2);
   else if (dtype == BMA_BF16)
-    hipLaunchKernelGGL((rope_kernel<BMA_BF16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch);
+    hipLaunchKernelGGL((rope_kernel<BMA_BF16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch, cph_log2);
   else
-    hipLaunchKernelGGL((rope_kernel<BMA_F16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch);
+    hipLaunchKernelGGL((rope_kernel<BMA_F16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch, cph_log2);
   BMA_PROF_END(BMA_K_ROPE, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
@@ -299,23 +321,22 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const uint4_t* __restri
                                                          const float* __restrict__ lse1, const float* __restrict__ lse2,
                                                          int B, int L, int H, int cph, uint4_t* __restrict__ out) {
   constexpr int NE = Chunk<DT>::NE;
-  const int64_t total = static_cast<int64_t>(B) * L * H * cph;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
-    int64_t r = i / cph;                       // (b, l, h)
-    const int h = static_cast<int>(r % H);
-    r /= H;
-    const int l = static_cast<int>(r % L);
-    const int b = static_cast<int>(r / L);
-    const float l1 = lse1[static_cast<int64_t>(h) * B * L + static_cast<int64_t>(b) * L + l];
+  const int row = blockIdx.x;                  // (b, l)
+  const int b = row / L, l = row - b * L;
+  const int n = H * cph;                       // chunks of this row
+  const int64_t base = static_cast<int64_t>(row) * n;
+  const int64_t BL = static_cast<int64_t>(B) * L;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int h = i / cph;                     // 32-bit, once per chunk
+    const float l1 = lse1[static_cast<int64_t>(h) * BL + row];
     const float l2 = lse2[(static_cast<int64_t>(b) * H + h) * L + l];
     const float w = 1.0f / (1.0f + expf(l2 - l1));
     float a[NE], c[NE], o[NE];
-    Chunk<DT>::unpack(o1[i], a);
-    Chunk<DT>::unpack(o2[i], c);
+    Chunk<DT>::unpack(o1[base + i], a);
+    Chunk<DT>::unpack(o2[base + i], c);
 #pragma unroll
     for (int j = 0; j < NE; ++j) o[j] = c[j] + w * (a[j] - c[j]);
-    out[i] = Chunk<DT>::pack(o);
+    out[base + i] = Chunk<DT>::pack(o);
   }
 }
 
@@ -332,11 +353,10 @@ extern "C" int bma_attn_merge(const void* o1, const void* o2, const float* lse1,
   if ((reinterpret_cast<uintptr_t>(o1) | reinterpret_cast<uintptr_t>(o2) | reinterpret_cast<uintptr_t>(out)) % 16)
     return BMA_EALIGN;
   const int cph = Dh * es / 16;
-  const int64_t total = static_cast<int64_t>(B) * L * H * cph;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  const int64_t rows = static_cast<int64_t>(B) * L;
+  if (rows > 0x7fffffffLL) return BMA_ELIMIT;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const dim3 grid(static_cast<unsigned>(rows)), block(256);
   const uint4_t* a = static_cast<const uint4_t*>(o1);
   const uint4_t* c = static_cast<const uint4_t*>(o2);
   uint4_t* y = static_cast<uint4_t*>(out);

@@ -92,6 +92,8 @@ class FusedInference:
                   and cos.dim() == 3 and cos.dtype == q.dtype and k.dtype == q.dtype and q.stride(3) == 1
                   and k.stride(3) == 1 and cos.shape[-1] == q.shape[-1]
                   and q.shape[-1] % (32 // q.element_size()) == 0
+                  and (q.shape[-1] * q.element_size() // 16) <= 64
+                  and ((q.shape[-1] * q.element_size() // 16) & (q.shape[-1] * q.element_size() // 16 - 1)) == 0
                   and all((s * q.element_size()) % 16 == 0 for s in q.stride()[:3] + k.stride()[:3]))
             if not ok:
                 return orig(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kw)

@@ -72,8 +72,37 @@ def cases():
             return ops.sample_scatter(ids, tk, pos, rank)
         return go
 
+    def rmsnorm(rows, D):
+        x = torch.randn((rows, D), generator=g, device=DEV).to(bf)
+        w = torch.randn((D,), generator=g, device=DEV).to(bf)
+        return lambda: ops.rmsnorm(x, w, 1e-5)
+
+    def swiglu(rows, I):
+        a = torch.randn((rows, I), generator=g, device=DEV).to(bf)
+        b = torch.randn((rows, I), generator=g, device=DEV).to(bf)
+        return lambda: ops.swiglu(a, b)
+
+    def rope(B, L, H, Dh):
+        q = torch.randn((B, L, H * Dh), generator=g, device=DEV).to(bf).view(B, L, H, Dh).transpose(1, 2)
+        ang = torch.rand((1, L, Dh), generator=g, device=DEV)
+        cos, sin = ang.cos().to(bf), ang.sin().to(bf)
+        return lambda: ops.rope_(q, cos, sin)
+
+    def merge(B, L, H, Dh):
+        o1 = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf)
+        o2 = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf)
+        l1 = torch.randn((H, B * L), generator=g, device=DEV)
+        l2 = torch.randn((B, H, L), generator=g, device=DEV)
+        return lambda: ops.attn_merge(o1, o2, l1, l2)
+
     return {
         # name: (kernel id in the profiler, thunk factory)
+        "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
+        "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
+        "rope/c3_B512_L44_H32_Dh128": ("rope", lambda: rope(512, 44, 32, 128)),
+        "attn_merge/c4_B512_L45_H32_Dh128": ("attn_merge", lambda: merge(512, 45, 32, 128)),
+        "rmsnorm/n8_2816x4096": ("rmsnorm", lambda: rmsnorm(2816, 4096)),
+        "swiglu/n8_2816x11008": ("swiglu", lambda: swiglu(2816, 11008)),
         "ce_rows/llava_B512_T20_V32064": ("ce_rows", lambda: ce(512, 20, 32064)),
         "ce_rows/llava_B64_T20_V32064": ("ce_rows", lambda: ce(64, 20, 32064)),
         "ce_rows/gemma_B64_T20_V262208": ("ce_rows", lambda: ce(64, 20, 262208)),
