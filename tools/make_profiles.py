@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turn one round's raw measurement directory (gpurun_out/<dir>) into the committed
+summaries under profiles/:  python tools/make_profiles.py gpurun_out/r1b r1"""
+import csv
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, tag = sys.argv[1], sys.argv[2]
+out = os.path.join(REPO, "profiles")
+os.makedirs(out, exist_ok=True)
+
+shutil.copyfile(os.path.join(src, "kernel_bench.json"), os.path.join(out, f"{tag}_kernel_bench.json"))
+for w in ("gcg", "joint"):
+    for a, b in ((f"kt_{w}_kernel_stats.csv", f"{tag}_bench_{w}_kernel_stats.csv"),
+                 (f"bench_{w}_under_rocprof.json", f"{tag}_bench_{w}_under_rocprof.json")):
+        if os.path.exists(os.path.join(src, a)):
+            shutil.copyfile(os.path.join(src, a), os.path.join(out, b))
+for c in ("fetch", "write"):
+    rows = list(csv.DictReader(open(os.path.join(src, f"{c}_counter_collection.csv"))))
+    keep = [r for r in rows if "anonymous namespace" in r["Kernel_Name"] and "at::native" not in r["Kernel_Name"]]
+    name = f"{tag}_kernel_bench_pmc_{'FETCH_SIZE' if c == 'fetch' else 'WRITE_SIZE'}.csv"
+    with open(os.path.join(out, name), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(keep)
+folded_path = os.path.join(src, "pmc_folded.json")
+subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), os.path.join(src, "fetch_counter_collection.csv"),
+                os.path.join(src, "write_counter_collection.csv"), folded_path], check=True, stdout=subprocess.DEVNULL)
+folded = json.load(open(folded_path))["kernels"]
+kb = json.load(open(os.path.join(src, "kernel_bench.json")))
+
+# kernel_bench case -> (bench kernel name, PMC key = "<symbol><template>/threads<total threads>")
+CASES = [
+    ("ce_rows/llava_B512_T20_V32064", "ce_rows", "ce_rows_kernel<1, true, false>/threads2621440", "B=512 T=20 V=32064 bf16 (C3/C4 scoring, one chunk)"),
+    ("ce_dlogits/llava_T20_V32064", "ce_dlogits", "ce_dlogits_kernel<1, true>/threads5120", "B=1 T=20 V=32064 bf16 (gradient pass)"),
+    ("splice/c3_tail_B512_S44_D4096", "splice", "splice_kernel<1>/threads720896", "C3 tail: B=512, 19 gathered + 25 shared rows, D=4096 bf16"),
+    ("splice/c3_full_B512_S65_D4096", "splice", "splice_kernel<1>/threads532480", "C3 full: B=512 S=65 D=4096 bf16"),
+    ("splice/c4_full_B512_S643_D4096", "splice", "splice_kernel<1>/threads5267456", "C4 full: B=512 S=643 D=4096 bf16"),
+    ("linf/gemma_3x896x896", "linf", "linf_step_vec4/threads524288", "Gemma image 3x896x896 fp32"),
+    ("linf/llava_3x336x336", "linf", "linf_step_vec4/threads84736", "LLaVA image 3x336x336 fp32"),
+    ("mask_topk/llava_19x32064_f32", "mask_topk", "mask_topk_kernel<0, true>/threads19456", "19 x 32064 fp32"),
+    ("rmsnorm/c3_22528x4096", "rmsnorm", "rmsnorm_kernel<1, 2, false>/threads5767168", "22528 x 4096 bf16 (C3 candidate forward)"),
+    ("swiglu/c3_22528x11008", "swiglu", "swiglu_kernel<1>/threads1048576", "22528 x 11008 bf16 (C3 candidate forward)"),
+    ("rope/c3_B512_L44_H32_Dh128", "rope", "rope_kernel<1>/threads5767168", "B=512 L=44 H=32 Dh=128 bf16"),
+    ("attn_merge/c4_B512_L45_H32_Dh128", "attn_merge", "attn_merge_kernel<1>/threads5898240", "B=512 L=45 H=32 Dh=128 bf16 (C4)"),
+]
+entries = []
+for case, kernel, key, shape in CASES:
+    if case not in kb:
+        continue
+    cands = [k for k in folded if k.rsplit("/run", 1)[0] == key] or [k for k in folded if k.split("/")[0] == key.split("/")[0]]
+    # several shapes can share a symbol: take the launch whose traffic is closest to the algorithmic bytes
+    algo = kb[case]["algorithmic_MB"] * 1e6
+    if not cands:
+        continue
+    best = min(cands, key=lambda k: abs(folded[k]["hbm_bytes_per_launch"] - algo))
+    v = folded[best]
+    entries.append(dict(kernel=kernel, shape=shape, pmc_key=best, algorithmic_bytes=algo,
+                        hbm_bytes_per_launch=v["hbm_bytes_per_launch"], fetch_bytes_corrected=v["fetch_bytes_per_launch_corrected"],
+                        write_bytes=v["write_bytes_per_launch"], ratio_to_algorithmic=v["hbm_bytes_per_launch"] / algo,
+                        avg_us=kb[case]["avg_us"], achieved_GBps=kb[case]["achieved_GBps"]))
+json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes with --kernel-trace only, of "
+                      "tools/kernel_bench.py --iters 5 on MI355X; raw rows in *_kernel_bench_pmc_*.csv",
+               corrections="counters are KiB; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM); WRITE_SIZE x1",
+               entries=entries), open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+for e in entries:
+    print(f"{e['kernel']:11s} {e['shape'][:52]:52s} {e['avg_us']:8.1f} us {e['achieved_GBps']:7.0f} GB/s  traffic/algorithmic = {e['ratio_to_algorithmic']:.3f}")
