@@ -472,8 +472,81 @@ def g6_tokens() -> None:
     save("g6_tokens.npz", not_allowed=na.numpy(), ids=ids, kept=kept.numpy())
 
 
+# --------------------------------------------------------------------------
+# G7 -- experiment artefacts (reference experiments.py:54-285, utils/experiments_utils.py:26-71)
+# --------------------------------------------------------------------------
+def g7_artifacts() -> None:
+    """Drive the reference's run_experiment() with canned attack results (its `bimodalattack.run`
+    replaced by a stub that returns them) and keep the text of every file it writes.  The
+    harness module needs matplotlib / torchvision / requests at import: stubbed; it also reads
+    data/advbench relative to the working directory and creates ./experiments: run from a
+    scratch directory with a symlink to the reference's data."""
+    import tempfile
+
+    work = tempfile.mkdtemp(prefix="bma_g7_")
+    os.symlink(os.path.join(REF, "data"), os.path.join(work, "data"))
+    for name in ("matplotlib", "matplotlib.pyplot", "torchvision.transforms", "requests"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            m.__path__ = []
+            sys.modules[name] = m
+    plt = sys.modules["matplotlib.pyplot"]
+    for fn in ("figure", "plot", "xlabel", "ylabel", "title", "savefig", "close"):
+        setattr(plt, fn, lambda *a, **k: None)
+    plt.gca = lambda: SimpleNamespace(text=lambda *a, **k: None, transAxes=None)
+    sys.modules["matplotlib"].pyplot = plt
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        import experiments as exp   # the reference's harness module
+        canned = [
+            dict(best_loss=1.25, best_string="x y z", losses=[3.5, 1.25, 2.0], strings=["a", "x y z", "b"],
+                 adversarial_suffixes=["a", "x y z", "b"], model_outputs=["out, with comma", "", "line\nbreak"],
+                 gradient_times=[0.5, 0.25, 0.125], sampling_times=[0.01, 0.02, 0.03], loss_times=[1.0, 2.0, 3.0],
+                 pgd_times=[0.001, 0.002, 0.003], total_times=[1.511, 2.272, 3.158]),
+            RuntimeError("boom"),          # a failed prompt becomes a NaN row (:116-137)
+            dict(best_loss=0.5, best_string='quote " inside', losses=[0.75, 0.5], strings=["q", 'quote " inside'],
+                 adversarial_suffixes=["q", 'quote " inside'], model_outputs=["", ""],
+                 gradient_times=[0.5, 0.5, 0.5, 0.5], sampling_times=[0.25, 0.25], loss_times=[1.5, 1.5],
+                 pgd_times=[], total_times=[2.25, 2.25]),
+        ]
+        kwargs = {"num_steps": 3, "search_width": 16, "dynamic_search": False, "min_search_width": 8,
+                  "pgd_attack": True, "gcg_attack": True, "alpha": 4 / 255, "eps": 64 / 255, "debug_output": False,
+                  "alpha_str": "4/255", "eps_str": "64/255", "joint_eval": True, "model": "llava"}
+        pairs = [("goal one", "target one"), ("goal, two", "target two"), ("goal three", 'target "three"')]
+        exp.model = exp.tokenizer = exp.processor = exp.image = exp.normalize = None
+        experiments = []
+        # experiment 1: the middle prompt fails; experiment 2: every prompt succeeds
+        for name, plan, prs in (("golden run", canned, pairs), ("clean run", [canned[0], canned[2]], [pairs[0], pairs[2]])):
+            it = iter(plan)
+
+            def fake_run(*a, **k):
+                c = next(it)
+                if isinstance(c, Exception):
+                    raise c
+                return exp.bimodalattack.BimodalAttackResult(**c)
+
+            exp.bimodalattack.run = fake_run
+            exp.run_experiment(name, kwargs, prs)
+            folder = os.path.join(work, "experiments", f"exp{len(experiments) + 1}")
+            files = {}
+            for fn in sorted(os.listdir(folder)):
+                path = os.path.join(folder, fn)
+                if os.path.isfile(path) and not fn.endswith(".png"):
+                    files[fn] = open(path, newline="").read()
+            dirs = sorted(d for d in os.listdir(folder) if os.path.isdir(os.path.join(folder, d)))
+            experiments.append(dict(name=name, pairs=prs, files=files, dirs=dirs, folder=f"exp{len(experiments) + 1}",
+                                    canned=[c if isinstance(c, dict) else {"raise": str(c)} for c in plan]))
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(HERE, "g7_artifacts.json"), "w") as f:
+        json.dump(dict(config_kwargs=kwargs, seed=1, experiments=experiments), f, indent=1)
+    print("wrote g7_artifacts.json:", [(e["folder"], sorted(e["files"]), e["dirs"]) for e in experiments])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     torch.set_num_threads(1)  # one reduction order
     if "g1" in which:
         g1_sampling()
@@ -487,3 +560,5 @@ if __name__ == "__main__":
         g6_tokens()
     if "g5" in which:
         g5_trajectories()
+    if "g7" in which:
+        g7_artifacts()

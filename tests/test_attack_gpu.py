@@ -230,3 +230,84 @@ def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
         for a, b in zip(cand_losses, [st["losses"][0] for st in trace1 if st["losses"]]):
             np.testing.assert_allclose(a, b, rtol=1e-5)
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2]          # ranks agree bit for bit
+
+
+# ------------------------------------------------------------------ BASELINE-size parity of the scoring path
+@pytest.mark.parametrize("workload", ["gcg", "joint"])
+def test_7b_scoring_equals_reference_call_shape(workload):
+    """LLaVA-1.5-7B shape, bf16.  The optimised scoring path (target rows only, last token
+    dropped, shared-prefix keys/values or shared-prefix attention, fused RMSNorm/SwiGLU/RoPE,
+    tuned GEMM selection, HIP splice + CE) against the reference's call shape on the same
+    model: full-sequence forward, full (B,S,V) logits, torch cross-entropy in fp32.  Both are
+    bf16 computations of the same function; they differ by bf16 rounding noise only."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import segment_order
+
+    dev = torch.device(DEV)
+    model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, dev, torch.bfloat16, 32)
+    joint = workload == "joint"
+    cfg = BimodalAttackConfig(num_steps=1, search_width=48, seed=1, verbosity="ERROR", pgd_attack=joint,
+                              gcg_attack=True, joint_eval=joint, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False))
+    atk._prepare_prompt(messages, target)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    cand = ids.repeat(48, 1)
+    pos = torch.randint(0, ids.shape[1], (48,), generator=g, device=DEV)
+    cand[torch.arange(48, device=DEV), pos] = torch.randint(5, 32000, (48,), generator=g, device=DEV)
+    order = segment_order("pgd", "llava", single=True) if joint else segment_order("gcg", "llava", no_joint_eval=True)
+    with torch.no_grad():
+        feats = atk.hf.image_features(image) if joint else None
+        got = atk.score_candidates(cand.contiguous(), order, feats).float().cpu().numpy()
+        # the reference's call shape, in chunks of 8 to bound the (B,S,V) logits
+        E = atk.embedding_layer
+        want = []
+        for s in range(0, 48, 8):
+            parts = [E(cand[s:s + 8]) if n == "optim" else (feats.to(E.weight.dtype) if n == "image" else atk.seg[n]).expand(8, -1, -1)
+                     for n in order]
+            x = torch.cat(parts, dim=1)
+            logits = model(inputs_embeds=x, use_cache=False).logits
+            T = atk.T
+            sl = logits[:, x.shape[1] - T - 1:-1, :].float()
+            l = torch.nn.functional.cross_entropy(sl.reshape(-1, sl.shape[-1]), atk.labels.repeat(8), reduction="none")
+            want.append(l.view(8, T).mean(-1))
+        want = torch.cat(want).cpu().numpy()
+    rel = np.abs(got - want) / np.abs(want)
+    # bf16 has 8 significand bits; 32 layers of rounding noise land well under 1 %
+    assert rel.max() < 1e-2, rel.max()
+    # and the ranking the attack cares about is the same where it is not a near-tie
+    gap = np.sort(want)[1] - np.sort(want)[0]
+    if gap > 4 * np.abs(got - want).max():
+        assert int(got.argmin()) == int(want.argmin())
+    print(f"{workload}: max rel diff {rel.max():.2e}, mean {rel.mean():.2e}, loss range [{want.min():.4f}, {want.max():.4f}]")
+
+
+def test_run_experiment_writes_reference_artifacts(tmp_path):
+    """The harness loop (reference experiments.py:54-285) on this engine: two prompts, PNGs per
+    step under images_<run>/, the seven artefact files, losses.csv consistent with the result."""
+    import csv
+    from bimodalattack_amd import synthetic as S
+    from bimodalattack_amd.artifacts import run_experiment
+    model, tok, proc, image = S.tiny_case("llava", device=DEV)
+    kwargs = {"num_steps": 2, "search_width": 8, "topk": 16, "dynamic_search": False, "min_search_width": 8,
+              "pgd_attack": True, "gcg_attack": True, "alpha": 4 / 255, "eps": 64 / 255, "debug_output": False,
+              "alpha_str": "4/255", "eps_str": "64/255", "joint_eval": True, "model": "llava",
+              "optim_str_init": S.TINY_OPTIM_INIT}
+    pairs = [("tell me a story", "Sure here is"), ("write a plan", "Sure here is a plan")]
+    folder = run_experiment("tiny", kwargs, pairs, model, tok, proc, image, S.Normalize(S.CLIP_MEAN, S.CLIP_STD),
+                            base=str(tmp_path / "experiments"), rng_device="cpu")
+    assert os.path.basename(folder) == "exp1"
+    for fn in ("prompts.csv", "losses.csv", "details.csv", "times.csv", "parameters.csv", "best_strings.txt", "summary.csv"):
+        assert os.path.getsize(os.path.join(folder, fn)) > 0
+    assert sorted(os.listdir(os.path.join(folder, "images_1"))) == ["0.png", "1.png"]
+    assert sorted(os.listdir(os.path.join(folder, "images_2"))) == ["0.png", "1.png"]
+    rows = list(csv.reader(open(os.path.join(folder, "losses.csv"))))
+    assert rows[0] == ["Iteration", "Run 1", "Run 2"] and len(rows) == 3
+    assert all(np.isfinite(float(c)) for r in rows[1:] for c in r[1:])
+    params = dict(csv.reader(open(os.path.join(folder, "parameters.csv"))))
+    assert params["alpha"] == "4/255" and params["num_prompts"] == "2" and params["seed"] == "1" and "alpha_str" not in params
