@@ -149,6 +149,7 @@ class BimodalAttack:
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
         self._grad_graph = None                    # None: not tried yet; False: eager for good
         self._prefix_cache: Dict[tuple, tuple] = {}
+        self._rescore_graphs: Dict[tuple, object] = {}
         self._match: Optional[Tensor] = None
         self.fused = FusedInference(model, self.opt.fused_elementwise)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
@@ -264,10 +265,11 @@ class BimodalAttack:
         else:
             parts = [self.seg["before"], emb, self.seg["after"], self.seg["target"]]
         x = torch.cat(parts, dim=1)
-        if self.opt.target_rows_only:
-            logits = self.hf.target_logits(x[:, :-1], self.T, rows_only=True)
-        else:
-            logits = self.hf.target_logits(x, self.T, rows_only=False)
+        with self.fused:
+            if self.opt.target_rows_only:
+                logits = self.hf.target_logits(x[:, :-1], self.T, rows_only=True)
+            else:
+                logits = self.hf.target_logits(x, self.T, rows_only=False)
         loss = ops.TargetCrossEntropy.apply(logits[0], self.labels)
         wanted = ([emb] if cfg.gcg_attack else []) + ([image] if cfg.pgd_attack else [])
         grads = list(torch.autograd.grad(loss, wanted))
@@ -319,12 +321,13 @@ class BimodalAttack:
                 out.append(("shared", self.seg[name]))
         return out
 
-    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
+    def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
+                         allow_prefix: bool = True) -> Tensor:
         """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
         all-gathered to the full vector.  `order` ends in "target".  Only enqueues work: the
         host does not wait for the device here (unless an OOM forces a retry)."""
         with self.fused:
-            return self._score_candidates(sampled, order, feats)
+            return self._score_candidates(sampled, order, feats, allow_prefix)
 
     def _prefix(self, prefix_names: List[str], feats: Optional[Tensor]):
         """Keys/values of the segments in front of the suffix.  They depend on nothing but
@@ -348,7 +351,8 @@ class BimodalAttack:
             self._prefix_cache[key] = out
         return out
 
-    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor]) -> Tensor:
+    def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
+                          allow_prefix: bool = True) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         lo, hi = self.shard.bounds(n)
@@ -358,7 +362,8 @@ class BimodalAttack:
         feats = None if feats is None else feats.to(E.dtype)
         rows_only = self.opt.target_rows_only
         prefix_names, tail_names = split_at_suffix(order)
-        use_prefix = bool(self.opt.prefix_reuse and rows_only and prefix_names and hf.prefix_ok is not False and m > 0)
+        use_prefix = bool(allow_prefix and self.opt.prefix_reuse and rows_only and prefix_names
+                          and hf.prefix_ok is not False and m > 0)
 
         cache, P = None, 0
         if use_prefix:
@@ -373,7 +378,7 @@ class BimodalAttack:
         segs = self._segments(names, feats)
         L = sum((mine.shape[1] if k == "gather" else t.shape[-2]) for k, t in segs)
 
-        free = torch.cuda.mem_get_info(self.model.device)[0]
+        free = torch.cuda.mem_get_info(self.model.device)[0] if m > 1 else (1 << 40)   # one candidate always fits
         chunk = plan_chunk(max(m, 1), L, P if (use_prefix and not shared) else 0, hf.kv_bytes_per_token,
                            hf.act_bytes_per_token, free,
                            cfg.batch_size if cfg.batch_size is not None else self.opt.chunk)
@@ -418,6 +423,32 @@ class BimodalAttack:
         if self.opt.loss_in_model_dtype:
             full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
         return full
+
+    def rescore_winner(self, winner: Tensor, order: List[str], feats: Tensor) -> Tensor:
+        """Loss of the step winner scored alone, with the image, on every rank (:605-612).
+        One candidate shares nothing with anybody: one plain full-sequence forward (no prefix
+        cache), fixed shapes, replayed from a hipGraph after the first call."""
+        def eager(ids, f):
+            keep, self.shard = self.shard, _SOLO
+            try:
+                return self.score_candidates(ids, order, f, allow_prefix=False)
+            finally:
+                self.shard = keep
+
+        key = tuple(order)
+        if not self.opt.graph_rescore or self._rescore_graphs.get(key) is False:
+            return eager(winner, feats)
+        g = self._rescore_graphs.get(key)
+        if g is None:
+            try:
+                g = _ReplayGraph(self.model.device, eager, winner, feats)
+            except Exception as e:
+                logger.warning(f"winner re-scoring not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._rescore_graphs[key] = False
+                torch.cuda.synchronize(self.model.device)
+                return eager(winner, feats)
+            self._rescore_graphs[key] = g
+        return g(winner, feats)
 
     # ------------------------------------------------------------ buffer init
     def init_buffer(self, image) -> AttackBuffer:
@@ -587,11 +618,7 @@ class BimodalAttack:
                         best_idx = int(loss.argmin().item()) if loss is not None else 0
                         winner = sampled[best_idx:best_idx + 1].contiguous()
                         # re-score the winner with the image (:605-612); on every rank, unsharded
-                        keep_shard, self.shard = self.shard, _SOLO
-                        try:
-                            full = self.score_candidates(winner, segment_order("gcg_pgd", mt), feats)
-                        finally:
-                            self.shard = keep_shard
+                        full = self.rescore_winner(winner, segment_order("gcg_pgd", mt), feats)
                         if cfg.early_stop and self._match is not None and bool(self._match.any().item()):
                             self.stop_flag = True
                         if self.shard.enabled:
@@ -689,6 +716,31 @@ class _GradientGraph:
             self.ids.copy_(optim_ids)
             if self.image is not None:
                 self.image.copy_(image)
+        self.graph.replay()
+        return self.out
+
+
+class _ReplayGraph:
+    """A fixed-shape, sync-free function of device tensors as one hipGraph: static input
+    buffers are overwritten before each replay, the (static) outputs stay valid until the
+    next one."""
+
+    def __init__(self, device, fn, *inputs: Tensor):
+        self.inputs = [t.detach().clone() for t in inputs]
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), torch.no_grad():      # lazy initialisations stay out of the capture
+            fn(*self.inputs)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = fn(*self.inputs)
+
+    def __call__(self, *inputs: Tensor):
+        with torch.no_grad():
+            for dst, src in zip(self.inputs, inputs):
+                dst.copy_(src)
         self.graph.replay()
         return self.out
 

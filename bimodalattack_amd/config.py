@@ -93,6 +93,9 @@ class EngineOptions:
     # (~1500 small kernels around 7 ms of weight streaming).  Falls back to eager, once and
     # for good, if the model's forward cannot be captured.
     graph_gradient: bool = True
+    # Likewise for the batch-1 re-scoring of the step winner with the image (reference
+    # :605-612; every PGD mode): prefix pass + tail forward + CE are launch-bound at batch 1.
+    graph_rescore: bool = True
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
@@ -130,6 +133,8 @@ class EngineOptions:
             opts.prefix_reuse = env["BMA_PREFIX_REUSE"] not in ("0", "false", "False")
         if "BMA_TARGET_ROWS_ONLY" in env:
             opts.target_rows_only = env["BMA_TARGET_ROWS_ONLY"] not in ("0", "false", "False")
+        if "BMA_GRAPH_RESCORE" in env:
+            opts.graph_rescore = env["BMA_GRAPH_RESCORE"] not in ("0", "false", "False")
         if "BMA_GRAPH_GRADIENT" in env:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:

@@ -368,3 +368,162 @@ extern "C" int bma_attn_merge(const void* o1, const void* o2, const float* lse1,
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }
+
+// ---------------------------------------------------------------------------- backward passes
+// The gradient pass (reference :953-1028) runs the same layers under autograd at batch 1:
+// ~2900 tiny eager kernels around 13 ms of weight-streaming GEMMs.  These kernels are the
+// backward halves of the fused forward ops, so the whole pass (captured in a hipGraph) needs
+// one launch per op and direction.  All math in fp32, one rounding to the model dtype.
+//
+//   rmsnorm_bwd : g = dy*w (Llama) or dy*(1+w) (Gemma);  r = rsqrt(mean(x^2)+eps)
+//                 dx = r*g - x * r^3 * sum(g*x)/D          (weights are constants here: no dw)
+//   swiglu_bwd  : s = sigmoid(g);  d_up = dy * dt(g*s);  d_gate = dy * u * s*(1 + g*(1-s))
+//   rope bwd    : the rotation is orthogonal -- backward is the forward kernel with -sin.
+namespace {
+
+template <int DT, int NCH, bool GEMMA>
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint4_t* __restrict__ x,
+                                                                   const uint4_t* __restrict__ w,
+                                                                   const uint4_t* __restrict__ dy, float eps, int cpr,
+                                                                   int D, uint4_t* __restrict__ dx) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  float xv[NCH][NE], gv[NCH][NE];
+  float ss = 0.0f, sg = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float wf[NE], dyf[NE];
+      Chunk<DT>::unpack(x[row * cpr + i], xv[c]);
+      Chunk<DT>::unpack(dy[row * cpr + i], dyf);
+      Chunk<DT>::unpack(w[i], wf);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        gv[c][j] = dyf[j] * (GEMMA ? 1.0f + wf[j] : wf[j]);
+        ss += xv[c][j] * xv[c][j];
+        sg += gv[c][j] * xv[c][j];
+      }
+    }
+  }
+  ss = bma::wave_sum(ss);
+  sg = bma::wave_sum(sg);
+  __shared__ float part[2][kNormThreads / 64];
+  if ((tid & 63) == 0) { part[0][tid >> 6] = ss; part[1][tid >> 6] = sg; }
+  __syncthreads();
+  float tss = 0.0f, tsg = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kNormThreads / 64; ++i) { tss += part[0][i]; tsg += part[1][i]; }
+  const float r = 1.0f / sqrtf(tss / static_cast<float>(D) + eps);
+  const float k = r * r * r * tsg / static_cast<float>(D);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float o[NE];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) o[j] = r * gv[c][j] - xv[c][j] * k;
+      dx[row * cpr + i] = Chunk<DT>::pack(o);
+    }
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
+                                                         const uint4_t* __restrict__ dy, int64_t n_chunks,
+                                                         uint4_t* __restrict__ dg, uint4_t* __restrict__ du) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_chunks; i += stride) {
+    float gf[NE], uf[NE], df[NE], og[NE], ou[NE];
+    Chunk<DT>::unpack(g[i], gf);
+    Chunk<DT>::unpack(u[i], uf);
+    Chunk<DT>::unpack(dy[i], df);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const float s = 1.0f / (1.0f + expf(-gf[j]));
+      ou[j] = df[j] * rnd<DT>(gf[j] * s);                       // the forward kept silu(g) in the model dtype
+      og[j] = df[j] * uf[j] * (s * (1.0f + gf[j] * (1.0f - s)));
+    }
+    dg[i] = Chunk<DT>::pack(og);
+    du[i] = Chunk<DT>::pack(ou);
+  }
+}
+
+template <int DT>
+int launch_rmsnorm_bwd(const void* x, const void* w, const void* dy, float eps, int64_t rows, int D, int gemma,
+                       void* dx, hipStream_t st) {
+  constexpr int ES = bma::elem_bytes<DT>::value;
+  const int cpr = static_cast<int>(static_cast<int64_t>(D) * ES / 16);
+  const int nch = (cpr + kNormThreads - 1) / kNormThreads;
+  if (nch > kNormMaxChunks) return BMA_ELIMIT;   // x and g rows stay in registers: D*es <= 16 KiB
+  const dim3 grid(static_cast<unsigned>(rows)), block(kNormThreads);
+  const uint4_t* xp = static_cast<const uint4_t*>(x);
+  const uint4_t* wp = static_cast<const uint4_t*>(w);
+  const uint4_t* dp = static_cast<const uint4_t*>(dy);
+  uint4_t* op = static_cast<uint4_t*>(dx);
+#define BMA_NB_GO(N)                                                                                                \
+  do {                                                                                                              \
+    if (gemma) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, N, true>), grid, block, 0, st, xp, wp, dp, eps, cpr, D, op); \
+    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, N, false>), grid, block, 0, st, xp, wp, dp, eps, cpr, D, op);      \
+  } while (0)
+  switch (nch) {
+    case 1: BMA_NB_GO(1); break;
+    case 2: BMA_NB_GO(2); break;
+    case 3: BMA_NB_GO(3); break;
+    default: BMA_NB_GO(4); break;
+  }
+#undef BMA_NB_GO
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+}  // namespace
+
+extern "C" int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy, float eps, int64_t rows, int D,
+                               int dtype, int gemma_style, void* dx, void* stream) {
+  if (rows < 0 || D <= 0 || rows > 0x7fffffffLL) return BMA_EINVAL;
+  if (rows == 0) return BMA_OK;
+  if (!x || !weight || !dy || !dx) return BMA_EINVAL;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((static_cast<int64_t>(D) * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(dy) |
+       reinterpret_cast<uintptr_t>(dx)) % 16)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BMA_F32: return launch_rmsnorm_bwd<BMA_F32>(x, weight, dy, eps, rows, D, gemma_style, dx, st);
+    case BMA_BF16: return launch_rmsnorm_bwd<BMA_BF16>(x, weight, dy, eps, rows, D, gemma_style, dx, st);
+    case BMA_F16: return launch_rmsnorm_bwd<BMA_F16>(x, weight, dy, eps, rows, D, gemma_style, dx, st);
+    default: return BMA_EDTYPE;
+  }
+}
+
+extern "C" int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, void* dgate,
+                              void* dup, void* stream) {
+  if (n < 0) return BMA_EINVAL;
+  if (n == 0) return BMA_OK;
+  if (!gate || !up || !dy || !dgate || !dup) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((n * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(up) | reinterpret_cast<uintptr_t>(dy) |
+       reinterpret_cast<uintptr_t>(dgate) | reinterpret_cast<uintptr_t>(dup)) % 16)
+    return BMA_EALIGN;
+  const int64_t chunks = n * es / 16;
+  int64_t blocks = (chunks + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const uint4_t* g = static_cast<const uint4_t*>(gate);
+  const uint4_t* u = static_cast<const uint4_t*>(up);
+  const uint4_t* d = static_cast<const uint4_t*>(dy);
+  uint4_t* og = static_cast<uint4_t*>(dgate);
+  uint4_t* ou = static_cast<uint4_t*>(dup);
+  if (dtype == BMA_F32) hipLaunchKernelGGL((swiglu_bwd_kernel<BMA_F32>), grid, block, 0, st, g, u, d, chunks, og, ou);
+  else if (dtype == BMA_BF16) hipLaunchKernelGGL((swiglu_bwd_kernel<BMA_BF16>), grid, block, 0, st, g, u, d, chunks, og, ou);
+  else hipLaunchKernelGGL((swiglu_bwd_kernel<BMA_F16>), grid, block, 0, st, g, u, d, chunks, og, ou);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}

@@ -1,10 +1,12 @@
 """Fused inference path for the elementwise tail of Llama-family decoder layers.
 
-While a :class:`FusedInference` context is active AND autograd is off, the RMSNorm
-modules, SiLU-gated MLPs and rotary-embedding function of the given HuggingFace model run
-the one-pass kernels of ``csrc/fused_elementwise.hip`` instead of their eager op chains.
-Outside the context -- and whenever gradients are recorded (the gradient pass), the input
-is not on the GPU, or a shape is beyond the kernels' limits -- the original code runs.
+While a :class:`FusedInference` context is active, the RMSNorm modules, SiLU-gated MLPs and
+rotary-embedding function of the given HuggingFace model run the one-pass kernels of
+``csrc/fused_elementwise.hip`` instead of their eager op chains: directly when autograd is
+off (candidate scoring), through autograd Functions with fused backward kernels when a
+gradient is being recorded (the gradient pass; weights are treated as constants -- if a
+norm weight requires grad the eager module runs).  Outside the context -- or when the input
+is not on the GPU or a shape is beyond the kernels' limits -- the original code runs.
 Nothing is left on the user's model afterwards: patches are instance attributes removed
 on exit.
 
@@ -65,7 +67,15 @@ class FusedInference:
     # -- the replacements ----------------------------------------------------------------
     @staticmethod
     def _usable(x: torch.Tensor) -> bool:
-        return (not torch.is_grad_enabled()) and x.is_cuda and x.dtype in _DTYPES
+        return x.is_cuda and x.dtype in _DTYPES
+
+    @staticmethod
+    def _tracking(*ts) -> bool:
+        return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
+    # NOTE on weights: inside this context they are constants.  The engine borrows the model
+    # read-only and calls torch.autograd.grad w.r.t. inputs only, so a norm weight that happens
+    # to have requires_grad=True (HF's default after from_pretrained) gets no gradient here.
 
     def _norm_forward(self, m, eps, gemma, orig):
         def forward(x):
@@ -73,6 +83,10 @@ class FusedInference:
             if not self._usable(x) or (D * x.element_size()) % 16 or D * x.element_size() > 16384 \
                     or m.weight.dtype != x.dtype:
                 return orig(x)
+            if self._tracking(x):
+                # the weight is a constant to the fused backward (the engine only ever asks for
+                # gradients w.r.t. inputs)
+                return ops.RMSNormFn.apply(x, m.weight, eps, gemma)
             return ops.rmsnorm(x, m.weight, eps, gemma)
         return forward
 
@@ -83,6 +97,8 @@ class FusedInference:
             g, u = m.gate_proj(x), m.up_proj(x)
             if (g.numel() * g.element_size()) % 16:
                 return m.down_proj(m.act_fn(g) * u)
+            if self._tracking(g, u):
+                return m.down_proj(ops.SwiGLUFn.apply(g, u))
             return m.down_proj(ops.swiglu(g, u))
         return forward
 
@@ -97,6 +113,10 @@ class FusedInference:
                   and all((s * q.element_size()) % 16 == 0 for s in q.stride()[:3] + k.stride()[:3]))
             if not ok:
                 return orig(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kw)
+            if self._tracking(q, k):
+                if cos.requires_grad or sin.requires_grad:
+                    return orig(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kw)
+                return ops.RoPEFn.apply(q, cos, sin), ops.RoPEFn.apply(k, cos, sin)
             ops.rope_(q, cos, sin)
             ops.rope_(k, cos, sin)
             return q, k

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "bma_swiglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bma_rope_inplace": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p]),
+    "bma_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bma_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "bma_attn_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p]),
     "bma_profile_enable": (c_int, [c_int]),

@@ -294,3 +294,58 @@ def attn_merge(o1: torch.Tensor, o2: torch.Tensor, lse1: torch.Tensor, lse2: tor
     check("bma_attn_merge", lib.bma_attn_merge(o1.data_ptr(), o2.data_ptr(), lse1.data_ptr(), lse2.data_ptr(), B, L, H, Dh,
                                                _dt(o2), out.data_ptr(), _stream(dev)))
     return out
+
+
+# ---------------------------------------------------------------------------
+# the same ops under autograd (the gradient pass): fused forward + fused backward
+class RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, eps, gemma_style):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc, weight)
+        ctx.eps, ctx.gemma = float(eps), bool(gemma_style)
+        return rmsnorm(xc, weight, eps, gemma_style)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        # the engine borrows the model's weights read-only and only ever asks autograd for
+        # gradients w.r.t. inputs: no weight gradient is produced, whatever requires_grad says
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        D = x.shape[-1]
+        check("bma_rmsnorm_bwd", lib.bma_rmsnorm_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), ctx.eps, x.numel() // D, D,
+                                                     _dt(x), 1 if ctx.gemma else 0, dx.data_ptr(), _stream(x.device)))
+        return dx, None, None, None
+
+
+class SwiGLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate, up):
+        g, u = gate.contiguous(), up.contiguous()
+        ctx.save_for_backward(g, u)
+        return swiglu(g, u)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g, u = ctx.saved_tensors
+        dy = dy.contiguous()
+        dg, du = torch.empty_like(g), torch.empty_like(u)
+        check("bma_swiglu_bwd", lib.bma_swiglu_bwd(g.data_ptr(), u.data_ptr(), dy.data_ptr(), g.numel(), _dt(g),
+                                                   dg.data_ptr(), du.data_ptr(), _stream(g.device)))
+        return dg, du
+
+
+class RoPEFn(torch.autograd.Function):
+    """Out of place under autograd (batch-1 tensors are tiny); the rotation is orthogonal, so
+    the backward is the same kernel with -sin."""
+
+    @staticmethod
+    def forward(ctx, q, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        return rope_(q.clone(), cos, sin)
+
+    @staticmethod
+    def backward(ctx, dq):
+        cos, sin = ctx.saved_tensors
+        return rope_(dq.clone(), cos, -sin), None, None

@@ -154,6 +154,13 @@ int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out
 int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l,
                      int B, int H, int L, int Dh, const void* cos, const void* sin,
                      int cos_batch, int dtype, void* stream);
+/* Backward halves, used by the gradient pass (autograd at batch 1; weights are constants, so no
+ * weight gradients): bma_rmsnorm_bwd: dx from x, weight, dy (D*es <= 16 KiB);
+ * bma_swiglu_bwd: dgate, dup from gate, up, dy.  RoPE's backward is bma_rope_inplace with -sin. */
+int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy, float eps, int64_t rows,
+                    int D, int dtype, int gemma_style, void* dx, void* stream);
+int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype,
+                   void* dgate, void* dup, void* stream);
 /* bma_attn_merge: merges the two partial attentions of the shared-prefix scheme (new tokens
  *   vs the prompt prefix shared by all candidates; new tokens vs themselves, causal):
  *   out = w*o1 + (1-w)*o2 with w = 1/(1+exp(lse2-lse1)).  o1, o2, out: [B][L][H][Dh] contiguous

@@ -188,3 +188,74 @@ def test_shared_prefix_forward_equals_cache_forward(dtype):
     assert torch.equal(again, want)                                   # attention implementation restored
     tol = 1e-4 if dtype == torch.float32 else 5e-2
     assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
+# ------------------------------------------------------------------ fused ops under autograd
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_backward_matches_eager_autograd(dtype):
+    """dL/dx of the fused Functions against autograd through the eager HuggingFace modules."""
+    from bimodalattack_amd import ops
+    from transformers.models.gemma3.modeling_gemma3 import Gemma3RMSNorm
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm, apply_rotary_pos_emb
+    g = torch.Generator(device=DEV).manual_seed(9)
+    tol = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+
+    def close(a, b, what):
+        a, b = a.float(), b.float()
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= tol["atol"] * scale + tol["rtol"] * scale, what
+
+    rows, D = 65, 4096
+    x = (torch.randn((1, rows, D), generator=g, device=DEV) * 2).to(dtype)
+    dy = torch.randn((1, rows, D), generator=g, device=DEV).to(dtype)
+    for gemma, cls in ((False, LlamaRMSNorm), (True, Gemma3RMSNorm)):
+        m = cls(D, eps=1e-5).to(DEV, dtype)
+        with torch.no_grad():
+            m.weight.copy_((torch.randn(D, generator=g, device=DEV) * 0.3 + (0.0 if gemma else 1.0)).to(dtype))
+        xe = x.clone().requires_grad_()
+        (we,) = torch.autograd.grad(m(xe), xe, dy)
+        xf = x.clone().requires_grad_()
+        (wf,) = torch.autograd.grad(ops.RMSNormFn.apply(xf, m.weight, 1e-5, gemma), xf, dy)
+        close(wf, we, f"rmsnorm gemma={gemma}")
+
+    a = (torch.randn((1, rows, 11008), generator=g, device=DEV) * 2).to(dtype)
+    b = torch.randn((1, rows, 11008), generator=g, device=DEV).to(dtype)
+    d = torch.randn((1, rows, 11008), generator=g, device=DEV).to(dtype)
+    ae, be = a.clone().requires_grad_(), b.clone().requires_grad_()
+    ge = torch.autograd.grad(torch.nn.functional.silu(ae) * be, (ae, be), d)
+    af, bf = a.clone().requires_grad_(), b.clone().requires_grad_()
+    gf = torch.autograd.grad(ops.SwiGLUFn.apply(af, bf), (af, bf), d)
+    close(gf[0], ge[0], "swiglu d_gate")
+    close(gf[1], ge[1], "swiglu d_up")
+
+    B, L, H, Dh = 1, rows, 32, 128
+    q = torch.randn((B, L, H * Dh), generator=g, device=DEV).to(dtype)
+    ang = torch.rand((1, L, Dh // 2), generator=g, device=DEV) * 6.28
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(dtype), emb.sin().to(dtype)
+    dq = torch.randn((B, H, L, Dh), generator=g, device=DEV).to(dtype)
+    qe = q.clone().requires_grad_()
+    (re,) = torch.autograd.grad(apply_rotary_pos_emb(qe.view(B, L, H, Dh).transpose(1, 2), qe.view(B, L, H, Dh).transpose(1, 2), cos, sin)[0], qe, dq)
+    qf = q.clone().requires_grad_()
+    (rf,) = torch.autograd.grad(ops.RoPEFn.apply(qf.view(B, L, H, Dh).transpose(1, 2), cos, sin), qf, dq)
+    close(rf, re, "rope")
+
+
+def test_gradient_pass_fused_equals_eager_gradient():
+    """The whole gradient pass on a small Llama: token gradient with the fused autograd ops
+    against the eager HuggingFace backward (fp32: to 1e-4 of the gradient's scale)."""
+    from bimodalattack_amd.fused import FusedInference
+    model = _small_llama(torch.float32)
+    D = model.get_input_embeddings().weight.shape[1]
+    x = (torch.randn((1, 20, D), device=DEV) * 0.5)
+    w = torch.randn((1, 20, 264), device=DEV)
+
+    def grad(fused):
+        xi = x.clone().requires_grad_()
+        ctx = FusedInference(model, fused)
+        with ctx:
+            out = model(inputs_embeds=xi, use_cache=False).logits
+        return torch.autograd.grad((out * w).sum(), xi)[0]
+
+    ge, gf = grad(False), grad(True)
+    assert float((ge - gf).abs().max()) <= 1e-4 * float(ge.abs().max())
