@@ -28,6 +28,9 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+# the CLIP patch-embedding convolution would otherwise trigger MIOpen's exhaustive kernel search on a
+# fresh machine (~2 minutes before the first PGD step); must be set before MIOpen initialises
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 _T0 = time.perf_counter()
 
