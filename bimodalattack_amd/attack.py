@@ -150,6 +150,8 @@ class BimodalAttack:
         self._grad_graph = None                    # None: not tried yet; False: eager for good
         self._prefix_cache: Dict[tuple, tuple] = {}
         self._rescore_graphs: Dict[tuple, object] = {}
+        self._feat_graph = None                    # image -> image features (no autograd)
+        self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
         self.fused = FusedInference(model, self.opt.fused_elementwise)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
@@ -279,7 +281,7 @@ class BimodalAttack:
             with torch.no_grad():
                 g_tok = (g_emb @ E.t()).unsqueeze(0)      # (1, n_opt, V), model dtype
         g_img = grads.pop(0) if cfg.pgd_attack else None
-        return g_tok, g_img
+        return g_tok, g_img, loss.detach()
 
     def perform_pgd_step(self, image: Tensor, eps: float, alpha: float, image_grad: Tensor,
                          image_original: Tensor) -> Tensor:
@@ -329,6 +331,28 @@ class BimodalAttack:
         with self.fused:
             return self._score_candidates(sampled, order, feats, allow_prefix)
 
+    def scoring_features(self, image: Tensor) -> Tensor:
+        """Image features for scoring (no autograd): the vision tower at batch 1 is launch-bound,
+        so it is replayed from a hipGraph after the first call."""
+        if not self.opt.graph_prefix or self._feat_graph is False:
+            return self.hf.image_features(image)
+        if self._feat_graph is None:
+            try:
+                self._feat_graph = _ReplayGraph(self.model.device, self.hf.image_features, image)
+            except Exception as e:
+                logger.warning(f"image features not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._feat_graph = False
+                torch.cuda.synchronize(self.model.device)
+                return self.hf.image_features(image)
+        return self._feat_graph(image)
+
+    def _wants_shared(self, P: int) -> bool:
+        # worth it when the prefix is long: for a 21-token prefix the merge pass costs what
+        # the per-candidate copy costs (measured: 270 vs 264 ms at P=21, 333 vs 714 ms at P=599)
+        hf = self.hf
+        return bool(self.opt.shared_prefix_attention and hf.shared_ok is not False
+                    and P >= self.opt.shared_prefix_min_tokens and hf.shared_prefix_configs())
+
     def _prefix(self, prefix_names: List[str], feats: Optional[Tensor]):
         """Keys/values of the segments in front of the suffix.  They depend on nothing but
         the prompt -- and on the image when it is part of the prefix -- so a text-only prefix
@@ -337,12 +361,20 @@ class BimodalAttack:
         key = tuple(prefix_names)
         if "image" not in prefix_names and key in self._prefix_cache:
             return self._prefix_cache[key]
-        prefix = torch.cat([feats if p == "image" else self.seg[p] for p in prefix_names], dim=1)
-        P = prefix.shape[1]
+        def cat_prefix(f):
+            return torch.cat([f if p == "image" else self.seg[p] for p in prefix_names], dim=1)
+
+        P = sum((feats.shape[1] if p == "image" else self.seg[p].shape[1]) for p in prefix_names)
         cache = None
         if P > 0:
             try:
-                cache = hf.build_prefix(prefix)
+                if self._wants_shared(P):
+                    try:
+                        cache = self._recorded_prefix(key, cat_prefix, feats)
+                    except Exception as e:
+                        logger.warning(f"recording prefix pass failed ({type(e).__name__}: {e}); using the HF cache")
+                if cache is None:
+                    cache = hf.build_prefix(cat_prefix(feats))
             except Exception as e:  # a model without cache support: remember, use the full sequence
                 logger.warning(f"prefix reuse disabled: {type(e).__name__}: {e}")
             hf.prefix_ok = cache is not None
@@ -350,6 +382,29 @@ class BimodalAttack:
         if "image" not in prefix_names:
             self._prefix_cache[key] = out
         return out
+
+    def _recorded_prefix(self, key: tuple, cat_prefix, feats: Optional[Tensor]):
+        """Prefix keys/values through a RecordingKV.  With an image in the prefix this runs every
+        step at batch 1 (launch-bound): captured into a hipGraph keyed by the layout."""
+        hf = self.hf
+
+        def build(f):
+            return hf.build_prefix_recording(cat_prefix(f))
+
+        if feats is None or not self.opt.graph_prefix or self._prefix_graphs.get(key) is False:
+            return build(feats)
+        g = self._prefix_graphs.get(key)
+        if g is None:
+            try:
+                with self.fused:
+                    g = _ReplayGraph(self.model.device, build, feats)
+            except Exception as e:
+                logger.warning(f"prefix pass not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._prefix_graphs[key] = False
+                torch.cuda.synchronize(self.model.device)
+                return build(feats)
+            self._prefix_graphs[key] = g
+        return g(feats)
 
     def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
                           allow_prefix: bool = True) -> Tensor:
@@ -369,10 +424,7 @@ class BimodalAttack:
         if use_prefix:
             cache, P = self._prefix(prefix_names, feats)
             use_prefix = cache is not None
-        # worth it when the prefix is long: for a 21-token prefix the merge pass costs what
-        # the per-candidate copy costs (measured: 270 vs 264 ms at P=21, 333 vs 714 ms at P=599)
-        shared = bool(use_prefix and self.opt.shared_prefix_attention and hf.shared_ok is not False
-                      and P >= self.opt.shared_prefix_min_tokens and hf.shared_prefix_configs())
+        shared = bool(use_prefix and self._wants_shared(P))
         names = tail_names if use_prefix else list(order)
         names = [("target_in" if (t == "target" and rows_only) else t) for t in names]
         segs = self._segments(names, feats)
@@ -402,6 +454,11 @@ class BimodalAttack:
                             raise
                         logger.warning(f"shared-prefix attention disabled: {type(e).__name__}: {e}")
                         hf.shared_ok, shared = False, False
+                        self._prefix_cache.clear()                  # rebuild the prefix as an HF cache
+                        cache, P = self._prefix(prefix_names, feats)
+                        use_prefix = cache is not None
+                        if not use_prefix:
+                            raise
                 if not shared:
                     kv = hf.expand_prefix(cache, b) if use_prefix else None
                     logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
@@ -530,6 +587,11 @@ class BimodalAttack:
         try:
             hook = self.opt.step_hook
             n_done = 0
+            pending = None
+            # PGD-only: nothing is sampled, so the loss of the updated image can come out of the
+            # next step's gradient pass (fuse_pgd_only); early_stop needs the argmax test of a
+            # scoring call, so it keeps the plain loop
+            fuse_pgd = bool(self.opt.fuse_pgd_only and cfg.pgd_attack and not cfg.gcg_attack and not cfg.early_stop)
             for i in range(cfg.num_steps):
                 if hook is not None:
                     hook(i)
@@ -540,20 +602,29 @@ class BimodalAttack:
                     st.update(optim_ids_in=optim_ids.cpu().numpy(), n_grad=0, grad_tok=[], grad_img=[], losses=[])
 
                 # ---- phase A: gradients --------------------------------------------------
-                def grad_pass():
-                    t0 = self._sync()
-                    g = self.compute_gradient(optim_ids, image if cfg.pgd_attack else None)
-                    dt = self._sync() - t0
-                    t_grad.append(dt)
+                def note(g):
                     if st is not None:
                         st["n_grad"] += 1
                         if g[0] is not None:
                             st["grad_tok"].append(g[0][0].float().cpu().numpy())
                         if g[1] is not None:
                             st["grad_img"].append(g[1].cpu().numpy())
+
+                def grad_pass(record: bool = True):
+                    t0 = self._sync()
+                    g = self.compute_gradient(optim_ids, image if cfg.pgd_attack else None)
+                    dt = self._sync() - t0
+                    t_grad.append(dt)
+                    if record:
+                        note(g)
                     return g, dt
 
-                (g_tok, g_img), grad_time = grad_pass()
+                if pending is not None:        # PGD-only: computed while scoring the previous step
+                    (g_tok, g_img, _), grad_time = pending
+                    note((g_tok, g_img))
+                    pending = None
+                else:
+                    (g_tok, g_img, _), grad_time = grad_pass()
 
                 # ---- phase B: PGD update; phase C: second gradient pass -------------------
                 pgd_time = 0.0
@@ -568,7 +639,7 @@ class BimodalAttack:
                     if st is not None:
                         st["image_after_pgd"] = image.detach().cpu().numpy()
                     if cfg.gcg_attack and not cfg.joint_eval:
-                        (g_tok, g_img), grad_time = grad_pass()
+                        (g_tok, g_img, _), grad_time = grad_pass()
 
                 # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
@@ -605,8 +676,23 @@ class BimodalAttack:
                             st["losses"].append(out[0].float().cpu().numpy())
                         return out
 
-                    if cfg.pgd_attack:
-                        feats = self.hf.image_features(image)
+                    prefetch_s = 0.0
+                    if fuse_pgd and i + 1 < cfg.num_steps:
+                        # the forward of the NEXT gradient pass scores the image just updated
+                        with torch.enable_grad():
+                            pending = grad_pass(record=False)
+                        prefetch_s = pending[1]
+                        full = pending[0][2].reshape(1)
+                        if self.opt.loss_in_model_dtype:
+                            full = full.to(self.model.dtype)
+                        if self.shard.enabled:
+                            self.shard.broadcast_(full)
+                        current_loss = full.item()
+                        best_idx, sampled, winner = 0, sampled_all, sampled_all[0:1].contiguous()
+                        if st is not None:
+                            st["losses"].append(full.float().cpu().numpy())
+                    elif cfg.pgd_attack:
+                        feats = self.scoring_features(image)
                         if cfg.joint_eval:
                             loss, sampled = survivors(self.score_candidates(
                                 sampled_all, segment_order("pgd", mt, single=True), feats))
@@ -641,7 +727,7 @@ class BimodalAttack:
                     self.n_scored.append(n)
                     if st is not None:
                         st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
-                loss_time = self._sync() - t0
+                loss_time = max(self._sync() - t0 - prefetch_s, 0.0)   # a prefetched gradient pass is booked as gradient time
                 if cfg.gcg_attack:
                     # the reference books the filter under "sampling"; it ran inside this section
                     samp_time += job.seconds

@@ -96,6 +96,9 @@ class EngineOptions:
     # Likewise for the batch-1 re-scoring of the step winner with the image (reference
     # :605-612; every PGD mode): prefix pass + tail forward + CE are launch-bound at batch 1.
     graph_rescore: bool = True
+    # ... and for the per-step image-features + shared-prefix pass of joint scoring (vision tower
+    # forward, then the prompt+image prefix through the LM with a recording cache).
+    graph_prefix: bool = True
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
@@ -107,6 +110,10 @@ class EngineOptions:
     # TunableOp in lookup-only mode when its validators (torch / hipBLASLt / rocBLAS versions,
     # arch) match this process; "off" leaves the library heuristics alone.
     gemm_tuning: str = "auto"
+    # PGD-only: the forward that scores the updated image at step i IS the forward of step
+    # i+1's gradient pass (same ids, same image).  Run it once: one forward+backward per step
+    # instead of two forwards and a backward.  Same numbers, same lists in the result.
+    fuse_pgd_only: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
     # Write images_folder/{i}.png every step (reference side effect, :744).
@@ -135,6 +142,8 @@ class EngineOptions:
             opts.target_rows_only = env["BMA_TARGET_ROWS_ONLY"] not in ("0", "false", "False")
         if "BMA_GRAPH_RESCORE" in env:
             opts.graph_rescore = env["BMA_GRAPH_RESCORE"] not in ("0", "false", "False")
+        if "BMA_GRAPH_PREFIX" in env:
+            opts.graph_prefix = env["BMA_GRAPH_PREFIX"] not in ("0", "false", "False")
         if "BMA_GRAPH_GRADIENT" in env:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
@@ -143,6 +152,8 @@ class EngineOptions:
             opts.shared_prefix_attention = env["BMA_SHARED_PREFIX_ATTENTION"] not in ("0", "false", "False")
         if "BMA_GEMM_TUNING" in env:
             opts.gemm_tuning = env["BMA_GEMM_TUNING"]
+        if "BMA_FUSE_PGD_ONLY" in env:
+            opts.fuse_pgd_only = env["BMA_FUSE_PGD_ONLY"] not in ("0", "false", "False")
         if "BMA_CHUNK" in env:
             opts.chunk = int(env["BMA_CHUNK"])
         if "BMA_SAVE_IMAGES" in env:

@@ -119,6 +119,17 @@ class HFAdapter:
             self._shared_cfgs = pa.eligible_configs(self.model) if ok else []
         return self._shared_cfgs
 
+    def build_prefix_recording(self, prefix_embeds: torch.Tensor):
+        """Prefix keys/values through a RecordingKV (prefix_attention.py): for the shared-prefix
+        attention path; no HuggingFace cache object is involved."""
+        from . import prefix_attention as pa
+        rec = pa.RecordingKV(self.n_layers)
+        kw = {"logits_to_keep": 1} if self.has_logits_to_keep else {}
+        self.model(inputs_embeds=prefix_embeds, past_key_values=rec, **kw)
+        if any(k is None for k in rec.k):
+            raise RuntimeError("the model did not report keys/values for every layer")
+        return rec
+
     def target_logits_shared_prefix(self, embeds: torch.Tensor, T: int, cache) -> torch.Tensor:
         """Like ``target_logits(..., cache=expand_prefix(cache, B))`` but the prefix keys/values
         are never copied per candidate (prefix_attention.py).  embeds: (B,L,D), the part behind

@@ -42,6 +42,43 @@ except Exception:  # pragma: no cover
     _CacheBase = object
 
 
+class RecordingKV(_CacheBase):
+    """The cache handed to the model for the PREFIX pass: it keeps a reference to every
+    layer's keys/values (after rotary embedding) and hands them straight back -- nothing is
+    concatenated, nothing is allocated, no host value reaches the device, so the pass can
+    be captured into a hipGraph (HF's DynamicCache cannot: replaying a capture that went
+    through it faulted)."""
+
+    def __init__(self, n_layers: int):
+        try:
+            super().__init__(layers=[])
+        except Exception:
+            pass
+        self.k: List[Optional[torch.Tensor]] = [None] * n_layers
+        self.v: List[Optional[torch.Tensor]] = [None] * n_layers
+        self._sliding = [False] * n_layers
+
+    @property
+    def is_sliding(self):
+        return self._sliding
+
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        self.k[layer_idx], self.v[layer_idx] = key_states, value_states
+        return key_states, value_states
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return 0
+
+    def get_mask_sizes(self, q, layer_idx: int = 0):
+        return (int(q) if isinstance(q, int) else int(q.shape[0])), 0
+
+    def get_max_cache_shape(self, layer_idx: int = 0) -> int:
+        return -1
+
+    def __len__(self):
+        return len(self.k)
+
+
 class SharedPrefixKV(_CacheBase):
     """Duck-typed HF cache holding the prefix keys/values of every layer, batch 1."""
 
@@ -50,9 +87,13 @@ class SharedPrefixKV(_CacheBase):
             super().__init__(layers=[])
         except Exception:
             pass
-        layers = base_cache.layers
-        self.k = [l.keys for l in layers]
-        self.v = [l.values for l in layers]
+        if isinstance(base_cache, RecordingKV):
+            self.k, self.v = list(base_cache.k), list(base_cache.v)
+            layers = self.k
+        else:
+            layers = base_cache.layers
+            self.k = [l.keys for l in layers]
+            self.v = [l.values for l in layers]
         self.P = int(self.k[0].shape[2])
         self._sliding = [False] * len(layers)
         self._rep = {}
