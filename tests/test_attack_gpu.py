@@ -316,3 +316,43 @@ def test_run_experiment_writes_reference_artifacts(tmp_path):
     assert all(np.isfinite(float(c)) for r in rows[1:] for c in r[1:])
     params = dict(csv.reader(open(os.path.join(folder, "parameters.csv"))))
     assert params["alpha"] == "4/255" and params["num_prompts"] == "2" and params["seed"] == "1" and "alpha_str" not in params
+
+
+def test_rccl_single_rank_collectives():
+    """The exact torch.distributed calls of dist.py / bench.py on the RCCL backend (a 1-rank
+    group: two ranks cannot share one GPU under RCCL; multi-rank semantics are covered by the
+    gloo tests).  Catches API / dtype / device misuse before the driver's 8-GPU run."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = r"""
+import os, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from bimodalattack_amd.dist import CandidateSharder
+sh = CandidateSharder()
+sh.enabled, sh.world = True, 1          # force the collective code path
+local = torch.arange(7, dtype=torch.float32, device=dev)
+full = sh.gather(local, 7)
+assert torch.equal(full, local)
+m = sh.gather(torch.ones(7, device=dev), 7, pad=0.0)
+assert float(m.sum()) == 7
+ids = torch.arange(12, device=dev).view(4, 3)
+assert torch.equal(sh.broadcast_ids(ids), ids)
+img = torch.rand(1, 3, 8, 8, device=dev)
+sh.broadcast_(img)
+t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+dist.destroy_process_group()
+print("rccl-ok")
+"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-2000:]
