@@ -347,8 +347,8 @@ class BimodalAttack:
         return self._feat_graph(image)
 
     def _wants_shared(self, P: int) -> bool:
-        # worth it when the prefix is long: for a 21-token prefix the merge pass costs what
-        # the per-candidate copy costs (measured: 270 vs 264 ms at P=21, 333 vs 714 ms at P=599)
+        # same-process A/B on MI355X, 512 candidates: P=21: 231 ms vs 254 ms through the HF cache
+        # (KV concat); P=599: 288 ms vs 714 ms
         hf = self.hf
         return bool(self.opt.shared_prefix_attention and hf.shared_ok is not False
                     and P >= self.opt.shared_prefix_min_tokens and hf.shared_prefix_configs())

@@ -105,7 +105,7 @@ class EngineOptions:
     # Attend to the shared prefix without copying its keys/values into every candidate
     # (two flash launches + a merge kernel; llama-family text models).  See prefix_attention.py.
     shared_prefix_attention: bool = True
-    shared_prefix_min_tokens: int = 64
+    shared_prefix_min_tokens: int = 1
     # GEMM selection: "auto" loads bimodalattack_amd/tuning/<arch>.csv into PyTorch's
     # TunableOp in lookup-only mode when its validators (torch / hipBLASLt / rocBLAS versions,
     # arch) match this process; "off" leaves the library heuristics alone.

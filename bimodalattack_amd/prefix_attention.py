@@ -130,12 +130,36 @@ class SharedPrefixKV(_CacheBase):
         return hit
 
 
+_BIAS = {}
+
+
+def _causal_bias(L: int, dtype, device) -> torch.Tensor:
+    """(1,1,L,L) additive mask, -inf above the diagonal (rows padded to a multiple of 8)."""
+    key = (L, dtype, str(device))
+    b = _BIAS.get(key)
+    if b is None:
+        Lp = (L + 7) // 8 * 8
+        full = torch.zeros((L, Lp), dtype=dtype, device=device)
+        full[:, :L].masked_fill_(~torch.tril(torch.ones((L, L), dtype=torch.bool, device=device)), float("-inf"))
+        b = full[:, :L].view(1, 1, L, L)
+        _BIAS[key] = b
+    return b
+
+
 def _partial_attention(q, k, v, causal: bool, scale: float):
-    """(out (B,H,L,Dh), lse (B,H,L) fp32) of softmax(q k^T * scale) v."""
-    if q.dtype in (torch.bfloat16, torch.float16):
-        out, lse = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, causal, False, scale=scale)[:2]
+    """(out (B,H,L,Dh), lse (B,H,L) fp32) of softmax(q k^T * scale) v.
+
+    The causal part goes through an explicit additive bias: on this ROCm build the is_causal
+    variant of the attention kernel takes ~800 us at (512,32,45,45) where the biased one takes
+    ~205 us (same outputs)."""
+    if causal:
+        B, H, L, _ = q.shape
+        bias = _causal_bias(L, q.dtype, q.device).expand(B, H, L, L)
+        out, lse = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, bias, True, 0.0, False, scale=scale)[:2]
+    elif q.dtype in (torch.bfloat16, torch.float16):
+        out, lse = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, False, False, scale=scale)[:2]
     else:
-        out, lse = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, None, True, 0.0, causal, scale=scale)[:2]
+        out, lse = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, None, True, 0.0, False, scale=scale)[:2]
     return out, lse[..., : q.shape[2]]
 
 

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# MIOpen's exhaustive kernel search for the CLIP patch-embedding convolution takes minutes on a
+# fresh machine; the heuristic mode is enough for tests.  Must be set before MIOpen initialises.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -137,11 +137,11 @@ def test_trajectory_matches_reference(golden_dir, name):
 @pytest.mark.parametrize("name", ["llava_joint", "opt_gcg", "gemma3_joint", "llava_pgd_gcg"])
 @pytest.mark.parametrize("engine", [dict(prefix_reuse=False), dict(prefix_reuse=False, target_rows_only=False),
                                     dict(chunk=5),
-                                    # force the shared-prefix attention + recorded/captured prefix pass on the
-                                    # tiny prompts too (by default it needs a prefix of >= 64 tokens)
-                                    dict(shared_prefix_min_tokens=1),
-                                    dict(shared_prefix_min_tokens=1, graph_prefix=False, graph_rescore=False,
-                                         graph_gradient=False, fused_elementwise=False)])
+                                    # the HF-cache path (KV concat) instead of shared-prefix attention
+                                    dict(shared_prefix_attention=False),
+                                    # everything eager and unfused
+                                    dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
+                                         fused_elementwise=False, gemm_tuning="off")])
 def test_restructurings_do_not_change_results(golden_dir, name, engine):
     """Full-sequence forward / full logits (the reference's call shape) and odd chunk
     sizes give the same trajectory as prefix reuse + target rows only."""
