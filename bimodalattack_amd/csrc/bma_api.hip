@@ -41,7 +41,15 @@ static Slot g_slot[BMA_K_COUNT];
 
 bool enabled() { return g_on; }
 
+// Events recorded while a stream is being captured into a graph would become graph nodes that
+// never fire outside a replay; skip them (the launch is then simply not tallied).
+static bool capturing(hipStream_t st) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &status) == hipSuccess && status != hipStreamCaptureStatusNone;
+}
+
 void begin(int k, hipStream_t st, double bytes) {
+  if (capturing(st)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
@@ -52,6 +60,7 @@ void begin(int k, hipStream_t st, double bytes) {
 }
 
 void end(int k, hipStream_t st) {
+  if (capturing(st)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_slot[k].end.empty()) return;
   (void)hipEventRecord(g_slot[k].end.back(), st);

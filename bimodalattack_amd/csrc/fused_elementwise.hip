@@ -121,7 +121,20 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4_t* __
 #define BMA_SILU(x) ((x) / (1.0f + expf(-(x))))   // accurate exp + IEEE division, as aten's silu kernel
 #endif
 
-template <int DT>
+// gelu(x, approximate="tanh") exactly as the main loop of aten's device kernel evaluates it in
+// fp32 (including the fused multiply-add its compiler forms for x + kappa*x^3): Gemma's gated
+// MLP.  (aten's partial last block is compiled with one more contraction and is 1 fp32 ulp off
+// its own main loop; tests/test_fused_gpu.py pins both facts.)
+__device__ __forceinline__ float gelu_tanh(float x) {
+  constexpr float kBeta = 0.7978845608028654f;     // sqrt(2/pi)
+  constexpr float kKappa = 0.044715f;
+  const float x3 = x * x * x;
+  const float inner = kBeta * fmaf(kKappa, x3, x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+// ACT: 0 = SiLU (Llama family), 1 = GELU-tanh (Gemma family)
+template <int DT, int ACT>
 __device__ __forceinline__ uint4_t swiglu_chunk(const uint4_t& gw, const uint4_t& uw) {
   constexpr int NE = Chunk<DT>::NE;
   float gf[NE], uf[NE], o[NE];
@@ -129,7 +142,7 @@ __device__ __forceinline__ uint4_t swiglu_chunk(const uint4_t& gw, const uint4_t
   Chunk<DT>::unpack(uw, uf);
 #pragma unroll
   for (int j = 0; j < NE; ++j) {
-    const float s = BMA_SILU(gf[j]);
+    const float s = ACT == 0 ? BMA_SILU(gf[j]) : gelu_tanh(gf[j]);
     o[j] = rnd<DT>(s) * uf[j];
   }
   return Chunk<DT>::pack(o);
@@ -142,7 +155,7 @@ __device__ __forceinline__ uint4_t swiglu_chunk(const uint4_t& gw, const uint4_t
 // the 6 TB/s a 2-read + 1-write stream gets on this part.)
 constexpr int kSwiChunks = 4;
 
-template <int DT>
+template <int DT, int ACT>
 __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
                                                      int64_t n_chunks, uint4_t* __restrict__ y) {
   const int64_t base = static_cast<int64_t>(blockIdx.x) * (kSwiChunks * 256) + threadIdx.x;
@@ -151,12 +164,12 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
 #pragma unroll
     for (int j = 0; j < kSwiChunks; ++j) { gw[j] = g[base + j * 256]; uw[j] = u[base + j * 256]; }
 #pragma unroll
-    for (int j = 0; j < kSwiChunks; ++j) y[base + j * 256] = swiglu_chunk<DT>(gw[j], uw[j]);
+    for (int j = 0; j < kSwiChunks; ++j) y[base + j * 256] = swiglu_chunk<DT, ACT>(gw[j], uw[j]);
   } else {
 #pragma unroll
     for (int j = 0; j < kSwiChunks; ++j) {
       const int64_t i = base + j * 256;
-      if (i < n_chunks) y[i] = swiglu_chunk<DT>(g[i], u[i]);
+      if (i < n_chunks) y[i] = swiglu_chunk<DT, ACT>(g[i], u[i]);
     }
   }
 }
@@ -256,8 +269,9 @@ extern "C" int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t
   }
 }
 
-extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream) {
-  if (n < 0) return BMA_EINVAL;
+extern "C" int bma_gated_act(const void* gate, const void* up, int64_t n, int dtype, int act, void* out,
+                             void* stream) {
+  if (n < 0 || (act != 0 && act != 1)) return BMA_EINVAL;
   if (n == 0) return BMA_OK;
   if (!gate || !up || !out) return BMA_EINVAL;
   if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
@@ -274,12 +288,22 @@ extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype
   const uint4_t* u = static_cast<const uint4_t*>(up);
   uint4_t* y = static_cast<uint4_t*>(out);
   BMA_PROF_BEGIN(BMA_K_SWIGLU, st, 3.0 * static_cast<double>(n) * es);
-  if (dtype == BMA_F32) hipLaunchKernelGGL((swiglu_kernel<BMA_F32>), grid, block, 0, st, g, u, chunks, y);
-  else if (dtype == BMA_BF16) hipLaunchKernelGGL((swiglu_kernel<BMA_BF16>), grid, block, 0, st, g, u, chunks, y);
-  else hipLaunchKernelGGL((swiglu_kernel<BMA_F16>), grid, block, 0, st, g, u, chunks, y);
+#define BMA_GA_GO(DT_)                                                                                   \
+  do {                                                                                                   \
+    if (act == 0) hipLaunchKernelGGL((swiglu_kernel<DT_, 0>), grid, block, 0, st, g, u, chunks, y);       \
+    else hipLaunchKernelGGL((swiglu_kernel<DT_, 1>), grid, block, 0, st, g, u, chunks, y);                \
+  } while (0)
+  if (dtype == BMA_F32) BMA_GA_GO(BMA_F32);
+  else if (dtype == BMA_BF16) BMA_GA_GO(BMA_BF16);
+  else BMA_GA_GO(BMA_F16);
+#undef BMA_GA_GO
   BMA_PROF_END(BMA_K_SWIGLU, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream) {
+  return bma_gated_act(gate, up, n, dtype, 0, out, stream);
 }
 
 extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, int B, int H, int L,
@@ -438,7 +462,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint4_t
   }
 }
 
-template <int DT>
+template <int DT, int ACT>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
                                                          const uint4_t* __restrict__ dy, int64_t n_chunks,
                                                          uint4_t* __restrict__ dg, uint4_t* __restrict__ du) {
@@ -451,9 +475,18 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint4_t* __restri
     Chunk<DT>::unpack(dy[i], df);
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-      const float s = 1.0f / (1.0f + expf(-gf[j]));
-      ou[j] = df[j] * rnd<DT>(gf[j] * s);                       // the forward kept silu(g) in the model dtype
-      og[j] = df[j] * uf[j] * (s * (1.0f + gf[j] * (1.0f - s)));
+      if (ACT == 0) {
+        const float s = 1.0f / (1.0f + expf(-gf[j]));
+        ou[j] = df[j] * rnd<DT>(gf[j] * s);                     // the forward kept act(g) in the model dtype
+        og[j] = df[j] * uf[j] * (s * (1.0f + gf[j] * (1.0f - s)));
+      } else {
+        constexpr float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+        const float x = gf[j], x2 = x * x;
+        const float t = tanhf(kBeta * fmaf(kKappa, x2 * x, x));
+        const float d = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * (kBeta * (1.0f + 3.0f * kKappa * x2));
+        ou[j] = df[j] * rnd<DT>(0.5f * x * (1.0f + t));
+        og[j] = df[j] * uf[j] * d;
+      }
     }
     dg[i] = Chunk<DT>::pack(og);
     du[i] = Chunk<DT>::pack(ou);
@@ -509,9 +542,9 @@ extern "C" int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy
   }
 }
 
-extern "C" int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, void* dgate,
-                              void* dup, void* stream) {
-  if (n < 0) return BMA_EINVAL;
+extern "C" int bma_gated_act_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, int act,
+                                 void* dgate, void* dup, void* stream) {
+  if (n < 0 || (act != 0 && act != 1)) return BMA_EINVAL;
   if (n == 0) return BMA_OK;
   if (!gate || !up || !dy || !dgate || !dup) return BMA_EINVAL;
   if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
@@ -530,9 +563,20 @@ extern "C" int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, 
   const uint4_t* d = static_cast<const uint4_t*>(dy);
   uint4_t* og = static_cast<uint4_t*>(dgate);
   uint4_t* ou = static_cast<uint4_t*>(dup);
-  if (dtype == BMA_F32) hipLaunchKernelGGL((swiglu_bwd_kernel<BMA_F32>), grid, block, 0, st, g, u, d, chunks, og, ou);
-  else if (dtype == BMA_BF16) hipLaunchKernelGGL((swiglu_bwd_kernel<BMA_BF16>), grid, block, 0, st, g, u, d, chunks, og, ou);
-  else hipLaunchKernelGGL((swiglu_bwd_kernel<BMA_F16>), grid, block, 0, st, g, u, d, chunks, og, ou);
+#define BMA_GB_GO(DT_)                                                                                         \
+  do {                                                                                                         \
+    if (act == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 0>), grid, block, 0, st, g, u, d, chunks, og, ou); \
+    else hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 1>), grid, block, 0, st, g, u, d, chunks, og, ou);          \
+  } while (0)
+  if (dtype == BMA_F32) BMA_GB_GO(BMA_F32);
+  else if (dtype == BMA_BF16) BMA_GB_GO(BMA_BF16);
+  else BMA_GB_GO(BMA_F16);
+#undef BMA_GB_GO
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+extern "C" int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, void* dgate,
+                              void* dup, void* stream) {
+  return bma_gated_act_bwd(gate, up, dy, n, dtype, 0, dgate, dup, stream);
 }

@@ -13,7 +13,7 @@ on exit.
 What qualifies (checked structurally, not by model name):
   * a module whose class name ends in ``RMSNorm`` with a 1-D ``weight`` and an epsilon
     (``variance_epsilon`` / ``eps``); classes named ``Gemma*`` use the (1 + w) form;
-  * a module with ``gate_proj``, ``up_proj``, ``down_proj`` and a SiLU ``act_fn``;
+  * a module with ``gate_proj``, ``up_proj``, ``down_proj`` and a SiLU or GELU-tanh ``act_fn``;
   * ``apply_rotary_pos_emb`` of the modelling file of known rotary families (full-head
     rotary, ``rotate_half`` convention): llama, mistral, qwen2, gemma3.
 """
@@ -56,13 +56,27 @@ class FusedInference:
             if cls.endswith("RMSNorm") and torch.is_tensor(w) and w.dim() == 1 and _eps_of(m) is not None:
                 self.norms.append((m, _eps_of(m), cls.startswith("Gemma")))
             elif all(hasattr(m, a) for a in ("gate_proj", "up_proj", "down_proj", "act_fn")) and \
-                    type(m.act_fn).__name__ in ("SiLU", "SiLUActivation"):
+                    self._act_code(m.act_fn) is not None:
                 self.mlps.append(m)
             files.add(type(m).__module__)
         for f in files:
             mod = sys.modules.get(f)
             if mod is not None and f.rsplit(".", 1)[-1] in _ROPE_FILES and hasattr(mod, "apply_rotary_pos_emb"):
                 self.rope_modules.append(mod)
+
+    @staticmethod
+    def _act_code(act_fn):
+        """0 for SiLU, 1 for gelu(approximate="tanh") through its C implementation, None otherwise."""
+        name = type(act_fn).__name__
+        if name in ("SiLU", "SiLUActivation"):
+            return ops.ACT_SILU
+        if name in ("GELUTanh", "PytorchGELUTanh"):
+            inner = getattr(act_fn, "act", None)          # HF: functools.partial(F.gelu, approximate="tanh")
+            if inner is None or getattr(inner, "func", None) is torch.nn.functional.gelu:
+                return ops.ACT_GELU_TANH
+        if isinstance(act_fn, torch.nn.GELU) and getattr(act_fn, "approximate", "none") == "tanh":
+            return ops.ACT_GELU_TANH
+        return None
 
     # -- the replacements ----------------------------------------------------------------
     @staticmethod
@@ -91,6 +105,8 @@ class FusedInference:
         return forward
 
     def _mlp_forward(self, m, orig):
+        act = self._act_code(m.act_fn)
+
         def forward(x):
             if not self._usable(x):
                 return orig(x)
@@ -98,8 +114,8 @@ class FusedInference:
             if (g.numel() * g.element_size()) % 16:
                 return m.down_proj(m.act_fn(g) * u)
             if self._tracking(g, u):
-                return m.down_proj(ops.SwiGLUFn.apply(g, u))
-            return m.down_proj(ops.swiglu(g, u))
+                return m.down_proj(ops.SwiGLUFn.apply(g, u, act))
+            return m.down_proj(ops.swiglu(g, u, act))
         return forward
 
     def _rope(self, orig):

@@ -54,6 +54,8 @@ PROTOTYPES = {
                            c_float, c_void_p, c_void_p]),
     "bma_rmsnorm": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bma_swiglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "bma_gated_act": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "bma_gated_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "bma_rope_inplace": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p]),
     "bma_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -254,14 +254,18 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, gemma_style: bool
     return out
 
 
-def swiglu(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+ACT_SILU, ACT_GELU_TANH = 0, 1
+
+
+def swiglu(gate: torch.Tensor, up: torch.Tensor, act: int = ACT_SILU) -> torch.Tensor:
+    """dt(dt(act(gate)) * up): the gate of a Llama (SiLU) or Gemma (GELU-tanh) MLP."""
     dev = _need_gpu(gate, up)
     if gate.shape != up.shape or gate.dtype != up.dtype:
         raise ValueError("gate and up must agree in shape and dtype")
     gate, up = gate.contiguous(), up.contiguous()
     out = torch.empty_like(gate)
-    check("bma_swiglu", lib.bma_swiglu(gate.data_ptr(), up.data_ptr(), gate.numel(), _dt(gate), out.data_ptr(),
-                                       _stream(dev)))
+    check("bma_gated_act", lib.bma_gated_act(gate.data_ptr(), up.data_ptr(), gate.numel(), _dt(gate), int(act),
+                                             out.data_ptr(), _stream(dev)))
     return out
 
 
@@ -321,19 +325,20 @@ class RMSNormFn(torch.autograd.Function):
 
 class SwiGLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gate, up):
+    def forward(ctx, gate, up, act=ACT_SILU):
         g, u = gate.contiguous(), up.contiguous()
         ctx.save_for_backward(g, u)
-        return swiglu(g, u)
+        ctx.act = int(act)
+        return swiglu(g, u, act)
 
     @staticmethod
     def backward(ctx, dy):
         g, u = ctx.saved_tensors
         dy = dy.contiguous()
         dg, du = torch.empty_like(g), torch.empty_like(u)
-        check("bma_swiglu_bwd", lib.bma_swiglu_bwd(g.data_ptr(), u.data_ptr(), dy.data_ptr(), g.numel(), _dt(g),
-                                                   dg.data_ptr(), du.data_ptr(), _stream(g.device)))
-        return dg, du
+        check("bma_gated_act_bwd", lib.bma_gated_act_bwd(g.data_ptr(), u.data_ptr(), dy.data_ptr(), g.numel(), _dt(g),
+                                                         ctx.act, dg.data_ptr(), du.data_ptr(), _stream(g.device)))
+        return dg, du, None
 
 
 class RoPEFn(torch.autograd.Function):

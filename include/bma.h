@@ -151,6 +151,9 @@ int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
 int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t rows, int D,
                 int dtype, int gemma_style, void* out, void* stream);
 int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream);
+/* bma_gated_act: out = dt(dt(act(gate)) * up); act 0 = SiLU (== bma_swiglu), 1 = GELU-tanh as
+ *   aten evaluates gelu(x, approximate="tanh") (Gemma's gated MLP). */
+int bma_gated_act(const void* gate, const void* up, int64_t n, int dtype, int act, void* out, void* stream);
 int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l,
                      int B, int H, int L, int Dh, const void* cos, const void* sin,
                      int cos_batch, int dtype, void* stream);
@@ -161,6 +164,8 @@ int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy, float eps
                     int D, int dtype, int gemma_style, void* dx, void* stream);
 int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype,
                    void* dgate, void* dup, void* stream);
+int bma_gated_act_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, int act,
+                      void* dgate, void* dup, void* stream);
 /* bma_attn_merge: merges the two partial attentions of the shared-prefix scheme (new tokens
  *   vs the prompt prefix shared by all candidates; new tokens vs themselves, causal):
  *   out = w*o1 + (1-w)*o2 with w = 1/(1+exp(lse2-lse1)).  o1, o2, out: [B][L][H][Dh] contiguous

@@ -149,15 +149,17 @@ def test_restructurings_do_not_change_results(golden_dir, name, engine):
     check_against_golden(golden_dir, name, m, res, trace, tmp)
 
 
-def test_device_rng_mode_and_bf16_run():
+@pytest.mark.parametrize("kind,dtype", [("llava", torch.bfloat16), ("llava", torch.float16),
+                                        ("gemma3", torch.bfloat16)])
+def test_device_rng_mode_and_16bit_run(kind, dtype):
     """Default mode draws the randoms on the device like the reference does on a GPU; a
-    bf16 model exercises the 16-bit kernels end to end.  No CPU golden exists for either,
+    bf16 / fp16 model exercises the 16-bit kernels end to end.  No CPU golden exists for either,
     so: same seed -> same run; losses finite; candidates differ from the parent in
     exactly n_replace positions; every top-k id is allowed."""
     from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
     out = []
     for _ in range(2):
-        model, tok, proc, image = S.tiny_case("llava", dtype=torch.bfloat16, device=DEV)
+        model, tok, proc, image = S.tiny_case(kind, dtype=dtype, device=DEV)
         trace = []
         cfg = BimodalAttackConfig(num_steps=3, search_width=32, topk=16, pgd_attack=True, gcg_attack=True,
                                   joint_eval=True, eps=64 / 255, alpha=4 / 255, seed=7, verbosity="ERROR",
