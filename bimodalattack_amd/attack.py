@@ -548,6 +548,13 @@ class BimodalAttack:
 
     def run(self, messages: Union[str, List[dict]], goal: str, target: str,
             image: Optional[Tensor] = None) -> BimodalAttackResult:
+        fill_flag = torch.utils.deterministic.fill_uninitialized_memory
+        try:
+            return self._run(messages, goal, target, image)
+        finally:
+            torch.utils.deterministic.fill_uninitialized_memory = fill_flag
+
+    def _run(self, messages, goal, target, image) -> BimodalAttackResult:
         from transformers import set_seed
 
         cfg, tok, mt = self.config, self.tokenizer, self.hf.model_type
@@ -556,6 +563,10 @@ class BimodalAttack:
         if cfg.seed is not None:
             set_seed(cfg.seed)
             torch.use_deterministic_algorithms(True, warn_only=True)
+            # Deterministic mode also NaN-fills every torch.empty() (a debugging aid that costs one
+            # HBM write per output tensor, ~3-5 % of a step); no kernel here reads memory it has not
+            # written, so the fill is skipped.  Process-wide switch: restored when run() returns.
+            torch.utils.deterministic.fill_uninitialized_memory = False
         if cfg.pgd_after_gcg:
             # the reference's pgd_after_gcg branch dies on iteration 0 (:661, current_loss is None)
             raise TypeError("unsupported format string passed to NoneType.__format__")

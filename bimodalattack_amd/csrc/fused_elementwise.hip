@@ -114,6 +114,40 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4_t* __
   }
 }
 
+// Short rows (per-head q/k norms: D = 128 or 256): LPR lanes per row, 256/LPR rows per workgroup,
+// one chunk per lane, the sum of squares reduced inside the LPR-lane group with xor shuffles.
+template <int DT, int LPR, bool GEMMA>
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_short_kernel(const uint4_t* __restrict__ x,
+                                                                     const uint4_t* __restrict__ w, float eps,
+                                                                     int64_t rows, int cpr, int D,
+                                                                     uint4_t* __restrict__ y) {
+  constexpr int NE = Chunk<DT>::NE;
+  constexpr int RPB = kNormThreads / LPR;
+  const int tid = threadIdx.x;
+  const int sub = tid % LPR;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * RPB + tid / LPR;
+  const bool live = row < rows && sub < cpr;
+  float v[NE];
+  float ss = 0.0f;
+  if (live) {
+    Chunk<DT>::unpack(x[row * cpr + sub], v);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) ss += v[j] * v[j];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, BMA_WAVE);
+  if (!live) return;
+  const float rstd = 1.0f / sqrtf(ss / static_cast<float>(D) + eps);
+  float wf[NE], o[NE];
+  Chunk<DT>::unpack(w[sub], wf);
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    if (GEMMA) o[j] = v[j] * rstd * (1.0f + wf[j]);
+    else o[j] = wf[j] * rnd<DT>(v[j] * rstd);
+  }
+  y[row * cpr + sub] = Chunk<DT>::pack(o);
+}
+
 // ---------------------------------------------------------------------------- swiglu
 #ifdef BMA_FAST_SILU
 #define BMA_SILU(x) __fdividef((x), 1.0f + __expf(-(x)))
@@ -232,6 +266,22 @@ int launch_rmsnorm(const void* x, const void* w, float eps, int64_t rows, int D,
   const uint4_t* wp = static_cast<const uint4_t*>(w);
   uint4_t* yp = static_cast<uint4_t*>(y);
   BMA_PROF_BEGIN(BMA_K_RMSNORM, st, 2.0 * static_cast<double>(rows) * D * ES);
+  if (cpr <= 64) {
+#define BMA_NORM_SHORT(L)                                                                                          \
+  do {                                                                                                             \
+    const dim3 g(static_cast<unsigned>((rows + kNormThreads / L - 1) / (kNormThreads / L)));                        \
+    if (gemma) hipLaunchKernelGGL((rmsnorm_short_kernel<DT, L, true>), g, block, 0, st, xp, wp, eps, rows, cpr, D, yp); \
+    else hipLaunchKernelGGL((rmsnorm_short_kernel<DT, L, false>), g, block, 0, st, xp, wp, eps, rows, cpr, D, yp); \
+  } while (0)
+    if (cpr <= 8) BMA_NORM_SHORT(8);
+    else if (cpr <= 16) BMA_NORM_SHORT(16);
+    else if (cpr <= 32) BMA_NORM_SHORT(32);
+    else BMA_NORM_SHORT(64);
+#undef BMA_NORM_SHORT
+    BMA_PROF_END(BMA_K_RMSNORM, st);
+    BMA_LAUNCH_CHECK();
+    return BMA_OK;
+  }
 #define BMA_NORM_GO(N)                                                                                          \
   do {                                                                                                          \
     if (gemma) hipLaunchKernelGGL((rmsnorm_kernel<DT, N, true>), grid, block, 0, st, xp, wp, eps, cpr, D, yp);   \

@@ -97,6 +97,10 @@ class FusedInference:
             if not self._usable(x) or (D * x.element_size()) % 16 or D * x.element_size() > 16384 \
                     or m.weight.dtype != x.dtype:
                 return orig(x)
+            if x.dim() == 4 and not x.is_contiguous() and x.transpose(1, 2).is_contiguous():
+                # per-head q/k norm on a (B,H,L,Dh) VIEW of the projection's (B,L,H,Dh) output: rows
+                # are rows in either order, so normalise in place of layout instead of copying
+                return forward(x.transpose(1, 2)).transpose(1, 2)
             if self._tracking(x):
                 # the weight is a constant to the fused backward (the engine only ever asks for
                 # gradients w.r.t. inputs)

@@ -21,7 +21,9 @@ def ulp_diff(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
-@pytest.mark.parametrize("rows,D", [(22528, 4096), (37, 2560), (5, 32), (3, 8192), (64, 256)])
+@pytest.mark.parametrize("rows,D", [(22528, 4096), (37, 2560), (5, 32), (3, 8192), (64, 256),
+                                    # short rows: several rows per workgroup, ragged last workgroup
+                                    (1001, 256), (77, 128), (33, 64), (9, 8), (13, 512), (7, 40), (129, 200)])
 def test_rmsnorm_vs_hf(dtype, rows, D):
     from bimodalattack_amd import ops
     from transformers.models.gemma3.modeling_gemma3 import Gemma3RMSNorm
@@ -46,6 +48,37 @@ def test_rmsnorm_vs_hf(dtype, rows, D):
             # a 1-ulp difference of the normalised value can become 2 ulp after the weight product
             stats = (int(d.max()), float((d > 0).float().mean()), float((d > 1).float().mean()))
             assert stats[0] <= 2 and stats[1] < 2e-3 and stats[2] < 1e-4, stats
+
+
+def test_head_norm_on_transposed_view_is_copy_free():
+    """Gemma's q_norm/k_norm see a (B,H,L,Dh) view of a (B,L,H,Dh) projection: the patched norm
+    works in the memory order it finds and hands back the same kind of view."""
+    from bimodalattack_amd.fused import FusedInference
+    from transformers.models.gemma3.modeling_gemma3 import Gemma3RMSNorm
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_norm = Gemma3RMSNorm(256, eps=1e-6)
+
+    h = Holder().to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        h.q_norm.weight.copy_(torch.randn(256, device=DEV) * 0.2)
+    base = torch.randn(3, 11, 8, 256, device=DEV).to(torch.bfloat16)
+    x = base.transpose(1, 2)
+    with torch.no_grad():
+        want = h.q_norm(x)
+        with FusedInference(h, True):
+            got = h.q_norm(x)
+    assert got.shape == want.shape and got.stride() == x.stride()          # still the transposed view
+    d = ulp_diff(got.contiguous(), want.contiguous())
+    assert int(d.max()) <= 2 and float((d > 0).float().mean()) < 2e-3
+    xg = x.clone().requires_grad_()
+    with FusedInference(h, True):
+        y = h.q_norm(xg)
+    ge, = torch.autograd.grad(h.q_norm(xg), xg, torch.ones_like(want))
+    gf, = torch.autograd.grad(y, xg, torch.ones_like(y))
+    np.testing.assert_allclose(gf.float().cpu().numpy(), ge.float().cpu().numpy(), rtol=5e-2, atol=5e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])

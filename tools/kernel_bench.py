@@ -102,6 +102,7 @@ def cases():
         "rope/c3_B512_L44_H32_Dh128": ("rope", lambda: rope(512, 44, 32, 128)),
         "attn_merge/c4_B512_L45_H32_Dh128": ("attn_merge", lambda: merge(512, 45, 32, 128)),
         "rmsnorm/n8_2816x4096": ("rmsnorm", lambda: rmsnorm(2816, 4096)),
+        "rmsnorm/head_391168x256": ("rmsnorm", lambda: rmsnorm(391168, 256)),
         "swiglu/n8_2816x11008": ("swiglu", lambda: swiglu(2816, 11008)),
         "ce_rows/llava_B512_T20_V32064": ("ce_rows", lambda: ce(512, 20, 32064)),
         "ce_rows/llava_B64_T20_V32064": ("ce_rows", lambda: ce(64, 20, 32064)),
