@@ -45,7 +45,7 @@ from .dist import CandidateSharder
 from .fused import FusedInference
 from . import gemm_tuning
 from .hf_adapter import HFAdapter
-from .layout import dynamic_width, segment_order, split_at_suffix
+from .layout import ragged_budget, ragged_plan, dynamic_width, segment_order, split_at_suffix
 from .utils import INIT_CHARS, FilterJob, get_nonascii_toks, is_oom, plan_chunk
 
 logger = logging.getLogger("gcg")
@@ -324,12 +324,12 @@ class BimodalAttack:
         return out
 
     def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
-                         allow_prefix: bool = True) -> Tensor:
+                         allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
         """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
-        all-gathered to the full vector.  `order` ends in "target".  Only enqueues work: the
-        host does not wait for the device here (unless an OOM forces a retry)."""
+        all-gathered to the full vector.  `order` ends in "target".  `parent` (1,n_opt): the ids
+        the candidates were sampled from, when the caller knows them (enables ragged scoring)."""
         with self.fused:
-            return self._score_candidates(sampled, order, feats, allow_prefix)
+            return self._score_candidates(sampled, order, feats, allow_prefix, parent)
 
     def scoring_features(self, image: Tensor) -> Tensor:
         """Image features for scoring (no autograd): the vision tower at batch 1 is launch-bound,
@@ -406,8 +406,27 @@ class BimodalAttack:
             self._prefix_graphs[key] = g
         return g(feats)
 
+    def _ragged_logits(self, mine: Tensor, parent: Tensor, segs, L: int, P: int, cache) -> Optional[Tensor]:
+        """Target logits (m,T,V) through the ragged forward, or None when this draw does not fit
+        the fixed row budget (then the caller scores the padded block)."""
+        cfg, hf = self.config, self.hf
+        m, n_opt = mine.shape
+        parent = parent.reshape(1, n_opt).to(mine.device)
+        both = torch.cat([mine, parent], dim=0)
+        host = both.cpu().numpy()                    # waits for the sampling kernels only
+        plan = ragged_plan(host[:m], host[m], L, self.T, P, ragged_budget(m, n_opt, L, cfg.n_replace))
+        if plan is None:
+            return None
+        from .prefix_attention import RaggedMaps
+        maps = RaggedMaps(plan, mine.device)
+        x = ops.splice(segs, m + 1, self.embedding_layer.weight, both.contiguous(), hf.emb_scale)
+        rows = ops.gather_rows(x.view((m + 1) * L, x.shape[-1]), maps.flat).unsqueeze(0)
+        del x
+        self._last_ragged = (int(plan["N"]), (m + 1) * L)
+        return hf.target_logits_ragged(rows, self.T, cache, maps)
+
     def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
-                          allow_prefix: bool = True) -> Tensor:
+                          allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         lo, hi = self.shard.bounds(n)
@@ -439,13 +458,27 @@ class BimodalAttack:
 
         losses = torch.empty(m, dtype=torch.float32, device=self.model.device)
         match = torch.zeros(m, dtype=torch.float32, device=self.model.device) if cfg.early_stop else None
+        ragged = bool(shared and parent is not None and self.opt.ragged_suffix and hf.ragged_ok is not False
+                      and chunk >= m > 1 and tail_names[0] == "optim" and L - self.T >= mine.shape[1] - 1)
         s = 0
         while s < m:
             b = min(chunk, m - s)
             try:
-                x = ops.splice(segs, b, E, mine[s:s + b].contiguous(), hf.emb_scale)
-                kv = None
-                if shared:
+                kv, x, logits = None, None, None
+                if ragged:
+                    try:
+                        logits = self._ragged_logits(mine, parent, segs, L, P, cache)
+                        hf.ragged_ok = True
+                    except Exception as e:
+                        if hf.ragged_ok or is_oom(e):
+                            raise
+                        logger.warning(f"ragged scoring disabled: {type(e).__name__}: {e}")
+                        hf.ragged_ok, ragged = False, False
+                if logits is None:
+                    x = ops.splice(segs, b, E, mine[s:s + b].contiguous(), hf.emb_scale)
+                if logits is not None:
+                    pass
+                elif shared:
                     try:
                         logits = hf.target_logits_shared_prefix(x, self.T, cache)
                         hf.shared_ok = True
@@ -459,7 +492,7 @@ class BimodalAttack:
                         use_prefix = cache is not None
                         if not use_prefix:
                             raise
-                if not shared:
+                if logits is None:
                     kv = hf.expand_prefix(cache, b) if use_prefix else None
                     logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
                 loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
@@ -688,6 +721,7 @@ class BimodalAttack:
                         return out
 
                     prefetch_s = 0.0
+                    parent = optim_ids if cfg.gcg_attack else None      # what the candidates were sampled from
                     if fuse_pgd and i + 1 < cfg.num_steps:
                         # the forward of the NEXT gradient pass scores the image just updated
                         with torch.enable_grad():
@@ -706,10 +740,10 @@ class BimodalAttack:
                         feats = self.scoring_features(image)
                         if cfg.joint_eval:
                             loss, sampled = survivors(self.score_candidates(
-                                sampled_all, segment_order("pgd", mt, single=True), feats))
+                                sampled_all, segment_order("pgd", mt, single=True), feats, parent=parent))
                         elif cfg.gcg_attack:
                             loss, sampled = survivors(self.score_candidates(
-                                sampled_all, segment_order("gcg", mt, single=True), None))
+                                sampled_all, segment_order("gcg", mt, single=True), None, parent=parent))
                         else:
                             loss, sampled = None, sampled_all
                         best_idx = int(loss.argmin().item()) if loss is not None else 0
@@ -725,7 +759,7 @@ class BimodalAttack:
                             st["losses"].append(full.float().cpu().numpy())
                     else:
                         loss, sampled = survivors(self.score_candidates(
-                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None))
+                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent))
                         best_idx = int(loss.argmin().item())
                         current_loss = loss[best_idx].item()
                         winner = sampled[best_idx:best_idx + 1].contiguous()

@@ -106,6 +106,10 @@ class EngineOptions:
     # (two flash launches + a merge kernel; llama-family text models).  See prefix_attention.py.
     shared_prefix_attention: bool = True
     shared_prefix_min_tokens: int = 1
+    # On top of it: compute, per candidate, only the tokens from its first replaced suffix
+    # position on -- the ones in front equal the parent suffix, whose keys/values are shared
+    # (layout.ragged_plan).  ~ (n_opt-1)/(2L) fewer rows through every GEMM, norm and MLP gate.
+    ragged_suffix: bool = True
     # GEMM selection: "auto" loads bimodalattack_amd/tuning/<arch>.csv into PyTorch's
     # TunableOp in lookup-only mode when its validators (torch / hipBLASLt / rocBLAS versions,
     # arch) match this process; "off" leaves the library heuristics alone.
@@ -150,6 +154,8 @@ class EngineOptions:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
         if "BMA_SHARED_PREFIX_ATTENTION" in env:
             opts.shared_prefix_attention = env["BMA_SHARED_PREFIX_ATTENTION"] not in ("0", "false", "False")
+        if "BMA_RAGGED_SUFFIX" in env:
+            opts.ragged_suffix = env["BMA_RAGGED_SUFFIX"] not in ("0", "false", "False")
         if "BMA_GEMM_TUNING" in env:
             opts.gemm_tuning = env["BMA_GEMM_TUNING"]
         if "BMA_FUSE_PGD_ONLY" in env:

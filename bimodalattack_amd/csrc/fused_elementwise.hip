@@ -399,28 +399,72 @@ extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int
 // with batch 1 and B*L queries), lse2: [B][H][L]; both fp32.
 namespace {
 
+// `map` (optional): row n of o1/lse1/out pairs with row map[n] of o2/lse2 -- the ragged scoring
+// layout, where o1 holds only the tokens that were computed and o2 the padded (B,L) block.
 template <int DT>
 __global__ __launch_bounds__(256) void attn_merge_kernel(const uint4_t* __restrict__ o1, const uint4_t* __restrict__ o2,
                                                          const float* __restrict__ lse1, const float* __restrict__ lse2,
-                                                         int B, int L, int H, int cph, uint4_t* __restrict__ out) {
+                                                         const int* __restrict__ map, int64_t N, int64_t rows2, int L,
+                                                         int H, int cph, uint4_t* __restrict__ out) {
   constexpr int NE = Chunk<DT>::NE;
-  const int row = blockIdx.x;                  // (b, l)
-  const int b = row / L, l = row - b * L;
+  const int row = blockIdx.x;                  // row of o1 / out
+  int64_t r2 = row;
+  if (map) {
+    r2 = map[row];
+    r2 = r2 < 0 ? 0 : (r2 >= rows2 ? rows2 - 1 : r2);
+  }
+  const int b = static_cast<int>(r2 / L), l = static_cast<int>(r2 - static_cast<int64_t>(b) * L);
   const int n = H * cph;                       // chunks of this row
   const int64_t base = static_cast<int64_t>(row) * n;
-  const int64_t BL = static_cast<int64_t>(B) * L;
+  const int64_t base2 = r2 * n;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int h = i / cph;                     // 32-bit, once per chunk
-    const float l1 = lse1[static_cast<int64_t>(h) * BL + row];
+    const float l1 = lse1[static_cast<int64_t>(h) * N + row];
     const float l2 = lse2[(static_cast<int64_t>(b) * H + h) * L + l];
     const float w = 1.0f / (1.0f + expf(l2 - l1));
     float a[NE], c[NE], o[NE];
     Chunk<DT>::unpack(o1[base + i], a);
-    Chunk<DT>::unpack(o2[base + i], c);
+    Chunk<DT>::unpack(o2[base2 + i], c);
 #pragma unroll
     for (int j = 0; j < NE; ++j) o[j] = c[j] + w * (a[j] - c[j]);
     out[base + i] = Chunk<DT>::pack(o);
   }
+}
+
+// out[r] = src[idx[r]]: rows of `cpr` 16-byte chunks, one workgroup per output row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4_t* __restrict__ src, const int* __restrict__ idx,
+                                                          int64_t n_src, int cpr, uint4_t* __restrict__ out) {
+  const int64_t r = blockIdx.x;
+  int64_t s = idx[r];
+  s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);
+  const uint4_t* in = src + s * cpr;
+  uint4_t* o = out + r * cpr;
+  for (int i = threadIdx.x; i < cpr; i += 256) o[i] = in[i];
+}
+
+int merge_common(const void* o1, const void* o2, const float* lse1, const float* lse2, const int* map, int64_t N,
+                 int64_t rows2, int L, int H, int Dh, int dtype, void* out, void* stream) {
+  if (N == 0) return BMA_OK;
+  if (!o1 || !o2 || !lse1 || !lse2 || !out) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((Dh * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(o1) | reinterpret_cast<uintptr_t>(o2) | reinterpret_cast<uintptr_t>(out)) % 16)
+    return BMA_EALIGN;
+  const int cph = Dh * es / 16;
+  if (N > 0x7fffffffLL || rows2 > 0x7fffffffLL) return BMA_ELIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(N)), block(256);
+  const uint4_t* a = static_cast<const uint4_t*>(o1);
+  const uint4_t* c = static_cast<const uint4_t*>(o2);
+  uint4_t* y = static_cast<uint4_t*>(out);
+  BMA_PROF_BEGIN(BMA_K_ATTN_MERGE, st, 3.0 * static_cast<double>(N) * H * Dh * es);
+  if (dtype == BMA_F32) hipLaunchKernelGGL((attn_merge_kernel<BMA_F32>), grid, block, 0, st, a, c, lse1, lse2, map, N, rows2, L, H, cph, y);
+  else if (dtype == BMA_BF16) hipLaunchKernelGGL((attn_merge_kernel<BMA_BF16>), grid, block, 0, st, a, c, lse1, lse2, map, N, rows2, L, H, cph, y);
+  else hipLaunchKernelGGL((attn_merge_kernel<BMA_F16>), grid, block, 0, st, a, c, lse1, lse2, map, N, rows2, L, H, cph, y);
+  BMA_PROF_END(BMA_K_ATTN_MERGE, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
 }
 
 }  // namespace
@@ -429,25 +473,30 @@ extern "C" int bma_attn_merge(const void* o1, const void* o2, const float* lse1,
                               int H, int Dh, int dtype, void* out, void* stream) {
   if (B < 0 || L < 0 || H <= 0 || Dh <= 0) return BMA_EINVAL;
   if (B == 0 || L == 0) return BMA_OK;
-  if (!o1 || !o2 || !lse1 || !lse2 || !out) return BMA_EINVAL;
-  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
-  const int es = dtype == BMA_F32 ? 4 : 2;
-  if ((Dh * es) % 16) return BMA_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(o1) | reinterpret_cast<uintptr_t>(o2) | reinterpret_cast<uintptr_t>(out)) % 16)
-    return BMA_EALIGN;
-  const int cph = Dh * es / 16;
   const int64_t rows = static_cast<int64_t>(B) * L;
-  if (rows > 0x7fffffffLL) return BMA_ELIMIT;
+  return merge_common(o1, o2, lse1, lse2, nullptr, rows, rows, L, H, Dh, dtype, out, stream);
+}
+
+extern "C" int bma_attn_merge_rows(const void* o1, const void* o2, const float* lse1, const float* lse2,
+                                   const int* map, int64_t N, int B2, int L, int H, int Dh, int dtype, void* out,
+                                   void* stream) {
+  if (N < 0 || B2 <= 0 || L <= 0 || H <= 0 || Dh <= 0 || !map) return BMA_EINVAL;
+  return merge_common(o1, o2, lse1, lse2, map, N, static_cast<int64_t>(B2) * L, L, H, Dh, dtype, out, stream);
+}
+
+extern "C" int bma_gather_rows(const void* src, const int* idx, int64_t n_out, int64_t n_src, int64_t row_bytes,
+                               void* out, void* stream) {
+  if (n_out < 0 || n_src <= 0 || row_bytes <= 0) return BMA_EINVAL;
+  if (n_out == 0) return BMA_OK;
+  if (!src || !idx || !out) return BMA_EINVAL;
+  if (row_bytes % 16 || (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) % 16) return BMA_EALIGN;
+  if (n_out > 0x7fffffffLL || row_bytes / 16 > 0x7fffffffLL) return BMA_ELIMIT;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(rows)), block(256);
-  const uint4_t* a = static_cast<const uint4_t*>(o1);
-  const uint4_t* c = static_cast<const uint4_t*>(o2);
-  uint4_t* y = static_cast<uint4_t*>(out);
-  BMA_PROF_BEGIN(BMA_K_ATTN_MERGE, st, 3.0 * static_cast<double>(B) * L * H * Dh * es);
-  if (dtype == BMA_F32) hipLaunchKernelGGL((attn_merge_kernel<BMA_F32>), grid, block, 0, st, a, c, lse1, lse2, B, L, H, cph, y);
-  else if (dtype == BMA_BF16) hipLaunchKernelGGL((attn_merge_kernel<BMA_BF16>), grid, block, 0, st, a, c, lse1, lse2, B, L, H, cph, y);
-  else hipLaunchKernelGGL((attn_merge_kernel<BMA_F16>), grid, block, 0, st, a, c, lse1, lse2, B, L, H, cph, y);
-  BMA_PROF_END(BMA_K_ATTN_MERGE, st);
+  BMA_PROF_BEGIN(BMA_K_GATHER_ROWS, st, 2.0 * static_cast<double>(n_out) * row_bytes);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(static_cast<unsigned>(n_out)), dim3(256), 0, st,
+                     static_cast<const uint4_t*>(src), idx, n_src, static_cast<int>(row_bytes / 16),
+                     static_cast<uint4_t*>(out));
+  BMA_PROF_END(BMA_K_GATHER_ROWS, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }

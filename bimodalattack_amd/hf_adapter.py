@@ -33,11 +33,46 @@ def features_tensor(out) -> torch.Tensor:
     return p if torch.is_tensor(p) else torch.stack(list(p))
 
 
+class CapturableNormalize:
+    """The caller's ``normalize`` when it is a per-channel (x - mean) / std -- torchvision's
+    ``Normalize`` or anything else exposing ``mean`` and ``std`` -- with the two constants kept
+    on the device.  torchvision rebuilds them from Python lists on every call: a host-to-device
+    copy per call, which cannot be captured into a hipGraph.  Same two ops in the same order;
+    checked once, bit for bit, against the caller's function, which is used instead on any
+    difference."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.ok = None if (hasattr(fn, "mean") and hasattr(fn, "std")) else False
+        self._consts = {}
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self.ok is False or x.dim() != 4:
+            return self.fn(x)
+        key = (x.device, x.dtype)
+        c = self._consts.get(key)
+        if c is None:
+            try:
+                c = tuple(torch.as_tensor(v, dtype=torch.float32).reshape(1, -1, 1, 1).to(x.device, x.dtype)
+                          for v in (self.fn.mean, self.fn.std))
+            except Exception:
+                self.ok = False
+                return self.fn(x)
+            self._consts[key] = c
+        out = (x - c[0]) / c[1]
+        if self.ok is None:
+            ref = self.fn(x)
+            self.ok = bool(ref.shape == out.shape and torch.equal(ref.detach(), out.detach()))
+            if not self.ok:
+                return ref
+        return out
+
+
 class HFAdapter:
     def __init__(self, model, processor, normalize=None):
         self.model = model
         self.processor = processor
-        self.normalize = normalize
+        self.normalize = CapturableNormalize(normalize) if callable(normalize) else normalize
         self.embedding = model.get_input_embeddings()
         self.device = model.device
         self.dtype = model.dtype
@@ -62,6 +97,7 @@ class HFAdapter:
         # shared-prefix attention (prefix_attention.py): None = not probed, [] = not applicable
         self._shared_cfgs = None
         self.shared_ok: Optional[bool] = None
+        self.ragged_ok: Optional[bool] = None
 
     # ------------------------------------------------------------ vision
     def image_features(self, image: torch.Tensor) -> torch.Tensor:
@@ -99,11 +135,14 @@ class HFAdapter:
         return logits[:, -T - 1:-1, :]
 
     def _keep_index(self, L: int, T: int, device) -> torch.Tensor:
+        # Entries are NEVER evicted: a captured hipGraph (winner re-score, gradient pass) holds the
+        # raw pointer of the tensor it was captured with; dropping it would let the allocator hand
+        # the memory to someone else and the replay would gather rows at garbage indices.
         key = (L, T, str(device))
-        cached = getattr(self, "_keep_cache", None)
-        if cached is None or cached[0] != key:
-            self._keep_cache = (key, torch.arange(L - T, L, device=device))
-        return self._keep_cache[1]
+        cache = self.__dict__.setdefault("_keep_cache", {})
+        if key not in cache:
+            cache[key] = torch.arange(L - T, L, device=device)
+        return cache[key]
 
     def build_prefix(self, prefix_embeds: torch.Tensor):
         """Keys/values of the shared prefix (1,P,D) -> an HF cache object, or None when
@@ -139,6 +178,18 @@ class HFAdapter:
         keep = self._keep_index(embeds.shape[1], T, embeds.device)
         with pa.active(self.shared_prefix_configs(), kv):
             return self.model(inputs_embeds=embeds, past_key_values=kv, logits_to_keep=keep).logits
+
+    def target_logits_ragged(self, rows: torch.Tensor, T: int, cache, maps) -> torch.Tensor:
+        """Ragged scoring (layout.ragged_plan): `rows` (1,N,D) holds, per candidate, only the tokens
+        from its first replaced suffix position on (and the parent suffix in front); returns the
+        (m,T,V) logits of the target-predicting rows."""
+        from . import prefix_attention as pa
+        kv = pa.SharedPrefixKV(cache)
+        kv.ragged = maps
+        with pa.active(self.shared_prefix_configs(), kv):
+            logits = self.model(inputs_embeds=rows, past_key_values=kv, position_ids=maps.pos,
+                                logits_to_keep=maps.keep).logits
+        return logits.view(maps.B2 - 1, T, logits.shape[-1])
 
     @staticmethod
     def expand_prefix(cache, batch: int):

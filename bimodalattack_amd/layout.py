@@ -63,3 +63,79 @@ def split_at_suffix(order: Sequence[str]) -> Tuple[List[str], List[str]]:
     keys/values can be computed once and shared."""
     i = list(order).index("optim")
     return list(order[:i]), list(order[i:])
+
+
+# ---------------------------------------------------------------------------------------------
+# Ragged scoring.  A candidate equals its parent suffix up to the first replaced position p, so
+# under causal attention its hidden states at suffix positions < p equal the parent's: only
+# tokens j >= p of the L tokens behind the shared prefix are computed (GEMMs, norms and MLP
+# gates see 1 - (n_opt-1)/(2L) of the rows), and attention reads the parent's keys/values for
+# the rest.  The parent's n_opt suffix tokens ride along as the first rows of the same forward.
+def first_diff_stats(n_opt: int, n_replace: int) -> Tuple[float, float]:
+    """Mean and variance of the first replaced position when `n_replace` distinct positions are
+    drawn uniformly from n_opt (the reference's argsort-of-uniforms draw, :150-152)."""
+    from math import comb
+    r = max(1, min(int(n_replace), n_opt))
+    tot = comb(n_opt, r)
+    # P(min >= k) = C(n_opt - k, r) / C(n_opt, r)
+    surv = [comb(n_opt - k, r) / tot for k in range(n_opt + 1)]
+    pk = [surv[k] - surv[k + 1] for k in range(n_opt)]
+    mean = sum(k * q for k, q in enumerate(pk))
+    var = sum((k - mean) ** 2 * q for k, q in enumerate(pk))
+    return mean, var
+
+
+def ragged_budget(m: int, n_opt: int, L: int, n_replace: int) -> int:
+    """A FIXED row count for a step's ragged forward (static GEMM shapes): the n_opt parent rows
+    plus the expected candidate rows + 5 sigma, rounded up; never more than computing every token.
+    A draw that needs more rows (p ~ 3e-7) is scored through the padded path instead."""
+    mean, var = first_diff_stats(n_opt, n_replace)
+    want = n_opt + m * (L - mean) + 5.0 * (m * var) ** 0.5
+    gran = 256 if m * L >= 8192 else 8
+    return min(int(-(-want // gran) * gran), n_opt + m * L)
+
+
+def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int):
+    """Index maps of one ragged scoring forward, numpy in / numpy out.
+
+    cand (m,n_opt) candidate suffix ids, parent (n_opt,) the ids they were sampled from, L tokens
+    per candidate behind the shared prefix (suffix first), T target rows, P prefix length, n_rows
+    the fixed row count (``ragged_budget``).  Returns None when the draw does not fit n_rows, else
+      flat  (N,)        row n -> padded slot b*L+j  (parent = block m; also the embedding gather)
+      q_src (B2*L,)     padded slot -> row holding its query (any own row where none is computed)
+      kv_src(B2*L,)     padded slot -> row holding its key/value (parent rows in front of p)
+      pos   (N,)        rotary position of row n
+      keep  (m*T,)      rows that predict the target tokens, candidate-major
+      p     (m,)        first computed position per candidate
+    with B2 = m + 1 and N = n_rows."""
+    import numpy as np
+    cand = np.asarray(cand)
+    parent = np.asarray(parent).reshape(-1)
+    m, n_opt = cand.shape
+    if parent.shape[0] != n_opt or L - T < n_opt - 1 or n_opt < 1:
+        raise ValueError("ragged_plan: inconsistent shapes")
+    diff = cand != parent[None, :]
+    p = np.where(diff.any(1), diff.argmax(1), n_opt - 1).astype(np.int64)
+    deficit = (n_rows - n_opt) - int((L - p).sum())
+    if deficit < 0:
+        return None
+    if deficit > 0:                                  # lower p (recompute a few parent rows): exact fit
+        before = np.cumsum(p) - p
+        p = p - np.minimum(p, np.maximum(0, deficit - before))
+        if int((L - p).sum()) != n_rows - n_opt:
+            return None                              # n_rows > n_opt + m*L: cannot happen via ragged_budget
+    lens = L - p
+    starts = n_opt + np.cumsum(lens) - lens
+    n_c = int(lens.sum())
+    tok_i = np.repeat(np.arange(m), lens)
+    tok_j = np.arange(n_c) - np.repeat(starts - n_opt, lens) + np.repeat(p, lens)
+    flat = np.concatenate([m * L + np.arange(n_opt), tok_i * L + tok_j]).astype(np.int32)
+    pos = np.concatenate([np.arange(n_opt), tok_j]).astype(np.int64) + P
+    J = np.arange(L)[None, :]
+    own = starts[:, None] + (J - p[:, None])
+    valid = J >= p[:, None]
+    par = np.minimum(np.arange(L), n_opt - 1)
+    q_src = np.concatenate([np.where(valid, own, starts[:, None]).reshape(-1), par]).astype(np.int32)
+    kv_src = np.concatenate([np.where(valid, own, J).reshape(-1), par]).astype(np.int32)
+    keep = (starts[:, None] + (L - T - p[:, None]) + np.arange(T)[None, :]).reshape(-1).astype(np.int64)
+    return dict(flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows))

@@ -300,6 +300,41 @@ def attn_merge(o1: torch.Tensor, o2: torch.Tensor, lse1: torch.Tensor, lse2: tor
     return out
 
 
+def attn_merge_rows(o1: torch.Tensor, o2: torch.Tensor, lse1: torch.Tensor, lse2: torch.Tensor,
+                    row_map: torch.Tensor) -> torch.Tensor:
+    """Ragged form: o1 (N,H,Dh), lse1 (H,N); o2 (B2,L,H,Dh), lse2 (B2,H,L); row_map (N,) int32 with the
+    padded row b*L+l each computed token pairs with.  Returns (N,H,Dh)."""
+    dev = _need_gpu(o1, o2, lse1, lse2, row_map)
+    N, H, Dh = o1.shape
+    B2, L = o2.shape[0], o2.shape[1]
+    if o2.shape != (B2, L, H, Dh) or o1.dtype != o2.dtype or not o1.is_contiguous() or not o2.is_contiguous():
+        raise ValueError("o1 must be (N,H,Dh) and o2 (B2,L,H,Dh), contiguous, one dtype")
+    if lse1.dtype != torch.float32 or lse2.dtype != torch.float32 or lse1.shape != (H, N) or \
+            lse2.shape != (B2, H, L) or not lse1.is_contiguous() or not lse2.is_contiguous():
+        raise ValueError("lse1 must be (H,N) and lse2 (B2,H,L), contiguous fp32")
+    if row_map.dtype != torch.int32 or row_map.shape != (N,) or not row_map.is_contiguous():
+        raise ValueError("row_map must be a contiguous int32 (N,) tensor")
+    out = torch.empty_like(o1)
+    check("bma_attn_merge_rows", lib.bma_attn_merge_rows(o1.data_ptr(), o2.data_ptr(), lse1.data_ptr(), lse2.data_ptr(),
+                                                         row_map.data_ptr(), N, B2, L, H, Dh, _dt(o1), out.data_ptr(),
+                                                         _stream(dev)))
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[r] = src[idx[r]] over the first dimension of a contiguous src; idx int32 (R,)."""
+    dev = _need_gpu(src, idx)
+    if not src.is_contiguous() or src.dim() < 2:
+        raise ValueError("src must be contiguous with at least two dimensions")
+    if idx.dtype != torch.int32 or idx.dim() != 1 or not idx.is_contiguous():
+        raise ValueError("idx must be a contiguous int32 vector")
+    row_bytes = src[0].numel() * src.element_size()
+    out = torch.empty((idx.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    check("bma_gather_rows", lib.bma_gather_rows(src.data_ptr(), idx.data_ptr(), idx.shape[0], src.shape[0], row_bytes,
+                                                 out.data_ptr(), _stream(dev)))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # the same ops under autograd (the gradient pass): fused forward + fused backward
 class RMSNormFn(torch.autograd.Function):

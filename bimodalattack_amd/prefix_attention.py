@@ -97,6 +97,7 @@ class SharedPrefixKV(_CacheBase):
         self.P = int(self.k[0].shape[2])
         self._sliding = [False] * len(layers)
         self._rep = {}
+        self.ragged: Optional["RaggedMaps"] = None     # set for a ragged scoring forward
 
     @property
     def is_sliding(self):                          # read-only property on the HF base class
@@ -128,6 +129,20 @@ class SharedPrefixKV(_CacheBase):
             hit = (self.k[layer_idx].repeat_interleave(n_rep, dim=1), self.v[layer_idx].repeat_interleave(n_rep, dim=1))
             self._rep[layer_idx] = hit
         return hit
+
+
+class RaggedMaps:
+    """Device copies of ``layout.ragged_plan``'s index maps for one scoring forward."""
+
+    def __init__(self, plan: dict, device):
+        def dev(a, dtype):
+            return torch.from_numpy(a).to(device=device, dtype=dtype, non_blocking=True)
+        self.N, self.L, self.B2 = int(plan["N"]), int(plan["L"]), int(plan["m"]) + 1
+        self.flat = dev(plan["flat"], torch.int32)
+        self.q_src = dev(plan["q_src"], torch.int32)
+        self.kv_src = dev(plan["kv_src"], torch.int32)
+        self.pos = dev(plan["pos"], torch.int64).unsqueeze(0)
+        self.keep = dev(plan["keep"], torch.int64)
 
 
 _BIAS = {}
@@ -169,10 +184,12 @@ def shared_prefix_attention(module, query, key, value, attention_mask=None, drop
     kv = _ACTIVE[-1]
     B, H, L, Dh = query.shape
     n_rep = H // key.shape[1]
+    scale = float(scaling) if scaling is not None else Dh ** -0.5
+    if kv.ragged is not None:
+        return _ragged_attention(kv, module.layer_idx, query, key, value, n_rep, scale), None
     if n_rep > 1:
         key, value = key.repeat_interleave(n_rep, dim=1), value.repeat_interleave(n_rep, dim=1)
     Kp, Vp = kv.prefix(module.layer_idx, n_rep)
-    scale = float(scaling) if scaling is not None else Dh ** -0.5
     qm = query.transpose(1, 2)                      # (B,L,H,Dh): the projection's own memory order
     if not qm.is_contiguous():
         qm = qm.contiguous()
@@ -183,6 +200,35 @@ def shared_prefix_attention(module, query, key, value, attention_mask=None, drop
     o2 = o2.transpose(1, 2).contiguous()
     out = ops.attn_merge(o1, o2, l1.reshape(H, B * L).contiguous(), l2.contiguous())
     return out, None
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """(1,H,N,Dh) view of a projection's (1,N,H,Dh) output -> the contiguous (N,H,Dh) row list."""
+    r = t.transpose(1, 2)
+    return (r if r.is_contiguous() else r.contiguous())[0]
+
+
+def _ragged_attention(kv: SharedPrefixKV, layer_idx: int, query, key, value, n_rep: int, scale: float):
+    """Attention of the ragged row list (layout.ragged_plan): every computed token against the
+    shared prefix (one batch-1 launch over all N rows), plus causal attention inside the padded
+    (B2,L) block whose slots are filled from the row list -- a candidate's slots in front of its
+    first replaced position hold its PARENT's keys/values, which are rows of the same forward."""
+    rg = kv.ragged
+    _, H, N, Dh = query.shape
+    Hk = key.shape[1]
+    q_rows, k_rows, v_rows = _rows(query), _rows(key), _rows(value)
+    Kp, Vp = kv.prefix(layer_idx, n_rep)
+    o1, l1 = _partial_attention(q_rows.unsqueeze(0).transpose(1, 2), Kp, Vp, False, scale)
+    o1 = o1.transpose(1, 2).reshape(N, H, Dh).contiguous()
+    qp = ops.gather_rows(q_rows, rg.q_src).view(rg.B2, rg.L, H, Dh).transpose(1, 2)
+    kp = ops.gather_rows(k_rows, rg.kv_src).view(rg.B2, rg.L, Hk, Dh).transpose(1, 2)
+    vp = ops.gather_rows(v_rows, rg.kv_src).view(rg.B2, rg.L, Hk, Dh).transpose(1, 2)
+    if n_rep > 1:
+        kp, vp = kp.repeat_interleave(n_rep, dim=1), vp.repeat_interleave(n_rep, dim=1)
+    o2, l2 = _partial_attention(qp, kp, vp, True, scale)
+    o2 = o2.transpose(1, 2).contiguous()
+    out = ops.attn_merge_rows(o1, o2, l1.reshape(H, N).contiguous(), l2.contiguous(), rg.flat)
+    return out.unsqueeze(0)                         # (1,N,H,Dh)
 
 
 def _no_mask(*args, **kwargs):

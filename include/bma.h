@@ -172,6 +172,18 @@ int bma_gated_act_bwd(const void* gate, const void* up, const void* dy, int64_t 
  *   of `dtype`; lse1: [H][B*L] fp32 (prefix launch: batch 1, B*L queries); lse2: [B][H][L] fp32. */
 int bma_attn_merge(const void* o1, const void* o2, const float* lse1, const float* lse2,
                    int B, int L, int H, int Dh, int dtype, void* out, void* stream);
+/* Ragged scoring (a candidate differs from its parent suffix from position p on, so only its
+ *   tokens >= p are computed; the N computed tokens of all candidates form one row list):
+ * bma_attn_merge_rows: as bma_attn_merge, with o1/out [N][H][Dh], lse1 [H][N], and row n paired
+ *   with row map[n] (= b*L + l) of the padded o2 [B2][L][H][Dh] / lse2 [B2][H][L];
+ * bma_gather_rows: out[r] = src[idx[r]] for rows of row_bytes (multiple of 16) bytes -- builds the
+ *   padded (B2,L) query/key/value blocks from the row list (a candidate's rows < p come from
+ *   its parent's rows).  Indices are clamped into the source. */
+int bma_attn_merge_rows(const void* o1, const void* o2, const float* lse1, const float* lse2,
+                        const int* map, int64_t N, int B2, int L, int H, int Dh, int dtype, void* out,
+                        void* stream);
+int bma_gather_rows(const void* src, const int* idx, int64_t n_out, int64_t n_src, int64_t row_bytes,
+                    void* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Measurement aid (bench.py).  When enabled, the dominant kernel of
@@ -185,7 +197,7 @@ enum {
   BMA_K_LINF = 0, BMA_K_CE_ROWS = 1 /* B > 1: candidate scoring */, BMA_K_CE_DLOGITS = 2,
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
-  BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_COUNT = 11
+  BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11, BMA_K_COUNT = 12
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

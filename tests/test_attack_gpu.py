@@ -139,6 +139,8 @@ def test_trajectory_matches_reference(golden_dir, name):
                                     dict(chunk=5),
                                     # the HF-cache path (KV concat) instead of shared-prefix attention
                                     dict(shared_prefix_attention=False),
+                                    # shared-prefix attention on the padded block (every suffix token computed)
+                                    dict(ragged_suffix=False),
                                     # everything eager and unfused
                                     dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
                                          fused_elementwise=False, gemm_tuning="off")])

@@ -231,6 +231,69 @@ def test_shared_prefix_forward_equals_cache_forward(dtype):
     assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
 
 
+def test_gather_rows_and_mapped_merge_vs_torch():
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(4)
+    for dtype in (torch.bfloat16, torch.float32):
+        src = torch.randn((37, 4, 64), generator=g, device=DEV).to(dtype)
+        idx = torch.randint(0, 37, (101,), generator=g, device=DEV).to(torch.int32)
+        assert torch.equal(ops.gather_rows(src, idx), src[idx.long()])
+        # out-of-range indices are clamped, never read outside the source
+        bad = torch.tensor([-5, 36, 37, 1000], device=DEV, dtype=torch.int32)
+        assert torch.equal(ops.gather_rows(src, bad), src[torch.tensor([0, 36, 36, 36], device=DEV)])
+        N, B2, L, H, Dh = 50, 5, 12, 4, 64
+        o1 = torch.randn((N, H, Dh), generator=g, device=DEV).to(dtype)
+        o2 = torch.randn((B2, L, H, Dh), generator=g, device=DEV).to(dtype)
+        l1 = torch.randn((H, N), generator=g, device=DEV)
+        l2 = torch.randn((B2, H, L), generator=g, device=DEV)
+        rmap = torch.randperm(B2 * L, generator=g, device=DEV)[:N].to(torch.int32)
+        got = ops.attn_merge_rows(o1, o2, l1, l2, rmap)
+        # the padded-layout kernel on the rows picked out by hand is the reference
+        o2r = o2.view(B2 * L, H, Dh)[rmap.long()]
+        l2r = l2.permute(0, 2, 1).reshape(B2 * L, H)[rmap.long()]                     # (N,H)
+        want = ops.attn_merge(o1.view(1, N, H, Dh), o2r.view(1, N, H, Dh).contiguous(), l1.contiguous(),
+                              l2r.t().reshape(1, H, N).contiguous())
+        assert torch.equal(got, want.view(N, H, Dh))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ragged_forward_equals_padded_forward(dtype):
+    """Whole-model check on a small Llama: candidates that differ from a parent suffix from
+    position p on, scored through the ragged row list, give the logits of the padded
+    shared-prefix forward."""
+    from bimodalattack_amd.hf_adapter import HFAdapter
+    from bimodalattack_amd import ops, prefix_attention as pa, synthetic as S
+    from bimodalattack_amd.layout import ragged_plan
+    model = _small_llama(dtype)
+    ad = HFAdapter(model, S.SyntheticProcessor(None), None)
+    D = model.get_input_embeddings().weight.shape[1]
+    m, P, n_opt, L, T = 9, 11, 6, 15, 4
+    g = torch.Generator(device=DEV).manual_seed(21)
+    prefix = (torch.randn((1, P, D), generator=g, device=DEV) * 0.5).to(dtype)
+    table = (torch.randn((64, D), generator=g, device=DEV) * 0.5).to(dtype)            # "embeddings"
+    rest = (torch.randn((1, L - n_opt, D), generator=g, device=DEV) * 0.5).to(dtype)    # after + target rows
+    parent = np.arange(n_opt)
+    cand = np.tile(parent, (m, 1))
+    firsts = [0, 1, 2, 3, 4, 5, 5, 2, 0]
+    for i, f in enumerate(firsts):
+        cand[i, f] = 10 + i
+    cand[6] = parent                                                                   # identical to the parent
+    both = torch.from_numpy(np.concatenate([cand, parent[None]])).to(DEV)
+    x = torch.cat([table[both], rest.expand(m + 1, -1, -1)], dim=1)                     # (m+1, L, D)
+    n_rows = n_opt + sum(L - f for f in firsts) + 8                                     # forces a little absorption
+    plan = ragged_plan(cand, parent, L, T, P, n_rows)
+    assert plan is not None and (plan["p"] <= np.array([0, 1, 2, 3, 4, 5, 5, 2, 0])).all()
+    maps = pa.RaggedMaps(plan, DEV)
+    rows = ops.gather_rows(x.view((m + 1) * L, D).contiguous(), maps.flat).unsqueeze(0)
+    with torch.no_grad():
+        cache = ad.build_prefix_recording(prefix)
+        want = ad.target_logits_shared_prefix(x[:m].contiguous(), T, cache).float()
+        got = ad.target_logits_ragged(rows, T, cache, maps).float()
+    assert got.shape == want.shape
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
 # ------------------------------------------------------------------ fused ops under autograd
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_backward_matches_eager_autograd(dtype):

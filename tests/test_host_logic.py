@@ -125,3 +125,91 @@ def test_hf_adapter_restructurings_are_identical_maths(kind):
         f = ad.image_features(image)
         assert f.dim() == 3 and f.shape[0] == 1 and f.shape[2] == D
     assert (ad.emb_scale != 1.0) == (kind == "gemma3")
+
+
+def test_keep_index_entries_outlive_other_shapes():
+    """A captured hipGraph holds the raw pointer of the index tensor it was captured with: the
+    adapter must hand back the SAME tensor for a shape however many other shapes were asked
+    for in between (an evicted entry was a use-after-free on graph replay)."""
+    from bimodalattack_amd import synthetic as S
+    from bimodalattack_amd.hf_adapter import HFAdapter
+    model, tok, proc, _ = S.tiny_case("opt")
+    hf = HFAdapter(model, proc)
+    a = hf._keep_index(40, 5, "cpu")
+    ptr = a.data_ptr()
+    for L in range(10, 30):
+        hf._keep_index(L, 5, "cpu")
+    b = hf._keep_index(40, 5, "cpu")
+    assert b is a and b.data_ptr() == ptr and b.tolist() == [35, 36, 37, 38, 39]
+
+
+def test_capturable_normalize_is_bit_identical_or_steps_aside():
+    from bimodalattack_amd import synthetic as S
+    from bimodalattack_amd.hf_adapter import CapturableNormalize
+    x = torch.rand(1, 3, 8, 8)
+    ref = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
+    n = CapturableNormalize(ref)
+    assert torch.equal(n(x), ref(x)) and n.ok is True
+    assert torch.equal(n(x * 0.5), ref(x * 0.5))
+
+    class ListStyle:                       # torchvision keeps Python lists
+        mean, std = list(S.CLIP_MEAN), list(S.CLIP_STD)
+
+        def __call__(self, t):
+            m = torch.as_tensor(self.mean, dtype=t.dtype).view(-1, 1, 1)
+            s = torch.as_tensor(self.std, dtype=t.dtype).view(-1, 1, 1)
+            return t.clone().sub_(m).div_(s)
+    n = CapturableNormalize(ListStyle())
+    assert torch.equal(n(x), ListStyle()(x)) and n.ok is True
+
+    class Liar:                            # exposes mean/std but computes something else
+        mean, std = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+
+        def __call__(self, t):
+            return t * 2
+    n = CapturableNormalize(Liar())
+    assert torch.equal(n(x), x * 2) and n.ok is False and torch.equal(n(x), x * 2)
+    n = CapturableNormalize(lambda t: t + 1)          # no mean/std: passed through
+    assert n.ok is False and torch.equal(n(x), x + 1)
+
+
+def test_ragged_plan_invariants():
+    """layout.ragged_plan: every computed token appears once, slots in front of the first
+    replaced position read the parent's rows, the fixed budget is met exactly, and a draw that
+    cannot fit is refused."""
+    from bimodalattack_amd.layout import first_diff_stats, ragged_budget, ragged_plan
+    mean, var = first_diff_stats(20, 1)
+    assert abs(mean - 9.5) < 1e-12 and abs(var - (20 ** 2 - 1) / 12) < 1e-9
+    assert first_diff_stats(20, 2)[0] < mean and first_diff_stats(5, 9) == (0.0, 0.0)
+    rng = np.random.default_rng(0)
+    for m, n_opt, L, T, r in [(512, 20, 45, 20, 1), (33, 6, 14, 5, 2), (7, 4, 8, 5, 1), (2, 1, 3, 3, 1)]:
+        parent = rng.integers(0, 50, n_opt)
+        cand = np.tile(parent, (m, 1))
+        for i in range(m):
+            for q in rng.choice(n_opt, size=min(r, n_opt), replace=False):
+                cand[i, q] = parent[q] + 100 + i
+        cand[m // 2] = parent                                  # a candidate equal to its parent
+        first = np.where((cand != parent).any(1), (cand != parent).argmax(1), n_opt - 1)
+        n_rows = ragged_budget(m, n_opt, L, r)
+        assert n_rows <= n_opt + m * L
+        plan = ragged_plan(cand, parent, L, T, 7, n_rows)
+        if plan is None:                                       # tiny m: 5 sigma may not cover the draw
+            plan = ragged_plan(cand, parent, L, T, 7, n_opt + m * L)
+        N, flat, p = plan["N"], plan["flat"], plan["p"]
+        assert len(flat) == N == len(plan["pos"]) and (p <= first).all() and (p >= 0).all()
+        assert len(set(flat.tolist())) == N
+        assert (flat[:n_opt] == m * L + np.arange(n_opt)).all() and (plan["pos"][:n_opt] == 7 + np.arange(n_opt)).all()
+        assert (plan["pos"] == 7 + flat % L).all()
+        qs, ks = plan["q_src"].reshape(m + 1, L), plan["kv_src"].reshape(m + 1, L)
+        for i in range(m):
+            for j in range(L):
+                if j >= p[i]:
+                    assert flat[qs[i, j]] == i * L + j and ks[i, j] == qs[i, j]
+                else:
+                    assert ks[i, j] == j and cand[i, j] == parent[j] and flat[qs[i, j]] // L == i
+        assert (ks[m, :n_opt] == np.arange(n_opt)).all() and (qs[m] < n_opt).all()
+        keep = plan["keep"].reshape(m, T)
+        assert (flat[keep] == (np.arange(m)[:, None] * L + (L - T) + np.arange(T)[None, :])).all()
+    assert ragged_plan(cand, parent, L, T, 7, n_opt + 1) is None
+    with pytest.raises(ValueError):
+        ragged_plan(np.zeros((2, 4), int), np.zeros(4, int), 5, 3, 0, 14)     # target rows would precede the suffix end
