@@ -27,6 +27,10 @@ def main():
                PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS="20", BMA_GRAPH_GRADIENT="0", BMA_GEMM_TUNING="off",
                MIOPEN_FIND_MODE="FAST")
     workloads = sys.argv[1:] or ["gcg", "joint"]
+    dst = os.path.join(REPO, "bimodalattack_amd", "tuning", f"{arch}.csv")
+    src = results.replace(".csv", "0.csv")
+    if os.path.exists(dst) and not os.path.exists(src):
+        shutil.copyfile(dst, src)            # keep what is already tuned: only new shapes are searched
     for wl in workloads:
         for sw in (512, 256, 128, 64):
             print(f"== tuning {wl} search_width={sw}", flush=True)
@@ -34,8 +38,6 @@ def main():
                                 "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=REPO)
             if r.returncode != 0:
                 print(f"   (failed with {r.returncode}; continuing)", flush=True)
-    src = results.replace(".csv", "0.csv")
-    dst = os.path.join(REPO, "bimodalattack_amd", "tuning", f"{arch}.csv")
     shutil.copyfile(src, dst)
     shutil.copyfile(src, os.path.join(out_dir, f"{arch}.csv"))
     print("wrote", dst, sum(1 for _ in open(dst)), "lines")
