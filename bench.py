@@ -231,6 +231,8 @@ def main() -> None:
     def hook(i: int) -> None:
         log(f"step {i}/{total}")
         if i == args.warmup:
+            for k_ in attack.score_stats:
+                attack.score_stats[k_] = 0
             native.profile_enable(True)          # tallies cover exactly the timed region
             marks["t0"] = barrier_clock()
         if i == total:
@@ -300,16 +302,25 @@ def main() -> None:
         seg = dict(before_img=20, optim=19, before_suffix=3, n_img=256, after=6, target=20)
     new_tok = (sum(seg.values()) - seg["before_img"] - 1) if wl.get("gemma") else (seg["optim"] + seg["after"] + seg["target"] - 1)
     full_tok = sum(v for k_, v in seg.items())
-    flops_cand = 2 * p_lm * new_tok + 2 * tc.hidden_size * tc.vocab_size * seg["target"]
+    # rows the scoring forwards needed behind the shared prefix, per candidate: with ragged scoring
+    # a candidate's suffix tokens in front of its first replaced position are not recomputed
+    ss = attack.score_stats
+    need_tok = ss["rows_needed"] / ss["candidates"] if ss["candidates"] else float(new_tok)
+    done_tok = ss["rows"] / ss["candidates"] if ss["candidates"] else float(new_tok)
+    flops_cand = 2 * p_lm * need_tok + 2 * tc.hidden_size * tc.vocab_size * seg["target"]
     fwd = None
     if loss_s > 0 and n_cand:
         ach = flops_cand * n_cand / loss_s / 1e12
         fwd = dict(bound="mfma", achieved=ach, peak=MFMA_PEAK_TFLOPS * world, unit="TFLOP/s",
                    frac=ach / (MFMA_PEAK_TFLOPS * world),
-                   algorithmic_flops_per_candidate=flops_cand, new_tokens_per_candidate=new_tok,
+                   algorithmic_flops_per_candidate=flops_cand, rows_needed_per_candidate=need_tok,
+                   rows_computed_per_candidate=done_tok, new_tokens_per_candidate=new_tok,
                    full_recompute_tokens_per_candidate=full_tok,
-                   note="scoring phase (splice + forward + CE + all-gather + argmin) over the timed steps; "
-                        "GEMMs are hipBLASLt/rocBLAS inside the HuggingFace model")
+                   ragged_calls=ss["ragged_calls"], padded_calls=ss["padded_calls"],
+                   note="scoring phase (splice + forward + CE + all-gather + argmin) over the timed steps, this "
+                        "rank's candidates; flops count the rows the ragged forward NEEDS (tokens from the first "
+                        "replaced suffix position on), not the padded block; GEMMs are hipBLASLt/rocBLAS inside "
+                        "the HuggingFace model")
 
     out = {
         "metric": "candidate_forwards_per_sec", "value": n_cand / elapsed, "unit": "candidate_forwards/s",

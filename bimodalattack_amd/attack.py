@@ -149,6 +149,9 @@ class BimodalAttack:
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
         self._grad_graph = None                    # None: not tried yet; False: eager for good
         self._prefix_cache: Dict[tuple, tuple] = {}
+        # what candidate scoring computed (calls with more than one candidate): `rows` token rows went
+        # through the model behind the shared prefix for `candidates` candidates; bench.py reads this
+        self.score_stats = dict(candidates=0, rows=0, rows_needed=0, ragged_calls=0, padded_calls=0)
         self._rescore_graphs: Dict[tuple, object] = {}
         self._feat_graph = None                    # image -> image features (no autograd)
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
@@ -422,7 +425,10 @@ class BimodalAttack:
         x = ops.splice(segs, m + 1, self.embedding_layer.weight, both.contiguous(), hf.emb_scale)
         rows = ops.gather_rows(x.view((m + 1) * L, x.shape[-1]), maps.flat).unsqueeze(0)
         del x
-        self._last_ragged = (int(plan["N"]), (m + 1) * L)
+        st = self.score_stats
+        st["ragged_calls"] += 1
+        st["rows"] += int(plan["N"])
+        st["rows_needed"] += int(plan["needed"])
         return hf.target_logits_ragged(rows, self.T, cache, maps)
 
     def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
@@ -474,8 +480,15 @@ class BimodalAttack:
                             raise
                         logger.warning(f"ragged scoring disabled: {type(e).__name__}: {e}")
                         hf.ragged_ok, ragged = False, False
+                if m > 1:
+                    self.score_stats["candidates"] += b
                 if logits is None:
                     x = ops.splice(segs, b, E, mine[s:s + b].contiguous(), hf.emb_scale)
+                    if m > 1:
+                        st = self.score_stats
+                        st["padded_calls"] += 1
+                        st["rows"] += b * L
+                        st["rows_needed"] += b * L
                 if logits is not None:
                     pass
                 elif shared:

@@ -116,7 +116,8 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int):
         raise ValueError("ragged_plan: inconsistent shapes")
     diff = cand != parent[None, :]
     p = np.where(diff.any(1), diff.argmax(1), n_opt - 1).astype(np.int64)
-    deficit = (n_rows - n_opt) - int((L - p).sum())
+    needed = n_opt + int((L - p).sum())
+    deficit = n_rows - needed
     if deficit < 0:
         return None
     if deficit > 0:                                  # lower p (recompute a few parent rows): exact fit
@@ -138,4 +139,5 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int):
     q_src = np.concatenate([np.where(valid, own, starts[:, None]).reshape(-1), par]).astype(np.int32)
     kv_src = np.concatenate([np.where(valid, own, J).reshape(-1), par]).astype(np.int32)
     keep = (starts[:, None] + (L - T - p[:, None]) + np.arange(T)[None, :]).reshape(-1).astype(np.int64)
-    return dict(flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows))
+    return dict(flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows),
+                needed=needed)

@@ -95,8 +95,35 @@ def cases():
         l2 = torch.randn((B, H, L), generator=g, device=DEV)
         return lambda: ops.attn_merge(o1, o2, l1, l2)
 
+    def rope_rows(N, H, Dh):
+        # the ragged row list: one "sequence" of N rows, per-row rotary angles
+        q = torch.randn((1, N, H * Dh), generator=g, device=DEV).to(bf).view(1, N, H, Dh).transpose(1, 2)
+        ang = torch.rand((1, N, Dh), generator=g, device=DEV)
+        cos, sin = ang.cos().to(bf), ang.sin().to(bf)
+        return lambda: ops.rope_(q, cos, sin)
+
+    def merge_rows(N, B2, L, H, Dh):
+        o1 = torch.randn((N, H, Dh), generator=g, device=DEV).to(bf)
+        o2 = torch.randn((B2, L, H, Dh), generator=g, device=DEV).to(bf)
+        l1 = torch.randn((H, N), generator=g, device=DEV)
+        l2 = torch.randn((B2, H, L), generator=g, device=DEV)
+        rmap = torch.randperm(B2 * L, generator=g, device=DEV)[:N].sort().values.to(torch.int32)
+        return lambda: ops.attn_merge_rows(o1, o2, l1, l2, rmap)
+
+    def gather(N, R, W):
+        src = torch.randn((N, W), generator=g, device=DEV).to(bf)
+        idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
+        return lambda: ops.gather_rows(src, idx)
+
     return {
         # name: (kernel id in the profiler, thunk factory)
+        # ragged scoring of C3 (search_width 512, 19 suffix + 25 tail tokens): 18688 computed rows,
+        # padded block 513 x 44
+        "rmsnorm/c3r_18688x4096": ("rmsnorm", lambda: rmsnorm(18688, 4096)),
+        "swiglu/c3r_18688x11008": ("swiglu", lambda: swiglu(18688, 11008)),
+        "rope/c3r_N18688_H32_Dh128": ("rope", lambda: rope_rows(18688, 32, 128)),
+        "attn_merge/c3r_N18688_B513_L44": ("attn_merge", lambda: merge_rows(18688, 513, 44, 32, 128)),
+        "gather_rows/c3r_22572_of_18688x4096": ("gather_rows", lambda: gather(18688, 513 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
         "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
         "rope/c3_B512_L44_H32_Dh128": ("rope", lambda: rope(512, 44, 32, 128)),
