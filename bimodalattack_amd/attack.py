@@ -417,13 +417,16 @@ class BimodalAttack:
         parent = parent.reshape(1, n_opt).to(mine.device)
         both = torch.cat([mine, parent], dim=0)
         host = both.cpu().numpy()                    # waits for the sampling kernels only
-        plan = ragged_plan(host[:m], host[m], L, self.T, P, ragged_budget(m, n_opt, L, cfg.n_replace))
+        plan = ragged_plan(host[:m], host[m], L, self.T, P, ragged_budget(m, n_opt, L, cfg.n_replace, cfg.topk))
         if plan is None:
             return None
         from .prefix_attention import RaggedMaps
         maps = RaggedMaps(plan, mine.device)
-        x = ops.splice(segs, m + 1, self.embedding_layer.weight, both.contiguous(), hf.emb_scale)
-        rows = ops.gather_rows(x.view((m + 1) * L, x.shape[-1]), maps.flat).unsqueeze(0)
+        import numpy as np
+        mu = int(plan["m"])           # distinct candidates, in the plan's (sorted) order: duplicates are computed once
+        both = torch.from_numpy(np.concatenate([plan["cand"], host[m:m + 1]])).to(mine.device, non_blocking=True)
+        x = ops.splice(segs, mu + 1, self.embedding_layer.weight, both.contiguous(), hf.emb_scale)
+        rows = ops.gather_rows(x.view((mu + 1) * L, x.shape[-1]), maps.flat).unsqueeze(0)
         del x
         st = self.score_stats
         st["ragged_calls"] += 1

@@ -189,7 +189,7 @@ class HFAdapter:
         with pa.active(self.shared_prefix_configs(), kv):
             logits = self.model(inputs_embeds=rows, past_key_values=kv, position_ids=maps.pos,
                                 logits_to_keep=maps.keep).logits
-        return logits.view(maps.B2 - 1, T, logits.shape[-1])
+        return logits.view(maps.m_out, T, logits.shape[-1])
 
     @staticmethod
     def expand_prefix(cache, batch: int):

@@ -85,17 +85,35 @@ def first_diff_stats(n_opt: int, n_replace: int) -> Tuple[float, float]:
     return mean, var
 
 
-def ragged_budget(m: int, n_opt: int, L: int, n_replace: int) -> int:
-    """A FIXED row count for a step's ragged forward (static GEMM shapes): the n_opt parent rows
-    plus the expected candidate rows + 5 sigma, rounded up; never more than computing every token.
-    A draw that needs more rows (p ~ 3e-7) is scored through the padded path instead."""
-    mean, var = first_diff_stats(n_opt, n_replace)
-    want = n_opt + m * (L - mean) + 5.0 * (m * var) ** 0.5
+def expected_unique(m: int, n_opt: int, n_replace: int, topk: int) -> Tuple[float, float]:
+    """Mean and variance of the number of DISTINCT candidates among m draws of (positions, top-k
+    ranks) -- the occupancy problem over K = C(n_opt, r) * topk^r equally likely outcomes (:150-160).
+    Exact duplicates score identically, so the ragged forward computes each distinct candidate once."""
+    from math import comb
+    r = max(1, min(int(n_replace), n_opt))
+    K = float(comb(n_opt, r)) * float(max(1, topk)) ** r
+    if K > 1e12 or m <= 1:
+        return float(m), 0.0
+    q1, q2 = (1.0 - 1.0 / K) ** m, (1.0 - 2.0 / K) ** m
+    mean = K * (1.0 - q1)
+    var = max(0.0, K * (K - 1.0) * q2 + K * q1 - K * K * q1 * q1)
+    return mean, var
+
+
+def ragged_budget(m: int, n_opt: int, L: int, n_replace: int, topk: int = 0, sigmas: float = 4.0) -> int:
+    """A FIXED row count for a step's ragged forward (static GEMM shapes): the n_opt parent rows plus
+    the expected rows of the distinct candidates + `sigmas` standard deviations, rounded up; never more
+    than computing every token.  A draw that needs more rows (p ~ 3e-5 at 4 sigma) is scored through
+    the padded path for that step.  topk = 0: no duplicate removal assumed."""
+    mean_p, var_p = first_diff_stats(n_opt, n_replace)
+    u, var_u = expected_unique(m, n_opt, n_replace, topk) if topk else (float(m), 0.0)
+    rows = L - mean_p
+    want = n_opt + u * rows + sigmas * (u * var_p + var_u * rows * rows) ** 0.5
     gran = 256 if m * L >= 8192 else 8
     return min(int(-(-want // gran) * gran), n_opt + m * L)
 
 
-def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int):
+def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int, dedup: bool = True):
     """Index maps of one ragged scoring forward, numpy in / numpy out.
 
     cand (m,n_opt) candidate suffix ids, parent (n_opt,) the ids they were sampled from, L tokens
@@ -105,12 +123,19 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int):
       q_src (B2*L,)     padded slot -> row holding its query (any own row where none is computed)
       kv_src(B2*L,)     padded slot -> row holding its key/value (parent rows in front of p)
       pos   (N,)        rotary position of row n
-      keep  (m*T,)      rows that predict the target tokens, candidate-major
-      p     (m,)        first computed position per candidate
-    with B2 = m + 1 and N = n_rows."""
+      keep  (m_out*T,)  rows that predict the target tokens, candidate-major, for EVERY input
+                        candidate (duplicates point at the rows of their one computed copy)
+      p     (m,)        first computed position per distinct candidate
+      cand  (m,n_opt)   the distinct candidates, in the order the maps number them
+    with m the number of distinct candidates (all of them with dedup=False), B2 = m + 1, N = n_rows."""
     import numpy as np
     cand = np.asarray(cand)
     parent = np.asarray(parent).reshape(-1)
+    m_out = cand.shape[0]
+    inv = None
+    if dedup and m_out > 1:
+        cand, inv = np.unique(cand, axis=0, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
     m, n_opt = cand.shape
     if parent.shape[0] != n_opt or L - T < n_opt - 1 or n_opt < 1:
         raise ValueError("ragged_plan: inconsistent shapes")
@@ -138,6 +163,9 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int):
     par = np.minimum(np.arange(L), n_opt - 1)
     q_src = np.concatenate([np.where(valid, own, starts[:, None]).reshape(-1), par]).astype(np.int32)
     kv_src = np.concatenate([np.where(valid, own, J).reshape(-1), par]).astype(np.int32)
-    keep = (starts[:, None] + (L - T - p[:, None]) + np.arange(T)[None, :]).reshape(-1).astype(np.int64)
-    return dict(flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows),
+    keep = starts[:, None] + (L - T - p[:, None]) + np.arange(T)[None, :]
+    if inv is not None:
+        keep = keep[inv]
+    keep = keep.reshape(-1).astype(np.int64)
+    return dict(m_out=m_out, cand=cand, flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows),
                 needed=needed)

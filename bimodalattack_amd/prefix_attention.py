@@ -138,6 +138,7 @@ class RaggedMaps:
         def dev(a, dtype):
             return torch.from_numpy(a).to(device=device, dtype=dtype, non_blocking=True)
         self.N, self.L, self.B2 = int(plan["N"]), int(plan["L"]), int(plan["m"]) + 1
+        self.m_out = int(plan.get("m_out", plan["m"]))
         self.flat = dev(plan["flat"], torch.int32)
         self.q_src = dev(plan["q_src"], torch.int32)
         self.kv_src = dev(plan["kv_src"], torch.int32)

@@ -278,13 +278,17 @@ def test_ragged_forward_equals_padded_forward(dtype):
     for i, f in enumerate(firsts):
         cand[i, f] = 10 + i
     cand[6] = parent                                                                   # identical to the parent
+    cand[8] = cand[1]                                                                  # an exact duplicate
     both = torch.from_numpy(np.concatenate([cand, parent[None]])).to(DEV)
     x = torch.cat([table[both], rest.expand(m + 1, -1, -1)], dim=1)                     # (m+1, L, D)
-    n_rows = n_opt + sum(L - f for f in firsts) + 8                                     # forces a little absorption
+    n_rows = n_opt + sum(L - f for f in firsts)                                         # more than the 8 distinct need
     plan = ragged_plan(cand, parent, L, T, P, n_rows)
-    assert plan is not None and (plan["p"] <= np.array([0, 1, 2, 3, 4, 5, 5, 2, 0])).all()
+    assert plan is not None and plan["m"] == 8 and plan["m_out"] == m
     maps = pa.RaggedMaps(plan, DEV)
-    rows = ops.gather_rows(x.view((m + 1) * L, D).contiguous(), maps.flat).unsqueeze(0)
+    mu = plan["m"]
+    xu = torch.cat([table[torch.from_numpy(np.concatenate([plan["cand"], parent[None]])).to(DEV)],
+                    rest.expand(mu + 1, -1, -1)], dim=1)                                # distinct candidates, plan order
+    rows = ops.gather_rows(xu.view((mu + 1) * L, D).contiguous(), maps.flat).unsqueeze(0)
     with torch.no_grad():
         cache = ad.build_prefix_recording(prefix)
         want = ad.target_logits_shared_prefix(x[:m].contiguous(), T, cache).float()

@@ -192,9 +192,9 @@ def test_ragged_plan_invariants():
         first = np.where((cand != parent).any(1), (cand != parent).argmax(1), n_opt - 1)
         n_rows = ragged_budget(m, n_opt, L, r)
         assert n_rows <= n_opt + m * L
-        plan = ragged_plan(cand, parent, L, T, 7, n_rows)
-        if plan is None:                                       # tiny m: 5 sigma may not cover the draw
-            plan = ragged_plan(cand, parent, L, T, 7, n_opt + m * L)
+        plan = ragged_plan(cand, parent, L, T, 7, n_rows, dedup=False)
+        if plan is None:                                       # tiny m: the margin may not cover the draw
+            plan = ragged_plan(cand, parent, L, T, 7, n_opt + m * L, dedup=False)
         N, flat, p = plan["N"], plan["flat"], plan["p"]
         assert len(flat) == N == len(plan["pos"]) and (p <= first).all() and (p >= 0).all()
         assert len(set(flat.tolist())) == N
@@ -211,5 +211,23 @@ def test_ragged_plan_invariants():
         keep = plan["keep"].reshape(m, T)
         assert (flat[keep] == (np.arange(m)[:, None] * L + (L - T) + np.arange(T)[None, :])).all()
     assert ragged_plan(cand, parent, L, T, 7, n_opt + 1) is None
+
+    # duplicates are computed once: every input candidate still gets its T rows
+    from bimodalattack_amd.layout import expected_unique
+    m, n_opt, L, T = 40, 5, 12, 4
+    parent = np.arange(n_opt)
+    base = np.tile(parent, (8, 1))
+    base[np.arange(8), np.arange(8) % n_opt] += 50 + np.arange(8)
+    cand = base[rng.integers(0, 8, m)]                         # 40 draws of 8 distinct candidates
+    plan = ragged_plan(cand, parent, L, T, 3, n_opt + 8 * L)
+    assert plan["m"] == len(np.unique(cand, axis=0)) <= 8 and plan["m_out"] == m
+    keep, flat = plan["keep"].reshape(m, T), plan["flat"]
+    for i in range(m):
+        u = int(np.where((plan["cand"] == cand[i]).all(1))[0][0])
+        assert (flat[keep[i]] == u * L + (L - T) + np.arange(T)).all()
+    mean, var = expected_unique(512, 19, 1, 256)
+    assert 480 < mean < 492 and 0 < var < 40
+    assert expected_unique(512, 19, 2, 256) == (512.0, 0.0) or expected_unique(512, 19, 2, 256)[0] > 511.9
+    assert ragged_budget(512, 19, 44, 1, 256) < ragged_budget(512, 19, 44, 1) <= 19 + 512 * 44
     with pytest.raises(ValueError):
         ragged_plan(np.zeros((2, 4), int), np.zeros(4, int), 5, 3, 0, 14)     # target rows would precede the suffix end
