@@ -119,6 +119,7 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_ROPE: return "rope_kernel";
     case BMA_K_ATTN_MERGE: return "attn_merge_kernel";
     case BMA_K_GATHER_ROWS: return "gather_rows_kernel";
+    case BMA_K_RAGGED_ATTN: return "ragged_attn_kernel";
     default: return "?";
   }
 }

@@ -1,0 +1,281 @@
+// bma_ragged_attention: attention of the ragged scoring row list in ONE launch.
+//
+// Candidate scoring (reference bimodal_attack.py:1278-1310) with ragged rows (layout.ragged_plan):
+// candidate i owns rows start[i] .. start[i]+len[i]-1 of the row list -- its tokens at positions
+// first[i] .. first[i]+len[i]-1 behind the shared prefix.  A query at position j attends to
+//   * the P prefix keys shared by every candidate,
+//   * positions t < first[i]: its PARENT's keys/values, rows t of the row list,
+//   * positions first[i] <= t <= j: its own rows.
+// The library route needs five launches for that (prefix flash attention over all rows, three
+// row gathers into a padded block, biased attention on the block, LSE merge) and moves every
+// q/k/v/o row through HBM three times.  Here one workgroup owns one (candidate, head), one wave
+// per 16 queries; the pair's key/value rows go through LDS once, 32 keys at a time:
+//
+//   S^T = K Q^T   v_mfma_f32_16x16x32: A = 16 keys x 32 dims (ds_read_b128 of an LDS row), B = 32 dims
+//                 x 16 queries (loaded once from global memory in operand layout, 16 B per lane)
+//   softmax       online over 32-key chunks; a query is a lane column, so its running max/sum
+//                 live in the lane (two xor-shuffles fold the four 16-lane groups)
+//   O^T = V^T P^T the S^T accumulator tile IS the B operand (keys on registers, query on the
+//                 lane): no shuffles; V^T comes from the LDS image of the chunk's value rows
+//                 (coalesced 16-byte loads in, ds_read_b64_tr_b16 transposing reads out)
+//   epilogue      normalise, optionally merge with a prefix partial (o1, lse1) computed elsewhere
+//                 (long image prefixes keep the library flash kernel), store 8 B per lane
+//
+// Algorithmic bytes per launch: q + k + v read once, o written once = 4 * N * H * Dh * es
+// (prefix and parent rows are re-read from L2).
+#include "bma_common.h"
+#include "bma_profile.h"
+
+namespace {
+
+using bma::uint4_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+
+struct Args {
+  const uint16_t *q, *k, *v, *pk, *pv, *o1;
+  const float* lse1;
+  uint16_t* out;
+  const int *start, *first, *len;
+  int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, pk_rs, pk_hs, pv_rs, pv_hs;
+  int B2, H, Hk, P, N;
+  float scale_log2e;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma(const uint4_t& a, const uint4_t& b, const f32x4& c) {
+  if (DT == BMA_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) { return bma::pack16<DT>(lo, hi); }
+
+// One workgroup per (candidate, head); wave w owns query tile w (16 queries), so a workgroup has QT
+// waves (len <= 16*QT).  The keys/values of the pair go through LDS once, 32 keys at a time, shared by
+// the waves; a wave skips chunks that lie entirely behind its last query (causal).
+template <int DT, int QT, int DH>
+__global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
+  constexpr int KS = DH / 32;      // k-steps of the QK product
+  constexpr int NT = DH / 16;      // 16-dim tiles of the output
+  constexpr int PITCH = DH + 16;   // elements per LDS row (row + 32 B: conflict-free transposing reads)
+  constexpr int PIECES = DH / 8;   // 16-byte pieces per row
+  constexpr int NTHR = 64 * QT;
+  __shared__ __attribute__((aligned(16))) uint16_t klds[32 * PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t vlds[32 * PITCH];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, qt = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int i = blockIdx.x, h = blockIdx.y;
+  const int hk = h / (a.H / a.Hk);
+  const int st = a.start[i], p0 = a.first[i], ln = a.len[i];
+  const int P = a.P;
+  const int nkeys = P + p0 + ln;
+  const float NEG = -__builtin_inff();
+
+  // Q tile as the B operand: lane (query r, dims 8g.. of k-step ks)
+  uint4_t qf[KS];
+  {
+    int qi = 16 * qt + r;
+    qi = qi < ln ? qi : ln - 1;
+    const uint16_t* qp = a.q + static_cast<int64_t>(st + qi) * a.q_rs + static_cast<int64_t>(h) * a.q_hs + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4_t*>(qp + 32 * ks);
+  }
+  const int jq = p0 + 16 * qt + r;                        // this lane's query position behind the prefix
+  const int last_key = P + p0 + 16 * qt + 15;             // last key index any query of the tile may see
+  const bool tile_live = 16 * qt < ln;
+
+  f32x4 oacc[NT];
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float mrun = NEG, lsum = 0.0f;
+
+  const int chunks = (nkeys + 31) >> 5;
+  for (int c = 0; c < chunks; ++c) {
+    // ---- stage the chunk's key and value rows: coalesced 16-byte loads, all waves ---------------
+    if (c) __syncthreads();                                // the previous chunk's readers are done
+    for (int idx = tid; idx < 32 * PIECES; idx += NTHR) {
+      const int key = idx / PIECES, piece = idx % PIECES;
+      int t = 32 * c + key;
+      t = t < nkeys ? t : nkeys - 1;
+      const uint16_t *kp, *vp;
+      if (t < P) {
+        kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs;
+        vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs;
+      } else {
+        const int tt = t - P;
+        const int64_t row = tt < p0 ? tt : st + (tt - p0);   // the parent's row, or this candidate's own
+        kp = a.k + row * a.k_rs + static_cast<int64_t>(hk) * a.k_hs;
+        vp = a.v + row * a.v_rs + static_cast<int64_t>(hk) * a.v_hs;
+      }
+      const uint4_t kw = *reinterpret_cast<const uint4_t*>(kp + 8 * piece);
+      const uint4_t vw = *reinterpret_cast<const uint4_t*>(vp + 8 * piece);
+      *reinterpret_cast<uint4_t*>(klds + key * PITCH + 8 * piece) = kw;
+      *reinterpret_cast<uint4_t*>(vlds + key * PITCH + 8 * piece) = vw;
+    }
+    __syncthreads();
+    if (!tile_live || 32 * c > last_key) continue;         // wave-uniform: nothing of this chunk is visible
+
+    // ---- S^T = K Q^T: A = 16 keys x 32 dims from LDS rows, B = the Q fragments -------------------
+    f32x4 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const uint16_t* kr = klds + (16 * kt + r) * PITCH + 8 * g;
+      f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = mfma<DT>(*reinterpret_cast<const uint4_t*>(kr + 32 * ks), qf[ks], acc);
+      s[kt] = acc;
+    }
+    // ---- online softmax; the probabilities become the B operand of the second product ------------
+    float e[2][4];
+    float cmax = NEG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int te = 32 * c + 16 * kt + 4 * g + rr;
+        const bool ok = te < nkeys && (te < P || te - P <= jq);
+        const float v = ok ? s[kt][rr] * a.scale_log2e : NEG;
+        e[kt][rr] = v;
+        cmax = fmaxf(cmax, v);
+      }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 16, BMA_WAVE));
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32, BMA_WAVE));
+    const float mnew = fmaxf(mrun, cmax);
+    const float mm = mnew == NEG ? 0.0f : mnew;             // nothing visible yet: keep everything at zero
+    const float alpha = __builtin_amdgcn_exp2f(mrun - mm);
+    float rs = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        e[kt][rr] = __builtin_amdgcn_exp2f(e[kt][rr] - mm);
+        rs += e[kt][rr];
+      }
+    lsum = lsum * alpha + rs;
+    mrun = mnew;
+    uint4_t pf;
+    pf.x = pack2<DT>(e[0][0], e[0][1]);
+    pf.y = pack2<DT>(e[0][2], e[0][3]);
+    pf.z = pack2<DT>(e[1][0], e[1][1]);
+    pf.w = pack2<DT>(e[1][2], e[1][3]);
+    // ---- O^T = alpha O^T + V^T P^T: element j of lane group g is key 32c + (j<4 ? 4g+j : 16+4g+j-4);
+    // ds_read_b64_tr_b16 hands each 16-lane group a 4-key x 16-dim block column-major, which is the
+    // A-operand fragment (dim on the lane, 4 keys in the elements)
+    const int q4 = r >> 2, p4 = r & 3;
+    const uint16_t* rd = vlds + (4 * g + q4) * PITCH + 4 * p4;
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(rd + 16 * dt));
+      const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) short4_t*)(rd + 16 * PITCH + 16 * dt));
+      const bma::uint2_t l2 = __builtin_bit_cast(bma::uint2_t, lo), h2 = __builtin_bit_cast(bma::uint2_t, hi);
+      uint4_t vf;
+      vf.x = l2.x; vf.y = l2.y; vf.z = h2.x; vf.w = h2.y;
+      f32x4 o = oacc[dt];
+      o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+      oacc[dt] = mfma<DT>(vf, pf, o);
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  float l = lsum;
+  l += __shfl_xor(l, 16, BMA_WAVE);
+  l += __shfl_xor(l, 32, BMA_WAVE);
+  const int qi = 16 * qt + r;
+  if (qi >= ln) return;
+  const int64_t o_rs = static_cast<int64_t>(a.H) * DH;
+  const int64_t row = st + qi;
+  const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+  float w1 = 0.0f;
+  if (a.o1) {
+    // natural-log LSE of this part; weight of the prefix partial = 1 / (1 + exp(lse2 - lse1))
+    const float lse2 = l > 0.0f ? (mrun + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : NEG;
+    const float l1 = a.lse1[static_cast<int64_t>(h) * a.N + row];
+    w1 = 1.0f / (1.0f + expf(lse2 - l1));
+  }
+  uint16_t* op = a.out + row * o_rs + static_cast<int64_t>(h) * DH + 4 * g;
+  const uint16_t* o1p = a.o1 ? a.o1 + row * o_rs + static_cast<int64_t>(h) * DH + 4 * g : nullptr;
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) {
+    float o[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) o[rr] = oacc[dt][rr] * inv;
+    if (o1p) {
+      const bma::uint2_t pw = *reinterpret_cast<const bma::uint2_t*>(o1p + 16 * dt);
+      const float p1[4] = {bma::unpack16<DT>(pw.x, 0), bma::unpack16<DT>(pw.x, 1), bma::unpack16<DT>(pw.y, 0),
+                           bma::unpack16<DT>(pw.y, 1)};
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) o[rr] = o[rr] + w1 * (p1[rr] - o[rr]);
+    }
+    bma::uint2_t ow;
+    ow.x = pack2<DT>(o[0], o[1]);
+    ow.y = pack2<DT>(o[2], o[3]);
+    *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
+  }
+}
+
+template <int DT, int DH>
+void launch_dh(const Args& a, int qt, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>(a.B2), static_cast<unsigned>(a.H));
+  switch (qt) {
+    case 1: hipLaunchKernelGGL((ragged_attn_kernel<DT, 1, DH>), grid, dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((ragged_attn_kernel<DT, 2, DH>), grid, dim3(128), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((ragged_attn_kernel<DT, 3, DH>), grid, dim3(192), 0, st, a); break;
+    default: hipLaunchKernelGGL((ragged_attn_kernel<DT, 4, DH>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+template <int DT>
+void launch_dt(const Args& a, int qt, int Dh, hipStream_t st) {
+  if (Dh == 32) launch_dh<DT, 32>(a, qt, st);
+  else if (Dh == 64) launch_dh<DT, 64>(a, qt, st);
+  else launch_dh<DT, 128>(a, qt, st);
+}
+
+}  // namespace
+
+extern "C" int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs,
+                                    int64_t k_hs, const void* v, int64_t v_rs, int64_t v_hs, const void* pk,
+                                    int64_t pk_rs, int64_t pk_hs, const void* pv, int64_t pv_rs, int64_t pv_hs,
+                                    int P, const int* start, const int* first, const int* len, int B2,
+                                    int max_len, int64_t N, int H, int Hk, int Dh, int dtype, float scale,
+                                    const void* o1, const float* lse1, void* out, void* stream) {
+  if (B2 < 0 || N < 0 || H <= 0 || Hk <= 0 || P < 0 || max_len <= 0) return BMA_EINVAL;
+  if (B2 == 0 || N == 0) return BMA_OK;
+  if (!q || !k || !v || !start || !first || !len || !out) return BMA_EINVAL;
+  if (P > 0 && (!pk || !pv)) return BMA_EINVAL;
+  if ((o1 == nullptr) != (lse1 == nullptr)) return BMA_EINVAL;
+  if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  if ((Dh != 32 && Dh != 64 && Dh != 128) || H % Hk || max_len > 64 || N > 0x7fffffffLL) return BMA_ELIMIT;
+  // 16-byte operand loads: every row/head stride a multiple of 8 elements, bases 16-byte aligned
+  const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, pk_rs, pk_hs, pv_rs, pv_hs};
+  for (int64_t s : strides)
+    if (s % 8) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(pk) | reinterpret_cast<uintptr_t>(pv) | reinterpret_cast<uintptr_t>(o1) |
+       reinterpret_cast<uintptr_t>(out)) % 16)
+    return BMA_EALIGN;
+  Args a;
+  a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
+  a.pk = static_cast<const uint16_t*>(pk); a.pv = static_cast<const uint16_t*>(pv);
+  a.o1 = static_cast<const uint16_t*>(o1); a.lse1 = lse1; a.out = static_cast<uint16_t*>(out);
+  a.start = start; a.first = first; a.len = len;
+  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs;
+  a.pk_rs = pk_rs; a.pk_hs = pk_hs; a.pv_rs = pv_rs; a.pv_hs = pv_hs;
+  a.B2 = B2; a.H = H; a.Hk = Hk; a.P = P; a.N = static_cast<int>(N);
+  a.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int es = 2;
+  BMA_PROF_BEGIN(BMA_K_RAGGED_ATTN, st, (2.0 * H + 2.0 * Hk) * static_cast<double>(N) * Dh * es);
+  const int qt = (max_len + 15) / 16;
+  if (dtype == BMA_BF16) launch_dt<BMA_BF16>(a, qt, Dh, st);
+  else launch_dt<BMA_F16>(a, qt, Dh, st);
+  BMA_PROF_END(BMA_K_RAGGED_ATTN, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}

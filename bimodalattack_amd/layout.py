@@ -127,6 +127,7 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int, dedup: bool =
                         candidate (duplicates point at the rows of their one computed copy)
       p     (m,)        first computed position per distinct candidate
       cand  (m,n_opt)   the distinct candidates, in the order the maps number them
+      cstart/cfirst/clen (B2,)  per block: first row, first position, row count (bma_ragged_attention)
     with m the number of distinct candidates (all of them with dedup=False), B2 = m + 1, N = n_rows."""
     import numpy as np
     cand = np.asarray(cand)
@@ -163,9 +164,13 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int, dedup: bool =
     par = np.minimum(np.arange(L), n_opt - 1)
     q_src = np.concatenate([np.where(valid, own, starts[:, None]).reshape(-1), par]).astype(np.int32)
     kv_src = np.concatenate([np.where(valid, own, J).reshape(-1), par]).astype(np.int32)
+    # per padded block (the parent is block m): rows it owns, its first position, how many
+    cstart = np.concatenate([starts, [0]]).astype(np.int32)
+    cfirst = np.concatenate([p, [0]]).astype(np.int32)
+    clen = np.concatenate([lens, [n_opt]]).astype(np.int32)
     keep = starts[:, None] + (L - T - p[:, None]) + np.arange(T)[None, :]
     if inv is not None:
         keep = keep[inv]
     keep = keep.reshape(-1).astype(np.int64)
-    return dict(m_out=m_out, cand=cand, flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows),
+    return dict(m_out=m_out, cand=cand, cstart=cstart, cfirst=cfirst, clen=clen, flat=flat, q_src=q_src, kv_src=kv_src, pos=pos, keep=keep, p=p, m=m, L=L, n_opt=n_opt, N=int(n_rows),
                 needed=needed)

@@ -335,6 +335,60 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+RAGGED_ATTN_MAX_LEN = 64
+
+
+def ragged_attention_ok(query: torch.Tensor, key: torch.Tensor, max_len: int) -> bool:
+    """Can bma_ragged_attention take these (1,H,N,Dh) / (1,Hk,N,Dh) tensors?"""
+    return (query.is_cuda and query.dtype in (torch.bfloat16, torch.float16) and key.dtype == query.dtype
+            and query.shape[-1] in (32, 64, 128) and 0 < max_len <= RAGGED_ATTN_MAX_LEN
+            and query.shape[1] % key.shape[1] == 0)
+
+
+def ragged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, prefix_k: Optional[torch.Tensor],
+                     prefix_v: Optional[torch.Tensor], start: torch.Tensor, first: torch.Tensor, length: torch.Tensor,
+                     max_len: int, scale: float, o1: Optional[torch.Tensor] = None,
+                     lse1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention of a ragged scoring row list (include/bma.h: bma_ragged_attention).
+
+    query (1,H,N,Dh), key/value (1,Hk,N,Dh): any row/head strides with a contiguous last dim;
+    prefix_k/prefix_v (1,Hk,P,Dh) or None; start/first/length int32 (B2,); o1 (N,H,Dh) + lse1 (H,N)
+    optionally carry a prefix partial to merge.  Returns (N,H,Dh)."""
+    dev = _need_gpu(query, key, value, start, first, length)
+    _, H, N, Dh = query.shape
+    Hk = key.shape[1]
+    for t in (query, key, value):
+        if t.dim() != 4 or t.shape[0] != 1 or t.stride(3) != 1 or t.shape[2] != N or t.shape[3] != Dh:
+            raise ValueError("query/key/value must be (1,heads,N,Dh) with a contiguous last dim")
+    for t in (start, first, length):
+        if t.dtype != torch.int32 or t.dim() != 1 or not t.is_contiguous() or t.shape != start.shape:
+            raise ValueError("start/first/length must be contiguous int32 vectors of one size")
+    P = 0
+    pk_ptr = pv_ptr = 0
+    pk_s = pv_s = (0, 0)
+    if prefix_k is not None:
+        if prefix_k.shape != prefix_v.shape or prefix_k.dim() != 4 or prefix_k.shape[0] != 1 or \
+                prefix_k.shape[1] != Hk or prefix_k.shape[3] != Dh or prefix_k.stride(3) != 1 or prefix_v.stride(3) != 1 \
+                or prefix_k.dtype != query.dtype:
+            raise ValueError("prefix_k/prefix_v must be (1,Hk,P,Dh) of the query dtype with a contiguous last dim")
+        P = prefix_k.shape[2]
+        pk_ptr, pv_ptr = prefix_k.data_ptr(), prefix_v.data_ptr()
+        pk_s, pv_s = (prefix_k.stride(2), prefix_k.stride(1)), (prefix_v.stride(2), prefix_v.stride(1))
+    o1_ptr = l1_ptr = 0
+    if o1 is not None:
+        if o1.shape != (N, H, Dh) or not o1.is_contiguous() or o1.dtype != query.dtype or lse1 is None or \
+                lse1.shape != (H, N) or lse1.dtype != torch.float32 or not lse1.is_contiguous():
+            raise ValueError("o1 must be contiguous (N,H,Dh) and lse1 contiguous fp32 (H,N)")
+        o1_ptr, l1_ptr = o1.data_ptr(), lse1.data_ptr()
+    out = torch.empty((N, H, Dh), dtype=query.dtype, device=query.device)
+    check("bma_ragged_attention", lib.bma_ragged_attention(
+        query.data_ptr(), query.stride(2), query.stride(1), key.data_ptr(), key.stride(2), key.stride(1),
+        value.data_ptr(), value.stride(2), value.stride(1), pk_ptr, pk_s[0], pk_s[1], pv_ptr, pv_s[0], pv_s[1], P,
+        start.data_ptr(), first.data_ptr(), length.data_ptr(), start.shape[0], int(max_len), N, H, Hk, Dh, _dt(query),
+        float(scale), o1_ptr, l1_ptr, out.data_ptr(), _stream(dev)))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # the same ops under autograd (the gradient pass): fused forward + fused backward
 class RMSNormFn(torch.autograd.Function):

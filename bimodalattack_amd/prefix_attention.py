@@ -25,12 +25,17 @@ generic path.
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import List, Optional
 
 import torch
 
 from . import ops
 
+# ragged scoring: attention in one MFMA launch (csrc/ragged_attention.hip) instead of the five-launch
+# library route; prefixes longer than FUSED_PREFIX_MAX keys stay with the library flash kernel
+FUSED_RAGGED_ATTENTION = os.environ.get("BMA_FUSED_RAGGED_ATTENTION", "1") not in ("0", "false", "False")
+FUSED_PREFIX_MAX = int(os.environ.get("BMA_FUSED_PREFIX_MAX", "128"))
 NAME = "bma_shared_prefix"
 _FAMILIES = ("modeling_llama", "modeling_mistral", "modeling_qwen2")
 _ACTIVE: List["SharedPrefixKV"] = []
@@ -144,6 +149,10 @@ class RaggedMaps:
         self.kv_src = dev(plan["kv_src"], torch.int32)
         self.pos = dev(plan["pos"], torch.int64).unsqueeze(0)
         self.keep = dev(plan["keep"], torch.int64)
+        self.cstart = dev(plan["cstart"], torch.int32)
+        self.cfirst = dev(plan["cfirst"], torch.int32)
+        self.clen = dev(plan["clen"], torch.int32)
+        self.fused_ok = True           # cleared if the one-launch attention kernel refuses the shapes
 
 
 _BIAS = {}
@@ -217,6 +226,20 @@ def _ragged_attention(kv: SharedPrefixKV, layer_idx: int, query, key, value, n_r
     rg = kv.ragged
     _, H, N, Dh = query.shape
     Hk = key.shape[1]
+    if FUSED_RAGGED_ATTENTION and rg.fused_ok and ops.ragged_attention_ok(query, key, rg.L):
+        # one launch: prefix + parent + own keys per (candidate, head) on the matrix cores
+        # (csrc/ragged_attention.hip).  A long prefix (the image in joint mode) keeps the library
+        # flash kernel for its part and is merged in the kernel's epilogue.
+        if kv.P <= FUSED_PREFIX_MAX:
+            Kp, Vp = kv.prefix(layer_idx, 1)
+            out = ops.ragged_attention(query, key, value, Kp, Vp, rg.cstart, rg.cfirst, rg.clen, rg.L, scale)
+        else:
+            Kp, Vp = kv.prefix(layer_idx, n_rep)
+            o1, l1 = _partial_attention(query, Kp, Vp, False, scale)
+            o1 = o1.transpose(1, 2).reshape(N, H, Dh).contiguous()
+            out = ops.ragged_attention(query, key, value, None, None, rg.cstart, rg.cfirst, rg.clen, rg.L, scale,
+                                       o1=o1, lse1=l1.reshape(H, N).contiguous())
+        return out.unsqueeze(0)
     q_rows, k_rows, v_rows = _rows(query), _rows(key), _rows(value)
     Kp, Vp = kv.prefix(layer_idx, n_rep)
     o1, l1 = _partial_attention(q_rows.unsqueeze(0).transpose(1, 2), Kp, Vp, False, scale)

@@ -185,6 +185,21 @@ int bma_attn_merge_rows(const void* o1, const void* o2, const float* lse1, const
 int bma_gather_rows(const void* src, const int* idx, int64_t n_out, int64_t n_src, int64_t row_bytes,
                     void* out, void* stream);
 
+/* bma_ragged_attention: the attention of a ragged scoring forward in one launch (bf16 / f16, MFMA).
+ *   Candidate i (0 <= i < B2) owns rows start[i] .. start[i]+len[i]-1 of the row list: its tokens at
+ *   positions first[i] .. first[i]+len[i]-1 behind the shared prefix (len[i] <= max_len <= 64).  A query
+ *   at position j attends to the P prefix keys (pk/pv), to rows t of the row list for positions
+ *   t < first[i] (its parent's keys/values) and to its own rows for first[i] <= t <= j.
+ *   q/k/v: row-list tensors addressed as base + row*rs + head*hs (elements; multiples of 8);
+ *   pk/pv likewise with P rows; H query heads, Hk key/value heads (H % Hk == 0), Dh in {32,64,128}.
+ *   out: [N][H][Dh] contiguous.  If o1/lse1 are given (o1 [N][H][Dh], lse1 [H][N] fp32: a prefix
+ *   partial computed elsewhere, then pass P = 0) the result is merged with it as bma_attn_merge does. */
+int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
+                         const void* v, int64_t v_rs, int64_t v_hs, const void* pk, int64_t pk_rs, int64_t pk_hs,
+                         const void* pv, int64_t pv_rs, int64_t pv_hs, int P, const int* start, const int* first,
+                         const int* len, int B2, int max_len, int64_t N, int H, int Hk, int Dh, int dtype,
+                         float scale, const void* o1, const float* lse1, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Measurement aid (bench.py).  When enabled, the dominant kernel of
  * each entry point is bracketed by HIP events on the launch stream and the launch's
@@ -197,7 +212,8 @@ enum {
   BMA_K_LINF = 0, BMA_K_CE_ROWS = 1 /* B > 1: candidate scoring */, BMA_K_CE_DLOGITS = 2,
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
-  BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11, BMA_K_COUNT = 12
+  BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11,
+  BMA_K_RAGGED_ATTN = 12, BMA_K_COUNT = 13
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

@@ -256,6 +256,62 @@ def test_gather_rows_and_mapped_merge_vs_torch():
         assert torch.equal(got, want.view(N, H, Dh))
 
 
+def _ragged_attention_reference(q, k, v, pk, pv, plan, P, scale):
+    """fp32 loops over (candidate, query, head): softmax over [prefix | parent rows < first | own rows <= query]."""
+    N, H, Dh = q.shape
+    rep = H // k.shape[1]
+    out = torch.zeros_like(q)
+    for st, p0, ln in zip(plan["cstart"].tolist(), plan["cfirst"].tolist(), plan["clen"].tolist()):
+        rows = list(range(p0)) + list(range(st, st + ln))
+        K, V = k[rows], v[rows]
+        if P:
+            K, V = torch.cat([pk, K]), torch.cat([pv, V])
+        for qi in range(ln):
+            vis = P + p0 + qi + 1
+            for h in range(H):
+                w = torch.softmax((K[:vis, h // rep] @ q[st + qi, h]) * scale, 0)
+                out[st + qi, h] = w @ V[:vis, h // rep]
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n_opt,L,T,P,H,Hk,Dh,merge", [
+    (7, 5, 13, 4, 9, 4, 2, 32, False),        # grouped heads, one query tile
+    (5, 6, 20, 5, 21, 8, 8, 128, False),      # two tiles, prefix not a multiple of the key chunk
+    (5, 6, 44, 20, 40, 4, 4, 64, False),      # three tiles (the C3 lengths)
+    (3, 4, 50, 10, 0, 4, 2, 128, False),      # no prefix, four tiles
+    (5, 6, 20, 5, 70, 8, 4, 128, True),       # prefix partial computed elsewhere, merged in the epilogue
+])
+def test_ragged_attention_kernel_vs_fp32_loops(dtype, m, n_opt, L, T, P, H, Hk, Dh, merge):
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.layout import ragged_plan
+    rng = np.random.default_rng(1)
+    parent = np.arange(n_opt)
+    cand = np.tile(parent, (m, 1))
+    for i in range(m):
+        cand[i, rng.integers(0, n_opt)] = 100 + i
+    plan = ragged_plan(cand, parent, L, T, P, n_opt + m * L - 3)
+    N = plan["N"]
+    g = torch.Generator(device=DEV).manual_seed(N)
+    q, k, v = (torch.randn((N, hh, Dh), generator=g, device=DEV).to(dtype) for hh in (H, Hk, Hk))
+    pk, pv = (torch.randn((max(P, 1), Hk, Dh), generator=g, device=DEV).to(dtype)[:P] for _ in range(2))
+    scale = Dh ** -0.5
+    ref = _ragged_attention_reference(q.float().cpu(), k.float().cpu(), v.float().cpu(), pk.float().cpu(),
+                                      pv.float().cpu(), plan, P, scale)
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    as4 = lambda t: t.unsqueeze(0).transpose(1, 2)                   # (1,heads,rows,Dh) view, rows strided
+    args = (dev(plan["cstart"]), dev(plan["cfirst"]), dev(plan["clen"]), L, scale)
+    if merge:
+        s = torch.einsum("nhd,phd->hnp", q.float(), pk.float().repeat_interleave(H // Hk, 1)) * scale
+        o1 = torch.einsum("hnp,phd->nhd", torch.softmax(s, -1), pv.float().repeat_interleave(H // Hk, 1)).to(dtype)
+        got = ops.ragged_attention(as4(q), as4(k), as4(v), None, None, *args, o1=o1.contiguous(),
+                                   lse1=torch.logsumexp(s, -1).contiguous())
+    else:
+        got = ops.ragged_attention(as4(q), as4(k), as4(v), as4(pk) if P else None, as4(pv) if P else None, *args)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert got.shape == (N, H, Dh) and float((got.float().cpu() - ref).abs().max()) < tol
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_ragged_forward_equals_padded_forward(dtype):
     """Whole-model check on a small Llama: candidates that differ from a parent suffix from

@@ -110,6 +110,20 @@ def cases():
         rmap = torch.randperm(B2 * L, generator=g, device=DEV)[:N].sort().values.to(torch.int32)
         return lambda: ops.attn_merge_rows(o1, o2, l1, l2, rmap)
 
+    def ragged_attn(m, n_opt, L, T, P, H, Dh):
+        import numpy as np
+        from bimodalattack_amd.layout import ragged_budget, ragged_plan
+        rng = np.random.default_rng(0)
+        parent = rng.integers(0, 32000, n_opt)
+        cand = np.tile(parent, (m, 1))
+        cand[np.arange(m), rng.integers(0, n_opt, m)] = rng.integers(0, 256, m) + 40000
+        plan = ragged_plan(cand, parent, L, T, P, ragged_budget(m, n_opt, L, 1, 256))
+        N = plan["N"]
+        q, k, v = (torch.randn((N, H, Dh), generator=g, device=DEV).to(bf).unsqueeze(0).transpose(1, 2) for _ in range(3))
+        pk, pv = (torch.randn((P, H, Dh), generator=g, device=DEV).to(bf).unsqueeze(0).transpose(1, 2) for _ in range(2))
+        cs, cf, cl = (torch.from_numpy(plan[n]).to(DEV) for n in ("cstart", "cfirst", "clen"))
+        return lambda: ops.ragged_attention(q, k, v, pk, pv, cs, cf, cl, L, Dh ** -0.5)
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -123,6 +137,7 @@ def cases():
         "swiglu/c3r_18688x11008": ("swiglu", lambda: swiglu(18688, 11008)),
         "rope/c3r_N18688_H32_Dh128": ("rope", lambda: rope_rows(18688, 32, 128)),
         "attn_merge/c3r_N18688_B513_L44": ("attn_merge", lambda: merge_rows(18688, 513, 44, 32, 128)),
+        "ragged_attn/c3r_sw512_P21_L44_H32_Dh128": ("ragged_attn", lambda: ragged_attn(512, 19, 44, 20, 21, 32, 128)),
         "gather_rows/c3r_22572_of_18688x4096": ("gather_rows", lambda: gather(18688, 513 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
         "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
