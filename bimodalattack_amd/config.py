@@ -102,6 +102,10 @@ class EngineOptions:
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
+    # Gradient pass with <= 128 rows (text-only attacks): keep a transposed copy of every decoder
+    # projection weight so the backward product streams weight rows along the reduction like the
+    # forward one (the faster library form for such shapes).  Costs one more copy of the LM weights.
+    backward_weight_copies: bool = True
     # Attend to the shared prefix without copying its keys/values into every candidate
     # (two flash launches + a merge kernel; llama-family text models).  See prefix_attention.py.
     shared_prefix_attention: bool = True
@@ -152,6 +156,8 @@ class EngineOptions:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
+        if "BMA_BACKWARD_WEIGHT_COPIES" in env:
+            opts.backward_weight_copies = env["BMA_BACKWARD_WEIGHT_COPIES"] not in ("0", "false", "False")
         if "BMA_SHARED_PREFIX_ATTENTION" in env:
             opts.shared_prefix_attention = env["BMA_SHARED_PREFIX_ATTENTION"] not in ("0", "false", "False")
         if "BMA_RAGGED_SUFFIX" in env:

@@ -8,7 +8,9 @@ gradient is being recorded (the gradient pass; weights are treated as constants 
 norm weight requires grad the eager module runs).  Outside the context -- or when the input
 is not on the GPU or a shape is beyond the kernels' limits -- the original code runs.
 Nothing is left on the user's model afterwards: patches are instance attributes removed
-on exit.
+on exit.  Under autograd with at most 128 rows (the text-only gradient pass) the decoder layers'
+bias-free projections additionally compute their input gradient through a transposed copy of the
+weight (``ops.FrozenLinearFn``; one extra copy of the language model's weights in HBM).
 
 What qualifies (checked structurally, not by model name):
   * a module whose class name ends in ``RMSNorm`` with a 1-D ``weight`` and an epsilon
@@ -39,13 +41,18 @@ def _eps_of(m):
     return None
 
 
+SKINNY_ROWS = 128      # "a handful of rows": the batch-1 gradient pass of a text-only attack
+
+
 class FusedInference:
-    def __init__(self, model: torch.nn.Module, enabled: bool = True):
+    def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True):
         self.enabled = enabled
         self.norms: List[Tuple[torch.nn.Module, float, bool]] = []
         self.mlps: List[torch.nn.Module] = []
+        self.linears: List[torch.nn.Module] = []
         self.rope_modules = []
         self._saved_rope = {}
+        self._wt = {}
         self.depth = 0
         if not enabled:
             return
@@ -53,6 +60,12 @@ class FusedInference:
         for m in model.modules():
             cls = type(m).__name__
             w = getattr(m, "weight", None)
+            if weight_copies and (hasattr(m, "q_proj") or hasattr(m, "gate_proj")):
+                # bias-free projections of the decoder layers (attention and MLP blocks)
+                for name in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"):
+                    lin = getattr(m, name, None)
+                    if isinstance(lin, torch.nn.Linear) and lin.bias is None and type(lin) is torch.nn.Linear:
+                        self.linears.append(lin)
             if cls.endswith("RMSNorm") and torch.is_tensor(w) and w.dim() == 1 and _eps_of(m) is not None:
                 self.norms.append((m, _eps_of(m), cls.startswith("Gemma")))
             elif all(hasattr(m, a) for a in ("gate_proj", "up_proj", "down_proj", "act_fn")) and \
@@ -108,6 +121,24 @@ class FusedInference:
             return ops.rmsnorm(x, m.weight, eps, gemma)
         return forward
 
+    def _linear_forward(self, m, orig):
+        """Gradient pass with a handful of rows: the backward product goes through a transposed
+        copy of the (constant) weight so that it, too, streams weight rows along the reduction."""
+        def forward(x):
+            w = m.weight
+            if not (self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
+                    and x.numel() // x.shape[-1] <= SKINNY_ROWS):
+                return orig(x)
+            wt = self._wt.get(id(m))
+            if wt is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return orig(x)
+                with torch.no_grad():
+                    wt = w.detach().t().contiguous()
+                self._wt[id(m)] = wt
+            return ops.FrozenLinearFn.apply(x, w, wt)
+        return forward
+
     def _mlp_forward(self, m, orig):
         act = self._act_code(m.act_fn)
 
@@ -151,6 +182,8 @@ class FusedInference:
             m.forward = self._norm_forward(m, eps, gemma, type(m).forward.__get__(m))
         for m in self.mlps:
             m.forward = self._mlp_forward(m, type(m).forward.__get__(m))
+        for m in self.linears:
+            m.forward = self._linear_forward(m, type(m).forward.__get__(m))
         for mod in self.rope_modules:
             self._saved_rope[mod] = mod.apply_rotary_pos_emb
             mod.apply_rotary_pos_emb = self._rope(mod.apply_rotary_pos_emb)
@@ -163,6 +196,8 @@ class FusedInference:
         for m, _, _ in self.norms:
             m.__dict__.pop("forward", None)
         for m in self.mlps:
+            m.__dict__.pop("forward", None)
+        for m in self.linears:
             m.__dict__.pop("forward", None)
         for mod, fn in self._saved_rope.items():
             mod.apply_rotary_pos_emb = fn

@@ -166,10 +166,19 @@ def test_fused_context_patches_and_restores(kind, dtype):
     assert not any("forward" in m.__dict__ for m in model.modules())
     tol = 1e-4 if dtype == torch.float32 else 6e-2
     assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
-    # with autograd on, the patches stand aside
+    # with autograd on, the fused Functions record a graph: input gradients equal eager autograd's
+    xe = x.clone().requires_grad_()
+    ge, = torch.autograd.grad(model(inputs_embeds=xe, use_cache=False).logits.float().square().mean(), xe)
+    xf = x.clone().requires_grad_()
     with fused:
-        y = model(inputs_embeds=x.clone().requires_grad_(), use_cache=False).logits
-    assert y.requires_grad
+        y = model(inputs_embeds=xf, use_cache=False).logits
+        assert y.requires_grad
+        gf, = torch.autograd.grad(y.float().square().mean(), xf)
+    if kind == "llama" and dtype != torch.float32:
+        assert len(fused._wt) == len(fused.linears) == 2 * 7          # 72 rows: the transposed-weight backward ran
+    gtol = 1e-4 if dtype == torch.float32 else 8e-2
+    assert float((gf.float() - ge.float()).abs().max()) <= gtol * float(ge.float().abs().max())
+    assert not any("forward" in m.__dict__ for m in model.modules())
 
 
 # ------------------------------------------------------------------ shared-prefix attention
