@@ -94,30 +94,48 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
   for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float mrun = NEG, lsum = 0.0f;
 
-  const int chunks = (nkeys + 31) >> 5;
-  for (int c = 0; c < chunks; ++c) {
-    // ---- stage the chunk's key and value rows: coalesced 16-byte loads, all waves ---------------
-    if (c) __syncthreads();                                // the previous chunk's readers are done
-    for (int idx = tid; idx < 32 * PIECES; idx += NTHR) {
-      const int key = idx / PIECES, piece = idx % PIECES;
-      int t = 32 * c + key;
-      t = t < nkeys ? t : nkeys - 1;
-      const uint16_t *kp, *vp;
-      if (t < P) {
-        kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs;
-        vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs;
-      } else {
-        const int tt = t - P;
-        const int64_t row = tt < p0 ? tt : st + (tt - p0);   // the parent's row, or this candidate's own
-        kp = a.k + row * a.k_rs + static_cast<int64_t>(hk) * a.k_hs;
-        vp = a.v + row * a.v_rs + static_cast<int64_t>(hk) * a.v_hs;
+  // chunk staging, software-pipelined: the rows of chunk c+1 are in flight (registers) while chunk c
+  // is multiplied out of LDS
+  constexpr int ITEMS = (32 * PIECES + NTHR - 1) / NTHR;
+  uint4_t kreg[ITEMS], vreg[ITEMS];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < 32 * PIECES) {
+        const int key = idx / PIECES, piece = idx % PIECES;
+        int t = 32 * c + key;
+        t = t < nkeys ? t : nkeys - 1;
+        const uint16_t *kp, *vp;
+        if (t < P) {
+          kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs;
+          vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs;
+        } else {
+          const int tt = t - P;
+          const int64_t row = tt < p0 ? tt : st + (tt - p0);   // the parent's row, or this candidate's own
+          kp = a.k + row * a.k_rs + static_cast<int64_t>(hk) * a.k_hs;
+          vp = a.v + row * a.v_rs + static_cast<int64_t>(hk) * a.v_hs;
+        }
+        kreg[it] = *reinterpret_cast<const uint4_t*>(kp + 8 * piece);
+        vreg[it] = *reinterpret_cast<const uint4_t*>(vp + 8 * piece);
       }
-      const uint4_t kw = *reinterpret_cast<const uint4_t*>(kp + 8 * piece);
-      const uint4_t vw = *reinterpret_cast<const uint4_t*>(vp + 8 * piece);
-      *reinterpret_cast<uint4_t*>(klds + key * PITCH + 8 * piece) = kw;
-      *reinterpret_cast<uint4_t*>(vlds + key * PITCH + 8 * piece) = vw;
+    }
+  };
+  const int chunks = (nkeys + 31) >> 5;
+  fetch(0);
+  for (int c = 0; c < chunks; ++c) {
+    if (c) __syncthreads();                                // the previous chunk's readers are done
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < 32 * PIECES) {
+        const int key = idx / PIECES, piece = idx % PIECES;
+        *reinterpret_cast<uint4_t*>(klds + key * PITCH + 8 * piece) = kreg[it];
+        *reinterpret_cast<uint4_t*>(vlds + key * PITCH + 8 * piece) = vreg[it];
+      }
     }
     __syncthreads();
+    if (c + 1 < chunks) fetch(c + 1);
     if (!tile_live || 32 * c > last_key) continue;         // wave-uniform: nothing of this chunk is visible
 
     // ---- S^T = K Q^T: A = 16 keys x 32 dims from LDS rows, B = the Q fragments -------------------

@@ -131,14 +131,15 @@ def cases():
 
     return {
         # name: (kernel id in the profiler, thunk factory)
-        # ragged scoring of C3 (search_width 512, 19 suffix + 25 tail tokens): 18688 computed rows,
-        # padded block 513 x 44
-        "rmsnorm/c3r_18688x4096": ("rmsnorm", lambda: rmsnorm(18688, 4096)),
-        "swiglu/c3r_18688x11008": ("swiglu", lambda: swiglu(18688, 11008)),
-        "rope/c3r_N18688_H32_Dh128": ("rope", lambda: rope_rows(18688, 32, 128)),
-        "attn_merge/c3r_N18688_B513_L44": ("attn_merge", lambda: merge_rows(18688, 513, 44, 32, 128)),
+        # ragged scoring of C3 (search_width 512, 19 suffix + 25 tail tokens): 17920 computed rows
+        # (distinct candidates only), attention in one launch; the padded-block kernels below
+        # (merge with a row map, row gather) serve fp32 models and heads the MFMA kernel does not take
+        "rmsnorm/c3r_17920x4096": ("rmsnorm", lambda: rmsnorm(17920, 4096)),
+        "swiglu/c3r_17920x11008": ("swiglu", lambda: swiglu(17920, 11008)),
+        "rope/c3r_N17920_H32_Dh128": ("rope", lambda: rope_rows(17920, 32, 128)),
+        "attn_merge/c3r_N17920_B488_L44": ("attn_merge", lambda: merge_rows(17920, 488, 44, 32, 128)),
         "ragged_attn/c3r_sw512_P21_L44_H32_Dh128": ("ragged_attn", lambda: ragged_attn(512, 19, 44, 20, 21, 32, 128)),
-        "gather_rows/c3r_22572_of_18688x4096": ("gather_rows", lambda: gather(18688, 513 * 44, 4096)),
+        "gather_rows/c3r_21472_of_17920x4096": ("gather_rows", lambda: gather(17920, 488 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
         "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
         "rope/c3_B512_L44_H32_Dh128": ("rope", lambda: rope(512, 44, 32, 128)),
