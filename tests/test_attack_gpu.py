@@ -360,3 +360,40 @@ print("rccl-ok")
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_graphs_are_really_captured_with_a_list_style_normalize():
+    """The hipGraph paths must not silently fall back to eager: with a torchvision-style normalize
+    (mean/std as Python lists, rebuilt as tensors on every call -- a host-to-device copy that aborts a
+    capture) the engine still captures the gradient pass, the vision tower, the prefix pass and the
+    winner re-score, and the run equals the all-eager run."""
+    from bimodalattack_amd import BimodalAttackConfig, synthetic as S
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.attack import BimodalAttack, _GradientGraph, _ReplayGraph
+
+    class ListNormalize:
+        mean, std = list(S.CLIP_MEAN), list(S.CLIP_STD)
+
+        def __call__(self, t):
+            m = torch.as_tensor(self.mean, dtype=t.dtype, device=t.device).view(-1, 1, 1)
+            s = torch.as_tensor(self.std, dtype=t.dtype, device=t.device).view(-1, 1, 1)
+            return (t - m) / s
+
+    out = {}
+    for eager in (False, True):
+        model, tok, proc, image = S.tiny_case("llava", device=DEV)
+        cfg = BimodalAttackConfig(num_steps=3, search_width=16, topk=8, pgd_attack=True, gcg_attack=True, joint_eval=True,
+                                  eps=64 / 255, alpha=4 / 255, seed=3, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
+                                  images_folder=tempfile.mkdtemp())
+        kw = dict(graph_gradient=False, graph_prefix=False, graph_rescore=False) if eager else {}
+        attack = BimodalAttack(model, tok, proc, cfg, ListNormalize(), EngineOptions.from_env(rng_device="cpu", **kw))
+        res = attack.run("tell me a story", "tell me a story", "Sure here is a story", image)
+        out[eager] = res
+        if not eager:
+            assert isinstance(attack._grad_graph, _GradientGraph)
+            assert isinstance(attack._feat_graph, _ReplayGraph)
+            assert attack._prefix_graphs and all(isinstance(g, _ReplayGraph) for g in attack._prefix_graphs.values())
+            assert attack._rescore_graphs and all(isinstance(g, _ReplayGraph) for g in attack._rescore_graphs.values())
+            assert attack.hf.normalize.ok is True
+    np.testing.assert_allclose(out[False].losses, out[True].losses, rtol=1e-5)
+    assert out[False].strings == out[True].strings
