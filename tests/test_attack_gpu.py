@@ -272,7 +272,14 @@ def test_7b_scoring_equals_reference_call_shape(workload):
     order = segment_order("pgd", "llava", single=True) if joint else segment_order("gcg", "llava", no_joint_eval=True)
     with torch.no_grad():
         feats = atk.hf.image_features(image) if joint else None
+        cand[7] = cand[3]                                   # an exact duplicate and a copy of the parent
+        cand[11] = ids[0]
         got = atk.score_candidates(cand.contiguous(), order, feats).float().cpu().numpy()
+        # the same candidates through ragged scoring (rows from the first replaced position on, duplicates
+        # once, attention in the one-launch MFMA kernel): what the attack loop runs
+        ragged = atk.score_candidates(cand.contiguous(), order, feats, parent=ids).float().cpu().numpy()
+        assert atk.score_stats["ragged_calls"] == 1 and atk.score_stats["padded_calls"] == 1
+        assert atk.score_stats["rows_needed"] < 2 * 48 * (ids.shape[1] + 25) * 0.95
         # the reference's call shape, in chunks of 8 to bound the (B,S,V) logits
         E = atk.embedding_layer
         want = []
@@ -287,13 +294,17 @@ def test_7b_scoring_equals_reference_call_shape(workload):
             want.append(l.view(8, T).mean(-1))
         want = torch.cat(want).cpu().numpy()
     rel = np.abs(got - want) / np.abs(want)
+    rel_r = np.abs(ragged - want) / np.abs(want)
     # bf16 has 8 significand bits; 32 layers of rounding noise land well under 1 %
     assert rel.max() < 1e-2, rel.max()
+    assert rel_r.max() < 1e-2, rel_r.max()
+    assert ragged[7] == ragged[3]                           # computed once
     # and the ranking the attack cares about is the same where it is not a near-tie
     gap = np.sort(want)[1] - np.sort(want)[0]
     if gap > 4 * np.abs(got - want).max():
         assert int(got.argmin()) == int(want.argmin())
-    print(f"{workload}: max rel diff {rel.max():.2e}, mean {rel.mean():.2e}, loss range [{want.min():.4f}, {want.max():.4f}]")
+    print(f"{workload}: max rel diff {rel.max():.2e} (ragged {rel_r.max():.2e}), mean {rel.mean():.2e} "
+          f"(ragged {rel_r.mean():.2e}), loss range [{want.min():.4f}, {want.max():.4f}]")
 
 
 def test_run_experiment_writes_reference_artifacts(tmp_path):
