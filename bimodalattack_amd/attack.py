@@ -156,7 +156,7 @@ class BimodalAttack:
         self._feat_graph = None                    # image -> image features (no autograd)
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
-        self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies)
+        self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")

@@ -106,6 +106,9 @@ class EngineOptions:
     # projection weight so the backward product streams weight rows along the reduction like the
     # forward one (the faster library form for such shapes).  Costs one more copy of the LM weights.
     backward_weight_copies: bool = True
+    # q_proj/k_proj/v_proj of an attention block as one GEMM against the concatenated weight (16-bit
+    # models; one more copy of those matrices): fewer partly filled tile rounds, one weight stream.
+    fuse_qkv: bool = True
     # Attend to the shared prefix without copying its keys/values into every candidate
     # (two flash launches + a merge kernel; llama-family text models).  See prefix_attention.py.
     shared_prefix_attention: bool = True
@@ -156,6 +159,8 @@ class EngineOptions:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
+        if "BMA_FUSE_QKV" in env:
+            opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:
             opts.backward_weight_copies = env["BMA_BACKWARD_WEIGHT_COPIES"] not in ("0", "false", "False")
         if "BMA_SHARED_PREFIX_ATTENTION" in env:

@@ -10,7 +10,9 @@ is not on the GPU or a shape is beyond the kernels' limits -- the original code 
 Nothing is left on the user's model afterwards: patches are instance attributes removed
 on exit.  Under autograd with at most 128 rows (the text-only gradient pass) the decoder layers'
 bias-free projections additionally compute their input gradient through a transposed copy of the
-weight (``ops.FrozenLinearFn``; one extra copy of the language model's weights in HBM).
+weight (``ops.FrozenLinearFn``; one extra copy of the language model's weights in HBM).  In 16-bit
+models the q/k/v projections of an attention block run as one product against their concatenated
+weight (one more copy of those three matrices).
 
 What qualifies (checked structurally, not by model name):
   * a module whose class name ends in ``RMSNorm`` with a 1-D ``weight`` and an epsilon
@@ -45,8 +47,12 @@ SKINNY_ROWS = 128      # "a handful of rows": the batch-1 gradient pass of a tex
 
 
 class FusedInference:
-    def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True):
+    def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
+                 fuse_qkv: bool = True):
         self.enabled = enabled
+        self.weight_copies = weight_copies
+        self.qkv: List[torch.nn.Module] = []        # attention blocks whose q/k/v projections run as one GEMM
+        self._wqkv = {}
         self.norms: List[Tuple[torch.nn.Module, float, bool]] = []
         self.mlps: List[torch.nn.Module] = []
         self.linears: List[torch.nn.Module] = []
@@ -60,6 +66,11 @@ class FusedInference:
         for m in model.modules():
             cls = type(m).__name__
             w = getattr(m, "weight", None)
+            if fuse_qkv and all(isinstance(getattr(m, n, None), torch.nn.Linear) and type(getattr(m, n)) is torch.nn.Linear
+                                and getattr(m, n).bias is None for n in ("q_proj", "k_proj", "v_proj")) \
+                    and m.q_proj.in_features == m.k_proj.in_features == m.v_proj.in_features \
+                    and m.q_proj.weight.dtype in (torch.bfloat16, torch.float16):
+                self.qkv.append(m)
             if weight_copies and (hasattr(m, "q_proj") or hasattr(m, "gate_proj")):
                 # bias-free projections of the decoder layers (attention and MLP blocks)
                 for name in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"):
@@ -139,6 +150,67 @@ class FusedInference:
             return ops.FrozenLinearFn.apply(x, w, wt)
         return forward
 
+    def _qkv_forwards(self, attn):
+        """q_proj / k_proj / v_proj of one attention block as ONE product against the concatenated
+        weight (16-bit models): three N = 4096 GEMMs fill 3 x 4.4 of 15 tile rounds on 256 CUs, one
+        N = 12288 GEMM 13.1 of 14; in the ~70-row gradient pass it is one weight stream instead of three
+        and one input-gradient product instead of three plus two adds.  The first of the three calls does
+        the product; the other two hand out their column slices of it (same input tensor, checked by
+        identity), so HF's attention code is untouched."""
+        mods = (attn.q_proj, attn.k_proj, attn.v_proj)
+        origs = [type(m).forward.__get__(m) for m in mods]
+        sizes = [m.out_features for m in mods]
+        offs = [0, sizes[0], sizes[0] + sizes[1], sum(sizes)]
+        slot = {}
+
+        def fused_weight():
+            w = self._wqkv.get(id(attn))
+            if w is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return None
+                with torch.no_grad():
+                    w = torch.cat([m.weight.detach() for m in mods], dim=0).contiguous()
+                self._wqkv[id(attn)] = w
+            return w
+
+        def first(x):
+            slot.clear()
+            w0 = mods[0].weight
+            if not (x.is_cuda and x.dtype == w0.dtype and x.dim() >= 2):
+                return origs[0](x)
+            w = fused_weight()
+            if w is None:
+                return origs[0](x)
+            if self._tracking(x):
+                if not self.weight_copies or x.numel() // x.shape[-1] > SKINNY_ROWS:
+                    y = torch.nn.functional.linear(x, w)
+                else:
+                    wt = self._wt.get(id(attn))
+                    if wt is None:
+                        if torch.cuda.is_current_stream_capturing():
+                            return origs[0](x)
+                        with torch.no_grad():
+                            wt = w.t().contiguous()
+                        self._wt[id(attn)] = wt
+                    y = ops.FrozenLinearFn.apply(x, w, wt)
+            else:
+                y = torch.nn.functional.linear(x, w)
+            slot["x"], slot["y"] = x, y
+            return y[..., offs[0]:offs[1]]
+
+        def later(i):
+            def forward(x):
+                y = slot.get("y")
+                if y is None or slot.get("x") is not x:
+                    return origs[i](x)
+                out = y[..., offs[i]:offs[i + 1]]
+                if i == 2:
+                    slot.clear()
+                return out
+            return forward
+
+        return first, later(1), later(2)
+
     def _mlp_forward(self, m, orig):
         act = self._act_code(m.act_fn)
 
@@ -184,6 +256,8 @@ class FusedInference:
             m.forward = self._mlp_forward(m, type(m).forward.__get__(m))
         for m in self.linears:
             m.forward = self._linear_forward(m, type(m).forward.__get__(m))
+        for attn in self.qkv:                      # after the per-projection patches: these win for q/k/v
+            attn.q_proj.forward, attn.k_proj.forward, attn.v_proj.forward = self._qkv_forwards(attn)
         for mod in self.rope_modules:
             self._saved_rope[mod] = mod.apply_rotary_pos_emb
             mod.apply_rotary_pos_emb = self._rope(mod.apply_rotary_pos_emb)
@@ -199,6 +273,9 @@ class FusedInference:
             m.__dict__.pop("forward", None)
         for m in self.linears:
             m.__dict__.pop("forward", None)
+        for attn in self.qkv:
+            for m in (attn.q_proj, attn.k_proj, attn.v_proj):
+                m.__dict__.pop("forward", None)
         for mod, fn in self._saved_rope.items():
             mod.apply_rotary_pos_emb = fn
         self._saved_rope.clear()
