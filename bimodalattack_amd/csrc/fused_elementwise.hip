@@ -217,9 +217,10 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
 // output), and the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
 // Requires cph = Dh*es/16 to be a power of two <= 64 (Dh = 64..512 for 16-bit dtypes).
 template <int DT>
-__global__ __launch_bounds__(256) void rope_kernel(void* __restrict__ q, int64_t sb, int64_t sh, int64_t sl, int B,
-                                                   int H, int L, int Dh, const void* __restrict__ cosp,
-                                                   const void* __restrict__ sinp, int cos_batch, int cph_log2) {
+__global__ __launch_bounds__(256) void rope_kernel(const void* q, int64_t sb, int64_t sh, int64_t sl, void* dst,
+                                                   int64_t db, int64_t dh, int64_t dl, int B, int H, int L, int Dh,
+                                                   const void* __restrict__ cosp, const void* __restrict__ sinp,
+                                                   int cos_batch, int cph_log2, float sin_sign) {
   constexpr int NE = Chunk<DT>::NE;
   constexpr int ES = bma::elem_bytes<DT>::value;
   const int cph = 1 << cph_log2;               // chunks per head vector
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256) void rope_kernel(void* __restrict__ q, int64_t
   // one workgroup per (b, l): no per-chunk division, only shifts and masks
   const int row = blockIdx.x;
   const int b = row / L, l = row - b * L;
-  char* qrow = static_cast<char*>(q) + (static_cast<int64_t>(b) * sb + static_cast<int64_t>(l) * sl) * ES;
+  const char* qrow = static_cast<const char*>(q) + (static_cast<int64_t>(b) * sb + static_cast<int64_t>(l) * sl) * ES;
+  char* drow = static_cast<char*>(dst) + (static_cast<int64_t>(b) * db + static_cast<int64_t>(l) * dl) * ES;
   const int64_t cs = (static_cast<int64_t>(cos_batch > 1 ? b : 0) * L + l) * Dh;
   const uint4_t* crow = reinterpret_cast<const uint4_t*>(static_cast<const char*>(cosp) + cs * ES);
   const uint4_t* srow = reinterpret_cast<const uint4_t*>(static_cast<const char*>(sinp) + cs * ES);
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void rope_kernel(void* __restrict__ q, int64_t
   for (int i = threadIdx.x; i < n; i += 256) {
     const int c = i & (cph - 1);
     const int h = i >> cph_log2;
-    uint4_t* px = reinterpret_cast<uint4_t*>(qrow + static_cast<int64_t>(h) * sh * ES) + c;
+    const uint4_t* px = reinterpret_cast<const uint4_t*>(qrow + static_cast<int64_t>(h) * sh * ES) + c;
+    uint4_t* pd = reinterpret_cast<uint4_t*>(drow + static_cast<int64_t>(h) * dh * ES) + c;
     const uint4_t cw = crow[c], sw = srow[c];
     const uint4_t xw = *px;
     uint4_t pw;                                 // the partner half's chunk
@@ -248,10 +251,11 @@ __global__ __launch_bounds__(256) void rope_kernel(void* __restrict__ q, int64_t
     Chunk<DT>::unpack(pw, p);
     Chunk<DT>::unpack(cw, cf);
     Chunk<DT>::unpack(sw, sf);
-    const float sign = (c < half) ? -1.0f : 1.0f;   // rotate_half(x) = cat(-x2, x1)
+    // rotate_half(x) = cat(-x2, x1); sin_sign = -1 turns the rotation into its inverse (the backward)
+    const float sign = ((c < half) ? -1.0f : 1.0f) * sin_sign;
 #pragma unroll
     for (int j = 0; j < NE; ++j) o[j] = rnd<DT>(rnd<DT>(x[j] * cf[j]) + rnd<DT>(sign * p[j] * sf[j]));
-    *px = Chunk<DT>::pack(o);
+    *pd = Chunk<DT>::pack(o);
   }
 }
 
@@ -356,11 +360,13 @@ extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype
   return bma_gated_act(gate, up, n, dtype, 0, out, stream);
 }
 
-extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, int B, int H, int L,
-                                int Dh, const void* cos, const void* sin, int cos_batch, int dtype, void* stream) {
+extern "C" int bma_rope(const void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, void* dst, int64_t dst_b,
+                        int64_t dst_h, int64_t dst_l, int B, int H, int L, int Dh, const void* cos, const void* sin,
+                        int cos_batch, float sin_sign, int dtype, void* stream) {
   if (B < 0 || H <= 0 || L < 0 || Dh <= 0 || (cos_batch != 1 && cos_batch != B)) return BMA_EINVAL;
+  if (sin_sign != 1.0f && sin_sign != -1.0f) return BMA_EINVAL;
   if (B == 0 || L == 0) return BMA_OK;
-  if (!q || !cos || !sin) return BMA_EINVAL;
+  if (!q || !dst || !cos || !sin) return BMA_EINVAL;
   if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
   const int es = dtype == BMA_F32 ? 4 : 2;
   const int ne = 16 / es;
@@ -368,7 +374,9 @@ extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int
   const int cph_host = Dh / ne;
   if (cph_host > 64 || (cph_host & (cph_host - 1))) return BMA_ELIMIT;   // partner exchange stays inside a wave
   if ((stride_b * es) % 16 || (stride_h * es) % 16 || (stride_l * es) % 16) return BMA_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin)) % 16)
+  if ((dst_b * es) % 16 || (dst_h * es) % 16 || (dst_l * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(cos) |
+       reinterpret_cast<uintptr_t>(sin)) % 16)
     return BMA_EALIGN;
   int cph_log2 = 0;
   while ((1 << cph_log2) < cph_host) ++cph_log2;
@@ -379,15 +387,22 @@ extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(rows)), block(256);
   BMA_PROF_BEGIN(BMA_K_ROPE, st, 2.0 * static_cast<double>(B) * H * L * Dh * es);
-  if (dtype == BMA_F32)
-    hipLaunchKernelGGL((rope_kernel<BMA_F32>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch, cph_log2);
-  else if (dtype == BMA_BF16)
-    hipLaunchKernelGGL((rope_kernel<BMA_BF16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch, cph_log2);
-  else
-    hipLaunchKernelGGL((rope_kernel<BMA_F16>), grid, block, 0, st, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch, cph_log2);
+#define BMA_ROPE_GO(DT_)                                                                                            \
+  hipLaunchKernelGGL((rope_kernel<DT_>), grid, block, 0, st, q, stride_b, stride_h, stride_l, dst, dst_b, dst_h, dst_l, \
+                     B, H, L, Dh, cos, sin, cos_batch, cph_log2, sin_sign)
+  if (dtype == BMA_F32) BMA_ROPE_GO(BMA_F32);
+  else if (dtype == BMA_BF16) BMA_ROPE_GO(BMA_BF16);
+  else BMA_ROPE_GO(BMA_F16);
+#undef BMA_ROPE_GO
   BMA_PROF_END(BMA_K_ROPE, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+extern "C" int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, int B, int H, int L,
+                                int Dh, const void* cos, const void* sin, int cos_batch, int dtype, void* stream) {
+  return bma_rope(q, stride_b, stride_h, stride_l, q, stride_b, stride_h, stride_l, B, H, L, Dh, cos, sin, cos_batch,
+                  1.0f, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------- attention merge

@@ -284,6 +284,22 @@ def rope_(q: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor
     return q
 
 
+def rope(q: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """Out-of-place rotary embedding (``inverse``: the rotation by -angle, i.e. the backward)."""
+    dev = _need_gpu(q, cos, sin)
+    if q.dim() != 4 or q.stride(3) != 1 or cos.shape != sin.shape or cos.dim() != 3:
+        raise ValueError("q must be (B,H,L,Dh) with a contiguous last dim; cos/sin (1|B,L,Dh)")
+    B, H, L, Dh = q.shape
+    if cos.shape[1] != L or cos.shape[2] != Dh or cos.shape[0] not in (1, B) or cos.dtype != q.dtype:
+        raise ValueError("cos/sin do not match q")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    out = torch.empty((B, L, H, Dh), dtype=q.dtype, device=q.device).transpose(1, 2)     # the projection's memory order
+    check("bma_rope", lib.bma_rope(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), out.data_ptr(), out.stride(0),
+                                   out.stride(1), out.stride(2), B, H, L, Dh, cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+                                   -1.0 if inverse else 1.0, _dt(q), _stream(dev)))
+    return out
+
+
 def attn_merge(o1: torch.Tensor, o2: torch.Tensor, lse1: torch.Tensor, lse2: torch.Tensor) -> torch.Tensor:
     """Merge prefix-attention (o1, lse1) and self-attention (o2, lse2) partial results.
     o1, o2: (B,L,H,Dh) contiguous; lse1: (H, B*L) fp32; lse2: (B,H,L) fp32."""
@@ -447,15 +463,15 @@ class SwiGLUFn(torch.autograd.Function):
 
 
 class RoPEFn(torch.autograd.Function):
-    """Out of place under autograd (batch-1 tensors are tiny); the rotation is orthogonal, so
-    the backward is the same kernel with -sin."""
+    """Out of place under autograd (one launch, no clone); the rotation is orthogonal, so the
+    backward is the same kernel with the sign of sin flipped (no negated copy of sin either)."""
 
     @staticmethod
     def forward(ctx, q, cos, sin):
         ctx.save_for_backward(cos, sin)
-        return rope_(q.clone(), cos, sin)
+        return rope(q, cos, sin)
 
     @staticmethod
     def backward(ctx, dq):
         cos, sin = ctx.saved_tensors
-        return rope_(dq.clone(), cos, -sin), None, None
+        return rope(dq, cos, sin, inverse=True), None, None

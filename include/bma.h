@@ -157,6 +157,11 @@ int bma_gated_act(const void* gate, const void* up, int64_t n, int dtype, int ac
 int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l,
                      int B, int H, int L, int Dh, const void* cos, const void* sin,
                      int cos_batch, int dtype, void* stream);
+/* bma_rope: the same rotation read from q and written to dst (own strides; dst == q is the in-place
+ *   form); sin_sign = -1 applies the inverse rotation, which is the backward of the forward one. */
+int bma_rope(const void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, void* dst, int64_t dst_b,
+             int64_t dst_h, int64_t dst_l, int B, int H, int L, int Dh, const void* cos, const void* sin,
+             int cos_batch, float sin_sign, int dtype, void* stream);
 /* Backward halves, used by the gradient pass (autograd at batch 1; weights are constants, so no
  * weight gradients): bma_rmsnorm_bwd: dx from x, weight, dy (D*es <= 16 KiB);
  * bma_swiglu_bwd: dgate, dup from gate, up, dy.  RoPE's backward is bma_rope_inplace with -sin. */

@@ -126,6 +126,9 @@ def test_rope_vs_hf(dtype):
         # per-batch cos/sin
         cosb, sinb = cos.expand(B, -1, -1).contiguous(), sin.expand(B, -1, -1).contiguous()
         assert torch.equal(ops.rope_(q.clone(), cosb, sinb), gq)
+        # out of place (what the gradient pass uses): same bits; the inverse flag equals rotating with -sin
+        assert torch.equal(ops.rope(q, cos, sin), gq) and torch.equal(ops.rope(k, cos, sin), gk)
+        assert torch.equal(ops.rope(q, cos, sin, inverse=True), ops.rope_(q.clone(), cos, -sin))
 
 
 def _small_llama(dtype):
