@@ -160,7 +160,6 @@ class FusedInference:
         mods = (attn.q_proj, attn.k_proj, attn.v_proj)
         origs = [type(m).forward.__get__(m) for m in mods]
         sizes = [m.out_features for m in mods]
-        offs = [0, sizes[0], sizes[0] + sizes[1], sum(sizes)]
         slot = {}
 
         def fused_weight():
@@ -195,15 +194,18 @@ class FusedInference:
                     y = ops.FrozenLinearFn.apply(x, w, wt)
             else:
                 y = torch.nn.functional.linear(x, w)
-            slot["x"], slot["y"] = x, y
-            return y[..., offs[0]:offs[1]]
+            # one split node: its backward is a single concatenation of the three gradients (three
+            # independent slices would each zero-fill a full-width buffer and add)
+            parts = torch.split(y, sizes, dim=-1)
+            slot["x"], slot["y"] = x, parts
+            return parts[0]
 
         def later(i):
             def forward(x):
                 y = slot.get("y")
                 if y is None or slot.get("x") is not x:
                     return origs[i](x)
-                out = y[..., offs[i]:offs[i + 1]]
+                out = y[i]
                 if i == 2:
                     slot.clear()
                 return out
