@@ -409,7 +409,8 @@ class BimodalAttack:
             self._prefix_graphs[key] = g
         return g(feats)
 
-    def _ragged_logits(self, mine: Tensor, parent: Tensor, segs, L: int, P: int, cache) -> Optional[Tensor]:
+    def _ragged_logits(self, mine: Tensor, parent: Tensor, segs, L: int, P: int, cache,
+                       n_rows: Optional[int] = None) -> Optional[Tensor]:
         """Target logits (m,T,V) through the ragged forward, or None when this draw does not fit
         the fixed row budget (then the caller scores the padded block)."""
         cfg, hf = self.config, self.hf
@@ -417,12 +418,13 @@ class BimodalAttack:
         parent = parent.reshape(1, n_opt).to(mine.device)
         both = torch.cat([mine, parent], dim=0)
         host = both.cpu().numpy()                    # waits for the sampling kernels only
-        plan = ragged_plan(host[:m], host[m], L, self.T, P, ragged_budget(m, n_opt, L, cfg.n_replace, cfg.topk))
+        if n_rows is None:
+            n_rows = ragged_budget(m, n_opt, L, cfg.n_replace, cfg.topk)
+        plan = ragged_plan(host[:m], host[m], L, self.T, P, n_rows)
         if plan is None:
             return None
         from .prefix_attention import RaggedMaps
         maps = RaggedMaps(plan, mine.device)
-        import numpy as np
         mu = int(plan["m"])           # distinct candidates, in the plan's (sorted) order: duplicates are computed once
         both = torch.from_numpy(np.concatenate([plan["cand"], host[m:m + 1]])).to(mine.device, non_blocking=True)
         x = ops.splice(segs, mu + 1, self.embedding_layer.weight, both.contiguous(), hf.emb_scale)
@@ -438,8 +440,28 @@ class BimodalAttack:
                           allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
-        lo, hi = self.shard.bounds(n)
-        mine = sampled[lo:hi].contiguous()
+        dealt = None           # (order over distinct candidates, inverse map, distinct count) when dealing
+        emulate = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else 0
+        world = emulate or self.shard.world
+        if (self.shard.enabled or emulate) and parent is not None and allow_prefix and self.opt.ragged_suffix \
+                and hf.ragged_ok is not False and hf.shared_ok is not False and n > world:
+            # Ragged scoring on several GPUs: every rank sees the same ids, so each can drop the
+            # duplicates, sort the distinct candidates by first replaced position and take every
+            # world-th one -- all ranks then compute (almost) the same number of rows, and the fixed
+            # per-rank row budget is the global one divided by the world size instead of a
+            # small-sample budget with its own safety margin.
+            host = sampled.cpu().numpy()
+            par = parent.reshape(-1).cpu().numpy()
+            uniq, inv = np.unique(host, axis=0, return_inverse=True)
+            diff = uniq != par[None, :]
+            first = np.where(diff.any(1), diff.argmax(1), uniq.shape[1] - 1)
+            by_cost = np.argsort(first, kind="stable")
+            dealt = (by_cost, np.asarray(inv).reshape(-1), uniq.shape[0])
+            take = by_cost[0::world] if emulate else self.shard.deal(by_cost)
+            mine = torch.from_numpy(uniq[take]).to(sampled.device)
+        else:
+            lo, hi = self.shard.bounds(n)
+            mine = sampled[lo:hi].contiguous()
         m = mine.shape[0]
         E = self.embedding_layer.weight
         feats = None if feats is None else feats.to(E.dtype)
@@ -476,7 +498,14 @@ class BimodalAttack:
                 kv, x, logits = None, None, None
                 if ragged:
                     try:
-                        logits = self._ragged_logits(mine, parent, segs, L, P, cache)
+                        n_rows = None
+                        if dealt is not None:
+                            # this rank's share of the budget of the whole step (+ one candidate of slack)
+                            n_opt = mine.shape[1]
+                            total = ragged_budget(n, n_opt, L, cfg.n_replace, cfg.topk)
+                            n_rows = n_opt + -(-(total - n_opt) // world) + L
+                            n_rows = min(-(-n_rows // 8) * 8, n_opt + m * L)
+                        logits = self._ragged_logits(mine, parent, segs, L, P, cache, n_rows)
                         hf.ragged_ok = True
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):
@@ -524,8 +553,19 @@ class BimodalAttack:
                 self._chunk_cap = chunk
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
-        full = self.shard.gather(losses, n)
-        self._match = self.shard.gather(match, n, pad=0.0) if match is not None else None
+        if dealt is not None:
+            by_cost, inv, n_u = dealt
+            inv_t = torch.from_numpy(inv).to(losses.device)
+            if emulate:        # GEMM tuning only: rank 0's shapes of an `emulate`-rank run, the other ranks' shares unscored
+                take_t = torch.from_numpy(np.ascontiguousarray(by_cost[0::world])).to(losses.device)
+                full = torch.full((n_u,), float("inf"), device=losses.device).index_put_((take_t,), losses)[inv_t]
+                self._match = None if match is None else torch.zeros(n_u, device=losses.device).index_put_((take_t,), match)[inv_t]
+            else:
+                full = self.shard.gather_dealt(losses, by_cost)[inv_t]
+                self._match = self.shard.gather_dealt(match, by_cost, pad=0.0)[inv_t] if match is not None else None
+        else:
+            full = self.shard.gather(losses, n)
+            self._match = self.shard.gather(match, n, pad=0.0) if match is not None else None
         if self.opt.loss_in_model_dtype:
             full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
         return full

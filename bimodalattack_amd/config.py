@@ -109,6 +109,10 @@ class EngineOptions:
     # q_proj/k_proj/v_proj of an attention block as one GEMM against the concatenated weight (16-bit
     # models; one more copy of those matrices): fewer partly filled tile rounds, one weight stream.
     fuse_qkv: bool = True
+    # GEMM tuning aid (tools/tune_gemms.py): in a single process, score only what rank 0 of an N-rank run
+    # would score, with that run's row budget -- the exact GEMM shapes of the multi-GPU run.  Results of the
+    # attack are meaningless with it.
+    emulate_world: int = 0
     # Attend to the shared prefix without copying its keys/values into every candidate
     # (two flash launches + a merge kernel; llama-family text models).  See prefix_attention.py.
     shared_prefix_attention: bool = True
@@ -159,6 +163,8 @@ class EngineOptions:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
+        if "BMA_EMULATE_WORLD" in env:
+            opts.emulate_world = int(env["BMA_EMULATE_WORLD"])
         if "BMA_FUSE_QKV" in env:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:

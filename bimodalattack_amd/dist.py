@@ -60,6 +60,31 @@ class CandidateSharder:
             recv = torch.cat(parts)
         return recv[:n].contiguous()
 
+    # -- dealt partition (ragged scoring) -----------------------------------------------
+    def deal(self, order, rank: Optional[int] = None):
+        """This rank's share of `order` (any sequence of candidate indices): every world-th entry.
+        With `order` sorted by a per-candidate cost, every rank gets the same mix of costs."""
+        r = self.rank if rank is None else rank
+        return order[r::self.world]
+
+    def gather_dealt(self, local: torch.Tensor, order, pad: float = float("inf")) -> torch.Tensor:
+        """Inverse of ``deal``: `local` holds this rank's values for ``deal(order)``, in that order;
+        returns the len(order) values indexed by candidate (order's entries) on every rank."""
+        import numpy as np
+        order = np.asarray(order)
+        n = int(order.shape[0])
+        if not self.enabled:
+            out = torch.empty((n,), dtype=torch.float32, device=local.device)
+            out[torch.from_numpy(order).to(local.device)] = local.to(torch.float32)
+            return out
+        per = self.per_rank(n)
+        recv = self.gather(local, self.world * per, pad=pad) if per else local.new_empty((0,), dtype=torch.float32)
+        src = np.empty((n,), dtype=np.int64)
+        for r in range(self.world):
+            idx = order[r::self.world]
+            src[idx] = r * per + np.arange(idx.shape[0])
+        return recv[torch.from_numpy(src).to(recv.device)]
+
     def gather_losses(self, local: torch.Tensor, n: int, flag: bool = False,
                       want_flag: bool = False) -> Tuple[torch.Tensor, bool]:
         """Losses plus the OR of a per-rank flag (kept for callers that stop per rank)."""

@@ -36,6 +36,18 @@ def _worker(rank, world, port, out):
             assert full.shape == (n,) and torch.equal(full, truth), (n, rank)
             assert flag == (n == 5)
             res[n] = int(full.argmin())
+        # dealt partition (ragged scoring): every world-th entry of a cost-sorted order; the gather
+        # puts each rank's values back under their candidate index
+        for n in (world, 5, 64, 487):
+            g = torch.Generator().manual_seed(n)
+            truth = torch.rand(n, generator=g) + 1.0
+            order = np.argsort(torch.rand(n, generator=g).numpy(), kind="stable")
+            take = sh.deal(order)
+            assert len(take) in (n // world, n // world + 1)
+            full = sh.gather_dealt(truth[torch.from_numpy(np.ascontiguousarray(take))].clone(), order)
+            assert torch.equal(full, truth), (n, rank)
+            # every candidate is dealt exactly once
+            assert sorted(np.concatenate([sh.deal(order, r) for r in range(world)]).tolist()) == list(range(n))
         # rank 0's ids win the broadcast even when another rank drifted (different N)
         ids = torch.arange(12, dtype=torch.int64).view(4, 3) if rank == 0 else torch.zeros((6, 3), dtype=torch.int64)
         got = sh.broadcast_ids(ids)

@@ -3,9 +3,8 @@
 
     python tools/tune_gemms.py            # ~15 GPU-minutes; writes bimodalattack_amd/tuning/<arch>.csv
 
-Runs bench.py under PyTorch TunableOp in tuning mode for the shard sizes of 1/2/4/8 GPUs
-(search_width 512/256/128/64 on one GPU gives the same per-rank GEMM shapes) on the GCG-only
-and joint workloads.  The gradient pass is run eagerly here (tuning cannot happen inside a
+Runs bench.py under PyTorch TunableOp in tuning mode for the per-rank shapes of 1/2/4/8 GPUs
+(one process emulating rank 0 of each world size) on the GCG-only and joint workloads.  The gradient pass is run eagerly here (tuning cannot happen inside a
 graph capture); at run time its captured graph picks the tuned kernels up by lookup.
 """
 import os
@@ -32,10 +31,12 @@ def main():
     if os.path.exists(dst) and not os.path.exists(src):
         shutil.copyfile(dst, src)            # keep what is already tuned: only new shapes are searched
     for wl in workloads:
-        for sw in (512, 256, 128, 64):
-            print(f"== tuning {wl} search_width={sw}", flush=True)
-            r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--search-width", str(sw),
-                                "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=REPO)
+        for world in (1, 2, 4, 8):
+            # rank 0's share of a `world`-GPU run, in one process (EngineOptions.emulate_world): the shapes
+            # candidate dealing produces, not those of a smaller search width
+            print(f"== tuning {wl} as rank 0 of {world}", flush=True)
+            r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--steps", "1", "--warmup", "1",
+                                "--no-cpu-baseline"], env=dict(env, BMA_EMULATE_WORLD=str(world)), cwd=REPO)
             if r.returncode != 0:
                 print(f"   (failed with {r.returncode}; continuing)", flush=True)
     shutil.copyfile(src, dst)
