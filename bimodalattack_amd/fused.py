@@ -69,7 +69,8 @@ class FusedInference:
             if fuse_qkv and all(isinstance(getattr(m, n, None), torch.nn.Linear) and type(getattr(m, n)) is torch.nn.Linear
                                 and getattr(m, n).bias is None for n in ("q_proj", "k_proj", "v_proj")) \
                     and m.q_proj.in_features == m.k_proj.in_features == m.v_proj.in_features \
-                    and m.q_proj.weight.dtype in (torch.bfloat16, torch.float16):
+                    and m.q_proj.weight.dtype in (torch.bfloat16, torch.float16) \
+                    and not hasattr(m, "q_norm"):      # per-head norms (Gemma-3) want dense projection outputs
                 self.qkv.append(m)
             if weight_copies and (hasattr(m, "q_proj") or hasattr(m, "gate_proj")):
                 # bias-free projections of the decoder layers (attention and MLP blocks)
