@@ -16,6 +16,7 @@ os.makedirs(out, exist_ok=True)
 shutil.copyfile(os.path.join(src, "kernel_bench.json"), os.path.join(out, f"{tag}_kernel_bench.json"))
 for w in ("gcg", "joint"):
     for a, b in ((f"kt_{w}_kernel_stats.csv", f"{tag}_bench_{w}_kernel_stats.csv"),
+                 (f"kt_{w}_by_grid.txt", f"{tag}_bench_{w}_kernel_by_grid.txt"),
                  (f"bench_{w}_under_rocprof.json", f"{tag}_bench_{w}_under_rocprof.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copyfile(os.path.join(src, a), os.path.join(out, b))

@@ -14,6 +14,7 @@ timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$D" -o write -- python3 tools/kernel_bench.py --iters 5 > /dev/null 2>&1; echo "write-rc=$?"
 for w in gcg joint; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$D" -o kt_$w -- python3 bench.py --workload $w --no-cpu-baseline > "$D/bench_${w}_under_rocprof.json" 2> /dev/null; echo "kt-$w-rc=$?"
+  python3 tools/trace_by_grid.py "$D/kt_${w}_kernel_trace.csv" "$D/kt_${w}_by_grid.txt"
 done
 rm -f "$D"/*_kernel_trace.csv
 for w in joint pgd_gcg pgd gemma_joint; do
