@@ -282,16 +282,22 @@ def main() -> None:
         traffic = None
         # HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_traffic.json):
         # the entry for this kernel whose launch shape has the same algorithmic bytes
-        for e in (pmc or {}).get("entries", []):
-            if e["kernel"] == dom and abs(e["algorithmic_bytes"] - k["algorithmic_MB_per_launch"] * 1e6) <= 0.02 * e["algorithmic_bytes"]:
-                traffic = e["hbm_bytes_per_launch"]
+        # (ragged scoring computes a slightly different row count every step: the PMC pass of the nearest
+        # shape, within 6 %, scaled by its measured traffic-to-algorithmic ratio)
+        live = k["algorithmic_MB_per_launch"] * 1e6
+        near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == dom
+                and abs(e["algorithmic_bytes"] - live) <= 0.06 * e["algorithmic_bytes"]]
+        if near:
+            e = min(near, key=lambda e: abs(e["algorithmic_bytes"] - live))
+            traffic = e["ratio_to_algorithmic"] * live
         roofline = dict(bound="hbm", kernel=k["symbol"], achieved=k["achieved_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=k["frac_of_8TBps"], traffic=traffic,
                         algorithmic_bytes_per_launch=k["algorithmic_MB_per_launch"] * 1e6,
                         avg_launch_us=k["avg_us"], launches=k["launches"],
                         note="dominant hand-written kernel by summed device time inside the timed region; achieved = "
                              "algorithmic bytes / HIP-event time on the launch stream (bma_profile_*); traffic = FETCH_SIZE*2 + "
-                             "WRITE_SIZE from separate rocprofv3 --pmc passes of the same launch shape (profiles/r1_pmc_traffic.json)")
+                             "WRITE_SIZE from separate rocprofv3 --pmc passes of the nearest launch shape, scaled by its traffic / "
+                             "algorithmic ratio to this run's average launch (profiles/r1_pmc_traffic.json)")
 
     # ---- the candidate forward: MFMA-bound, algorithmic FLOPs with prefix reuse ----------
     tc = model.config.text_config

@@ -45,7 +45,7 @@ from .dist import CandidateSharder
 from .fused import FusedInference
 from . import gemm_tuning
 from .hf_adapter import HFAdapter
-from .layout import ragged_budget, ragged_plan, dynamic_width, segment_order, split_at_suffix
+from .layout import ragged_plan, ragged_rows, dynamic_width, segment_order, split_at_suffix
 from .utils import INIT_CHARS, FilterJob, get_nonascii_toks, is_oom, plan_chunk
 
 logger = logging.getLogger("gcg")
@@ -418,8 +418,6 @@ class BimodalAttack:
         parent = parent.reshape(1, n_opt).to(mine.device)
         both = torch.cat([mine, parent], dim=0)
         host = both.cpu().numpy()                    # waits for the sampling kernels only
-        if n_rows is None:
-            n_rows = ragged_budget(m, n_opt, L, cfg.n_replace, cfg.topk)
         plan = ragged_plan(host[:m], host[m], L, self.T, P, n_rows)
         if plan is None:
             return None
@@ -435,6 +433,13 @@ class BimodalAttack:
         st["rows"] += int(plan["N"])
         st["rows_needed"] += int(plan["needed"])
         return hf.target_logits_ragged(rows, self.T, cache, maps)
+
+    @staticmethod
+    def _dealt_rows(dealt, world: int, L: int, n_opt: int) -> int:
+        by_cost, _, _, first = dealt
+        need = max(n_opt + int((L - first[by_cost[r::world]]).sum()) for r in range(world))
+        cap = n_opt + len(by_cost[0::world]) * L
+        return ragged_rows(need, cap)
 
     def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
                           allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
@@ -456,7 +461,7 @@ class BimodalAttack:
             diff = uniq != par[None, :]
             first = np.where(diff.any(1), diff.argmax(1), uniq.shape[1] - 1)
             by_cost = np.argsort(first, kind="stable")
-            dealt = (by_cost, np.asarray(inv).reshape(-1), uniq.shape[0])
+            dealt = (by_cost, np.asarray(inv).reshape(-1), uniq.shape[0], first)
             take = by_cost[0::world] if emulate else self.shard.deal(by_cost)
             mine = torch.from_numpy(uniq[take]).to(sampled.device)
         else:
@@ -500,11 +505,9 @@ class BimodalAttack:
                     try:
                         n_rows = None
                         if dealt is not None:
-                            # this rank's share of the budget of the whole step (+ one candidate of slack)
-                            n_opt = mine.shape[1]
-                            total = ragged_budget(n, n_opt, L, cfg.n_replace, cfg.topk)
-                            n_rows = n_opt + -(-(total - n_opt) // world) + L
-                            n_rows = min(-(-n_rows // 8) * 8, n_opt + m * L)
+                            # every rank builds the row count of the rank with the most rows (they differ by
+                            # a few rows after dealing): one set of GEMM shapes per step on all ranks
+                            n_rows = self._dealt_rows(dealt, world, L, mine.shape[1])
                         logits = self._ragged_logits(mine, parent, segs, L, P, cache, n_rows)
                         hf.ragged_ok = True
                     except Exception as e:
@@ -554,7 +557,7 @@ class BimodalAttack:
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
         if dealt is not None:
-            by_cost, inv, n_u = dealt
+            by_cost, inv, n_u, _ = dealt
             inv_t = torch.from_numpy(inv).to(losses.device)
             if emulate:        # GEMM tuning only: rank 0's shapes of an `emulate`-rank run, the other ranks' shares unscored
                 take_t = torch.from_numpy(np.ascontiguousarray(by_cost[0::world])).to(losses.device)

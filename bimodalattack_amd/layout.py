@@ -7,7 +7,7 @@ Table-driven: a layout is looked up, not branched to.
 
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 # Sequence layouts WITH the image, keyed by "is the model gemma3".  Gemma-3 puts
 # the suffix in front of the image, everything else behind it (:1153-1162).
@@ -113,12 +113,21 @@ def ragged_budget(m: int, n_opt: int, L: int, n_replace: int, topk: int = 0, sig
     return min(int(-(-want // gran) * gran), n_opt + m * L)
 
 
-def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int, dedup: bool = True):
+def ragged_rows(needed: int, cap: int) -> int:
+    """Rows a ragged forward computes for `needed` useful ones: the next point of a coarse grid (GEMM
+    shapes then come from a small set that the selection table covers: tools/tune_rows.py), never more
+    than `cap` (every token of every candidate)."""
+    gran = 256 if needed >= 8192 else 128 if needed >= 4096 else 64 if needed >= 1024 else 8
+    return min(-(-needed // gran) * gran, cap)
+
+
+def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: Optional[int] = None, dedup: bool = True):
     """Index maps of one ragged scoring forward, numpy in / numpy out.
 
     cand (m,n_opt) candidate suffix ids, parent (n_opt,) the ids they were sampled from, L tokens
     per candidate behind the shared prefix (suffix first), T target rows, P prefix length, n_rows
-    the fixed row count (``ragged_budget``).  Returns None when the draw does not fit n_rows, else
+    the row count to build (None: ``ragged_rows`` of what this draw needs).  Returns None when the draw
+    does not fit n_rows, else
       flat  (N,)        row n -> padded slot b*L+j  (parent = block m; also the embedding gather)
       q_src (B2*L,)     padded slot -> row holding its query (any own row where none is computed)
       kv_src(B2*L,)     padded slot -> row holding its key/value (parent rows in front of p)
@@ -143,6 +152,8 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: int, dedup: bool =
     diff = cand != parent[None, :]
     p = np.where(diff.any(1), diff.argmax(1), n_opt - 1).astype(np.int64)
     needed = n_opt + int((L - p).sum())
+    if n_rows is None:
+        n_rows = ragged_rows(needed, n_opt + m * L)
     deficit = n_rows - needed
     if deficit < 0:
         return None

@@ -229,5 +229,12 @@ def test_ragged_plan_invariants():
     assert 480 < mean < 492 and 0 < var < 40
     assert expected_unique(512, 19, 2, 256) == (512.0, 0.0) or expected_unique(512, 19, 2, 256)[0] > 511.9
     assert ragged_budget(512, 19, 44, 1, 256) < ragged_budget(512, 19, 44, 1) <= 19 + 512 * 44
+
+    # the row count the engine builds: what the draw needs, on the next point of a coarse grid
+    from bimodalattack_amd.layout import ragged_rows
+    assert [ragged_rows(v, 10 ** 6) for v in (17029, 17152, 17153, 4300, 2150, 700)] == [17152, 17152, 17408, 4352, 2176, 704]
+    assert ragged_rows(17029, 17000) == 17000
+    plan = ragged_plan(cand, parent, L, T, 3)
+    assert plan["N"] == ragged_rows(plan["needed"], n_opt + plan["m"] * L) >= plan["needed"]
     with pytest.raises(ValueError):
         ragged_plan(np.zeros((2, 4), int), np.zeros(4, int), 5, 3, 0, 14)     # target rows would precede the suffix end

@@ -112,12 +112,12 @@ def cases():
 
     def ragged_attn(m, n_opt, L, T, P, H, Dh):
         import numpy as np
-        from bimodalattack_amd.layout import ragged_budget, ragged_plan
+        from bimodalattack_amd.layout import ragged_plan
         rng = np.random.default_rng(0)
         parent = rng.integers(0, 32000, n_opt)
         cand = np.tile(parent, (m, 1))
         cand[np.arange(m), rng.integers(0, n_opt, m)] = rng.integers(0, 256, m) + 40000
-        plan = ragged_plan(cand, parent, L, T, P, ragged_budget(m, n_opt, L, 1, 256))
+        plan = ragged_plan(cand, parent, L, T, P)
         N = plan["N"]
         q, k, v = (torch.randn((N, H, Dh), generator=g, device=DEV).to(bf).unsqueeze(0).transpose(1, 2) for _ in range(3))
         pk, pv = (torch.randn((P, H, Dh), generator=g, device=DEV).to(bf).unsqueeze(0).transpose(1, 2) for _ in range(2))
@@ -131,15 +131,15 @@ def cases():
 
     return {
         # name: (kernel id in the profiler, thunk factory)
-        # ragged scoring of C3 (search_width 512, 19 suffix + 25 tail tokens): 17920 computed rows
+        # ragged scoring of C3 (search_width 512, 19 suffix + 25 tail tokens): 17152 computed rows
         # (distinct candidates only), attention in one launch; the padded-block kernels below
         # (merge with a row map, row gather) serve fp32 models and heads the MFMA kernel does not take
-        "rmsnorm/c3r_17920x4096": ("rmsnorm", lambda: rmsnorm(17920, 4096)),
-        "swiglu/c3r_17920x11008": ("swiglu", lambda: swiglu(17920, 11008)),
-        "rope/c3r_N17920_H32_Dh128": ("rope", lambda: rope_rows(17920, 32, 128)),
-        "attn_merge/c3r_N17920_B488_L44": ("attn_merge", lambda: merge_rows(17920, 488, 44, 32, 128)),
+        "rmsnorm/c3r_17152x4096": ("rmsnorm", lambda: rmsnorm(17152, 4096)),
+        "swiglu/c3r_17152x11008": ("swiglu", lambda: swiglu(17152, 11008)),
+        "rope/c3r_N17152_H32_Dh128": ("rope", lambda: rope_rows(17152, 32, 128)),
+        "attn_merge/c3r_N17152_B481_L44": ("attn_merge", lambda: merge_rows(17152, 481, 44, 32, 128)),
         "ragged_attn/c3r_sw512_P21_L44_H32_Dh128": ("ragged_attn", lambda: ragged_attn(512, 19, 44, 20, 21, 32, 128)),
-        "gather_rows/c3r_21472_of_17920x4096": ("gather_rows", lambda: gather(17920, 488 * 44, 4096)),
+        "gather_rows/c3r_21164_of_17152x4096": ("gather_rows", lambda: gather(17152, 481 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
         "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
         "rope/c3_B512_L44_H32_Dh128": ("rope", lambda: rope(512, 44, 32, 128)),

@@ -44,12 +44,12 @@ kb = json.load(open(os.path.join(src, "kernel_bench.json")))
 
 # kernel_bench case -> (bench kernel name, PMC key = "<symbol><template>/threads<total threads>")
 CASES = [
-    ("rmsnorm/c3r_17920x4096", "rmsnorm", "rmsnorm_kernel<1, 2, false>/threads4587520", "17920 x 4096 bf16 (C3 ragged candidate forward)"),
-    ("swiglu/c3r_17920x11008", "swiglu", "swiglu_kernel<1, 0>/threads6164480", "17920 x 11008 bf16 (C3 ragged candidate forward)"),
-    ("rope/c3r_N17920_H32_Dh128", "rope", "rope_kernel<1>/threads4587520", "17920 rows, H=32 Dh=128 bf16 (C3 ragged)"),
-    ("ragged_attn/c3r_sw512_P21_L44_H32_Dh128", "ragged_attn", "ragged_attn_kernel<1, 3, 128>/threads92160", "17920 rows, 480 candidates x 32 heads, 21 prefix keys (C3 ragged)"),
-    ("attn_merge/c3r_N17920_B488_L44", "attn_merge", "attn_merge_kernel<1>/threads4587520", "17920 rows vs padded 488 x 44, H=32 Dh=128 bf16 (library-attention route)"),
-    ("gather_rows/c3r_21472_of_17920x4096", "gather_rows", "gather_rows_kernel/threads5496832", "21472 padded slots from 17920 rows of 8 KiB (library-attention route)"),
+    ("rmsnorm/c3r_17152x4096", "rmsnorm", "rmsnorm_kernel<1, 2, false>/threads4390912", "17152 x 4096 bf16 (C3 ragged candidate forward)"),
+    ("swiglu/c3r_17152x11008", "swiglu", "swiglu_kernel<1, 0>/threads5900288", "17152 x 11008 bf16 (C3 ragged candidate forward)"),
+    ("rope/c3r_N17152_H32_Dh128", "rope", "rope_kernel<1>/threads4390912", "17152 rows, H=32 Dh=128 bf16 (C3 ragged)"),
+    ("ragged_attn/c3r_sw512_P21_L44_H32_Dh128", "ragged_attn", "ragged_attn_kernel<1, 3, 128>/threads92160", "17152 rows, 480 candidates x 32 heads, 21 prefix keys (C3 ragged)"),
+    ("attn_merge/c3r_N17152_B481_L44", "attn_merge", "attn_merge_kernel<1>/threads4390912", "17152 rows vs padded 481 x 44, H=32 Dh=128 bf16 (library-attention route)"),
+    ("gather_rows/c3r_21164_of_17152x4096", "gather_rows", "gather_rows_kernel/threads5417984", "21164 padded slots from 17152 rows of 8 KiB (library-attention route)"),
     ("ce_rows/llava_B512_T20_V32064", "ce_rows", "ce_rows_kernel<1, true, false>/threads2621440", "B=512 T=20 V=32064 bf16 (C3/C4 scoring, one chunk)"),
     ("ce_dlogits/llava_T20_V32064", "ce_dlogits", "ce_dlogits_kernel<1, true>/threads5120", "B=1 T=20 V=32064 bf16 (gradient pass)"),
     ("splice/c3_tail_B512_S44_D4096", "splice", "splice_kernel<1>/threads720896", "C3 tail: B=512, 19 gathered + 25 shared rows, D=4096 bf16"),

@@ -39,6 +39,9 @@ def main():
                                 "--no-cpu-baseline"], env=dict(env, BMA_EMULATE_WORLD=str(world)), cwd=REPO)
             if r.returncode != 0:
                 print(f"   (failed with {r.returncode}; continuing)", flush=True)
+    if not sys.argv[1:] or "gcg" in workloads:
+        print("== tuning the row-count grid of ragged scoring", flush=True)
+        subprocess.run([sys.executable, os.path.join(REPO, "tools", "tune_rows.py")], env=env, cwd=REPO)
     shutil.copyfile(src, dst)
     shutil.copyfile(src, os.path.join(out_dir, f"{arch}.csv"))
     print("wrote", dst, sum(1 for _ in open(dst)), "lines")
