@@ -357,6 +357,10 @@ full = sh.gather(local, 7)
 assert torch.equal(full, local)
 m = sh.gather(torch.ones(7, device=dev), 7, pad=0.0)
 assert float(m.sum()) == 7
+import numpy as np
+order = np.array([3, 0, 4, 1, 2])
+vals = torch.tensor([30., 0., 40., 10., 20.], device=dev)      # values of candidates 3, 0, 4, 1, 2
+assert sh.gather_dealt(vals, order).tolist() == [0., 10., 20., 30., 40.]
 ids = torch.arange(12, device=dev).view(4, 3)
 assert torch.equal(sh.broadcast_ids(ids), ids)
 img = torch.rand(1, 3, 8, 8, device=dev)
