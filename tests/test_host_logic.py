@@ -238,3 +238,29 @@ def test_ragged_plan_invariants():
     assert plan["N"] == ragged_rows(plan["needed"], n_opt + plan["m"] * L) >= plan["needed"]
     with pytest.raises(ValueError):
         ragged_plan(np.zeros((2, 4), int), np.zeros(4, int), 5, 3, 0, 14)     # target rows would precede the suffix end
+
+
+def test_row_count_grid_covers_what_steps_meet():
+    """tools/tune_rows.py walks the grid points a run can meet; simulate draws of the bench configuration
+    (512 candidates, 19 suffix positions, top-256) and check that every step's row count -- one GPU, and the
+    dealt per-rank share of 2 / 4 / 8 -- is in the tuned set."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from tune_rows import row_counts
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.layout import ragged_plan
+    m, n_opt, L, T, topk = 512, 19, 44, 20, 256
+    tuned = set(row_counts(m, n_opt, L, 1, topk))
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        parent = rng.integers(0, 32000, n_opt)
+        cand = np.tile(parent, (m, 1))
+        pos = rng.integers(0, n_opt, m)
+        cand[np.arange(m), pos] = 40000 + pos * topk + rng.integers(0, topk, m)     # token = f(position, rank)
+        assert ragged_plan(cand, parent, L, T, 21)["N"] in tuned
+        uniq = np.unique(cand, axis=0)
+        diff = uniq != parent[None, :]
+        first = np.where(diff.any(1), diff.argmax(1), n_opt - 1)
+        by_cost = np.argsort(first, kind="stable")
+        for world in (2, 4, 8):
+            assert BimodalAttack._dealt_rows((by_cost, None, len(uniq), first), world, L, n_opt) in tuned, world
