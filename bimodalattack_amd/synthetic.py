@@ -16,7 +16,7 @@ container, on the GPU box, on CPU and on the device.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
