@@ -807,10 +807,17 @@ class BimodalAttack:
                             loss, sampled = None, sampled_all
                         best_idx = int(loss.argmin().item()) if loss is not None else 0
                         winner = sampled[best_idx:best_idx + 1].contiguous()
-                        # re-score the winner with the image (:605-612); on every rank, unsharded
-                        full = self.rescore_winner(winner, segment_order("gcg_pgd", mt), feats)
-                        if cfg.early_stop and self._match is not None and bool(self._match.any().item()):
-                            self.stop_flag = True
+                        # re-score the winner with the image (:605-612); on every rank, unsharded.  With
+                        # joint_eval the candidates WERE scored with the image, in the very segment order of
+                        # the re-score: the winner's row of that batch is the same function of the same
+                        # inputs, so it is taken instead of a second forward (joint_winner_from_batch).
+                        if cfg.joint_eval and loss is not None and self.opt.joint_winner_from_batch and \
+                                segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt):
+                            full = loss[best_idx].reshape(1).clone()
+                        else:
+                            full = self.rescore_winner(winner, segment_order("gcg_pgd", mt), feats)
+                            if cfg.early_stop and self._match is not None and bool(self._match.any().item()):
+                                self.stop_flag = True
                         if self.shard.enabled:
                             self.shard.broadcast_(full)
                         current_loss = full.item()

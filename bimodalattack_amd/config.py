@@ -109,6 +109,9 @@ class EngineOptions:
     # q_proj/k_proj/v_proj of an attention block as one GEMM against the concatenated weight (16-bit
     # models; one more copy of those matrices): fewer partly filled tile rounds, one weight stream.
     fuse_qkv: bool = True
+    # joint_eval: the step's loss is the winner's row of the candidate batch (scored with the image, in the
+    # re-score's own segment order) instead of a second, batch-1 forward of the same sequence (:605-612).
+    joint_winner_from_batch: bool = True
     # GEMM tuning aid (tools/tune_gemms.py): in a single process, score only what rank 0 of an N-rank run
     # would score, with that run's row budget -- the exact GEMM shapes of the multi-GPU run.  Results of the
     # attack are meaningless with it.
@@ -165,6 +168,8 @@ class EngineOptions:
             opts.fused_elementwise = env["BMA_FUSED_ELEMENTWISE"] not in ("0", "false", "False")
         if "BMA_EMULATE_WORLD" in env:
             opts.emulate_world = int(env["BMA_EMULATE_WORLD"])
+        if "BMA_JOINT_WINNER_FROM_BATCH" in env:
+            opts.joint_winner_from_batch = env["BMA_JOINT_WINNER_FROM_BATCH"] not in ("0", "false", "False")
         if "BMA_FUSE_QKV" in env:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:

@@ -141,6 +141,8 @@ def test_trajectory_matches_reference(golden_dir, name):
                                     dict(shared_prefix_attention=False),
                                     # shared-prefix attention on the padded block (every suffix token computed)
                                     dict(ragged_suffix=False),
+                                    # the reference's separate batch-1 re-score of the joint winner
+                                    dict(joint_winner_from_batch=False),
                                     # everything eager and unfused
                                     dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
                                          fused_elementwise=False, gemm_tuning="off")])
@@ -401,6 +403,7 @@ def test_graphs_are_really_captured_with_a_list_style_normalize():
                                   eps=64 / 255, alpha=4 / 255, seed=3, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
                                   images_folder=tempfile.mkdtemp())
         kw = dict(graph_gradient=False, graph_prefix=False, graph_rescore=False) if eager else {}
+        kw["joint_winner_from_batch"] = False           # keep the batch-1 winner re-score (and its graph) in play
         attack = BimodalAttack(model, tok, proc, cfg, ListNormalize(), EngineOptions.from_env(rng_device="cpu", **kw))
         res = attack.run("tell me a story", "tell me a story", "Sure here is a story", image)
         out[eager] = res
