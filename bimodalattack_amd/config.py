@@ -102,7 +102,7 @@ class EngineOptions:
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
-    # Gradient pass with <= 128 rows (text-only attacks): keep a transposed copy of every decoder
+    # Gradient pass (batch 1, <= 1024 rows): keep a transposed copy of every decoder
     # projection weight so the backward product streams weight rows along the reduction like the
     # forward one (the faster library form for such shapes).  Costs one more copy of the LM weights.
     backward_weight_copies: bool = True

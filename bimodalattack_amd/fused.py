@@ -8,7 +8,8 @@ gradient is being recorded (the gradient pass; weights are treated as constants 
 norm weight requires grad the eager module runs).  Outside the context -- or when the input
 is not on the GPU or a shape is beyond the kernels' limits -- the original code runs.
 Nothing is left on the user's model afterwards: patches are instance attributes removed
-on exit.  Under autograd with at most 128 rows (the text-only gradient pass) the decoder layers'
+on exit.  Under autograd with at most 1024 rows (the batch-1 gradient pass, with or without the image
+tokens) the decoder layers'
 bias-free projections additionally compute their input gradient through a transposed copy of the
 weight (``ops.FrozenLinearFn``; one extra copy of the language model's weights in HBM).  In 16-bit
 models the q/k/v projections of an attention block run as one product against their concatenated
@@ -43,7 +44,7 @@ def _eps_of(m):
     return None
 
 
-SKINNY_ROWS = 128      # "a handful of rows": the batch-1 gradient pass of a text-only attack
+SKINNY_ROWS = 1024     # rows up to which the gradient pass takes its input gradients through transposed weight copies
 
 
 class FusedInference:
