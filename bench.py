@@ -2,14 +2,17 @@
 """bench.py -- the attack-step benchmark of BASELINE.json on synthetic random-weight
 LLaVA-1.5-7B (bf16), search_width = 512.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gcg|joint|pgd|pgd_gcg]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gcg|joint|pgd|pgd_gcg|gemma_joint|opt125m]
 
 A "step" is one full pass of the hot path: gradient pass -> (PGD projection) ->
 mask/top-k/scatter sampling -> retokenisation filter -> candidate splice + forward +
 target cross-entropy -> argmin + bookkeeping.  Inputs (weights, embeddings, prompt
-segments, image) are resident in HBM before the timed region.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU over RCCL) the candidates of every step are
-sharded across ranks; the work per step is fixed, so scaling is "strong".
+segments, image) are resident in HBM before the timed region.  With N > 1 (one rank per
+GPU over RCCL: under torch.distributed.run, or started by this script itself when it is
+called bare with --gpus N) the candidates of every step are sharded across ranks; the work
+per step is fixed, so scaling is "strong".  The K timed steps carry no instrumentation; the
+per-kernel HIP-event brackets behind `roofline`, `gemms` and `kernels` run in
+--profile-steps extra steps AFTER the timed region.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `value` is whole-step
 candidate forwards per second (all ranks, wall clock, max over ranks); the per-phase
@@ -60,7 +63,33 @@ WORKLOADS = {
                 name="PGD-only, LLaVA-1.5-7B-shaped bf16 (BASELINE configs[1])"),
     "gemma_joint": dict(pgd_attack=True, gcg_attack=True, joint_eval=True, gemma=True,
                         name="Joint GCG+PGD, Gemma-3-4b-it-shaped bf16, dynamic_search 512->128 (BASELINE configs[4])"),
+    # BASELINE configs[0] / BASELINE.md 3: the plumbing case, timed IN FULL on the host cores beside the GPU run
+    "opt125m": dict(pgd_attack=False, gcg_attack=True, joint_eval=False, fp32=True, search_width=16, topk=256, cpu_full=True,
+                    name="GCG-only, OPT-125M-shaped fp32, search_width=16, 10 steps (BASELINE configs[0])"),
 }
+
+
+def wl_segments(workload: str, attack) -> dict:
+    """Token counts of one candidate sequence as the engine split it: the shared prefix (what sits in front of
+    the suffix -- under causal attention identical in every candidate), everything else, the target."""
+    seg = {k: int(v.shape[1]) for k, v in attack.seg.items() if k != "target_in"}
+    cfg = attack.config
+    from bimodalattack_amd.layout import segment_order, split_at_suffix
+    mt = attack.hf.model_type
+    if cfg.pgd_attack and cfg.joint_eval:
+        order = segment_order("pgd", mt, single=True)
+    elif cfg.pgd_attack and cfg.gcg_attack:
+        order = segment_order("gcg", mt, single=True)
+    elif cfg.pgd_attack:
+        order = segment_order("gcg_pgd", mt)
+    else:
+        order = segment_order("gcg", mt, no_joint_eval=True)
+    n_img = {"llava": 576, "gemma3": 256}.get(mt, 0)
+    n_opt = 19
+    length = lambda name: n_opt if name == "optim" else (n_img if name == "image" else seg[name])   # noqa: E731
+    prefix, tail = split_at_suffix(order)
+    return {"shared_prefix": sum(length(n) for n in prefix), "per_candidate": sum(length(n) for n in tail if n != "target"),
+            "target": seg["target"]}
 
 
 def build_plugins(workload: str, device, dtype, layers: int):
@@ -78,6 +107,15 @@ def build_plugins(workload: str, device, dtype, layers: int):
         goal, target = S.synthetic_prompt(tok, 18, 20, seed=0)        # <start_of_turn>user + 18 + BOS = 20
         image = S.synthetic_image(896, 896, seed=0, device=device)
         return model, tok, proc, goal, goal, target, image, S.Normalize((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    if workload == "opt125m":
+        # OPT-125M shape (768 / 12 layers / 12 heads / 3072), fp32, vocabulary = the tokenizer's 50272 words
+        tok = S.build_tokenizer(50272, 0, 0)
+        proc = S.SyntheticProcessor(tok)
+        model = S.opt_125m_shaped(50272, dtype=dtype, device=device, seed=0)
+        log(f"OPT-125M-shaped model ready on {model.device} ({sum(p.numel() for p in model.parameters()) / 1e6:.0f} M parameters)")
+        goal, target = S.synthetic_prompt(tok, SEG["gcg"]["before"] - 1, SEG["gcg"]["target"], seed=0)
+        after, _ = S.synthetic_prompt(tok, SEG["gcg"]["after"], 1, seed=1)
+        return model, tok, proc, f"{goal} {{optim_str}} {after}", goal, target, None, None
     tok = S.build_tokenizer(32000, 0, 0)
     proc = S.SyntheticProcessor(tok)
     log("tokenizer built; building LLaVA-1.5-7B-shaped model on the device")
@@ -109,10 +147,11 @@ def build_plugins(workload: str, device, dtype, layers: int):
     return model, tok, proc, messages, goal, target, image, norm
 
 
-def cpu_baseline(args, model, tok, proc, messages, goal, target, image, norm, cfg_kw):
-    """The oracle (CPU restatement of the reference loop, pinned by the reference's
-    goldens) timed on this box's host cores on a bounded sample of the same workload:
-    same model shape and prompt, 1 step at search_width = args.cpu_width."""
+def cpu_baseline(args, wl, model, tok, proc, messages, goal, target, image, norm, cfg_kw):
+    """The oracle (CPU restatement of the reference loop, pinned by the reference's goldens) timed on this box's
+    host cores.  7B / 4B shapes: a bounded sample of the same workload (same model shape and prompt,
+    --cpu-steps steps at search_width --cpu-width).  BASELINE configs[0] (`cpu_full`): the whole
+    configuration, 10 steps at search_width 16, as BASELINE.md 3 promises."""
     import torch
     from bimodalattack_amd.config import BimodalAttackConfig
     from oracle.attack_loop import run_oracle          # the checker / baseline, never the product path
@@ -130,20 +169,25 @@ def cpu_baseline(args, model, tok, proc, messages, goal, target, image, norm, cf
     t0 = time.perf_counter()
     cmodel = model.to("cpu")                 # the GPU measurement is over: move, do not copy
     cimage = None if image is None else image.detach().clone().cpu()
-    # bf16 GEMMs are slow on hosts without AVX512-BF16/AMX: probe, and fall back to fp32
-    a = torch.randn(512, 4096).to(cmodel.dtype)
-    b = torch.randn(4096, 4096).to(cmodel.dtype)
-    (a @ b)
-    tp = time.perf_counter()
-    (a @ b)
-    rate = 2 * 512 * 4096 * 4096 / (time.perf_counter() - tp)
     cpu_dtype = cmodel.dtype
-    if rate < 2e11:
-        cmodel = cmodel.float()
-        cpu_dtype = torch.float32
+    rate = None
+    if cpu_dtype != torch.float32:
+        # bf16 GEMMs are slow on hosts without AVX512-BF16/AMX: probe, and fall back to fp32
+        a = torch.randn(512, 4096).to(cmodel.dtype)
+        b = torch.randn(4096, 4096).to(cmodel.dtype)
+        (a @ b)
+        tp = time.perf_counter()
+        (a @ b)
+        rate = 2 * 512 * 4096 * 4096 / (time.perf_counter() - tp)
+        if rate < 2e11:
+            cmodel = cmodel.float()
+            cpu_dtype = torch.float32
     t_copy = time.perf_counter() - t0
-    log(f"cpu baseline: host GEMM probe {rate / 1e12:.2f} TFLOP/s in {cmodel.dtype}; running the oracle loop in {cpu_dtype}")
-    kw = dict(cfg_kw, num_steps=args.cpu_steps, search_width=args.cpu_width, images_folder=tempfile.mkdtemp(prefix="bma_cpu_"))
+    full = bool(wl.get("cpu_full"))
+    steps, width = (args.warmup + args.steps, cfg_kw["search_width"]) if full else (args.cpu_steps, args.cpu_width)
+    log(f"cpu baseline: running the oracle loop in {cpu_dtype}, {steps} steps at search_width {width}"
+        + (f" (host GEMM probe {rate / 1e12:.2f} TFLOP/s)" if rate else ""))
+    kw = dict(cfg_kw, num_steps=steps, search_width=width, images_folder=tempfile.mkdtemp(prefix="bma_cpu_"))
     t0 = time.perf_counter()
     res, trace, _ = run_oracle(cmodel, tok, proc, messages, goal, target, cimage, BimodalAttackConfig(**kw), normalize=norm)
     wall = time.perf_counter() - t0
@@ -154,44 +198,131 @@ def cpu_baseline(args, model, tok, proc, messages, goal, target, image, norm, cf
         cpu_name = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         cpu_name = "unknown"
+    what = (f"the WHOLE configuration: {steps} steps at search_width={width}" if full else
+            f"{steps} step(s) at search_width={width} (reduced from {cfg_kw['search_width']})")
     return {
         "value": n / wall, "unit": "candidate_forwards/s", "cores": threads, "kind": "port",
-        "sample": f"{args.cpu_steps} step(s) at search_width={args.cpu_width} (reduced from 512), same model shape, "
-                  f"prompt, host dtype {str(cpu_dtype).replace('torch.', '')}, incl. init-buffer scoring; "
-                  f"{n} candidates in {wall:.1f} s",
-        "attack_steps_per_s": args.cpu_steps / wall, "scoring_phase_cand_per_s": n / loss_s if loss_s else None,
+        "sample": f"{what}, same model shape, prompt, host dtype {str(cpu_dtype).replace('torch.', '')}, incl. init-buffer "
+                  f"scoring; {n} candidates in {wall:.1f} s",
+        "attack_steps_per_s": steps / wall, "scoring_phase_cand_per_s": n / loss_s if loss_s else None,
         "gradient_pass_s": sum(res["gradient_times"]) / max(1, len(res["gradient_times"])),
+        "final_loss": res["losses"][-1],
         "cpu_model": cpu_name, "host_cores_total": cores, "copy_to_host_s": round(t_copy, 2),
     }
+
+
+class GemmTimer:
+    """HIP-event brackets around the decoder's linear layers during the profiled steps (never inside the
+    timed region): the library GEMMs are launched on torch's current stream, which is where the events are
+    recorded.  Only calls with at least `min_rows` rows are tallied -- the candidate forward, not the batch-1
+    passes (those are replayed from hipGraphs and run no Python anyway)."""
+
+    ROLES = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj", "lm_head")
+
+    def __init__(self, model, fused_qkv_blocks, min_rows: int = 1024):
+        import torch
+        self.torch, self.on, self.min_rows, self.rec = torch, False, min_rows, []
+        fused_q = {id(b.q_proj): sum(m.out_features for m in (b.q_proj, b.k_proj, b.v_proj)) for b in fused_qkv_blocks}
+        skip = {id(m) for b in fused_qkv_blocks for m in (b.k_proj, b.v_proj)}
+        for name, mod in model.named_modules():
+            role = name.rsplit(".", 1)[-1]
+            if not isinstance(mod, torch.nn.Linear) or role not in self.ROLES or "vision" in name or "multi_modal" in name:
+                continue
+            if id(mod) in skip:
+                continue            # their output is a slice of the block's one fused q/k/v product
+            n_out = fused_q.get(id(mod), mod.out_features)
+            label = "qkv_proj" if id(mod) in fused_q else role
+            mod.register_forward_pre_hook(self._pre)
+            mod.register_forward_hook(self._post(label, n_out, mod.in_features))
+
+    def _pre(self, mod, args):
+        if self.on and args and args[0].numel() // args[0].shape[-1] >= self.min_rows:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            mod._bma_t0 = e
+
+    def _post(self, label, n_out, k_in):
+        def hook(mod, args, out):
+            e0 = mod.__dict__.pop("_bma_t0", None)
+            if e0 is not None:
+                e1 = self.torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.rec.append((label, args[0].numel() // args[0].shape[-1], n_out, k_in, e0, e1))
+        return hook
+
+    def table(self) -> dict:
+        """{"role MxNxK": dict(launches, avg_us, flops_per_launch, achieved_TFLOPs, frac_of_peak, total_ms)}"""
+        out = {}
+        for label, M, N, K, e0, e1 in self.rec:
+            d = out.setdefault(f"{label} M={M} N={N} K={K}", dict(role=label, M=M, N=N, K=K, launches=0, total_ms=0.0))
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["total_ms"] / d["launches"]
+            d["flops_per_launch"] = 2.0 * d["M"] * d["N"] * d["K"]
+            d["achieved_TFLOPs"] = d["flops_per_launch"] / (d["avg_us"] * 1e-6) / 1e12
+            d["frac_of_peak"] = d["achieved_TFLOPs"] / MFMA_PEAK_TFLOPS
+        return out
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1) before this process has touched the GPU, pass
+    their output through and exit with their code.  Nothing is exec'ed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"--gpus {args.gpus} without a launcher: starting {args.gpus} ranks with torch.distributed.run on port {port}")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 8 for opt125m: 2 + 8 = its 10 steps)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="gcg", choices=sorted(WORKLOADS))
-    ap.add_argument("--search-width", type=int, default=512)
+    ap.add_argument("--search-width", type=int, default=None)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers is NOT the benchmark")
+    ap.add_argument("--profile-steps", type=int, default=2,
+                    help="extra steps AFTER the timed region with HIP-event brackets around kernels (rooflines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-prefix-reuse", action="store_true")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
+    if args.steps is None:
+        args.steps = 8 if args.workload == "opt125m" else 5
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)                       # never returns
+    args.gpus = world
+    if os.environ.get("BMA_BENCH_LAUNCH_PROBE"):        # CPU test of the launcher: report the rank layout, touch nothing
+        sys.stdout.write(json.dumps({"probe": True, "rank": rank, "local_rank": local, "n_gpus": world,
+                                     "master": os.environ.get("MASTER_ADDR")}) + "\n")     # one write: ranks share the pipe
+        sys.stdout.flush()
+        return
+
+    import torch
+    import torch.distributed as dist
+
     if os.environ.get("BMA_DIST_BACKEND", "nccl") != "nccl":
         local = 0                                               # rehearsal: every rank on the one GPU
+    elif world > 1 and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPUs visible "
+                 "(BMA_DIST_BACKEND=gloo rehearses the ranks on one GPU)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
@@ -208,14 +339,17 @@ def main() -> None:
     native.check_single_hip_runtime()
 
     wl = WORKLOADS[args.workload]
-    dtype = torch.bfloat16
+    dtype = torch.float32 if wl.get("fp32") else torch.bfloat16
+    sw = args.search_width if args.search_width is not None else wl.get("search_width", 512)
     model, tok, proc, messages, goal, target, image, norm = build_plugins(args.workload, device, dtype, args.layers)
-    cfg_kw = dict(search_width=args.search_width, topk=256, n_replace=1, seed=1, verbosity="ERROR",
+    cfg_kw = dict(search_width=sw, topk=wl.get("topk", 256), n_replace=1, seed=1, verbosity="ERROR",
                   pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
                   eps=64 / 255, alpha=4 / 255)
     if wl.get("gemma"):
         cfg_kw.update(dynamic_search=True, min_search_width=128)
-    total = args.warmup + args.steps
+    n_prof = max(0, args.profile_steps)
+    timed_end = args.warmup + args.steps
+    total = timed_end + n_prof
     cfg = BimodalAttackConfig(num_steps=total, images_folder=tempfile.mkdtemp(prefix="bma_bench_"), **cfg_kw)
 
     marks = {}
@@ -229,18 +363,25 @@ def main() -> None:
         return t
 
     def hook(i: int) -> None:
-        log(f"step {i}/{total}")
+        log(f"step {i}/{total}" + (" (profiled, outside the timed region)" if timed_end <= i < total else ""))
         if i == args.warmup:
             for k_ in attack.score_stats:
                 attack.score_stats[k_] = 0
-            native.profile_enable(True)          # tallies cover exactly the timed region
             marks["t0"] = barrier_clock()
-        if i == total:
+        if i == timed_end:
             marks["t1"] = barrier_clock()
+            marks["stats"] = dict(attack.score_stats)
+            if n_prof:
+                native.profile_enable(True)      # event brackets cost a few us per launch: kept OUT of the timing
+                gemms.on = True
+        if i == total and n_prof:
+            torch.cuda.synchronize(device)
+            gemms.on = False
 
     gcg_logger.setLevel("ERROR")
     attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(
         step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse))
+    gemms = GemmTimer(model, attack.fused.qkv if attack.fused.enabled else [])
     log("engine constructed; running")
     res = attack.run(messages, goal, target, image)
     log("run finished")
@@ -252,15 +393,15 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    timed = attack.n_scored[args.warmup:]
+    timed = attack.n_scored[args.warmup:timed_end]
     n_cand = sum(timed)
-    loss_s = sum(res.loss_times[args.warmup:])
+    loss_s = sum(res.loss_times[args.warmup:timed_end])
     grad_per_step = len(res.gradient_times) // total
-    grad_s = sum(res.gradient_times[args.warmup * grad_per_step:])
-    samp_s = sum(res.sampling_times[args.warmup:]) if res.sampling_times else 0.0
-    pgd_s = sum(res.pgd_times[args.warmup:]) if res.pgd_times else 0.0
+    grad_s = sum(res.gradient_times[args.warmup * grad_per_step:timed_end * grad_per_step])
+    samp_s = sum(res.sampling_times[args.warmup:timed_end]) if res.sampling_times else 0.0
+    pgd_s = sum(res.pgd_times[args.warmup:timed_end]) if res.pgd_times else 0.0
 
-    # ---- per-kernel rooflines from the in-library HIP events (this run, timed region) ----
+    # ---- per-kernel rooflines from the in-library HIP events (profiled steps after the timed region) ----
     kernels = {}
     for name, p in prof.items():
         if p["launches"] == 0:
@@ -268,49 +409,66 @@ def main() -> None:
         gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None
         kernels[name] = dict(symbol=p["symbol"], launches=p["launches"], avg_us=1e3 * p["ms"] / p["launches"],
                              algorithmic_MB_per_launch=p["bytes"] / p["launches"] / 1e6,
-                             achieved_GBps=gbs, frac_of_8TBps=None if gbs is None else gbs / HBM_PEAK_GBS)
-    dom = max(kernels, key=lambda k: prof[k]["ms"]) if kernels else None
+                             achieved_GBps=gbs, frac_of_8TBps=None if gbs is None else gbs / HBM_PEAK_GBS,
+                             total_ms=p["ms"])
+    gemm_table = gemms.table()
     pmc = None
     try:
-        with open(os.path.join(REPO, "profiles", "r1_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r2_pmc_traffic.json")) as f:
             pmc = json.load(f)
     except Exception:
         pass
+
+    def pmc_traffic(kernel: str, live_bytes: float):
+        """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE): the entry
+        of this kernel whose launch shape is within 6 % of this run's algorithmic bytes, scaled by its measured
+        traffic / algorithmic ratio.  None when no such pass is committed."""
+        near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == kernel
+                and abs(e["algorithmic_bytes"] - live_bytes) <= 0.06 * e["algorithmic_bytes"]]
+        if not near:
+            return None
+        e = min(near, key=lambda e: abs(e["algorithmic_bytes"] - live_bytes))
+        return e["ratio_to_algorithmic"] * live_bytes
+
+    # the dominant kernel of a step BY DEVICE TIME, hand-written or library: that is the headline roofline
+    by_time = [("hip:" + k, v["total_ms"]) for k, v in kernels.items()] + [("gemm:" + k, v["total_ms"]) for k, v in gemm_table.items()]
     roofline = None
-    if dom:
-        k = kernels[dom]
-        traffic = None
-        # HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_traffic.json):
-        # the entry for this kernel whose launch shape has the same algorithmic bytes
-        # (ragged scoring computes a slightly different row count every step: the PMC pass of the nearest
-        # shape, within 6 %, scaled by its measured traffic-to-algorithmic ratio)
-        live = k["algorithmic_MB_per_launch"] * 1e6
-        near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == dom
-                and abs(e["algorithmic_bytes"] - live) <= 0.06 * e["algorithmic_bytes"]]
-        if near:
-            e = min(near, key=lambda e: abs(e["algorithmic_bytes"] - live))
-            traffic = e["ratio_to_algorithmic"] * live
-        roofline = dict(bound="hbm", kernel=k["symbol"], achieved=k["achieved_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=k["frac_of_8TBps"], traffic=traffic,
-                        algorithmic_bytes_per_launch=k["algorithmic_MB_per_launch"] * 1e6,
-                        avg_launch_us=k["avg_us"], launches=k["launches"],
-                        note="dominant hand-written kernel by summed device time inside the timed region; achieved = "
-                             "algorithmic bytes / HIP-event time on the launch stream (bma_profile_*); traffic = FETCH_SIZE*2 + "
-                             "WRITE_SIZE from separate rocprofv3 --pmc passes of the nearest launch shape, scaled by its traffic / "
-                             "algorithmic ratio to this run's average launch (profiles/r1_pmc_traffic.json)")
+    if by_time:
+        top = max(by_time, key=lambda kv: kv[1])[0]
+        if top.startswith("gemm:"):
+            gk = gemm_table[top[5:]]
+            es = 2 if dtype != torch.float32 else 4
+            roofline = dict(bound="mfma", kernel=f"hipBLASLt/rocBLAS GEMM {top[5:]} (decoder {gk['role']}, {('bf16' if es == 2 else 'f32')})",
+                            achieved=gk["achieved_TFLOPs"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=gk["frac_of_peak"],
+                            traffic=pmc_traffic("gemm_" + gk["role"], es * (gk["M"] * gk["K"] + gk["N"] * gk["K"] + gk["M"] * gk["N"])),
+                            algorithmic_flops_per_launch=gk["flops_per_launch"], avg_launch_us=gk["avg_us"], launches=gk["launches"],
+                            note="dominant kernel of the step by summed device time; achieved = 2*M*N*K / HIP-event time around "
+                                 "the library call on torch's current stream, over the profiled steps that follow the timed "
+                                 "region; the rocprofv3 kernel-trace line of the same launch shape is in "
+                                 "profiles/r2_bench_*_kernel_by_grid.txt (top line); peak = 2.5 PFLOP/s dense bf16")
+        else:
+            k = kernels[top[4:]]
+            live = k["algorithmic_MB_per_launch"] * 1e6
+            roofline = dict(bound="hbm", kernel=k["symbol"], achieved=k["achieved_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=k["frac_of_8TBps"], traffic=pmc_traffic(top[4:], live), algorithmic_bytes_per_launch=live,
+                            avg_launch_us=k["avg_us"], launches=k["launches"],
+                            note="dominant kernel of the step by summed device time; achieved = algorithmic bytes / HIP-event "
+                                 "time on the launch stream (bma_profile_*) over the profiled steps that follow the timed region; "
+                                 "traffic = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json)")
 
     # ---- the candidate forward: MFMA-bound, algorithmic FLOPs with prefix reuse ----------
-    tc = model.config.text_config
-    p_layer = 4 * tc.hidden_size ** 2 + 3 * tc.hidden_size * tc.intermediate_size
+    tc = getattr(model.config, "text_config", None) or model.config
+    inter = getattr(tc, "intermediate_size", None) or getattr(tc, "ffn_dim")
+    heads = tc.num_attention_heads
+    head_dim = getattr(tc, "head_dim", None) or tc.hidden_size // heads
+    kv_heads = getattr(tc, "num_key_value_heads", None) or heads
+    n_mlp = 3 if hasattr(tc, "intermediate_size") else 2
+    p_layer = tc.hidden_size * head_dim * (2 * heads + 2 * kv_heads) + n_mlp * tc.hidden_size * inter
     p_lm = tc.num_hidden_layers * p_layer
-    seg = SEG["gcg" if args.workload == "gcg" else "joint"]
-    if wl.get("gemma"):   # everything behind before_img is per candidate in the Gemma layout
-        seg = dict(before_img=20, optim=19, before_suffix=3, n_img=256, after=6, target=20)
-    new_tok = (sum(seg.values()) - seg["before_img"] - 1) if wl.get("gemma") else (seg["optim"] + seg["after"] + seg["target"] - 1)
-    full_tok = sum(v for k_, v in seg.items())
-    # rows the scoring forwards needed behind the shared prefix, per candidate: with ragged scoring
-    # a candidate's suffix tokens in front of its first replaced position are not recomputed
-    ss = attack.score_stats
+    seg = wl_segments(args.workload, attack)
+    full_tok = sum(seg.values())
+    new_tok = full_tok - seg["shared_prefix"] - 1
+    ss = marks.get("stats", attack.score_stats)
     need_tok = ss["rows_needed"] / ss["candidates"] if ss["candidates"] else float(new_tok)
     done_tok = ss["rows"] / ss["candidates"] if ss["candidates"] else float(new_tok)
     flops_cand = 2 * p_lm * need_tok + 2 * tc.hidden_size * tc.vocab_size * seg["target"]
@@ -323,16 +481,17 @@ def main() -> None:
                    rows_computed_per_candidate=done_tok, new_tokens_per_candidate=new_tok,
                    full_recompute_tokens_per_candidate=full_tok,
                    ragged_calls=ss["ragged_calls"], padded_calls=ss["padded_calls"],
-                   note="scoring phase (splice + forward + CE + all-gather + argmin) over the timed steps, this "
-                        "rank's candidates; flops count the rows the ragged forward NEEDS (tokens from the first "
-                        "replaced suffix position on), not the padded block; GEMMs are hipBLASLt/rocBLAS inside "
-                        "the HuggingFace model")
+                   note="scoring phase (splice + forward + CE + all-gather + argmin) over the timed steps, all ranks' "
+                        "candidates against all ranks' peak; flops count the rows the ragged forward NEEDS (tokens from "
+                        "the first replaced suffix position on), not the padded block; GEMMs are hipBLASLt/rocBLAS "
+                        "inside the HuggingFace model")
 
     out = {
         "metric": "candidate_forwards_per_sec", "value": n_cand / elapsed, "unit": "candidate_forwards/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": wl["name"], "search_width": args.search_width, "topk": 256, "n_optim": 19,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if dtype == torch.float32 else "bf16", "data": "synthetic",
+        "config": {"workload": wl["name"], "search_width": sw, "topk": cfg_kw["topk"], "n_optim": 19,
                    "target_tokens": seg["target"], "seq_len": full_tok, "candidates_per_step_after_filter":
                    n_cand / max(1, len(timed)), "sharding": f"candidates/{world}" if world > 1 else "none",
                    "text_layers": tc.num_hidden_layers, "prefix_reuse": not args.no_prefix_reuse},
@@ -340,13 +499,15 @@ def main() -> None:
         "scoring_phase_candidate_forwards_per_sec": n_cand / loss_s if loss_s else None,
         "phase_s_per_step": {"gradient": grad_s / args.steps, "pgd": pgd_s / args.steps,
                              "sampling_incl_filter": samp_s / args.steps, "scoring": loss_s / args.steps},
-        "roofline": roofline, "kernels": kernels, "forward_roofline": fwd,
-        "final_loss": res.losses[-1],
-        "gradient_pass_ms_each": [round(1e3 * t, 2) for t in res.gradient_times],
+        "roofline": roofline, "forward_roofline": fwd, "gemms": gemm_table, "kernels": kernels,
+        "profiled_steps_after_timed_region": n_prof,
+        "engine": attack.engine_state(),
+        "final_loss": res.losses[timed_end - 1],
+        "gradient_pass_ms_each": [round(1e3 * t, 2) for t in res.gradient_times[:timed_end * grad_per_step]],
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args, model, tok, proc, messages, goal, target, image, norm, cfg_kw)
+            out["cpu_baseline"] = cpu_baseline(args, wl, model, tok, proc, messages, goal, target, image, norm, cfg_kw)
         except Exception as e:  # the GPU numbers stand on their own
             out["cpu_baseline"] = {"value": None, "unit": "candidate_forwards/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}

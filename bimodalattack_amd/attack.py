@@ -27,6 +27,7 @@ model; greedy acceptance of the step winner; losses rounded to the model dtype.
 
 from __future__ import annotations
 
+import bisect
 import copy
 import logging
 import os
@@ -61,39 +62,44 @@ TEMPLATE_GCG = "{% for message in messages %}{{ message['content'] }}{% endfor %
 
 
 class AttackBuffer:
-    """Best-so-far suffixes, ascending by loss (reference :91-124)."""
+    """The `size` lowest-loss suffixes seen so far (reference :91-124; `size` 0 keeps only the
+    latest one).  Two parallel lists kept in ascending loss order by binary insertion: a newcomer
+    lands behind entries of equal loss, and when the pool is full it first displaces the current
+    worst entry -- whatever its own loss, as the reference does (the loop only offers suffixes that
+    beat the worst one, :618-620)."""
 
     def __init__(self, size: int):
         self.size = size
-        self.buffer: List[tuple] = []
+        self._loss: List[float] = []
+        self._ids: List[Tensor] = []
+
+    def __len__(self) -> int:
+        return len(self._loss)
 
     def add(self, loss: float, optim_ids: Tensor) -> None:
         if self.size == 0:
-            self.buffer = [(loss, optim_ids)]
+            self._loss, self._ids = [loss], [optim_ids]
             return
-        if len(self.buffer) < self.size:
-            self.buffer.append((loss, optim_ids))
-        else:
-            self.buffer[-1] = (loss, optim_ids)
-        self.buffer.sort(key=lambda e: e[0])
+        if len(self._loss) >= self.size:
+            del self._loss[-1], self._ids[-1]
+        at = bisect.bisect_right(self._loss, loss)
+        self._loss.insert(at, loss)
+        self._ids.insert(at, optim_ids)
 
     def get_best_ids(self) -> Tensor:
-        return self.buffer[0][1]
+        return self._ids[0]
 
     def get_lowest_loss(self) -> float:
-        return self.buffer[0][0]
+        return self._loss[0]
 
     def get_highest_loss(self) -> float:
-        return self.buffer[-1][0]
+        return self._loss[-1]
 
     def log_buffer(self, tokenizer) -> None:
         if not logger.isEnabledFor(logging.INFO):
             return
-        lines = ["buffer:"]
-        for loss, ids in self.buffer:
-            s = tokenizer.batch_decode(ids)[0].replace("\\", "\\\\").replace("\n", "\\n")
-            lines.append(f"loss: {loss} | string: {s}")
-        logger.info("\n".join(lines))
+        shown = (tokenizer.batch_decode(ids)[0].replace("\\", "\\\\").replace("\n", "\\n") for ids in self._ids)
+        logger.info("buffer:" + "".join(f"\nloss: {l} | string: {t}" for l, t in zip(self._loss, shown)))
 
 
 class _PngWriter:
@@ -156,6 +162,8 @@ class BimodalAttack:
         self._feat_graph = None                    # image -> image features (no autograd)
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
+        self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
+        self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         if hasattr(model.config, "model_type"):
@@ -168,6 +176,24 @@ class BimodalAttack:
                            + ("GCG+PGD attack." if config.pgd_attack else "GCG only attack."))
             tokenizer.chat_template = tpl
             self.processor.chat_template = tpl
+
+    def _fallback(self, what: str, exc: BaseException, msg: str) -> None:
+        """A fast path failed on this model and a slower, equivalent one takes over.  Never silent:
+        recorded in ``fallbacks`` (bench.py prints ``engine_state()``), logged, and fatal with the
+        ``strict`` engine option -- which the GPU tests set for the model families the fast paths
+        are written for, so a regression fails a test instead of showing up as a slower number."""
+        self.fallbacks[what] = f"{type(exc).__name__}: {exc}"
+        if self.opt.strict:
+            raise RuntimeError(f"strict engine: {msg} ({type(exc).__name__}: {exc})") from exc
+        logger.warning(f"{msg} ({type(exc).__name__}: {exc})")
+
+    def engine_state(self) -> dict:
+        """Which fast paths this attack actually ran through."""
+        hf = self.hf
+        return dict(tuned_gemms=self.tuned_gemms, prefix_ok=hf.prefix_ok, shared_ok=hf.shared_ok, ragged_ok=hf.ragged_ok,
+                    graphs_captured=list(self.graphs_captured), fallbacks=dict(self.fallbacks),
+                    fused_elementwise=bool(self.fused.enabled), chunk_cap=self._chunk_cap,
+                    collectives=self.shard.n_collectives if self.shard.enabled else 0)
 
     # ------------------------------------------------------------------ setup
     def _encode(self, text, special: bool) -> Tensor:
@@ -248,8 +274,9 @@ class BimodalAttack:
         if self._grad_graph is None:           # first call of the attack: warm up eagerly, capture, replay
             try:
                 self._grad_graph = _GradientGraph(self, optim_ids, image)
+                self.graphs_captured.append("gradient")
             except Exception as e:            # not capturable with this model: stay eager
-                logger.warning(f"gradient pass not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._fallback("graph_gradient", e, "gradient pass not captured into a graph; running eager")
                 self._grad_graph = False
                 torch.cuda.synchronize(self.model.device)
                 return self._gradient_eager(optim_ids, image)
@@ -297,20 +324,24 @@ class BimodalAttack:
         return out.requires_grad_()
 
     # ------------------------------------------------------------ sampling
-    def candidate_sampling(self, step: int, optim_ids: Tensor, g_tok: Optional[Tensor]):
+    def candidate_sampling(self, step: int, optim_ids: Tensor, g_tok: Optional[Tensor], image: Optional[Tensor] = None):
         """mask -> top-k -> random position/rank -> scatter (:130-163).  Returns every sampled
         candidate and a FilterJob: the retokenisation filter (:166-186) runs on the host while
-        the GPU scores, and is applied to the losses afterwards."""
+        the GPU scores, and is applied to the losses afterwards.  On several GPUs rank 0's
+        candidates -- and its PGD image, when there is one -- overwrite every rank's here, in one
+        broadcast (the shapes are a function of the step number, so nothing else is exchanged)."""
         cfg = self.config
         width = dynamic_width(step, cfg.search_width, cfg.num_steps, cfg.min_search_width, cfg.dynamic_search)
         if not cfg.gcg_attack:
+            if image is not None:
+                self.shard.sync_state(image)
             return optim_ids, FilterJob(optim_ids, self.tokenizer, False)
         ids = optim_ids[0].contiguous()
         rnd, rank = self._draw(width, ids.numel())
         topk_idx = ops.mask_topk(g_tok[0], self.mask_bits, cfg.topk)
         pos = ops.rand_positions(rnd, cfg.n_replace)
         sampled = ops.sample_scatter(ids, topk_idx, pos, rank)
-        sampled = self.shard.broadcast_ids(sampled)          # rank 0's candidates everywhere
+        self.shard.sync_state(*([sampled] if image is None else [sampled, image]))
         self._last = dict(topk_idx=topk_idx, pos=pos, rank=rank, sampled=sampled)
         return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids)
 
@@ -342,8 +373,9 @@ class BimodalAttack:
         if self._feat_graph is None:
             try:
                 self._feat_graph = _ReplayGraph(self.model.device, self.hf.image_features, image)
+                self.graphs_captured.append("image_features")
             except Exception as e:
-                logger.warning(f"image features not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._fallback("graph_features", e, "image features not captured into a graph; running eager")
                 self._feat_graph = False
                 torch.cuda.synchronize(self.model.device)
                 return self.hf.image_features(image)
@@ -375,11 +407,11 @@ class BimodalAttack:
                     try:
                         cache = self._recorded_prefix(key, cat_prefix, feats)
                     except Exception as e:
-                        logger.warning(f"recording prefix pass failed ({type(e).__name__}: {e}); using the HF cache")
+                        self._fallback("recorded_prefix", e, "recording prefix pass failed; using the HF cache")
                 if cache is None:
                     cache = hf.build_prefix(cat_prefix(feats))
             except Exception as e:  # a model without cache support: remember, use the full sequence
-                logger.warning(f"prefix reuse disabled: {type(e).__name__}: {e}")
+                self._fallback("prefix_reuse", e, "prefix reuse disabled")
             hf.prefix_ok = cache is not None
         out = (cache, P)
         if "image" not in prefix_names:
@@ -402,11 +434,12 @@ class BimodalAttack:
                 with self.fused:
                     g = _ReplayGraph(self.model.device, build, feats)
             except Exception as e:
-                logger.warning(f"prefix pass not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._fallback("graph_prefix", e, "prefix pass not captured into a graph; running eager")
                 self._prefix_graphs[key] = False
                 torch.cuda.synchronize(self.model.device)
                 return build(feats)
             self._prefix_graphs[key] = g
+            self.graphs_captured.append("prefix:" + "|".join(key))
         return g(feats)
 
     def _ragged_logits(self, mine: Tensor, parent: Tensor, segs, L: int, P: int, cache,
@@ -513,7 +546,7 @@ class BimodalAttack:
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):
                             raise
-                        logger.warning(f"ragged scoring disabled: {type(e).__name__}: {e}")
+                        self._fallback("ragged_suffix", e, "ragged scoring disabled")
                         hf.ragged_ok, ragged = False, False
                 if m > 1:
                     self.score_stats["candidates"] += b
@@ -533,7 +566,7 @@ class BimodalAttack:
                     except Exception as e:
                         if hf.shared_ok or is_oom(e):
                             raise
-                        logger.warning(f"shared-prefix attention disabled: {type(e).__name__}: {e}")
+                        self._fallback("shared_prefix_attention", e, "shared-prefix attention disabled")
                         hf.shared_ok, shared = False, False
                         self._prefix_cache.clear()                  # rebuild the prefix as an HF cache
                         cache, P = self._prefix(prefix_names, feats)
@@ -554,6 +587,7 @@ class BimodalAttack:
                     raise
                 chunk = max(1, chunk // 2)
                 self._chunk_cap = chunk
+                ragged = False        # the ragged forward scores all m at once: retry through padded chunks
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
         if dealt is not None:
@@ -563,12 +597,13 @@ class BimodalAttack:
                 take_t = torch.from_numpy(np.ascontiguousarray(by_cost[0::world])).to(losses.device)
                 full = torch.full((n_u,), float("inf"), device=losses.device).index_put_((take_t,), losses)[inv_t]
                 self._match = None if match is None else torch.zeros(n_u, device=losses.device).index_put_((take_t,), match)[inv_t]
+            elif match is None:
+                full, self._match = self.shard.gather_dealt(losses, by_cost)[inv_t], None
             else:
-                full = self.shard.gather_dealt(losses, by_cost)[inv_t]
-                self._match = self.shard.gather_dealt(match, by_cost, pad=0.0)[inv_t] if match is not None else None
+                full, hits = self.shard.gather_dealt(losses, by_cost, extra=match)
+                full, self._match = full[inv_t], hits[inv_t]
         else:
-            full = self.shard.gather(losses, n)
-            self._match = self.shard.gather(match, n, pad=0.0) if match is not None else None
+            full, self._match = self.shard.gather2(losses, match, n)
         if self.opt.loss_in_model_dtype:
             full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
         return full
@@ -580,24 +615,29 @@ class BimodalAttack:
         def eager(ids, f):
             keep, self.shard = self.shard, _SOLO
             try:
-                return self.score_candidates(ids, order, f, allow_prefix=False)
+                loss = self.score_candidates(ids, order, f, allow_prefix=False)
+                return loss, self._match          # the early-stop hit belongs to the outputs (None without early_stop)
             finally:
                 self.shard = keep
 
         key = tuple(order)
         if not self.opt.graph_rescore or self._rescore_graphs.get(key) is False:
-            return eager(winner, feats)
+            return eager(winner, feats)[0]
         g = self._rescore_graphs.get(key)
         if g is None:
             try:
                 g = _ReplayGraph(self.model.device, eager, winner, feats)
+                self.graphs_captured.append("rescore:" + "|".join(order))
             except Exception as e:
-                logger.warning(f"winner re-scoring not captured into a graph ({type(e).__name__}: {e}); running eager")
+                self._fallback("graph_rescore", e, "winner re-scoring not captured into a graph; running eager")
                 self._rescore_graphs[key] = False
                 torch.cuda.synchronize(self.model.device)
-                return eager(winner, feats)
+                return eager(winner, feats)[0]
             self._rescore_graphs[key] = g
-        return g(winner, feats)
+        # a replay runs no Python: the hit tensor of THIS forward is the graph's static output, not
+        # whatever the last eager scoring call left in self._match
+        loss, self._match = g(winner, feats)
+        return loss
 
     # ------------------------------------------------------------ buffer init
     def init_buffer(self, image) -> AttackBuffer:
@@ -694,7 +734,13 @@ class BimodalAttack:
             # PGD-only: nothing is sampled, so the loss of the updated image can come out of the
             # next step's gradient pass (fuse_pgd_only); early_stop needs the argmax test of a
             # scoring call, so it keeps the plain loop
-            fuse_pgd = bool(self.opt.fuse_pgd_only and cfg.pgd_attack and not cfg.gcg_attack and not cfg.early_stop)
+            # ... and the gradient pass must compute the very function the reference scores the winner
+            # with: it always uses the llava segment order and the unscaled table (:968, :981-991), the
+            # re-score the model's own order and embedding scale (:1142, :1150-1163) -- Gemma-3 differs
+            # in both, so it keeps the separate re-score
+            fuse_pgd = bool(self.opt.fuse_pgd_only and cfg.pgd_attack and not cfg.gcg_attack and not cfg.early_stop
+                            and segment_order("gcg_pgd", mt) == segment_order("gcg_pgd", "llava")
+                            and self.hf.emb_scale == 1.0)
             for i in range(cfg.num_steps):
                 if hook is not None:
                     hook(i)
@@ -734,9 +780,6 @@ class BimodalAttack:
                 if cfg.pgd_attack:
                     t0 = self._sync()
                     image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
-                    if self.shard.enabled:
-                        with torch.no_grad():
-                            self.shard.broadcast_(image)
                     pgd_time = self._sync() - t0
                     t_pgd.append(pgd_time)
                     if st is not None:
@@ -747,7 +790,7 @@ class BimodalAttack:
                 # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
                 t0 = self._sync()
-                sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok)
+                sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, image if cfg.pgd_attack else None)
                 if cfg.gcg_attack:
                     samp_time = self._sync() - t0
                     if st is not None:
@@ -789,8 +832,6 @@ class BimodalAttack:
                         full = pending[0][2].reshape(1)
                         if self.opt.loss_in_model_dtype:
                             full = full.to(self.model.dtype)
-                        if self.shard.enabled:
-                            self.shard.broadcast_(full)
                         current_loss = full.item()
                         best_idx, sampled, winner = 0, sampled_all, sampled_all[0:1].contiguous()
                         if st is not None:
@@ -816,10 +857,16 @@ class BimodalAttack:
                             full = loss[best_idx].reshape(1).clone()
                         else:
                             full = self.rescore_winner(winner, segment_order("gcg_pgd", mt), feats)
-                            if cfg.early_stop and self._match is not None and bool(self._match.any().item()):
-                                self.stop_flag = True
-                        if self.shard.enabled:
-                            self.shard.broadcast_(full)
+                            if cfg.early_stop and self._match is not None:
+                                hit = self._match.reshape(-1)[:1].to(torch.float32)
+                                if self.shard.enabled:
+                                    # every rank re-scored the winner itself: rank 0's verdict decides, or ranks
+                                    # could leave the loop at different steps
+                                    both = torch.cat([full.reshape(-1)[:1].to(torch.float32), hit])
+                                    self.shard.broadcast_(both)
+                                    full, hit = both[:1].to(full.dtype), both[1:]
+                                if bool(hit.any().item()):
+                                    self.stop_flag = True
                         current_loss = full.item()
                         if st is not None:
                             st["losses"].append(full.float().cpu().numpy())
@@ -951,12 +998,8 @@ class _Solo:
         return 0, n
 
     @staticmethod
-    def gather(local, n, pad=float("inf")):
-        return local
-
-    @staticmethod
-    def gather_losses(local, n, flag=False, want_flag=False):
-        return local, bool(flag)
+    def gather2(local, extra, n, pad=float("inf"), pad_extra=0.0):
+        return local, extra
 
 
 _SOLO = _Solo()

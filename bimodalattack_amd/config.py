@@ -134,6 +134,9 @@ class EngineOptions:
     fuse_pgd_only: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
+    # Raise instead of falling back when a fast path (hipGraph capture, shared-prefix attention, ragged
+    # scoring, prefix reuse) fails on this model.  Off by default: an unknown model family must still run.
+    strict: bool = False
     # Write images_folder/{i}.png every step (reference side effect, :744).
     save_images: bool = True
     # Record per-step internals (sampled ids, N after filter, best_idx, ...).
@@ -184,6 +187,8 @@ class EngineOptions:
             opts.fuse_pgd_only = env["BMA_FUSE_PGD_ONLY"] not in ("0", "false", "False")
         if "BMA_CHUNK" in env:
             opts.chunk = int(env["BMA_CHUNK"])
+        if "BMA_STRICT" in env:
+            opts.strict = env["BMA_STRICT"] not in ("0", "false", "False")
         if "BMA_SAVE_IMAGES" in env:
             opts.save_images = env["BMA_SAVE_IMAGES"] not in ("0", "false", "False")
         for k, v in overrides.items():

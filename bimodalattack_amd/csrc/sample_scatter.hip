@@ -4,9 +4,9 @@
 //   out  = ids.repeat(B,1).scatter_(1, pos, topk_idx[pos, rank])   (bma_sample_scatter)
 //
 // Index work on a few KB per step: launch-bound.  One lane per candidate; the
-// n_opt <= 64 random keys of a candidate are selected with an n_rep-pass
-// running minimum (n_rep is 1 in every BASELINE config), ties by position, which
-// is what a stable argsort yields.
+// n_opt random keys of a candidate are selected with an n_rep-pass running minimum
+// (n_rep is 1 in every BASELINE config), ties by position, which is what a stable
+// argsort yields.  Any suffix length.
 
 #include "bma_common.h"
 #include "bma_profile.h"
@@ -18,19 +18,23 @@ __global__ __launch_bounds__(256) void rand_positions_kernel(const float* __rest
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* r = rnd + static_cast<int64_t>(b) * n_opt;
-  uint64_t taken = 0;  // n_opt <= 64
+  // pass j picks the smallest (key, position) pair that is larger than pass j-1's pick: the
+  // order a stable argsort yields, for any n_opt and without a "taken" set
+  float pv = 0.0f;
+  int pp = -1;
   for (int j = 0; j < n_rep; ++j) {
     int best = -1;
     float bv = 0.0f;
     for (int p = 0; p < n_opt; ++p) {
-      if ((taken >> p) & 1ull) continue;
       const float v = r[p];
+      if (pp >= 0 && !(v > pv || (v == pv && p > pp))) continue;   // picked already (or in front of the last pick)
       if (best < 0 || v < bv) {
         best = p;
         bv = v;
       }
     }
-    taken |= 1ull << best;
+    pv = bv;
+    pp = best;
     pos_out[static_cast<int64_t>(b) * n_rep + j] = best;
   }
 }
@@ -63,7 +67,6 @@ __global__ __launch_bounds__(256) void sample_scatter_kernel(const int64_t* __re
 extern "C" int bma_rand_positions(const float* rnd, int B, int n_opt, int n_rep, int64_t* pos_out,
                                   void* stream) {
   if (B < 0 || n_opt <= 0 || n_rep <= 0 || n_rep > n_opt) return BMA_EINVAL;
-  if (n_opt > 64) return BMA_ELIMIT;
   if (B == 0) return BMA_OK;
   if (!rnd || !pos_out) return BMA_EINVAL;
   hipLaunchKernelGGL(rand_positions_kernel, dim3((B + 255) / 256), dim3(256), 0,

@@ -8,8 +8,16 @@ in total at search_width 512) -- latency-bound, so a single one-shot collective,
 never a ring of point-to-point hops.  N varies per step (filter, dynamic width):
 slices are padded to `per` slots with +inf, which can never win the argmin.
 
-Rank 0's sampled ids, PGD image and winner loss are broadcast so that ranks cannot
-drift apart through last-bit differences in redundantly computed gradients.
+Every rank runs gradient -> PGD -> sampling redundantly; rank 0's sampled ids and PGD
+image then overwrite everybody's in ONE packed broadcast per step (``sync_state``), so ranks
+cannot drift apart through last-bit differences in redundantly computed gradients.  With the
+loss all-gather that makes two collectives per step (early_stop adds a third, two floats).
+
+The C ABI has no collective entry point: SURVEY.md 8b sketched ``bma_allgather_f32(local,
+n_local, out, rank, world, comm)``, but the communicator belongs to the host framework --
+torch.distributed owns the RCCL communicator, its stream ordering and its error handling, and a
+second communicator inside libbma_hip.so would need its own bootstrap (unique-id exchange) for a
+<= 2 KiB payload.  The boundary for the exchange is therefore this module.
 """
 
 from __future__ import annotations
@@ -30,6 +38,7 @@ class CandidateSharder:
         else:
             self.world, self.rank = 1, 0
         self.enabled = self.enabled and self.world > 1
+        self.n_collectives = 0          # data-path collectives issued (tests and bench.py read it)
 
     # -- partition ---------------------------------------------------------
     def per_rank(self, n: int) -> int:
@@ -46,19 +55,33 @@ class CandidateSharder:
         """local: this rank's slice (length hi-lo) of a per-candidate fp32 vector.  Returns the
         n values in candidate order on every rank.  One collective of per_rank(n) floats per
         rank; short slices are padded with `pad` (+inf can never win an argmin)."""
+        return self.gather2(local, None, n, pad)[0]
+
+    def gather2(self, local: torch.Tensor, extra: Optional[torch.Tensor], n: int, pad: float = float("inf"),
+                pad_extra: float = 0.0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """``gather`` of two per-candidate vectors (losses and early-stop hits) in ONE collective:
+        each rank sends [per losses | per hits]."""
         if not self.enabled:
-            return local
+            return local, extra
         per = self.per_rank(n)
-        send = torch.full((per,), pad, dtype=torch.float32, device=local.device)
-        send[: local.numel()] = local.to(torch.float32)
+        k = 1 if extra is None else 2
+        send = torch.empty((k, per), dtype=torch.float32, device=local.device)
+        send[0].fill_(pad)
+        send[0, : local.numel()] = local.to(torch.float32)
+        if extra is not None:
+            send[1].fill_(pad_extra)
+            send[1, : extra.numel()] = extra.to(torch.float32)
+        self.n_collectives += 1
         if dist.get_backend(self.group) == "nccl":
-            recv = torch.empty((self.world * per,), dtype=torch.float32, device=local.device)
-            dist.all_gather_into_tensor(recv, send, group=self.group)
+            recv = torch.empty((self.world, k, per), dtype=torch.float32, device=local.device)
+            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
         else:
             parts = [torch.empty_like(send) for _ in range(self.world)]
             dist.all_gather(parts, send, group=self.group)
-            recv = torch.cat(parts)
-        return recv[:n].contiguous()
+            recv = torch.stack(parts)
+        a = recv[:, 0, :].reshape(-1)[:n].contiguous()
+        b = recv[:, 1, :].reshape(-1)[:n].contiguous() if extra is not None else None
+        return a, b
 
     # -- dealt partition (ragged scoring) -----------------------------------------------
     def deal(self, order, rank: Optional[int] = None):
@@ -67,50 +90,56 @@ class CandidateSharder:
         r = self.rank if rank is None else rank
         return order[r::self.world]
 
-    def gather_dealt(self, local: torch.Tensor, order, pad: float = float("inf")) -> torch.Tensor:
+    def gather_dealt(self, local: torch.Tensor, order, pad: float = float("inf"),
+                     extra: Optional[torch.Tensor] = None):
         """Inverse of ``deal``: `local` holds this rank's values for ``deal(order)``, in that order;
-        returns the len(order) values indexed by candidate (order's entries) on every rank."""
+        returns the len(order) values indexed by candidate (order's entries) on every rank (and, with
+        `extra`, a second vector gathered in the same collective: a pair is returned)."""
         import numpy as np
         order = np.asarray(order)
         n = int(order.shape[0])
         if not self.enabled:
-            out = torch.empty((n,), dtype=torch.float32, device=local.device)
-            out[torch.from_numpy(order).to(local.device)] = local.to(torch.float32)
-            return out
+            at = torch.from_numpy(order).to(local.device)
+            outs = []
+            for v in (local, extra):
+                if v is None:
+                    outs.append(None)
+                    continue
+                o = torch.empty((n,), dtype=torch.float32, device=local.device)
+                o[at] = v.to(torch.float32)
+                outs.append(o)
+            return outs[0] if extra is None else tuple(outs)
         per = self.per_rank(n)
-        recv = self.gather(local, self.world * per, pad=pad) if per else local.new_empty((0,), dtype=torch.float32)
+        if per:
+            recv, recv2 = self.gather2(local, extra, self.world * per, pad=pad)
+        else:
+            recv = local.new_empty((0,), dtype=torch.float32)
+            recv2 = None if extra is None else recv
         src = np.empty((n,), dtype=np.int64)
         for r in range(self.world):
             idx = order[r::self.world]
             src[idx] = r * per + np.arange(idx.shape[0])
-        return recv[torch.from_numpy(src).to(recv.device)]
-
-    def gather_losses(self, local: torch.Tensor, n: int, flag: bool = False,
-                      want_flag: bool = False) -> Tuple[torch.Tensor, bool]:
-        """Losses plus the OR of a per-rank flag (kept for callers that stop per rank)."""
-        full = self.gather(local, n)
-        if not self.enabled:
-            return full, bool(flag)
-        any_flag = False
-        if want_flag:
-            f = self.gather(torch.tensor([1.0 if flag else 0.0], device=local.device), self.world, pad=0.0)
-            any_flag = bool((f > 0).any().item())
-        return full, any_flag
+        at = torch.from_numpy(src).to(recv.device)
+        return recv[at] if extra is None else (recv[at], recv2[at])
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.enabled:
+            self.n_collectives += 1
             dist.broadcast(t, src=dist.get_global_rank(self.group, src) if self.group is not None else src,
                            group=self.group)
         return t
 
-    def broadcast_ids(self, ids: torch.Tensor) -> torch.Tensor:
-        """Rank 0's (N, n_opt) candidate ids to everyone; N itself may differ per rank
-        only if ranks have drifted, so it is sent first."""
+    def sync_state(self, *tensors: torch.Tensor) -> None:
+        """Rank 0's values of `tensors` (any dtypes, fixed shapes known to every rank: the sampled
+        ids, the PGD image) overwrite everybody's, in ONE broadcast of their packed bytes."""
         if not self.enabled:
-            return ids
-        shape = torch.tensor(list(ids.shape), dtype=torch.int64, device=ids.device)
-        self.broadcast_(shape)
-        n, w = (int(v) for v in shape.tolist())
-        if tuple(ids.shape) != (n, w):
-            ids = torch.empty((n, w), dtype=torch.int64, device=ids.device)
-        return self.broadcast_(ids.contiguous())
+            return
+        flat = [t.detach().contiguous().view(-1).view(torch.uint8) for t in tensors]
+        buf = flat[0] if len(flat) == 1 else torch.cat(flat)
+        self.broadcast_(buf)
+        if self.rank != 0:
+            at = 0
+            with torch.no_grad():
+                for t, f in zip(tensors, flat):
+                    t.detach().copy_(buf[at:at + f.numel()].view(t.dtype).view(t.shape))
+                    at += f.numel()

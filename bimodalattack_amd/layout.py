@@ -100,19 +100,6 @@ def expected_unique(m: int, n_opt: int, n_replace: int, topk: int) -> Tuple[floa
     return mean, var
 
 
-def ragged_budget(m: int, n_opt: int, L: int, n_replace: int, topk: int = 0, sigmas: float = 4.0) -> int:
-    """A FIXED row count for a step's ragged forward (static GEMM shapes): the n_opt parent rows plus
-    the expected rows of the distinct candidates + `sigmas` standard deviations, rounded up; never more
-    than computing every token.  A draw that needs more rows (p ~ 3e-5 at 4 sigma) is scored through
-    the padded path for that step.  topk = 0: no duplicate removal assumed."""
-    mean_p, var_p = first_diff_stats(n_opt, n_replace)
-    u, var_u = expected_unique(m, n_opt, n_replace, topk) if topk else (float(m), 0.0)
-    rows = L - mean_p
-    want = n_opt + u * rows + sigmas * (u * var_p + var_u * rows * rows) ** 0.5
-    gran = 256 if m * L >= 8192 else 8
-    return min(int(-(-want // gran) * gran), n_opt + m * L)
-
-
 def ragged_rows(needed: int, cap: int) -> int:
     """Rows a ragged forward computes for `needed` useful ones: the next point of a coarse grid (GEMM
     shapes then come from a small set that the selection table covers: tools/tune_rows.py), never more
@@ -161,7 +148,7 @@ def ragged_plan(cand, parent, L: int, T: int, P: int, n_rows: Optional[int] = No
         before = np.cumsum(p) - p
         p = p - np.minimum(p, np.maximum(0, deficit - before))
         if int((L - p).sum()) != n_rows - n_opt:
-            return None                              # n_rows > n_opt + m*L: cannot happen via ragged_budget
+            return None                              # n_rows > n_opt + m*L: more rows than tokens
     lens = L - p
     starts = n_opt + np.cumsum(lens) - lens
     n_c = int(lens.sum())

@@ -100,7 +100,7 @@ int bma_mask_topk(const void* grad, int64_t ld_row, int rows, int V, int dtype,
  * a3  sample_ids_from_grad, second half  (:150-162)
  * bma_rand_positions: pos[b, 0:n_rep] = the n_rep positions of row b of `rnd`
  *   (B x n_opt uniform floats) with the smallest values, in ascending order of
- *   value (ties by position) == argsort(rnd)[..., :n_rep].  n_opt <= 64.
+ *   value (ties by position) == argsort(rnd)[..., :n_rep].  Any n_opt >= n_rep.
  * bma_sample_scatter: out[b,:] = ids; out[b, pos[b,j]] = topk_idx[pos[b,j]*k +
  *   rank[b,j]] for j < n_rep.   ids [n_opt], topk_idx [n_opt*k], pos/rank
  *   [B*n_rep], out [B*n_opt], all int64.

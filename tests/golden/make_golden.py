@@ -403,27 +403,73 @@ TRAJ = {
                                     joint_eval=True, eps=64 / 255, alpha=4 / 255), None),
     "gemma3_pgd_gcg": ("gemma3", dict(num_steps=2, search_width=16, topk=32, pgd_attack=True, gcg_attack=True,
                                       joint_eval=False, eps=64 / 255, alpha=4 / 255), None),
+    # BASELINE configs[4] in miniature: Gemma-3 segment order (:1150-1163) with the decaying width (:919-923)
+    "gemma3_joint_dyn": ("gemma3", dict(num_steps=5, search_width=24, topk=32, pgd_attack=True, gcg_attack=True,
+                                        joint_eval=True, dynamic_search=True, min_search_width=8,
+                                        eps=64 / 255, alpha=4 / 255), None),
+    # PGD-only on Gemma-3: the step loss comes from the gemma order with the SCALED embedding (:1150-1163, :1142)
+    # while the gradient pass uses the llava order and the unscaled table (:968, :981-991)
+    "gemma3_pgd": ("gemma3", dict(num_steps=3, pgd_attack=True, gcg_attack=False, eps=64 / 255, alpha=4 / 255), None),
+    # early_stop=True runs that DO stop (:1300-1306, :785-787): the target is found by `_early_target`
+    "llava_gcg_early": ("llava", dict(num_steps=6, search_width=24, topk=32, pgd_attack=False, gcg_attack=True,
+                                      early_stop=True), "early"),
+    "llava_pgd_gcg_early": ("llava", dict(num_steps=6, search_width=24, topk=32, pgd_attack=True, gcg_attack=True,
+                                          joint_eval=False, early_stop=True, eps=64 / 255, alpha=4 / 255), "early"),
+    "llava_joint_early": ("llava", dict(num_steps=6, search_width=24, topk=32, pgd_attack=True, gcg_attack=True,
+                                        joint_eval=True, early_stop=True, eps=64 / 255, alpha=4 / 255), "early"),
 }
 
-def g5_trajectories() -> None:
+
+def _run_reference(kind, over, goal, target, trace=True):
     import tempfile
 
-    meta = {}
-    for name, (kind, over, _) in TRAJ.items():
-        model, tok, proc, image = S.tiny_case(kind)
-        if kind != "opt":
-            _adapt_image_features(model)
-        goal, target = "tell me a story about cats", "Sure here is a story"
-        tmp = tempfile.mkdtemp(prefix="bma_golden_")
-        cfg = ref.BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
-                                      images_folder=tmp, **over)
-        norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
-        tr = _Trace()
+    model, tok, proc, image = S.tiny_case(kind)
+    if kind != "opt":
+        _adapt_image_features(model)
+    tmp = tempfile.mkdtemp(prefix="bma_golden_")
+    cfg = ref.BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
+                                  images_folder=tmp, **over)
+    norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
+    tr = _Trace() if trace else None
+    if tr is not None:
         tr.install()
-        try:
-            res = ref.run(model, tok, proc, goal, goal, target, image, cfg, normalize=norm)
-        finally:
+    try:
+        res = ref.run(model, tok, proc, goal, goal, target, image, cfg, normalize=norm)
+    finally:
+        if tr is not None:
             tr.uninstall()
+    return res, tr, model, tmp
+
+
+def _early_target(kind, over, goal):
+    """A target for which the reference's early_stop fires in the MIDDLE of the run: the first
+    one-word target, in vocabulary order, whose run ends after step 1..num_steps-2 (so the
+    initial suffix does not match, a later candidate does, and steps remain to be skipped)."""
+    tok = S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, S.TINY_UNRT)
+    words = [w for w, i in sorted(tok.get_vocab().items(), key=lambda kv: kv[1])
+             if i >= len(S.SPECIALS) and " " not in w and w.isascii() and not w.startswith("<")]
+    for w in words:
+        res, _, _, _ = _run_reference(kind, over, goal, w, trace=False)
+        if 2 <= len(res.losses) <= over["num_steps"] - 1:
+            return w
+    raise RuntimeError(f"no one-word target stops {kind} {over} mid-run")
+
+
+def g5_trajectories(only=None) -> None:
+    meta_path = os.path.join(HERE, "g5_meta.json")
+    meta = {}
+    if only and os.path.exists(meta_path):
+        meta = json.load(open(meta_path))["cases"]
+    for name, (kind, over, special) in TRAJ.items():
+        if only and name not in only:
+            continue
+        goal, target = "tell me a story about cats", "Sure here is a story"
+        if special == "early":
+            target = _early_target(kind, over, goal)
+            print(f"{name}: early-stop target {target!r}")
+        res, tr, model, tmp = _run_reference(kind, over, goal, target)
+        if special == "early":
+            assert 2 <= len(res.losses) < over["num_steps"], len(res.losses)
         arrays = dict(
             losses=np.array(res.losses, np.float64), best_loss=np.array(res.best_loss),
             init_losses=tr.init_losses, state_checksum=np.array(S.state_checksum(model)),
@@ -559,6 +605,6 @@ if __name__ == "__main__":
     if "g6" in which:
         g6_tokens()
     if "g5" in which:
-        g5_trajectories()
+        g5_trajectories([w for w in which if w in TRAJ] or None)
     if "g7" in which:
         g7_artifacts()

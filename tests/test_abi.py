@@ -43,7 +43,7 @@ def test_argument_validation_launches_nothing():
     assert lib.bma_mask_topk(16, 100, 1, 100, 0, None, 101, 16, None) == -1   # k > V
     assert lib.bma_mask_topk(16, 5000, 1, 5000, 0, None, 4096, 16, None) == -5  # k > 2048
     assert lib.bma_mask_topk(16, 100, 0, 100, 0, None, 5, 16, None) == 0
-    assert lib.bma_rand_positions(16, 4, 65, 1, 16, None) == -5
+    assert lib.bma_rand_positions(16, 0, 65, 1, 16, None) == 0              # any suffix length; empty batch launches nothing
     assert lib.bma_rand_positions(16, 4, 8, 9, 16, None) == -1
     assert lib.bma_sample_scatter(16, 16, 16, 16, 0, 8, 1, 4, 16, None) == 0
     segs = (BmaSegment * 1)(BmaSegment(16, 4, 0))

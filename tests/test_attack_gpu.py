@@ -32,6 +32,7 @@ def run_case(name, **engine):
     cfg = BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=m["optim_str_init"], images_folder=tmp,
                               **m["config"])
     trace = []
+    engine.setdefault("strict", True)        # a fast path that silently gives up on these models is a failure
     res = run(model, tok, proc, m["goal"], m["goal"], m["target"], image, cfg,
               normalize=S.Normalize(S.CLIP_MEAN, S.CLIP_STD), rng_device="cpu", trace=trace, **engine)
     return m, res, trace, tmp
@@ -153,6 +154,22 @@ def test_restructurings_do_not_change_results(golden_dir, name, engine):
     check_against_golden(golden_dir, name, m, res, trace, tmp)
 
 
+@pytest.mark.parametrize("name", ["llava_gcg_early", "llava_pgd_gcg_early", "llava_joint_early", "gemma3_pgd",
+                                  "gemma3_joint_dyn"])
+@pytest.mark.parametrize("engine", [dict(graph_rescore=False, graph_gradient=False, graph_prefix=False),
+                                    dict(joint_winner_from_batch=False),
+                                    dict(fuse_pgd_only=False),
+                                    dict(ragged_suffix=False, chunk=7)])
+def test_early_stop_and_gemma_orders_under_restructurings(golden_dir, name, engine):
+    """early_stop runs that stop mid-run (reference :1300-1306, :785-787) and the Gemma-3 segment orders
+    (:1150-1163) give the reference's trajectory whether the winner re-score is a hipGraph replay or eager,
+    whether the joint winner's loss comes from the batch or from a re-score, with and without the PGD-only
+    fusion, and through odd chunks."""
+    m, res, trace, tmp = run_case(name, **engine)
+    assert len(res.losses) == m["steps"] < m["config"]["num_steps"] or "early" not in name
+    check_against_golden(golden_dir, name, m, res, trace, tmp)
+
+
 @pytest.mark.parametrize("kind,dtype", [("llava", torch.bfloat16), ("llava", torch.float16),
                                         ("gemma3", torch.bfloat16)])
 def test_device_rng_mode_and_16bit_run(kind, dtype):
@@ -201,12 +218,19 @@ def test_early_stop_and_errors():
 
 
 # ------------------------------------------------------------------ sharded engine, 2 ranks on one GPU
-def _sharded_worker(rank, world, port, name, out):
+def _sharded_worker(rank, world, port, name, out, backend="gloo"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves the GPU tensors through the host
+    if backend == "nccl":                                                 # RCCL: one GPU per rank
+        global DEV
+        DEV = f"cuda:{rank}"
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves the GPU tensors through the host
     try:
-        torch.cuda.set_device(0)
+        if backend != "nccl":
+            torch.cuda.set_device(0)
         m, res, trace, tmp = run_case(name)
         out.put((rank, res.losses, res.strings, [st["n_scored"] for st in trace],
                  [st["losses"][0].tolist() for st in trace if st["losses"]]))
@@ -214,7 +238,7 @@ def _sharded_worker(rank, world, port, name, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["llava_joint", "llava_joint_dyn", "opt_gcg"])
+@pytest.mark.parametrize("name", ["llava_joint", "llava_joint_dyn", "opt_gcg", "llava_pgd_gcg_early", "gemma3_joint_dyn"])
 def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
     """Candidate scoring sharded over 2 ranks (rehearsed with gloo, both ranks on cuda:0 --
     the driver's 8-GPU run uses RCCL): every rank returns the single-process result."""
@@ -243,14 +267,85 @@ def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2]          # ranks agree bit for bit
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL cannot put two ranks on one)")
+@pytest.mark.parametrize("name", ["llava_joint", "llava_pgd_gcg_early"])
+def test_sharded_engine_two_ranks_rccl(golden_dir, name):
+    """The same equality over RCCL/xGMI, one GPU per rank (skipped on a one-GPU box)."""
+    import socket
+    import torch.multiprocessing as mp
+    m, res1, trace1, _ = run_case(name)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, name, out, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, losses, strings, n_scored, cand_losses in got:
+        assert strings == res1.strings, f"rank {rank}"
+        np.testing.assert_allclose(losses, res1.losses, rtol=1e-5)
+    assert got[0][2] == got[1][2]
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver calls it (no launcher): the script starts its two ranks itself
+    (rehearsed with gloo on the one GPU of this box; the driver's node runs RCCL), prints ONE JSON line with
+    n_gpus = 2, candidates sharded, two data-path collectives per step."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMA_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2",
+                        "--warmup", "1", "--profile-steps", "1", "--search-width", "64", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["sharding"] == "candidates/2" and d["scaling"] == "strong"
+    assert d["engine"]["collectives"] == 2 * (1 + 2 + 1) and not d["engine"]["fallbacks"]     # 2 per step, 4 steps
+    assert d["roofline"]["bound"] in ("mfma", "hbm") and d["value"] > 0
+
+
 # ------------------------------------------------------------------ BASELINE-size parity of the scoring path
-@pytest.mark.parametrize("workload", ["gcg", "joint"])
-def test_7b_scoring_equals_reference_call_shape(workload):
+def _reference_call_shape_losses(model, atk, cand, order, feats, chunk=8):
+    """What the reference computes for these candidates (:1112-1225, :1278-1310): emb(ids) + repeated
+    segments concatenated, a full-sequence forward, full (B,S,V) logits, torch cross-entropy in fp32."""
+    E = atk.embedding_layer
+    want = []
+    n = cand.shape[0]
+    for s in range(0, n, chunk):
+        b = min(chunk, n - s)
+        parts = [E(cand[s:s + b]) if nm == "optim" else (feats.to(E.weight.dtype) if nm == "image" else atk.seg[nm]).expand(b, -1, -1)
+                 for nm in order]
+        x = torch.cat(parts, dim=1)
+        logits = model(inputs_embeds=x, use_cache=False).logits
+        T = atk.T
+        sl = logits[:, x.shape[1] - T - 1:-1, :].float()
+        l = torch.nn.functional.cross_entropy(sl.reshape(-1, sl.shape[-1]), atk.labels.repeat(b), reduction="none")
+        want.append(l.view(b, T).mean(-1))
+        del logits, sl, x
+    return torch.cat(want).cpu().numpy()
+
+
+@pytest.mark.parametrize("workload,n", [("gcg", 48), ("joint", 48), ("gcg", 512), ("joint", 512)])
+def test_7b_scoring_equals_reference_call_shape(workload, n):
     """LLaVA-1.5-7B shape, bf16.  The optimised scoring path (target rows only, last token
     dropped, shared-prefix keys/values or shared-prefix attention, fused RMSNorm/SwiGLU/RoPE,
     tuned GEMM selection, HIP splice + CE) against the reference's call shape on the same
     model: full-sequence forward, full (B,S,V) logits, torch cross-entropy in fp32.  Both are
-    bf16 computations of the same function; they differ by bf16 rounding noise only."""
+    bf16 computations of the same function; they differ by bf16 rounding noise only.
+    n = 512 is BASELINE's search_width in ONE chunk, candidates drawn like the sampler draws them
+    (a position, one of 256 tokens for it): ~26 exact duplicates, the coarse row grid and the
+    `keep` maps of ragged scoring are asserted at full width."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import build_plugins
@@ -262,51 +357,107 @@ def test_7b_scoring_equals_reference_call_shape(workload):
     dev = torch.device(DEV)
     model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, dev, torch.bfloat16, 32)
     joint = workload == "joint"
-    cfg = BimodalAttackConfig(num_steps=1, search_width=48, seed=1, verbosity="ERROR", pgd_attack=joint,
+    cfg = BimodalAttackConfig(num_steps=1, search_width=n, seed=1, verbosity="ERROR", pgd_attack=joint,
                               gcg_attack=True, joint_eval=joint, images_folder=tempfile.mkdtemp())
-    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False))
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False,
+                                                                            strict=True))
     atk._prepare_prompt(messages, target)
     g = torch.Generator(device=DEV).manual_seed(0)
     ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
-    cand = ids.repeat(48, 1)
-    pos = torch.randint(0, ids.shape[1], (48,), generator=g, device=DEV)
-    cand[torch.arange(48, device=DEV), pos] = torch.randint(5, 32000, (48,), generator=g, device=DEV)
+    n_opt = ids.shape[1]
+    cand = ids.repeat(n, 1)
+    pos = torch.randint(0, n_opt, (n,), generator=g, device=DEV)
+    pool = torch.randint(5, 32000, (n_opt, 256), generator=g, device=DEV)      # a "top-k" table per position
+    cand[torch.arange(n, device=DEV), pos] = pool[pos, torch.randint(0, 256, (n,), generator=g, device=DEV)]
     order = segment_order("pgd", "llava", single=True) if joint else segment_order("gcg", "llava", no_joint_eval=True)
     with torch.no_grad():
         feats = atk.hf.image_features(image) if joint else None
         cand[7] = cand[3]                                   # an exact duplicate and a copy of the parent
         cand[11] = ids[0]
+        distinct = len(np.unique(cand.cpu().numpy(), axis=0))
         got = atk.score_candidates(cand.contiguous(), order, feats).float().cpu().numpy()
         # the same candidates through ragged scoring (rows from the first replaced position on, duplicates
         # once, attention in the one-launch MFMA kernel): what the attack loop runs
         ragged = atk.score_candidates(cand.contiguous(), order, feats, parent=ids).float().cpu().numpy()
-        assert atk.score_stats["ragged_calls"] == 1 and atk.score_stats["padded_calls"] == 1
-        assert atk.score_stats["rows_needed"] < 2 * 48 * (ids.shape[1] + 25) * 0.95
-        # the reference's call shape, in chunks of 8 to bound the (B,S,V) logits
-        E = atk.embedding_layer
-        want = []
-        for s in range(0, 48, 8):
-            parts = [E(cand[s:s + 8]) if n == "optim" else (feats.to(E.weight.dtype) if n == "image" else atk.seg[n]).expand(8, -1, -1)
-                     for n in order]
-            x = torch.cat(parts, dim=1)
-            logits = model(inputs_embeds=x, use_cache=False).logits
-            T = atk.T
-            sl = logits[:, x.shape[1] - T - 1:-1, :].float()
-            l = torch.nn.functional.cross_entropy(sl.reshape(-1, sl.shape[-1]), atk.labels.repeat(8), reduction="none")
-            want.append(l.view(8, T).mean(-1))
-        want = torch.cat(want).cpu().numpy()
+        st = atk.score_stats
+        assert st["ragged_calls"] == 1 and st["padded_calls"] == 1 and not atk.fallbacks
+        L = n_opt + 25
+        assert st["rows_needed"] < 2 * n * L * 0.95
+        # ragged leg alone: exactly the rows of the distinct candidates from their first replaced position on
+        first = np.where((cand != ids).any(1).cpu().numpy(), (cand != ids).int().argmax(1).cpu().numpy(), n_opt - 1)
+        _, keep_first = np.unique(cand.cpu().numpy(), axis=0, return_index=True)
+        need = n_opt + int((L - first[keep_first]).sum())
+        assert st["rows_needed"] - n * L == need, (st["rows_needed"] - n * L, need)
+        if n == 512:
+            assert distinct < n - 5                          # the draw has duplicates to remove
+            assert (st["rows"] - n * L) % 256 == 0 and 0 <= (st["rows"] - n * L) - need < 256     # coarse grid
+        want = _reference_call_shape_losses(model, atk, cand, order, feats)
     rel = np.abs(got - want) / np.abs(want)
     rel_r = np.abs(ragged - want) / np.abs(want)
     # bf16 has 8 significand bits; 32 layers of rounding noise land well under 1 %
     assert rel.max() < 1e-2, rel.max()
     assert rel_r.max() < 1e-2, rel_r.max()
     assert ragged[7] == ragged[3]                           # computed once
+    cn = cand.cpu().numpy()
+    _, inv = np.unique(cn, axis=0, return_inverse=True)
+    for u in np.unique(inv):                                # EVERY duplicate group gets one value
+        grp = np.where(np.asarray(inv).reshape(-1) == u)[0]
+        assert (ragged[grp] == ragged[grp[0]]).all()
     # and the ranking the attack cares about is the same where it is not a near-tie
     gap = np.sort(want)[1] - np.sort(want)[0]
     if gap > 4 * np.abs(got - want).max():
         assert int(got.argmin()) == int(want.argmin())
-    print(f"{workload}: max rel diff {rel.max():.2e} (ragged {rel_r.max():.2e}), mean {rel.mean():.2e} "
-          f"(ragged {rel_r.mean():.2e}), loss range [{want.min():.4f}, {want.max():.4f}]")
+    if gap > 4 * np.abs(ragged - want).max():
+        assert int(ragged.argmin()) == int(want.argmin())
+    print(f"{workload} n={n}: max rel diff {rel.max():.2e} (ragged {rel_r.max():.2e}), mean {rel.mean():.2e} "
+          f"(ragged {rel_r.mean():.2e}), loss range [{want.min():.4f}, {want.max():.4f}], {distinct} distinct")
+
+
+def test_gemma3_4b_scoring_equals_reference_call_shape():
+    """Gemma-3-4b-it shape, bf16 (BASELINE configs[4]): 34 layers, 256-wide heads, grouped K/V heads, V = 262208,
+    suffix in FRONT of the image (:1150-1163), scaled embedding (:1142).  The engine's scoring path for the joint
+    layout against the reference's call shape on the same model."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import segment_order
+
+    dev = torch.device(DEV)
+    n = 40
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("gemma_joint", dev, torch.bfloat16, 34)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=n, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=True,
+                              joint_eval=True, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False,
+                                                                            strict=True))
+    atk._prepare_prompt(messages, target)
+    assert atk.hf.model_type == "gemma3" and atk.hf.emb_scale != 1.0 and atk.embedding_layer.num_embeddings == 262208
+    g = torch.Generator(device=DEV).manual_seed(0)
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    n_opt = ids.shape[1]
+    cand = ids.repeat(n, 1)
+    pos = torch.randint(0, n_opt, (n,), generator=g, device=DEV)
+    cand[torch.arange(n, device=DEV), pos] = torch.randint(5, 262144, (n,), generator=g, device=DEV)
+    cand[7] = cand[3]
+    cand[11] = ids[0]
+    order = segment_order("pgd", "gemma3", single=True)
+    assert order.index("optim") < order.index("image")
+    with torch.no_grad():
+        feats = atk.hf.image_features(image)
+        got = atk.score_candidates(cand.contiguous(), order, feats, parent=ids).float().cpu().numpy()
+        chunked = atk.score_candidates(cand.contiguous(), order, feats).float().cpu().numpy()
+        assert not atk.fallbacks, atk.fallbacks
+        want = _reference_call_shape_losses(model, atk, cand, order, feats, chunk=4)
+    rel = np.abs(got - want) / np.abs(want)
+    assert rel.max() < 1e-2, rel.max()
+    assert (np.abs(chunked - want) / np.abs(want)).max() < 1e-2
+    assert got[7] == got[3]
+    gap = np.sort(want)[1] - np.sort(want)[0]
+    if gap > 4 * np.abs(got - want).max():
+        assert int(got.argmin()) == int(want.argmin())
+    print(f"gemma3-4b joint: max rel diff {rel.max():.2e}, mean {rel.mean():.2e}, loss range [{want.min():.4f}, {want.max():.4f}]")
 
 
 def test_run_experiment_writes_reference_artifacts(tmp_path):
@@ -363,10 +514,17 @@ import numpy as np
 order = np.array([3, 0, 4, 1, 2])
 vals = torch.tensor([30., 0., 40., 10., 20.], device=dev)      # values of candidates 3, 0, 4, 1, 2
 assert sh.gather_dealt(vals, order).tolist() == [0., 10., 20., 30., 40.]
+full, hits = sh.gather2(local, torch.ones(7, device=dev), 7)
+assert torch.equal(full, local) and float(hits.sum()) == 7
+a, b = sh.gather_dealt(vals, order, extra=-vals)
+assert a.tolist() == [0., 10., 20., 30., 40.] and b.tolist() == [-0., -10., -20., -30., -40.]
 ids = torch.arange(12, device=dev).view(4, 3)
-assert torch.equal(sh.broadcast_ids(ids), ids)
-img = torch.rand(1, 3, 8, 8, device=dev)
-sh.broadcast_(img)
+img = torch.rand(1, 3, 8, 8, device=dev).requires_grad_()
+keep = img.detach().clone()
+sh.sync_state(ids, img)
+assert torch.equal(ids, torch.arange(12, device=dev).view(4, 3)) and torch.equal(img.detach(), keep)
+both = torch.tensor([1.25, 1.0], device=dev)
+sh.broadcast_(both)
 t = torch.tensor([1.5], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()

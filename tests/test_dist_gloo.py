@@ -31,10 +31,13 @@ def _worker(rank, world, port, out):
         for n in (1, 2, 5, 64, 511, 512):
             truth = torch.arange(n, dtype=torch.float32).mul(0.37).sin() + 3.0     # every rank knows all
             lo, hi = sh.bounds(n)
-            full, flag = sh.gather_losses(truth[lo:hi].clone(), n, flag=(rank == world - 1 and n == 5),
-                                          want_flag=True)
+            hits = (torch.arange(n) == n - 1).float()                              # one hit, on the last rank's slice
+            before = sh.n_collectives
+            full, got = sh.gather2(truth[lo:hi].clone(), hits[lo:hi].clone(), n)
+            assert sh.n_collectives == before + 1                                   # losses and hits share ONE collective
             assert full.shape == (n,) and torch.equal(full, truth), (n, rank)
-            assert flag == (n == 5)
+            assert torch.equal(got, hits)
+            assert torch.equal(sh.gather(truth[lo:hi].clone(), n), truth)
             res[n] = int(full.argmin())
         # dealt partition (ragged scoring): every world-th entry of a cost-sorted order; the gather
         # puts each rank's values back under their candidate index
@@ -44,17 +47,21 @@ def _worker(rank, world, port, out):
             order = np.argsort(torch.rand(n, generator=g).numpy(), kind="stable")
             take = sh.deal(order)
             assert len(take) in (n // world, n // world + 1)
-            full = sh.gather_dealt(truth[torch.from_numpy(np.ascontiguousarray(take))].clone(), order)
+            mine = torch.from_numpy(np.ascontiguousarray(take))
+            full = sh.gather_dealt(truth[mine].clone(), order)
             assert torch.equal(full, truth), (n, rank)
+            full, neg = sh.gather_dealt(truth[mine].clone(), order, extra=-truth[mine])
+            assert torch.equal(full, truth) and torch.equal(neg, -truth)
             # every candidate is dealt exactly once
             assert sorted(np.concatenate([sh.deal(order, r) for r in range(world)]).tolist()) == list(range(n))
-        # rank 0's ids win the broadcast even when another rank drifted (different N)
-        ids = torch.arange(12, dtype=torch.int64).view(4, 3) if rank == 0 else torch.zeros((6, 3), dtype=torch.int64)
-        got = sh.broadcast_ids(ids)
-        assert got.shape == (4, 3) and torch.equal(got, torch.arange(12).view(4, 3))
-        img = torch.full((1, 3, 4, 4), float(rank))
-        sh.broadcast_(img)
-        assert float(img.sum()) == 0.0
+        # rank 0's ids and image overwrite a drifted rank's, in one packed broadcast
+        ids = torch.arange(12, dtype=torch.int64).view(4, 3) + (0 if rank == 0 else 100 * rank)
+        img = torch.full((1, 3, 4, 4), float(rank) + 0.25).requires_grad_()
+        before = sh.n_collectives
+        sh.sync_state(ids, img)
+        assert sh.n_collectives == before + 1
+        assert torch.equal(ids, torch.arange(12).view(4, 3)) and img.requires_grad
+        assert float(img.detach().sum()) == 0.25 * 48
         out.put((rank, res))
     finally:
         dist.destroy_process_group()

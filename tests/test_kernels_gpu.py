@@ -184,6 +184,30 @@ def test_ce_baseline_size(ops):
     np.testing.assert_allclose(loss.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
 
 
+def test_ce_gemma_size(ops):
+    """Gemma-3-4b vocabulary (BASELINE configs[4]): B=64, T=20, V=262208, bf16 (671 MB) -- 4 KiB-unaligned row
+    length, 8x the LLaVA row; a sample of candidates against the oracle, the early-stop argmax, properties."""
+    B, T, V = 64, 20, 262208
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = (torch.randn((B, T, V), generator=g, device=DEV, dtype=torch.float32) * 2).to(torch.bfloat16)
+    lab = torch.randint(0, V, (T,), generator=g, device=DEV)
+    x[5, torch.arange(T, device=DEV), lab] = 40.0                  # candidate 5 predicts every target token
+    x[6, torch.arange(T - 1, device=DEV), lab[:-1]] = 40.0         # candidate 6 misses the last one
+    loss, match, _, rows = ops.ce_target(x, lab, want_match=True)
+    pick = [0, 5, 6, 63]
+    want, wmatch = K.ce_target(x[pick].float().cpu().numpy(), lab.cpu().numpy())
+    np.testing.assert_allclose(loss[pick].cpu().numpy(), want, rtol=1e-5)
+    assert match.cpu().tolist() == [int(i == 5) for i in range(B)] and wmatch.tolist() == [False, True, False, False]
+    perm = torch.randperm(B, generator=g, device=DEV)
+    assert torch.equal(ops.ce_target(x[perm].contiguous(), lab)[0], loss[perm])
+    ref = torch.nn.functional.cross_entropy(x.float().reshape(-1, V), lab.repeat(B), reduction="none").view(B, T).mean(1)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
+    # the gradient-pass form at this width: dlogits of one candidate against the oracle
+    _, _, dlog, _ = ops.ce_target(x[:1], lab, want_dlogits=True)
+    np.testing.assert_allclose(dlog[0].float().cpu().numpy(), K.ce_target_grad(x[0].float().cpu().numpy(), lab.cpu().numpy()),
+                               rtol=1e-2, atol=1e-6)
+
+
 # ------------------------------------------------------------------ a3 sampling
 @pytest.mark.parametrize("case", ["a", "b", "c", "d"])
 def test_sampling_golden(ops, golden_dir, case):
@@ -242,7 +266,8 @@ def test_topk_strided_rows_and_grad_untouched(ops):
 
 def test_rand_positions_and_scatter_vs_oracle(ops):
     rs = np.random.RandomState(9)
-    for B, n_opt, n_rep, k in [(512, 19, 1, 256), (128, 19, 3, 64), (1, 1, 1, 4), (77, 64, 64, 8)]:
+    for B, n_opt, n_rep, k in [(512, 19, 1, 256), (128, 19, 3, 64), (1, 1, 1, 4), (77, 64, 64, 8),
+                            (33, 100, 2, 16), (9, 257, 257, 4)]:
         rnd = rs.uniform(size=(B, n_opt)).astype(np.float32)
         rnd[0, :] = 0.5 if n_opt > 1 else rnd[0, :]              # ties: lowest position first
         pos = ops.rand_positions(dev(rnd), n_rep)
