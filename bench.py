@@ -231,7 +231,9 @@ class GemmTimer:
             if id(mod) in skip:
                 continue            # their output is a slice of the block's one fused q/k/v product
             n_out = fused_q.get(id(mod), mod.out_features)
-            label = "qkv_proj" if id(mod) in fused_q else role
+            # gate_proj and up_proj are the same product shape served by the same library kernel: one line, as in
+            # a kernel trace folded by (symbol, grid)
+            label = "qkv_proj" if id(mod) in fused_q else ("gate_up_proj" if role in ("gate_proj", "up_proj") else role)
             mod.register_forward_pre_hook(self._pre)
             mod.register_forward_hook(self._post(label, n_out, mod.in_features))
 
@@ -345,11 +347,26 @@ def main() -> None:
     cfg_kw = dict(search_width=sw, topk=wl.get("topk", 256), n_replace=1, seed=1, verbosity="ERROR",
                   pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
                   eps=64 / 255, alpha=4 / 255)
-    if wl.get("gemma"):
-        cfg_kw.update(dynamic_search=True, min_search_width=128)
     n_prof = max(0, args.profile_steps)
     timed_end = args.warmup + args.steps
     total = timed_end + n_prof
+    width_of = None
+    if wl.get("gemma"):
+        # BASELINE configs[4]: dynamic_search 512 -> 128 over 600 steps (reference :919-923).  K timed steps sample
+        # that schedule at evenly spaced points (mean width 271 at K = 5; the 600-step mean is 272); warm-up runs
+        # the widest step, the profiled steps the middle one.
+        from bimodalattack_amd.layout import dynamic_width
+        cfg_kw.update(dynamic_search=True, min_search_width=128)
+        SCHED = 600
+
+        def width_of(i: int) -> int:
+            if i < args.warmup:
+                v = 0
+            elif i < timed_end:
+                v = int(round((i - args.warmup + 0.5) * SCHED / args.steps))
+            else:
+                v = SCHED // 2
+            return dynamic_width(min(v, SCHED - 1), sw, SCHED, 128, True)
     cfg = BimodalAttackConfig(num_steps=total, images_folder=tempfile.mkdtemp(prefix="bma_bench_"), **cfg_kw)
 
     marks = {}
@@ -380,7 +397,7 @@ def main() -> None:
 
     gcg_logger.setLevel("ERROR")
     attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(
-        step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse))
+        step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse, width_override=width_of))
     gemms = GemmTimer(model, attack.fused.qkv if attack.fused.enabled else [])
     log("engine constructed; running")
     res = attack.run(messages, goal, target, image)
@@ -494,7 +511,9 @@ def main() -> None:
         "config": {"workload": wl["name"], "search_width": sw, "topk": cfg_kw["topk"], "n_optim": 19,
                    "target_tokens": seg["target"], "seq_len": full_tok, "candidates_per_step_after_filter":
                    n_cand / max(1, len(timed)), "sharding": f"candidates/{world}" if world > 1 else "none",
-                   "text_layers": tc.num_hidden_layers, "prefix_reuse": not args.no_prefix_reuse},
+                   "text_layers": tc.num_hidden_layers, "prefix_reuse": not args.no_prefix_reuse,
+                   "width_schedule": None if width_of is None else
+                   {"of": "600-step dynamic_search 512->128, sampled evenly", "timed_widths": [width_of(i) for i in range(args.warmup, timed_end)]}},
         "attack_steps_per_sec": args.steps / elapsed,
         "scoring_phase_candidate_forwards_per_sec": n_cand / loss_s if loss_s else None,
         "phase_s_per_step": {"gradient": grad_s / args.steps, "pgd": pgd_s / args.steps,

@@ -332,6 +332,8 @@ class BimodalAttack:
         broadcast (the shapes are a function of the step number, so nothing else is exchanged)."""
         cfg = self.config
         width = dynamic_width(step, cfg.search_width, cfg.num_steps, cfg.min_search_width, cfg.dynamic_search)
+        if self.opt.width_override is not None:
+            width = int(self.opt.width_override(step))
         if not cfg.gcg_attack:
             if image is not None:
                 self.shard.sync_state(image)
@@ -381,14 +383,14 @@ class BimodalAttack:
                 return self.hf.image_features(image)
         return self._feat_graph(image)
 
-    def _wants_shared(self, P: int) -> bool:
+    def _wants_shared(self, P: int, total_len: int = 0) -> bool:
         # same-process A/B on MI355X, 512 candidates: P=21: 231 ms vs 254 ms through the HF cache
         # (KV concat); P=599: 288 ms vs 714 ms
         hf = self.hf
         return bool(self.opt.shared_prefix_attention and hf.shared_ok is not False
-                    and P >= self.opt.shared_prefix_min_tokens and hf.shared_prefix_configs())
+                    and P >= self.opt.shared_prefix_min_tokens and hf.shared_prefix_configs(total_len))
 
-    def _prefix(self, prefix_names: List[str], feats: Optional[Tensor]):
+    def _prefix(self, prefix_names: List[str], feats: Optional[Tensor], total_len: int = 0):
         """Keys/values of the segments in front of the suffix.  They depend on nothing but
         the prompt -- and on the image when it is part of the prefix -- so a text-only prefix
         is computed once per attack and an image prefix once per call."""
@@ -403,7 +405,7 @@ class BimodalAttack:
         cache = None
         if P > 0:
             try:
-                if self._wants_shared(P):
+                if self._wants_shared(P, total_len):
                     try:
                         cache = self._recorded_prefix(key, cat_prefix, feats)
                     except Exception as e:
@@ -509,10 +511,12 @@ class BimodalAttack:
                           and hf.prefix_ok is not False and m > 0)
 
         cache, P = None, 0
+        total_len = sum((mine.shape[1] if nm == "optim" else (feats.shape[1] if nm == "image" else self.seg[nm].shape[1]))
+                        for nm in order)
         if use_prefix:
-            cache, P = self._prefix(prefix_names, feats)
+            cache, P = self._prefix(prefix_names, feats, total_len)
             use_prefix = cache is not None
-        shared = bool(use_prefix and self._wants_shared(P))
+        shared = bool(use_prefix and self._wants_shared(P, total_len))
         names = tail_names if use_prefix else list(order)
         names = [("target_in" if (t == "target" and rows_only) else t) for t in names]
         segs = self._segments(names, feats)
@@ -569,7 +573,7 @@ class BimodalAttack:
                         self._fallback("shared_prefix_attention", e, "shared-prefix attention disabled")
                         hf.shared_ok, shared = False, False
                         self._prefix_cache.clear()                  # rebuild the prefix as an HF cache
-                        cache, P = self._prefix(prefix_names, feats)
+                        cache, P = self._prefix(prefix_names, feats, total_len)
                         use_prefix = cache is not None
                         if not use_prefix:
                             raise

@@ -134,6 +134,10 @@ class EngineOptions:
     fuse_pgd_only: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
+    # Measurement only: the candidate count of loop step i (bench.py samples the dynamic-width schedule of a
+    # 600-step run, reference :919-923, at evenly spaced points of a handful of timed steps).  None: the
+    # reference's schedule of this run's own num_steps.
+    width_override: object = None
     # Raise instead of falling back when a fast path (hipGraph capture, shared-prefix attention, ragged
     # scoring, prefix reuse) fails on this model.  Off by default: an unknown model family must still run.
     strict: bool = False

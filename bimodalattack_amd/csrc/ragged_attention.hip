@@ -8,8 +8,10 @@
 //   * positions first[i] <= t <= j: its own rows.
 // The library route needs five launches for that (prefix flash attention over all rows, three
 // row gathers into a padded block, biased attention on the block, LSE merge) and moves every
-// q/k/v/o row through HBM three times.  Here one workgroup owns one (candidate, head), one wave
-// per 16 queries; the pair's key/value rows go through LDS once, 32 keys at a time:
+// q/k/v/o row through HBM three times.  Here one workgroup owns one (candidate, head) -- and, for blocks
+// longer than 64 tokens (a padded Gemma-3 candidate is the trivially ragged block first = 0, len = L), one
+// stretch of 64 queries of it -- with one wave per 16 queries; the key/value rows it may see go through LDS
+// once, 32 keys at a time:
 //
 //   S^T = K Q^T   v_mfma_f32_16x16x32: A = 16 keys x 32 dims (ds_read_b128 of an LDS row), B = 32 dims
 //                 x 16 queries (loaded once from global memory in operand layout, 16 B per lane)
@@ -54,9 +56,14 @@ __device__ __forceinline__ f32x4 mfma(const uint4_t& a, const uint4_t& b, const 
 template <int DT>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return bma::pack16<DT>(lo, hi); }
 
-// One workgroup per (candidate, head); wave w owns query tile w (16 queries), so a workgroup has QT
-// waves (len <= 16*QT).  The keys/values of the pair go through LDS once, 32 keys at a time, shared by
-// the waves; a wave skips chunks that lie entirely behind its last query (causal).
+// One workgroup per (candidate, head, block of 16*QT queries); wave w owns query tile w of the block.  The
+// keys/values the block may see go through LDS once, 32 keys at a time, shared by the waves; a wave skips
+// chunks that lie entirely behind its last query (causal).  Staging: ONE image pair, chunk c+1 in flight in
+// registers while chunk c is multiplied, two barriers per chunk -- the least LDS (18 KB at 128-wide heads, 35 KB
+// at 256), hence the most workgroups per CU.  Measured alternatives on MI355X (tools/kernel_bench.py, C3 row
+// list / Gemma-3 blocks / C4 blocks): two image pairs with one barrier per chunk 164 / 363 / 176 us, every chunk
+// resident in LDS with a single barrier 284 / 367 / 196 us, against 157 / 344 / 166 us for this scheme: the
+// kernel is bound by how many workgroups a CU holds, not by its barriers.
 template <int DT, int QT, int DH>
 __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
   constexpr int KS = DH / 32;      // k-steps of the QK product
@@ -64,91 +71,71 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
   constexpr int PITCH = DH + 16;   // elements per LDS row (row + 32 B: conflict-free transposing reads)
   constexpr int PIECES = DH / 8;   // 16-byte pieces per row
   constexpr int NTHR = 64 * QT;
-  __shared__ __attribute__((aligned(16))) uint16_t klds[32 * PITCH];
-  __shared__ __attribute__((aligned(16))) uint16_t vlds[32 * PITCH];
+  constexpr int IMG = 32 * PITCH;  // elements of one 32-row image
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * IMG];   // K image, V image
   const int tid = threadIdx.x;
   const int lane = tid & 63, qt = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int i = blockIdx.x, h = blockIdx.y;
+  const int q0 = 16 * QT * blockIdx.z;                    // first query of this workgroup inside the block
   const int hk = h / (a.H / a.Hk);
   const int st = a.start[i], p0 = a.first[i], ln = a.len[i];
+  if (q0 >= ln) return;                                   // uniform over the workgroup
   const int P = a.P;
   const int nkeys = P + p0 + ln;
+  const int qend = q0 + 16 * QT < ln ? q0 + 16 * QT : ln; // one past the last query of this workgroup
+  const int kend = P + p0 + qend;                         // keys any of its queries may see
   const float NEG = -__builtin_inff();
 
   // Q tile as the B operand: lane (query r, dims 8g.. of k-step ks)
   uint4_t qf[KS];
   {
-    int qi = 16 * qt + r;
+    int qi = q0 + 16 * qt + r;
     qi = qi < ln ? qi : ln - 1;
     const uint16_t* qp = a.q + static_cast<int64_t>(st + qi) * a.q_rs + static_cast<int64_t>(h) * a.q_hs + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const uint4_t*>(qp + 32 * ks);
   }
-  const int jq = p0 + 16 * qt + r;                        // this lane's query position behind the prefix
-  const int last_key = P + p0 + 16 * qt + 15;             // last key index any query of the tile may see
-  const bool tile_live = 16 * qt < ln;
+  const int jq = p0 + q0 + 16 * qt + r;                   // this lane's query position behind the prefix
+  const int last_key = P + p0 + q0 + 16 * qt + 15;        // last key index any query of the tile may see
+  const bool tile_live = q0 + 16 * qt < ln;
 
   f32x4 oacc[NT];
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float mrun = NEG, lsum = 0.0f;
 
-  // chunk staging, software-pipelined: the rows of chunk c+1 are in flight (registers) while chunk c
-  // is multiplied out of LDS
   constexpr int ITEMS = (32 * PIECES + NTHR - 1) / NTHR;
-  uint4_t kreg[ITEMS], vreg[ITEMS];
-  auto fetch = [&](int c) {
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * NTHR;
-      if (idx < 32 * PIECES) {
-        const int key = idx / PIECES, piece = idx % PIECES;
-        int t = 32 * c + key;
-        t = t < nkeys ? t : nkeys - 1;
-        const uint16_t *kp, *vp;
-        if (t < P) {
-          kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs;
-          vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs;
-        } else {
-          const int tt = t - P;
-          const int64_t row = tt < p0 ? tt : st + (tt - p0);   // the parent's row, or this candidate's own
-          kp = a.k + row * a.k_rs + static_cast<int64_t>(hk) * a.k_hs;
-          vp = a.v + row * a.v_rs + static_cast<int64_t>(hk) * a.v_hs;
-        }
-        kreg[it] = *reinterpret_cast<const uint4_t*>(kp + 8 * piece);
-        vreg[it] = *reinterpret_cast<const uint4_t*>(vp + 8 * piece);
-      }
+  // the 16-byte piece `idx` of chunk c: key row (prefix, parent's or own) and where it lands in an image
+  auto src = [&](int c, int idx, const uint16_t*& kp, const uint16_t*& vp) {
+    const int key = idx / PIECES, piece = idx % PIECES;
+    int t = 32 * c + key;
+    t = t < nkeys ? t : nkeys - 1;
+    if (t < P) {
+      kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs + 8 * piece;
+      vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs + 8 * piece;
+    } else {
+      const int tt = t - P;
+      const int64_t row = tt < p0 ? tt : st + (tt - p0);   // the parent's row, or this candidate's own
+      kp = a.k + row * a.k_rs + static_cast<int64_t>(hk) * a.k_hs + 8 * piece;
+      vp = a.v + row * a.v_rs + static_cast<int64_t>(hk) * a.v_hs + 8 * piece;
     }
   };
-  const int chunks = (nkeys + 31) >> 5;
-  fetch(0);
-  for (int c = 0; c < chunks; ++c) {
-    if (c) __syncthreads();                                // the previous chunk's readers are done
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * NTHR;
-      if (idx < 32 * PIECES) {
-        const int key = idx / PIECES, piece = idx % PIECES;
-        *reinterpret_cast<uint4_t*>(klds + key * PITCH + 8 * piece) = kreg[it];
-        *reinterpret_cast<uint4_t*>(vlds + key * PITCH + 8 * piece) = vreg[it];
-      }
-    }
-    __syncthreads();
-    if (c + 1 < chunks) fetch(c + 1);
-    if (!tile_live || 32 * c > last_key) continue;         // wave-uniform: nothing of this chunk is visible
+  const int chunks = (kend + 31) >> 5;
 
-    // ---- S^T = K Q^T: A = 16 keys x 32 dims from LDS rows, B = the Q fragments -------------------
+  // ---- one chunk out of LDS images kl / vl ------------------------------------------------------
+  auto compute = [&](int c, const uint16_t* kl, const uint16_t* vl) {
+    // S^T = K Q^T: A = 16 keys x 32 dims from LDS rows, B = the Q fragments
     f32x4 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      const uint16_t* kr = klds + (16 * kt + r) * PITCH + 8 * g;
+      const uint16_t* kr = kl + (16 * kt + r) * PITCH + 8 * g;
       f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = mfma<DT>(*reinterpret_cast<const uint4_t*>(kr + 32 * ks), qf[ks], acc);
       s[kt] = acc;
     }
-    // ---- online softmax; the probabilities become the B operand of the second product ------------
+    // online softmax; the probabilities become the B operand of the second product
     float e[2][4];
     float cmax = NEG;
 #pragma unroll
@@ -181,11 +168,11 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
     pf.y = pack2<DT>(e[0][2], e[0][3]);
     pf.z = pack2<DT>(e[1][0], e[1][1]);
     pf.w = pack2<DT>(e[1][2], e[1][3]);
-    // ---- O^T = alpha O^T + V^T P^T: element j of lane group g is key 32c + (j<4 ? 4g+j : 16+4g+j-4);
+    // O^T = alpha O^T + V^T P^T: element j of lane group g is key 32c + (j<4 ? 4g+j : 16+4g+j-4);
     // ds_read_b64_tr_b16 hands each 16-lane group a 4-key x 16-dim block column-major, which is the
     // A-operand fragment (dim on the lane, 4 keys in the elements)
     const int q4 = r >> 2, p4 = r & 3;
-    const uint16_t* rd = vlds + (4 * g + q4) * PITCH + 4 * p4;
+    const uint16_t* rd = vl + (4 * g + q4) * PITCH + 4 * p4;
 #pragma unroll
     for (int dt = 0; dt < NT; ++dt) {
       const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(rd + 16 * dt));
@@ -198,13 +185,43 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
       o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
       oacc[dt] = mfma<DT>(vf, pf, o);
     }
+  };
+
+  uint4_t kreg[ITEMS], vreg[ITEMS];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < 32 * PIECES) {
+        const uint16_t *kp, *vp;
+        src(c, idx, kp, vp);
+        kreg[it] = *reinterpret_cast<const uint4_t*>(kp);
+        vreg[it] = *reinterpret_cast<const uint4_t*>(vp);
+      }
+    }
+  };
+  fetch(0);
+  for (int c = 0; c < chunks; ++c) {
+    if (c) __syncthreads();                               // the previous chunk's readers are done
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < 32 * PIECES) {
+        const int off = (idx / PIECES) * PITCH + 8 * (idx % PIECES);
+        *reinterpret_cast<uint4_t*>(lds + off) = kreg[it];
+        *reinterpret_cast<uint4_t*>(lds + IMG + off) = vreg[it];
+      }
+    }
+    __syncthreads();
+    if (c + 1 < chunks) fetch(c + 1);                     // in flight while chunk c is multiplied
+    if (tile_live && 32 * c <= last_key) compute(c, lds, lds + IMG);
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
   float l = lsum;
   l += __shfl_xor(l, 16, BMA_WAVE);
   l += __shfl_xor(l, 32, BMA_WAVE);
-  const int qi = 16 * qt + r;
+  const int qi = q0 + 16 * qt + r;
   if (qi >= ln) return;
   const int64_t o_rs = static_cast<int64_t>(a.H) * DH;
   const int64_t row = st + qi;
@@ -238,21 +255,25 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
 }
 
 template <int DT, int DH>
-void launch_dh(const Args& a, int qt, hipStream_t st) {
-  const dim3 grid(static_cast<unsigned>(a.B2), static_cast<unsigned>(a.H));
+int launch_dh(const Args& a, int max_len, hipStream_t st) {
+  const int qt = max_len >= 64 ? 4 : (max_len + 15) / 16;
+  const dim3 grid(static_cast<unsigned>(a.B2), static_cast<unsigned>(a.H),
+                  static_cast<unsigned>((max_len + 16 * qt - 1) / (16 * qt)));
   switch (qt) {
     case 1: hipLaunchKernelGGL((ragged_attn_kernel<DT, 1, DH>), grid, dim3(64), 0, st, a); break;
     case 2: hipLaunchKernelGGL((ragged_attn_kernel<DT, 2, DH>), grid, dim3(128), 0, st, a); break;
     case 3: hipLaunchKernelGGL((ragged_attn_kernel<DT, 3, DH>), grid, dim3(192), 0, st, a); break;
     default: hipLaunchKernelGGL((ragged_attn_kernel<DT, 4, DH>), grid, dim3(256), 0, st, a); break;
   }
+  return BMA_OK;
 }
 
 template <int DT>
-void launch_dt(const Args& a, int qt, int Dh, hipStream_t st) {
-  if (Dh == 32) launch_dh<DT, 32>(a, qt, st);
-  else if (Dh == 64) launch_dh<DT, 64>(a, qt, st);
-  else launch_dh<DT, 128>(a, qt, st);
+int launch_dt(const Args& a, int max_len, int Dh, hipStream_t st) {
+  if (Dh == 32) return launch_dh<DT, 32>(a, max_len, st);
+  if (Dh == 64) return launch_dh<DT, 64>(a, max_len, st);
+  if (Dh == 128) return launch_dh<DT, 128>(a, max_len, st);
+  return launch_dh<DT, 256>(a, max_len, st);
 }
 
 }  // namespace
@@ -269,7 +290,7 @@ extern "C" int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   if (P > 0 && (!pk || !pv)) return BMA_EINVAL;
   if ((o1 == nullptr) != (lse1 == nullptr)) return BMA_EINVAL;
   if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
-  if ((Dh != 32 && Dh != 64 && Dh != 128) || H % Hk || max_len > 64 || N > 0x7fffffffLL) return BMA_ELIMIT;
+  if ((Dh != 32 && Dh != 64 && Dh != 128 && Dh != 256) || H % Hk || max_len > 4096 || N > 0x7fffffffLL) return BMA_ELIMIT;
   // 16-byte operand loads: every row/head stride a multiple of 8 elements, bases 16-byte aligned
   const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, pk_rs, pk_hs, pv_rs, pv_hs};
   for (int64_t s : strides)
@@ -290,10 +311,9 @@ extern "C" int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int es = 2;
   BMA_PROF_BEGIN(BMA_K_RAGGED_ATTN, st, (2.0 * H + 2.0 * Hk) * static_cast<double>(N) * Dh * es);
-  const int qt = (max_len + 15) / 16;
-  if (dtype == BMA_BF16) launch_dt<BMA_BF16>(a, qt, Dh, st);
-  else launch_dt<BMA_F16>(a, qt, Dh, st);
+  const int rc = dtype == BMA_BF16 ? launch_dt<BMA_BF16>(a, max_len, Dh, st) : launch_dt<BMA_F16>(a, max_len, Dh, st);
   BMA_PROF_END(BMA_K_RAGGED_ATTN, st);
+  if (rc != BMA_OK) return rc;
   BMA_LAUNCH_CHECK();
   return BMA_OK;
 }

@@ -96,6 +96,7 @@ class HFAdapter:
         self.prefix_ok: Optional[bool] = None   # learnt on first use
         # shared-prefix attention (prefix_attention.py): None = not probed, [] = not applicable
         self._shared_cfgs = None
+        self.shared_window: Optional[int] = None
         self.shared_ok: Optional[bool] = None
         self.ragged_ok: Optional[bool] = None
 
@@ -151,11 +152,16 @@ class HFAdapter:
         out = self.model(inputs_embeds=prefix_embeds, use_cache=True, **kw)
         return getattr(out, "past_key_values", None)
 
-    def shared_prefix_configs(self) -> list:
+    def shared_prefix_configs(self, total_len: int = 0) -> list:
+        """Text-layer configs to switch to the shared-prefix attention, [] when it does not apply -- to this
+        model at all, or to a sequence of `total_len` tokens (longer than a sliding window)."""
         if self._shared_cfgs is None:
             from . import prefix_attention as pa
             ok = self.device.type == "cuda" and self.has_logits_to_keep and pa.register()
             self._shared_cfgs = pa.eligible_configs(self.model) if ok else []
+            self.shared_window = pa.min_sliding_window(self.model) if self._shared_cfgs else None
+        if self._shared_cfgs and self.shared_window is not None and total_len > self.shared_window:
+            return []
         return self._shared_cfgs
 
     def build_prefix_recording(self, prefix_embeds: torch.Tensor):

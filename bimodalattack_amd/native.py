@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 100
+ABI_VERSION = 101
 
 
 class BmaSegment(Structure):
@@ -46,7 +46,8 @@ PROTOTYPES = {
     "bma_ce_target_ws_bytes": (c_size_t, [c_int, c_int]),
     "bma_ce_target": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
-    "bma_mask_topk": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "bma_mask_topk_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "bma_mask_topk": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "bma_rand_positions": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bma_sample_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p]),

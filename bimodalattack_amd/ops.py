@@ -140,9 +140,11 @@ def mask_topk(grad: torch.Tensor, mask_bits: Optional[torch.Tensor], k: int) -> 
                 or not mask_bits.is_contiguous():
             raise ValueError("mask_bits must be ceil(V/32) contiguous int32 words on the gradient's device")
     out = torch.empty((rows, k), dtype=torch.int64, device=dev)
+    nws = lib.bma_mask_topk_ws_bytes(rows, V, k)      # long rows are cut across workgroups: slice winners pass through it
+    ws = torch.empty(nws // 8, dtype=torch.int64, device=dev) if nws else None
     check("bma_mask_topk", lib.bma_mask_topk(grad.data_ptr(), grad.stride(0), rows, V, _dt(grad),
                                              mask_bits.data_ptr() if mask_bits is not None else None, k,
-                                             out.data_ptr(), _stream(dev)))
+                                             out.data_ptr(), ws.data_ptr() if ws is not None else None, _stream(dev)))
     return out
 
 
@@ -351,13 +353,13 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-RAGGED_ATTN_MAX_LEN = 64
+RAGGED_ATTN_MAX_LEN = 4096
 
 
 def ragged_attention_ok(query: torch.Tensor, key: torch.Tensor, max_len: int) -> bool:
-    """Can bma_ragged_attention take these (1,H,N,Dh) / (1,Hk,N,Dh) tensors?"""
+    """Can bma_ragged_attention take these (.,H,.,Dh) / (.,Hk,.,Dh) tensors?"""
     return (query.is_cuda and query.dtype in (torch.bfloat16, torch.float16) and key.dtype == query.dtype
-            and query.shape[-1] in (32, 64, 128) and 0 < max_len <= RAGGED_ATTN_MAX_LEN
+            and query.shape[-1] in (32, 64, 128, 256) and 0 < max_len <= RAGGED_ATTN_MAX_LEN
             and query.shape[1] % key.shape[1] == 0)
 
 

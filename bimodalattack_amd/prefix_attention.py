@@ -17,9 +17,15 @@ candidate, so joint-mode scoring no longer needs small chunks.
 Plumbing (transformers >= 4.48 attention interface): a registered attention function
 ``bma_shared_prefix`` + a no-op mask function, switched on for the duration of one forward;
 a cache object that hands the new keys/values back untouched and reports the prefix length
-so rotary positions are right.  Used only for model families whose text layers are all
-full causal attention (llama / mistral / qwen2 modelling files); anything else keeps the
-generic path.
+so rotary positions are right.  Used only for model families whose text layers are plain
+causal attention (llama / mistral / qwen2 / gemma3 modelling files) -- a sliding-window
+layer IS plain causal attention while the whole sequence fits its window, which the engine
+checks per call (``min_sliding_window``); anything else keeps the generic path.
+
+Where the head size and dtype allow (16-bit, Dh <= 256, prefix <= FUSED_PREFIX_MAX keys) the
+two library launches + merge collapse into ONE launch of ``bma_ragged_attention``: a padded
+candidate block is the trivially ragged row list (first = 0, len = L), grouped key/value
+heads are read in place (no ``repeat_kv`` copies: Gemma-3 has 8 query heads on 4).
 """
 
 from __future__ import annotations
@@ -37,7 +43,7 @@ from . import ops
 FUSED_RAGGED_ATTENTION = os.environ.get("BMA_FUSED_RAGGED_ATTENTION", "1") not in ("0", "false", "False")
 FUSED_PREFIX_MAX = int(os.environ.get("BMA_FUSED_PREFIX_MAX", "128"))
 NAME = "bma_shared_prefix"
-_FAMILIES = ("modeling_llama", "modeling_mistral", "modeling_qwen2")
+_FAMILIES = ("modeling_llama", "modeling_mistral", "modeling_qwen2", "modeling_gemma3")
 _ACTIVE: List["SharedPrefixKV"] = []
 _REGISTERED = {"done": False}
 
@@ -103,6 +109,7 @@ class SharedPrefixKV(_CacheBase):
         self._sliding = [False] * len(layers)
         self._rep = {}
         self.ragged: Optional["RaggedMaps"] = None     # set for a ragged scoring forward
+        self.fused_ok = True                           # padded blocks through the one-launch MFMA kernel
 
     @property
     def is_sliding(self):                          # read-only property on the HF base class
@@ -197,6 +204,10 @@ def shared_prefix_attention(module, query, key, value, attention_mask=None, drop
     scale = float(scaling) if scaling is not None else Dh ** -0.5
     if kv.ragged is not None:
         return _ragged_attention(kv, module.layer_idx, query, key, value, n_rep, scale), None
+    if FUSED_RAGGED_ATTENTION and kv.fused_ok and kv.P <= FUSED_PREFIX_MAX and ops.ragged_attention_ok(query, key, L):
+        out = _fused_block_attention(kv, module.layer_idx, query, key, value, scale)
+        if out is not None:
+            return out, None
     if n_rep > 1:
         key, value = key.repeat_interleave(n_rep, dim=1), value.repeat_interleave(n_rep, dim=1)
     Kp, Vp = kv.prefix(module.layer_idx, n_rep)
@@ -210,6 +221,46 @@ def shared_prefix_attention(module, query, key, value, attention_mask=None, drop
     o2 = o2.transpose(1, 2).contiguous()
     out = ops.attn_merge(o1, o2, l1.reshape(H, B * L).contiguous(), l2.contiguous())
     return out, None
+
+
+_BLOCKS = {}
+
+
+def _block_maps(B: int, L: int, device):
+    """start / first / len of B padded blocks of L tokens as a (trivially) ragged row list.  Entries are
+    never evicted (a captured graph may hold their pointers)."""
+    key = (B, L, str(device))
+    m = _BLOCKS.get(key)
+    if m is None:
+        m = (torch.arange(B, dtype=torch.int32, device=device) * L, torch.zeros(B, dtype=torch.int32, device=device),
+             torch.full((B,), L, dtype=torch.int32, device=device))
+        _BLOCKS[key] = m
+    return m
+
+
+def _fused_block_attention(kv: "SharedPrefixKV", layer_idx: int, query, key, value, scale: float):
+    """Shared prefix + causal self attention of B padded candidate blocks in one launch of the MFMA kernel
+    (csrc/ragged_attention.hip); (B,L,H,Dh) output, or None when the tensors are not views of the projections'
+    (B,L,heads,Dh) memory (then the library route runs)."""
+    B, H, L, Dh = query.shape
+    Hk = key.shape[1]
+
+    def rows(t, heads):
+        m = t.transpose(1, 2)                       # (B,L,heads,Dh)
+        if not m.is_contiguous():
+            return None
+        return m.view(1, B * L, heads, Dh).transpose(1, 2)     # (1,heads,B*L,Dh) view, no copy
+
+    q, k, v = rows(query, H), rows(key, Hk), rows(value, Hk)
+    if q is None or k is None or v is None:
+        return None
+    start, first, length = _block_maps(B, L, query.device)
+    if kv.P:
+        Kp, Vp = kv.prefix(layer_idx, 1)
+    else:
+        Kp = Vp = None
+    out = ops.ragged_attention(q, k, v, Kp, Vp, start, first, length, L, scale)
+    return out.view(B, L, H, Dh)
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -273,25 +324,37 @@ def register() -> bool:
     return True
 
 
+def _text_attention_layers(model):
+    return [m for m in model.modules()
+            if type(m).__name__.endswith("Attention") and hasattr(m, "layer_idx") and hasattr(m, "q_proj")]
+
+
 def eligible_configs(model) -> list:
-    """Config objects of the text attention layers when EVERY text layer is full causal
-    attention from a known modelling file; [] otherwise."""
-    cfgs, ok = {}, False
-    for m in model.modules():
-        if type(m).__name__.endswith("Attention") and hasattr(m, "layer_idx") and hasattr(m, "q_proj"):
-            f = type(m).__module__.rsplit(".", 1)[-1]
-            if f not in _FAMILIES or getattr(m, "sliding_window", None):
-                return []
-            cfgs[id(m.config)] = m.config
-            ok = True
-    if not ok:
+    """Config objects of the text attention layers when EVERY text layer is causal attention (full, or
+    sliding-window -- see ``min_sliding_window``) from a known modelling file; [] otherwise."""
+    cfgs = {}
+    layers = _text_attention_layers(model)
+    for m in layers:
+        if type(m).__module__.rsplit(".", 1)[-1] not in _FAMILIES:
+            return []
+        cfgs[id(m.config)] = m.config
+    if not layers:
         return []
     for c in cfgs.values():
         types = getattr(c, "layer_types", None)
-        if types and any(t != "full_attention" for t in types):
+        if types and any(t not in ("full_attention", "sliding_attention") for t in types):
+            return []
+        if getattr(c, "use_bidirectional_attention", False) or getattr(c, "attn_logit_softcapping", None):
             return []
     # the decoder stack's own config object drives mask creation: same object as the layers'
     return list(cfgs.values())
+
+
+def min_sliding_window(model) -> Optional[int]:
+    """Smallest sliding window among the text attention layers, None when there is none.  A sliding layer is
+    plain causal attention as long as prefix + new tokens <= window; beyond that the generic path must run."""
+    w = [int(m.sliding_window) for m in _text_attention_layers(model) if getattr(m, "sliding_window", None)]
+    return min(w) if w else None
 
 
 @contextlib.contextmanager

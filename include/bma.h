@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 100 /* 0.1.0 */
+#define BMA_VERSION 101 /* 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -92,9 +92,14 @@ int bma_ce_target(const void* logits, int64_t ld_cand, int64_t ld_row,
  *   gradients rank first (torch.topk ranks NaN highest in -grad); -0.0 == +0.0.
  *   The gradient itself is not modified.
  * Limits: 1 <= k <= 2048, k <= V, V < 2^31.
+ * Workspace: rows longer than 4096 tokens are cut across workgroups (slice-local
+ *   select, then a merge per row); the two stages hand over through `ws`,
+ *   bma_mask_topk_ws_bytes(rows, V, k) bytes, 8-byte aligned (0 = not needed).
+ *   ws == NULL is allowed: one workgroup per row then does the whole select.
  * ------------------------------------------------------------------------- */
+size_t bma_mask_topk_ws_bytes(int rows, int V, int k);
 int bma_mask_topk(const void* grad, int64_t ld_row, int rows, int V, int dtype,
-                  const uint32_t* mask_bits, int k, int64_t* idx_out, void* stream);
+                  const uint32_t* mask_bits, int k, int64_t* idx_out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a3  sample_ids_from_grad, second half  (:150-162)

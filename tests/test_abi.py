@@ -40,9 +40,11 @@ def test_argument_validation_launches_nothing():
     assert lib.bma_ce_target(16, 40, 10, 16, 4, 4, 10, 7, 16, 16, None, None, 1.0, None) == -2   # dtype
     assert lib.bma_ce_target(None, 0, 10, None, 0, 4, 10, 0, None, None, None, None, 1.0, None) == 0
     assert lib.bma_ce_target_ws_bytes(512, 20) == 3 * 512 * 20 * 4
-    assert lib.bma_mask_topk(16, 100, 1, 100, 0, None, 101, 16, None) == -1   # k > V
-    assert lib.bma_mask_topk(16, 5000, 1, 5000, 0, None, 4096, 16, None) == -5  # k > 2048
-    assert lib.bma_mask_topk(16, 100, 0, 100, 0, None, 5, 16, None) == 0
+    assert lib.bma_mask_topk(16, 100, 1, 100, 0, None, 101, 16, None, None) == -1   # k > V
+    assert lib.bma_mask_topk(16, 5000, 1, 5000, 0, None, 4096, 16, None, None) == -5  # k > 2048
+    assert lib.bma_mask_topk(16, 100, 0, 100, 0, None, 5, 16, None, None) == 0
+    assert lib.bma_mask_topk_ws_bytes(19, 32064, 256) == 19 * 8 * 256 * 8 and lib.bma_mask_topk_ws_bytes(19, 4096, 256) == 0
+    assert lib.bma_mask_topk(16, 9000, 1, 9000, 0, None, 5, 16, 4, None) == -3       # misaligned workspace
     assert lib.bma_rand_positions(16, 0, 65, 1, 16, None) == 0              # any suffix length; empty batch launches nothing
     assert lib.bma_rand_positions(16, 4, 8, 9, 16, None) == -1
     assert lib.bma_sample_scatter(16, 16, 16, 16, 0, 8, 1, 4, 16, None) == 0

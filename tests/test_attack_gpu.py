@@ -311,7 +311,8 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "candidates/2" and d["scaling"] == "strong"
-    assert d["engine"]["collectives"] == 2 * (1 + 2 + 1) and not d["engine"]["fallbacks"]     # 2 per step, 4 steps
+    # one loss gather for the initial suffix, then two collectives per step (ids broadcast + loss gather), 4 steps
+    assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) and not d["engine"]["fallbacks"]
     assert d["roofline"]["bound"] in ("mfma", "hbm") and d["value"] > 0
 
 
@@ -450,14 +451,29 @@ def test_gemma3_4b_scoring_equals_reference_call_shape():
         chunked = atk.score_candidates(cand.contiguous(), order, feats).float().cpu().numpy()
         assert not atk.fallbacks, atk.fallbacks
         want = _reference_call_shape_losses(model, atk, cand, order, feats, chunk=4)
+        # the yardstick for "bf16 rounding noise" on THIS model: the same reference call shape in fp32.  The
+        # engine must be as close to it as the reference's own bf16 forward is (Gemma-3's sqrt(D)-scaled
+        # embeddings and 34 layers make that noise ~1 %, larger than on the Llama shape).
+        segs16 = atk.seg
+        model.float()
+        # same function in fp32: the embedding scale keeps the bf16-rounded value the bf16 model multiplies by
+        atk.embedding_layer.embed_scale.fill_(atk.hf.emb_scale)
+        atk.seg = {k_: v_.float() for k_, v_ in segs16.items()}
+        want32 = _reference_call_shape_losses(model, atk, cand, order, feats.float(), chunk=4)
+        atk.seg = segs16
     rel = np.abs(got - want) / np.abs(want)
-    assert rel.max() < 1e-2, rel.max()
-    assert (np.abs(chunked - want) / np.abs(want)).max() < 1e-2
+    noise = (np.abs(want - want32) / np.abs(want32)).max()
+    err = (np.abs(got - want32) / np.abs(want32)).max()
+    err_chunked = (np.abs(chunked - want32) / np.abs(want32)).max()
+    print(f"gemma3-4b joint: engine vs fp32 {err:.2e} (chunked {err_chunked:.2e}), reference-bf16 vs fp32 {noise:.2e}, "
+          f"engine vs reference-bf16 max {rel.max():.2e} mean {rel.mean():.2e}, loss range [{want.min():.4f}, {want.max():.4f}]")
+    assert noise < 3e-2                                      # the reference's own bf16 computation
+    assert err < 1.5 * noise + 2e-3 and err_chunked < 1.5 * noise + 2e-3
+    assert rel.max() < 3e-2, rel.max()
     assert got[7] == got[3]
-    gap = np.sort(want)[1] - np.sort(want)[0]
-    if gap > 4 * np.abs(got - want).max():
-        assert int(got.argmin()) == int(want.argmin())
-    print(f"gemma3-4b joint: max rel diff {rel.max():.2e}, mean {rel.mean():.2e}, loss range [{want.min():.4f}, {want.max():.4f}]")
+    gap = np.sort(want32)[1] - np.sort(want32)[0]
+    if gap > 4 * np.abs(got - want32).max():
+        assert int(got.argmin()) == int(want32.argmin())
 
 
 def test_run_experiment_writes_reference_artifacts(tmp_path):

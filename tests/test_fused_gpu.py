@@ -294,6 +294,10 @@ def _ragged_attention_reference(q, k, v, pk, pv, plan, P, scale):
     (5, 6, 44, 20, 40, 4, 4, 64, False),      # three tiles (the C3 lengths)
     (3, 4, 50, 10, 0, 4, 2, 128, False),      # no prefix, four tiles
     (5, 6, 20, 5, 70, 8, 4, 128, True),       # prefix partial computed elsewhere, merged in the epilogue
+    (3, 4, 303, 20, 20, 8, 4, 256, False),    # Gemma-3 joint block: 256-wide grouped heads, five 64-query stretches, streamed keys
+    (4, 6, 100, 10, 21, 4, 4, 128, False),    # 121 keys x 128: past the resident-LDS budget, streamed, two stretches
+    (5, 6, 70, 10, 5, 4, 2, 64, False),       # two stretches with every chunk resident in LDS
+    (2, 3, 303, 5, 0, 2, 1, 256, True),       # long blocks + merged prefix partial
 ])
 def test_ragged_attention_kernel_vs_fp32_loops(dtype, m, n_opt, L, T, P, H, Hk, Dh, merge):
     from bimodalattack_amd import ops
@@ -303,7 +307,7 @@ def test_ragged_attention_kernel_vs_fp32_loops(dtype, m, n_opt, L, T, P, H, Hk, 
     cand = np.tile(parent, (m, 1))
     for i in range(m):
         cand[i, rng.integers(0, n_opt)] = 100 + i
-    plan = ragged_plan(cand, parent, L, T, P, n_opt + m * L - 3)
+    plan = ragged_plan(cand, parent, L, T, P, n_opt + m * L - 3) or ragged_plan(cand, parent, L, T, P)
     N = plan["N"]
     g = torch.Generator(device=DEV).manual_seed(N)
     q, k, v = (torch.randn((N, hh, Dh), generator=g, device=DEV).to(dtype) for hh in (H, Hk, Hk))
@@ -323,6 +327,39 @@ def test_ragged_attention_kernel_vs_fp32_loops(dtype, m, n_opt, L, T, P, H, Hk, 
         got = ops.ragged_attention(as4(q), as4(k), as4(v), as4(pk) if P else None, as4(pv) if P else None, *args)
     tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
     assert got.shape == (N, H, Dh) and float((got.float().cpu() - ref).abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Hk,L,Dh,P", [(5, 8, 4, 303, 256, 20), (7, 4, 4, 44, 128, 21), (3, 4, 2, 65, 64, 0),
+                                           (2, 2, 1, 17, 32, 128)])
+def test_fused_block_attention_equals_sdpa(dtype, B, H, Hk, L, Dh, P):
+    """Padded candidate blocks through the one-launch kernel (shared prefix + causal self attention, grouped
+    heads in place) against torch's attention over the concatenated [prefix | own] sequence in fp32."""
+    from bimodalattack_amd import prefix_attention as pa
+    g = torch.Generator(device=DEV).manual_seed(B * L + P)
+    # the projections' memory order is (B,L,heads,Dh); HF hands the attention function (B,heads,L,Dh) views
+    q, k, v = (torch.randn((B, L, hh, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2) for hh in (H, Hk, Hk))
+    pk, pv = (torch.randn((1, max(P, 1), Hk, Dh), generator=g, device=DEV).to(dtype)[:, :P].transpose(1, 2) for _ in range(2))
+
+    class KV:                                                  # the two things _fused_block_attention asks of the cache
+        pass
+    kv = KV()
+    kv.P = P
+    kv.prefix = lambda layer, n_rep: (pk, pv)
+    scale = Dh ** -0.5
+    got = pa._fused_block_attention(kv, 0, q, k, v, scale)
+    assert got is not None and got.shape == (B, L, H, Dh)
+    rep = H // Hk
+    kk = torch.cat([pk.expand(B, -1, -1, -1), k], dim=2).float().repeat_interleave(rep, dim=1)
+    vv = torch.cat([pv.expand(B, -1, -1, -1), v], dim=2).float().repeat_interleave(rep, dim=1)
+    mask = torch.ones((L, P + L), dtype=torch.bool, device=DEV)
+    mask[:, P:] = torch.tril(torch.ones((L, L), dtype=torch.bool, device=DEV))
+    s_ = (q.float() @ kk.transpose(-1, -2)) * scale
+    want = (torch.softmax(s_.masked_fill(~mask, float("-inf")), -1) @ vv).transpose(1, 2)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert float((got.float() - want).abs().max()) < tol
+    # a (B,heads,L,Dh) tensor that is NOT a view of (B,L,heads,Dh) memory is refused, not mis-read
+    assert pa._fused_block_attention(kv, 0, q.contiguous(), k, v, scale) is None or H == 1
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -124,6 +124,16 @@ def cases():
         cs, cf, cl = (torch.from_numpy(plan[n]).to(DEV) for n in ("cstart", "cfirst", "clen"))
         return lambda: ops.ragged_attention(q, k, v, pk, pv, cs, cf, cl, L, Dh ** -0.5)
 
+    def block_attn(B, L, P, H, Hk, Dh):
+        # padded candidate blocks (trivially ragged: first = 0, len = L) with grouped key/value heads: Gemma-3 joint
+        q = torch.randn((1, B * L, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2)
+        k, v = (torch.randn((1, B * L, Hk, Dh), generator=g, device=DEV).to(bf).transpose(1, 2) for _ in range(2))
+        pk, pv = (torch.randn((1, P, Hk, Dh), generator=g, device=DEV).to(bf).transpose(1, 2) for _ in range(2))
+        cs = torch.arange(B, dtype=torch.int32, device=DEV) * L
+        cf = torch.zeros(B, dtype=torch.int32, device=DEV)
+        cl = torch.full((B,), L, dtype=torch.int32, device=DEV)
+        return lambda: ops.ragged_attention(q, k, v, pk, pv, cs, cf, cl, L, Dh ** -0.5)
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -139,6 +149,8 @@ def cases():
         "rope/c3r_N17152_H32_Dh128": ("rope", lambda: rope_rows(17152, 32, 128)),
         "attn_merge/c3r_N17152_B481_L44": ("attn_merge", lambda: merge_rows(17152, 481, 44, 32, 128)),
         "ragged_attn/c3r_sw512_P21_L44_H32_Dh128": ("ragged_attn", lambda: ragged_attn(512, 19, 44, 20, 21, 32, 128)),
+        "ragged_attn/gemma_B164_L303_P20_H8_Hk4_Dh256": ("ragged_attn", lambda: block_attn(164, 303, 20, 8, 4, 256)),
+        "ragged_attn/c4_B512_L45_P0_H32_Dh128": ("ragged_attn", lambda: block_attn(512, 45, 0, 32, 32, 128)),
         "gather_rows/c3r_21164_of_17152x4096": ("gather_rows", lambda: gather(17152, 481 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
         "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
