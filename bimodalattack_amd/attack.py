@@ -46,7 +46,7 @@ from .dist import CandidateSharder
 from .fused import FusedInference
 from . import gemm_tuning
 from .hf_adapter import HFAdapter
-from .layout import ragged_plan, ragged_rows, dynamic_width, segment_order, split_at_suffix
+from .layout import ragged_plan, ragged_rows, dynamic_width, segment_order, split_at_suffix, unique_rows
 from .utils import INIT_CHARS, FilterJob, get_nonascii_toks, is_oom, plan_chunk
 
 logger = logging.getLogger("gcg")
@@ -162,6 +162,7 @@ class BimodalAttack:
         self._feat_graph = None                    # image -> image features (no autograd)
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
+        self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv)
@@ -444,23 +445,21 @@ class BimodalAttack:
             self.graphs_captured.append("prefix:" + "|".join(key))
         return g(feats)
 
-    def _ragged_logits(self, mine: Tensor, parent: Tensor, segs, L: int, P: int, cache,
-                       n_rows: Optional[int] = None) -> Optional[Tensor]:
-        """Target logits (m,T,V) through the ragged forward, or None when this draw does not fit
-        the fixed row budget (then the caller scores the padded block)."""
-        cfg, hf = self.config, self.hf
-        m, n_opt = mine.shape
-        parent = parent.reshape(1, n_opt).to(mine.device)
-        both = torch.cat([mine, parent], dim=0)
-        host = both.cpu().numpy()                    # waits for the sampling kernels only
-        plan = ragged_plan(host[:m], host[m], L, self.T, P, n_rows)
+    def _ragged_logits(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
+                       n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None) -> Optional[Tensor]:
+        """Target logits (m_out,T,V) through the ragged forward, or None when this draw does not fit the row
+        count asked for (then the caller scores the padded block).  host_ids: this rank's DISTINCT candidates
+        (host copy); inverse: which of them each candidate to report is (None: one each, in order)."""
+        hf, dev = self.hf, self.model.device
+        fused = bool(self.model.dtype in (torch.bfloat16, torch.float16) and hf.head_dim in (32, 64, 128, 256))
+        plan = ragged_plan(host_ids, host_parent, L, self.T, P, n_rows, dedup=False, padded_maps=not fused,
+                           inverse=inverse)
         if plan is None:
             return None
         from .prefix_attention import RaggedMaps
-        maps = RaggedMaps(plan, mine.device)
-        mu = int(plan["m"])           # distinct candidates, in the plan's (sorted) order: duplicates are computed once
-        both = torch.from_numpy(np.concatenate([plan["cand"], host[m:m + 1]])).to(mine.device, non_blocking=True)
-        x = ops.splice(segs, mu + 1, self.embedding_layer.weight, both.contiguous(), hf.emb_scale)
+        mu = int(plan["m"])           # distinct candidates, in the plan's order: duplicates are computed once
+        maps = RaggedMaps(plan, dev, ids=np.concatenate([plan["cand"], host_parent.reshape(1, -1)]), stage=self._stage)
+        x = ops.splice(segs, mu + 1, self.embedding_layer.weight, maps.ids, hf.emb_scale)
         rows = ops.gather_rows(x.view((mu + 1) * L, x.shape[-1]), maps.flat).unsqueeze(0)
         del x
         st = self.score_stats
@@ -480,28 +479,40 @@ class BimodalAttack:
                           allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
-        dealt = None           # (order over distinct candidates, inverse map, distinct count) when dealing
+        dealt = None           # (order over distinct candidates, inverse map, distinct count, first positions) when dealing
         emulate = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else 0
         world = emulate or self.shard.world
-        if (self.shard.enabled or emulate) and parent is not None and allow_prefix and self.opt.ragged_suffix \
-                and hf.ragged_ok is not False and hf.shared_ok is not False and n > world:
+        want_ragged = bool(parent is not None and allow_prefix and self.opt.ragged_suffix and hf.ragged_ok is not False
+                           and hf.shared_ok is not False and n > 1 and self.opt.prefix_reuse and self.opt.target_rows_only
+                           and self.opt.shared_prefix_attention and hf.shared_prefix_configs())
+        host_mine = host_par = inv_mine = None
+        if want_ragged:
+            # ONE device-to-host copy (ids + parent) and ONE exact dedup per step feed both the partition over
+            # ranks and the ragged plan
+            both_h = torch.cat([sampled, parent.reshape(1, -1).to(sampled.device)], dim=0).cpu().numpy()
+            host_all, host_par = both_h[:n], both_h[n]
+            uniq, inv = unique_rows(host_all)
+        if want_ragged and (self.shard.enabled or emulate) and n > world:
             # Ragged scoring on several GPUs: every rank sees the same ids, so each can drop the
             # duplicates, sort the distinct candidates by first replaced position and take every
             # world-th one -- all ranks then compute (almost) the same number of rows, and the fixed
             # per-rank row budget is the global one divided by the world size instead of a
             # small-sample budget with its own safety margin.
-            host = sampled.cpu().numpy()
-            par = parent.reshape(-1).cpu().numpy()
-            uniq, inv = np.unique(host, axis=0, return_inverse=True)
-            diff = uniq != par[None, :]
+            diff = uniq != host_par[None, :]
             first = np.where(diff.any(1), diff.argmax(1), uniq.shape[1] - 1)
             by_cost = np.argsort(first, kind="stable")
-            dealt = (by_cost, np.asarray(inv).reshape(-1), uniq.shape[0], first)
+            dealt = (by_cost, inv, uniq.shape[0], first)
             take = by_cost[0::world] if emulate else self.shard.deal(by_cost)
-            mine = torch.from_numpy(uniq[take]).to(sampled.device)
+            host_mine = np.ascontiguousarray(uniq[take])
+            mine = torch.from_numpy(host_mine).to(sampled.device)
         else:
             lo, hi = self.shard.bounds(n)
             mine = sampled[lo:hi].contiguous()
+            if want_ragged:
+                if (lo, hi) == (0, n):
+                    host_mine, inv_mine = uniq, inv
+                else:
+                    host_mine, inv_mine = unique_rows(host_all[lo:hi])
         m = mine.shape[0]
         E = self.embedding_layer.weight
         feats = None if feats is None else feats.to(E.dtype)
@@ -531,7 +542,7 @@ class BimodalAttack:
 
         losses = torch.empty(m, dtype=torch.float32, device=self.model.device)
         match = torch.zeros(m, dtype=torch.float32, device=self.model.device) if cfg.early_stop else None
-        ragged = bool(shared and parent is not None and self.opt.ragged_suffix and hf.ragged_ok is not False
+        ragged = bool(shared and want_ragged and host_mine is not None
                       and chunk >= m > 1 and tail_names[0] == "optim" and L - self.T >= mine.shape[1] - 1)
         s = 0
         while s < m:
@@ -545,7 +556,7 @@ class BimodalAttack:
                             # every rank builds the row count of the rank with the most rows (they differ by
                             # a few rows after dealing): one set of GEMM shapes per step on all ranks
                             n_rows = self._dealt_rows(dealt, world, L, mine.shape[1])
-                        logits = self._ragged_logits(mine, parent, segs, L, P, cache, n_rows)
+                        logits = self._ragged_logits(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine)
                         hf.ragged_ok = True
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):

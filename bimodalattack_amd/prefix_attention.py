@@ -144,21 +144,56 @@ class SharedPrefixKV(_CacheBase):
 
 
 class RaggedMaps:
-    """Device copies of ``layout.ragged_plan``'s index maps for one scoring forward."""
+    """Device copies of ``layout.ragged_plan``'s index maps for one scoring forward, plus the ids the
+    forward embeds (the distinct candidates, then the parent): everything the host planned goes to the
+    device in ONE copy out of a pinned staging buffer (`stage`: a dict the owner keeps between steps)."""
 
-    def __init__(self, plan: dict, device):
-        def dev(a, dtype):
-            return torch.from_numpy(a).to(device=device, dtype=dtype, non_blocking=True)
+    _INT32 = ("flat", "cstart", "cfirst", "clen", "q_src", "kv_src")
+    _INT64 = ("pos", "keep", "ids")
+
+    def __init__(self, plan: dict, device, ids=None, stage: Optional[dict] = None):
+        import numpy as np
         self.N, self.L, self.B2 = int(plan["N"]), int(plan["L"]), int(plan["m"]) + 1
         self.m_out = int(plan.get("m_out", plan["m"]))
-        self.flat = dev(plan["flat"], torch.int32)
-        self.q_src = dev(plan["q_src"], torch.int32)
-        self.kv_src = dev(plan["kv_src"], torch.int32)
-        self.pos = dev(plan["pos"], torch.int64).unsqueeze(0)
-        self.keep = dev(plan["keep"], torch.int64)
-        self.cstart = dev(plan["cstart"], torch.int32)
-        self.cfirst = dev(plan["cfirst"], torch.int32)
-        self.clen = dev(plan["clen"], torch.int32)
+        arrays = {k: plan[k] for k in self._INT32 + ("pos", "keep") if plan.get(k) is not None}
+        if ids is not None:
+            arrays["ids"] = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        # int64 arrays first: every piece stays aligned to its element size
+        order = [k for k in self._INT64 if k in arrays] + [k for k in self._INT32 if k in arrays]
+        sizes = [arrays[k].size * (8 if k in self._INT64 else 4) for k in order]
+        total = (sum(sizes) + 7) // 8 * 8
+        pin = None if stage is None else stage.get("pin")
+        if stage is not None and stage.get("event") is not None:
+            stage["event"].synchronize()          # last step's copy has left the staging buffer (long since)
+        if pin is None or pin.numel() < total:
+            pin = torch.empty(max(total, 1 << 16), dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+            if stage is not None:
+                stage["pin"] = pin
+        host = pin.numpy()
+        at, where = 0, {}
+        for k, nb in zip(order, sizes):
+            dt = np.int64 if k in self._INT64 else np.int32
+            host[at:at + nb].view(dt)[:] = arrays[k].astype(dt, copy=False).reshape(-1)
+            where[k] = (at, nb)
+            at += nb
+        dev = torch.empty(total, dtype=torch.uint8, device=device)
+        dev.copy_(pin[:total], non_blocking=True)
+        if stage is not None:
+            # the staging buffer is rewritten next step: that copy must have left it by then
+            stage["event"] = torch.cuda.Event()
+            stage["event"].record(torch.cuda.current_stream(device))
+
+        def view(k):
+            if k not in where:
+                return None
+            a, nb = where[k]
+            return dev[a:a + nb].view(torch.int64 if k in self._INT64 else torch.int32)
+
+        self.flat, self.q_src, self.kv_src = view("flat"), view("q_src"), view("kv_src")
+        self.pos = view("pos").unsqueeze(0)
+        self.keep = view("keep")
+        self.cstart, self.cfirst, self.clen = view("cstart"), view("cfirst"), view("clen")
+        self.ids = None if ids is None else view("ids").view(-1, int(plan["n_opt"]))
         self.fused_ok = True           # cleared if the one-launch attention kernel refuses the shapes
 
 
@@ -291,6 +326,8 @@ def _ragged_attention(kv: SharedPrefixKV, layer_idx: int, query, key, value, n_r
             out = ops.ragged_attention(query, key, value, None, None, rg.cstart, rg.cfirst, rg.clen, rg.L, scale,
                                        o1=o1, lse1=l1.reshape(H, N).contiguous())
         return out.unsqueeze(0)
+    if rg.q_src is None:
+        raise RuntimeError("ragged maps were built without the padded-block maps the library attention route needs")
     q_rows, k_rows, v_rows = _rows(query), _rows(key), _rows(value)
     Kp, Vp = kv.prefix(layer_idx, n_rep)
     o1, l1 = _partial_attention(q_rows.unsqueeze(0).transpose(1, 2), Kp, Vp, False, scale)

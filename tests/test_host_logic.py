@@ -282,3 +282,24 @@ def test_bench_launches_its_own_ranks():
                        env=dict(env, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and json.loads(r.stdout.strip())["rank"] == 1
+
+
+def test_unique_rows_is_exact_and_ordered_by_first_appearance(monkeypatch):
+    """layout.unique_rows: np.unique(axis=0)'s groups, in order of first appearance; a hash collision (forced
+    here by a constant hash) falls back to the exact path instead of merging different rows."""
+    from bimodalattack_amd import layout
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        a = rng.integers(0, 3, (int(rng.integers(1, 300)), int(rng.integers(1, 22))))
+        u, inv = layout.unique_rows(a)
+        assert np.array_equal(u[inv], a) and len(u) == len(np.unique(a, axis=0))
+        firsts = [int(np.where((a == r).all(1))[0][0]) for r in u]
+        assert firsts == sorted(firsts)
+    big = rng.integers(0, 2 ** 40, (512, 19))
+    big[100] = big[7]
+    u, inv = layout.unique_rows(big)
+    assert len(u) == 511 and inv[100] == inv[7] == 7
+    monkeypatch.setattr(layout, "_HASH_MUL", np.zeros(64, dtype=np.uint64))       # every row hashes to 0
+    a = rng.integers(0, 5, (40, 6))
+    u, inv = layout.unique_rows(a)
+    assert np.array_equal(u[inv], a) and len(u) == len(np.unique(a, axis=0))
