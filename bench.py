@@ -237,6 +237,20 @@ class GemmTimer:
             mod.register_forward_pre_hook(self._pre)
             mod.register_forward_hook(self._post(label, n_out, mod.in_features))
 
+    # products issued outside an nn.Linear (the fused gate/up product, fused.py) are bracketed through these
+    def begin(self, x):
+        if x.numel() // x.shape[-1] < self.min_rows:
+            return None
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, e0, label, x, n_out, k_in):
+        if e0 is not None:
+            e1 = self.torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.rec.append((label, x.numel() // x.shape[-1], n_out, k_in, e0, e1))
+
     def _pre(self, mod, args):
         if self.on and args and args[0].numel() // args[0].shape[-1] >= self.min_rows:
             e = self.torch.cuda.Event(enable_timing=True)
@@ -399,6 +413,7 @@ def main() -> None:
     attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(
         step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse, width_override=width_of))
     gemms = GemmTimer(model, attack.fused.qkv if attack.fused.enabled else [])
+    attack.fused.gemm_probe = gemms
     log("engine constructed; running")
     res = attack.run(messages, goal, target, image)
     log("run finished")

@@ -165,7 +165,8 @@ class BimodalAttack:
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
-        self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv)
+        self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
+                                    self.opt.fuse_gate_up)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")

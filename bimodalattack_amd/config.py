@@ -109,6 +109,9 @@ class EngineOptions:
     # q_proj/k_proj/v_proj of an attention block as one GEMM against the concatenated weight (16-bit
     # models; one more copy of those matrices): fewer partly filled tile rounds, one weight stream.
     fuse_qkv: bool = True
+    # gate_proj / up_proj of a gated MLP as one GEMM against their chunk-interleaved weights (16-bit models; one
+    # more copy of those two matrices, two in the gradient pass): see fused.py.
+    fuse_gate_up: bool = True
     # joint_eval: the step's loss is the winner's row of the candidate batch (scored with the image, in the
     # re-score's own segment order) instead of a second, batch-1 forward of the same sequence (:605-612).
     joint_winner_from_batch: bool = True
@@ -179,6 +182,8 @@ class EngineOptions:
             opts.joint_winner_from_batch = env["BMA_JOINT_WINNER_FROM_BATCH"] not in ("0", "false", "False")
         if "BMA_FUSE_QKV" in env:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
+        if "BMA_FUSE_GATE_UP" in env:
+            opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:
             opts.backward_weight_copies = env["BMA_BACKWARD_WEIGHT_COPIES"] not in ("0", "false", "False")
         if "BMA_SHARED_PREFIX_ATTENTION" in env:

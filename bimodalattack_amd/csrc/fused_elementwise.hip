@@ -189,21 +189,25 @@ __device__ __forceinline__ uint4_t swiglu_chunk(const uint4_t& gw, const uint4_t
 // the 6 TB/s a 2-read + 1-write stream gets on this part.)
 constexpr int kSwiChunks = 4;
 
-template <int DT, int ACT>
+// IL: gate and up come as alternating 16-byte chunks of ONE array (the output of the gate_proj/up_proj
+// product against their chunk-interleaved weights, fused.py): chunk i of the output reads chunks 2i and 2i+1.
+template <int DT, int ACT, bool IL>
 __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
                                                      int64_t n_chunks, uint4_t* __restrict__ y) {
   const int64_t base = static_cast<int64_t>(blockIdx.x) * (kSwiChunks * 256) + threadIdx.x;
+  constexpr int S = IL ? 2 : 1;
+  if (IL) u = g + 1;
   if (base + (kSwiChunks - 1) * 256 < n_chunks) {
     uint4_t gw[kSwiChunks], uw[kSwiChunks];
 #pragma unroll
-    for (int j = 0; j < kSwiChunks; ++j) { gw[j] = g[base + j * 256]; uw[j] = u[base + j * 256]; }
+    for (int j = 0; j < kSwiChunks; ++j) { gw[j] = g[S * (base + j * 256)]; uw[j] = u[S * (base + j * 256)]; }
 #pragma unroll
     for (int j = 0; j < kSwiChunks; ++j) y[base + j * 256] = swiglu_chunk<DT, ACT>(gw[j], uw[j]);
   } else {
 #pragma unroll
     for (int j = 0; j < kSwiChunks; ++j) {
       const int64_t i = base + j * 256;
-      if (i < n_chunks) y[i] = swiglu_chunk<DT, ACT>(g[i], u[i]);
+      if (i < n_chunks) y[i] = swiglu_chunk<DT, ACT>(g[S * i], u[S * i]);
     }
   }
 }
@@ -323,11 +327,11 @@ extern "C" int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t
   }
 }
 
-extern "C" int bma_gated_act(const void* gate, const void* up, int64_t n, int dtype, int act, void* out,
-                             void* stream) {
+static int gated_act_launch(const void* gate, const void* up, bool interleaved, int64_t n, int dtype, int act, void* out,
+                            void* stream) {
   if (n < 0 || (act != 0 && act != 1)) return BMA_EINVAL;
   if (n == 0) return BMA_OK;
-  if (!gate || !up || !out) return BMA_EINVAL;
+  if (!gate || (!interleaved && !up) || !out) return BMA_EINVAL;
   if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
   const int es = dtype == BMA_F32 ? 4 : 2;
   if ((n * es) % 16) return BMA_EALIGN;
@@ -342,10 +346,15 @@ extern "C" int bma_gated_act(const void* gate, const void* up, int64_t n, int dt
   const uint4_t* u = static_cast<const uint4_t*>(up);
   uint4_t* y = static_cast<uint4_t*>(out);
   BMA_PROF_BEGIN(BMA_K_SWIGLU, st, 3.0 * static_cast<double>(n) * es);
-#define BMA_GA_GO(DT_)                                                                                   \
-  do {                                                                                                   \
-    if (act == 0) hipLaunchKernelGGL((swiglu_kernel<DT_, 0>), grid, block, 0, st, g, u, chunks, y);       \
-    else hipLaunchKernelGGL((swiglu_kernel<DT_, 1>), grid, block, 0, st, g, u, chunks, y);                \
+#define BMA_GA_GO(DT_)                                                                                          \
+  do {                                                                                                          \
+    if (interleaved) {                                                                                          \
+      if (act == 0) hipLaunchKernelGGL((swiglu_kernel<DT_, 0, true>), grid, block, 0, st, g, u, chunks, y);      \
+      else hipLaunchKernelGGL((swiglu_kernel<DT_, 1, true>), grid, block, 0, st, g, u, chunks, y);               \
+    } else {                                                                                                    \
+      if (act == 0) hipLaunchKernelGGL((swiglu_kernel<DT_, 0, false>), grid, block, 0, st, g, u, chunks, y);     \
+      else hipLaunchKernelGGL((swiglu_kernel<DT_, 1, false>), grid, block, 0, st, g, u, chunks, y);              \
+    }                                                                                                           \
   } while (0)
   if (dtype == BMA_F32) BMA_GA_GO(BMA_F32);
   else if (dtype == BMA_BF16) BMA_GA_GO(BMA_BF16);
@@ -354,6 +363,15 @@ extern "C" int bma_gated_act(const void* gate, const void* up, int64_t n, int dt
   BMA_PROF_END(BMA_K_SWIGLU, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+extern "C" int bma_gated_act(const void* gate, const void* up, int64_t n, int dtype, int act, void* out,
+                             void* stream) {
+  return gated_act_launch(gate, up, false, n, dtype, act, out, stream);
+}
+
+extern "C" int bma_gated_act_il(const void* gate_up, int64_t n, int dtype, int act, void* out, void* stream) {
+  return gated_act_launch(gate_up, nullptr, true, n, dtype, act, out, stream);
 }
 
 extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream) {
@@ -576,16 +594,18 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint4_t
   }
 }
 
-template <int DT, int ACT>
+template <int DT, int ACT, bool IL>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint4_t* __restrict__ g, const uint4_t* __restrict__ u,
                                                          const uint4_t* __restrict__ dy, int64_t n_chunks,
                                                          uint4_t* __restrict__ dg, uint4_t* __restrict__ du) {
   constexpr int NE = Chunk<DT>::NE;
+  constexpr int S = IL ? 2 : 1;                 // IL: gate/up and their gradients as alternating chunks of one array
+  if (IL) { u = g + 1; du = dg + 1; }
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_chunks; i += stride) {
     float gf[NE], uf[NE], df[NE], og[NE], ou[NE];
-    Chunk<DT>::unpack(g[i], gf);
-    Chunk<DT>::unpack(u[i], uf);
+    Chunk<DT>::unpack(g[S * i], gf);
+    Chunk<DT>::unpack(u[S * i], uf);
     Chunk<DT>::unpack(dy[i], df);
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
@@ -602,8 +622,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint4_t* __restri
         og[j] = df[j] * uf[j] * d;
       }
     }
-    dg[i] = Chunk<DT>::pack(og);
-    du[i] = Chunk<DT>::pack(ou);
+    dg[S * i] = Chunk<DT>::pack(og);
+    du[S * i] = Chunk<DT>::pack(ou);
   }
 }
 
@@ -656,11 +676,11 @@ extern "C" int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy
   }
 }
 
-extern "C" int bma_gated_act_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, int act,
-                                 void* dgate, void* dup, void* stream) {
+static int gated_act_bwd_launch(const void* gate, const void* up, bool interleaved, const void* dy, int64_t n, int dtype,
+                                int act, void* dgate, void* dup, void* stream) {
   if (n < 0 || (act != 0 && act != 1)) return BMA_EINVAL;
   if (n == 0) return BMA_OK;
-  if (!gate || !up || !dy || !dgate || !dup) return BMA_EINVAL;
+  if (!gate || !dy || !dgate || (!interleaved && (!up || !dup))) return BMA_EINVAL;
   if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
   const int es = dtype == BMA_F32 ? 4 : 2;
   if ((n * es) % 16) return BMA_EALIGN;
@@ -677,10 +697,15 @@ extern "C" int bma_gated_act_bwd(const void* gate, const void* up, const void* d
   const uint4_t* d = static_cast<const uint4_t*>(dy);
   uint4_t* og = static_cast<uint4_t*>(dgate);
   uint4_t* ou = static_cast<uint4_t*>(dup);
-#define BMA_GB_GO(DT_)                                                                                         \
-  do {                                                                                                         \
-    if (act == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 0>), grid, block, 0, st, g, u, d, chunks, og, ou); \
-    else hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 1>), grid, block, 0, st, g, u, d, chunks, og, ou);          \
+#define BMA_GB_GO(DT_)                                                                                                  \
+  do {                                                                                                                  \
+    if (interleaved) {                                                                                                  \
+      if (act == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 0, true>), grid, block, 0, st, g, u, d, chunks, og, ou);  \
+      else hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 1, true>), grid, block, 0, st, g, u, d, chunks, og, ou);           \
+    } else {                                                                                                            \
+      if (act == 0) hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 0, false>), grid, block, 0, st, g, u, d, chunks, og, ou); \
+      else hipLaunchKernelGGL((swiglu_bwd_kernel<DT_, 1, false>), grid, block, 0, st, g, u, d, chunks, og, ou);          \
+    }                                                                                                                   \
   } while (0)
   if (dtype == BMA_F32) BMA_GB_GO(BMA_F32);
   else if (dtype == BMA_BF16) BMA_GB_GO(BMA_BF16);
@@ -688,6 +713,16 @@ extern "C" int bma_gated_act_bwd(const void* gate, const void* up, const void* d
 #undef BMA_GB_GO
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+extern "C" int bma_gated_act_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, int act,
+                                 void* dgate, void* dup, void* stream) {
+  return gated_act_bwd_launch(gate, up, false, dy, n, dtype, act, dgate, dup, stream);
+}
+
+extern "C" int bma_gated_act_il_bwd(const void* gate_up, const void* dy, int64_t n, int dtype, int act, void* dgate_up,
+                                    void* stream) {
+  return gated_act_bwd_launch(gate_up, nullptr, true, dy, n, dtype, act, dgate_up, nullptr, stream);
 }
 
 extern "C" int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, void* dgate,

@@ -49,9 +49,12 @@ SKINNY_ROWS = 1024     # rows up to which the gradient pass takes its input grad
 
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
-                 fuse_qkv: bool = True):
+                 fuse_qkv: bool = True, fuse_gate_up: bool = True):
         self.enabled = enabled
         self.weight_copies = weight_copies
+        self.fuse_gate_up = fuse_gate_up
+        self.gemm_probe = None                       # measurement hook for products no nn.Linear module owns
+        self._wgu = {}                               # MLP -> chunk-interleaved [gate_proj; up_proj] weight
         self.qkv: List[torch.nn.Module] = []        # attention blocks whose q/k/v projections run as one GEMM
         self._wqkv = {}
         self.norms: List[Tuple[torch.nn.Module, float, bool]] = []
@@ -215,12 +218,58 @@ class FusedInference:
 
         return first, later(1), later(2)
 
+    def _gate_up_weight(self, m):
+        """The chunk-interleaved [gate_proj; up_proj] weight of a 16-bit MLP (ops.interleave_gate_up), or None when
+        the block does not qualify (or a capture is running and the copy does not exist yet)."""
+        if not self.fuse_gate_up:
+            return None
+        w = self._wgu.get(id(m))
+        if w is None:
+            g, u = m.gate_proj, m.up_proj
+            ok = all(type(l) is torch.nn.Linear and l.bias is None for l in (g, u)) \
+                and g.weight.shape == u.weight.shape and g.weight.dtype == u.weight.dtype \
+                and g.weight.dtype in (torch.bfloat16, torch.float16) and g.out_features % 8 == 0
+            if not ok:
+                self._wgu[id(m)] = False
+                return None
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            with torch.no_grad():
+                w = ops.interleave_gate_up(g.weight.detach(), u.weight.detach())
+            self._wgu[id(m)] = w
+        return w if w is not False else None
+
     def _mlp_forward(self, m, orig):
         act = self._act_code(m.act_fn)
 
         def forward(x):
             if not self._usable(x):
                 return orig(x)
+            w = self._gate_up_weight(m) if x.dtype == m.gate_proj.weight.dtype else None
+            if w is not None:
+                # gate_proj and up_proj as ONE product against their chunk-interleaved weights: N = 2I fills the
+                # 256-CU tile rounds better than two N = I products (22.5 of 23 rounds instead of 2 x 11.25 of 12
+                # at 17k rows; 3.0 of 4 instead of 2 x 1.5 of 2 at an eighth of them), one weight stream and one
+                # input-gradient product in the ~70-row gradient pass; the gate kernel reads the alternating chunks
+                if self._tracking(x):
+                    if self.weight_copies and x.numel() // x.shape[-1] <= SKINNY_ROWS:
+                        wt = self._wt.get(("gu", id(m)))
+                        if wt is None and not torch.cuda.is_current_stream_capturing():
+                            with torch.no_grad():
+                                wt = w.t().contiguous()
+                            self._wt[("gu", id(m))] = wt
+                        y = ops.FrozenLinearFn.apply(x, w, wt) if wt is not None else torch.nn.functional.linear(x, w)
+                    else:
+                        y = torch.nn.functional.linear(x, w)
+                    return m.down_proj(ops.SwiGLUInterleavedFn.apply(y, act))
+                probe = self.gemm_probe
+                if probe is not None and probe.on:       # bench.py's HIP-event bracket (profiled steps only)
+                    t0 = probe.begin(x)
+                    y = torch.nn.functional.linear(x, w)
+                    probe.end(t0, "gate_up_proj", x, w.shape[0], w.shape[1])
+                else:
+                    y = torch.nn.functional.linear(x, w)
+                return m.down_proj(ops.swiglu_il(y, act))
             g, u = m.gate_proj(x), m.up_proj(x)
             if (g.numel() * g.element_size()) % 16:
                 return m.down_proj(m.act_fn(g) * u)

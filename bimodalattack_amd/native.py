@@ -56,6 +56,8 @@ PROTOTYPES = {
     "bma_rmsnorm": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bma_swiglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bma_gated_act": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "bma_gated_act_il": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "bma_gated_act_il_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "bma_gated_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "bma_rope": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int,
                          c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),

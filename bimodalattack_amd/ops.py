@@ -271,6 +271,48 @@ def swiglu(gate: torch.Tensor, up: torch.Tensor, act: int = ACT_SILU) -> torch.T
     return out
 
 
+def interleave_gate_up(gate_w: torch.Tensor, up_w: torch.Tensor) -> torch.Tensor:
+    """(2I, D) weight whose product with x gives gate and up as alternating 16-byte chunks: rows
+    [16j, 16j+8) are gate rows [8j, 8j+8), rows [16j+8, 16j+16) the matching up rows (8 = 16 B of a 16-bit
+    dtype, 4 for fp32)."""
+    I, D = gate_w.shape
+    ne = 16 // gate_w.element_size()
+    if up_w.shape != (I, D) or I % ne:
+        raise ValueError("gate/up weights must agree in shape, with a row count that is a multiple of one 16-byte chunk")
+    return torch.stack([gate_w.reshape(I // ne, ne, D), up_w.reshape(I // ne, ne, D)], dim=1).reshape(2 * I, D).contiguous()
+
+
+def swiglu_il(gate_up: torch.Tensor, act: int = ACT_SILU) -> torch.Tensor:
+    """dt(dt(act(gate)) * up) for gate/up interleaved in 16-byte chunks along the last dimension (2I -> I)."""
+    dev = _need_gpu(gate_up)
+    gate_up = gate_up.contiguous()
+    two_i = gate_up.shape[-1]
+    if two_i % (2 * (16 // gate_up.element_size())):
+        raise ValueError("last dimension must hold whole pairs of 16-byte chunks")
+    out = torch.empty(gate_up.shape[:-1] + (two_i // 2,), dtype=gate_up.dtype, device=dev)
+    check("bma_gated_act_il", lib.bma_gated_act_il(gate_up.data_ptr(), out.numel(), _dt(gate_up), int(act), out.data_ptr(),
+                                                   _stream(dev)))
+    return out
+
+
+class SwiGLUInterleavedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate_up, act=ACT_SILU):
+        gu = gate_up.contiguous()
+        ctx.save_for_backward(gu)
+        ctx.act = int(act)
+        return swiglu_il(gu, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (gu,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dgu = torch.empty_like(gu)
+        check("bma_gated_act_il_bwd", lib.bma_gated_act_il_bwd(gu.data_ptr(), dy.data_ptr(), dy.numel(), _dt(gu), ctx.act,
+                                                               dgu.data_ptr(), _stream(gu.device)))
+        return dgu, None
+
+
 def rope_(q: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
     """In-place rotary embedding of q (B,H,L,Dh; any strides with a contiguous last dim);
     cos/sin (1|B, L, Dh)."""

@@ -159,6 +159,10 @@ int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out
 /* bma_gated_act: out = dt(dt(act(gate)) * up); act 0 = SiLU (== bma_swiglu), 1 = GELU-tanh as
  *   aten evaluates gelu(x, approximate="tanh") (Gemma's gated MLP). */
 int bma_gated_act(const void* gate, const void* up, int64_t n, int dtype, int act, void* out, void* stream);
+/* bma_gated_act_il: the same with gate and up as ALTERNATING 16-byte chunks of one array of 2n elements (chunk
+ *   2i = gate chunk i, chunk 2i+1 = up chunk i): the output of ONE product against the chunk-interleaved
+ *   gate_proj/up_proj weights instead of two products.  out: n elements, contiguous. */
+int bma_gated_act_il(const void* gate_up, int64_t n, int dtype, int act, void* out, void* stream);
 int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l,
                      int B, int H, int L, int Dh, const void* cos, const void* sin,
                      int cos_batch, int dtype, void* stream);
@@ -176,6 +180,9 @@ int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, int64_t n, 
                    void* dgate, void* dup, void* stream);
 int bma_gated_act_bwd(const void* gate, const void* up, const void* dy, int64_t n, int dtype, int act,
                       void* dgate, void* dup, void* stream);
+/* ... and for the chunk-interleaved layout of bma_gated_act_il: dgate_up has gate_up's layout (2n elements). */
+int bma_gated_act_il_bwd(const void* gate_up, const void* dy, int64_t n, int dtype, int act, void* dgate_up,
+                         void* stream);
 /* bma_attn_merge: merges the two partial attentions of the shared-prefix scheme (new tokens
  *   vs the prompt prefix shared by all candidates; new tokens vs themselves, causal):
  *   out = w*o1 + (1-w)*o2 with w = 1/(1+exp(lse2-lse1)).  o1, o2, out: [B][L][H][Dh] contiguous

@@ -598,7 +598,7 @@ def test_16bit_engine_paths_agree(dtype):
     model: same candidates (CPU draws), first-step candidate losses equal to 16-bit rounding noise."""
     from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
     variants = [dict(), dict(ragged_suffix=False), dict(shared_prefix_attention=False), dict(prefix_reuse=False),
-                dict(fuse_qkv=False, backward_weight_copies=False, graph_gradient=False)]
+                dict(fuse_qkv=False, fuse_gate_up=False, backward_weight_copies=False, graph_gradient=False)]
     out = []
     for eng in variants:
         model, tok, proc, image = S.tiny_case("llava", dtype=dtype, device=DEV)

@@ -104,6 +104,40 @@ def test_swiglu_vs_eager(dtype):
                 np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), rtol=2 * ulp, atol=0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_interleaved_gate_up_equals_separate(dtype):
+    """gate_proj / up_proj as one product against chunk-interleaved weights + the interleaved gate kernel:
+    the weight layout puts gate and up rows in alternating 16-byte chunks, the kernel output is bit-identical
+    to the two-array kernel on the de-interleaved halves, forward and backward; the whole MLP agrees with the
+    HuggingFace module to GEMM rounding."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    I, D, M = 11008, 512, 77
+    wg = (torch.randn((I, D), generator=g, device=DEV) * 0.05).to(dtype)
+    wu = (torch.randn((I, D), generator=g, device=DEV) * 0.05).to(dtype)
+    w = ops.interleave_gate_up(wg, wu)
+    assert w.shape == (2 * I, D)
+    assert torch.equal(w[:8], wg[:8]) and torch.equal(w[8:16], wu[:8]) and torch.equal(w[16:24], wg[8:16])
+    x = torch.randn((M, D), generator=g, device=DEV).to(dtype)
+    y = torch.nn.functional.linear(x, w)                                   # (M, 2I) interleaved
+    yg = y.view(M, I // 8, 2, 8)[:, :, 0].reshape(M, I).contiguous()
+    yu = y.view(M, I // 8, 2, 8)[:, :, 1].reshape(M, I).contiguous()
+    for act in (ops.ACT_SILU, ops.ACT_GELU_TANH):
+        assert torch.equal(ops.swiglu_il(y, act), ops.swiglu(yg, yu, act))
+        yy = y.clone().requires_grad_()
+        a, b = yg.clone().requires_grad_(), yu.clone().requires_grad_()
+        dy = torch.randn((M, I), generator=g, device=DEV).to(dtype)
+        (d_il,) = torch.autograd.grad(ops.SwiGLUInterleavedFn.apply(yy, act), yy, dy)
+        da, db = torch.autograd.grad(ops.SwiGLUFn.apply(a, b, act), (a, b), dy)
+        assert torch.equal(d_il.view(M, I // 8, 2, 8)[:, :, 0].reshape(M, I), da)
+        assert torch.equal(d_il.view(M, I // 8, 2, 8)[:, :, 1].reshape(M, I), db)
+    # a ragged tail (fewer chunks than one workgroup slab) and 3-D inputs
+    z = torch.randn((3, 5, 48), generator=g, device=DEV).to(dtype)
+    zg = z.view(3, 5, 3, 2, 8)[..., 0, :].reshape(3, 5, 24).contiguous()
+    zu = z.view(3, 5, 3, 2, 8)[..., 1, :].reshape(3, 5, 24).contiguous()
+    assert torch.equal(ops.swiglu_il(z), ops.swiglu(zg, zu))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 def test_rope_vs_hf(dtype):
     from bimodalattack_amd import ops

@@ -52,7 +52,7 @@ def main():
     import torch
     dev, dt = "cuda", torch.bfloat16
     D, I, KV = args.hidden, args.intermediate, args.kv_hidden
-    shapes = [(D + 2 * KV, D), (D, D), (I, D), (D, I)]          # fused q/k/v, o_proj, gate/up, down  as (out, in)
+    shapes = [(D + 2 * KV, D), (D, D), (I, D), (2 * I, D), (D, I)]   # fused q/k/v, o_proj, gate/up (alone, fused), down  as (out, in)
     weights = {s: (torch.randn(s, device=dev) * 0.02).to(dt) for s in shapes}
     counts = row_counts(args.search_width, args.n_opt, args.tail, args.n_replace, args.topk)
     print(f"{len(counts)} row counts x {len(shapes)} projection shapes: {counts}", flush=True)
