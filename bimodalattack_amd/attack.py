@@ -535,9 +535,10 @@ class BimodalAttack:
         L = sum((mine.shape[1] if k == "gather" else t.shape[-2]) for k, t in segs)
 
         free = torch.cuda.mem_get_info(self.model.device)[0] if m > 1 else (1 << 40)   # one candidate always fits
+        fixed = cfg.batch_size if cfg.batch_size is not None else self.opt.chunk
+        quantum = self.opt.chunk_quantum if (fixed is None and m > self.opt.chunk_quantum > 1) else 1
         chunk = plan_chunk(max(m, 1), L, P if (use_prefix and not shared) else 0, hf.kv_bytes_per_token,
-                           hf.act_bytes_per_token, free,
-                           cfg.batch_size if cfg.batch_size is not None else self.opt.chunk)
+                           hf.act_bytes_per_token, free, fixed, quantum=quantum)
         if self._chunk_cap is not None:
             chunk = min(chunk, self._chunk_cap)
 
@@ -567,11 +568,15 @@ class BimodalAttack:
                 if m > 1:
                     self.score_stats["candidates"] += b
                 if logits is None:
-                    x = ops.splice(segs, b, E, mine[s:s + b].contiguous(), hf.emb_scale)
+                    ids_b = mine[s:s + b]
+                    pad = (-b) % quantum if not self._chunk_cap else 0
+                    if pad:                      # a short last chunk: up to the next multiple, with copies of its last candidate
+                        ids_b = torch.cat([ids_b, ids_b[-1:].expand(pad, -1)], dim=0)
+                    x = ops.splice(segs, b + pad, E, ids_b.contiguous(), hf.emb_scale)
                     if m > 1:
                         st = self.score_stats
                         st["padded_calls"] += 1
-                        st["rows"] += b * L
+                        st["rows"] += (b + pad) * L
                         st["rows_needed"] += b * L
                 if logits is not None:
                     pass
@@ -593,9 +598,9 @@ class BimodalAttack:
                     kv = hf.expand_prefix(cache, b) if use_prefix else None
                     logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
                 loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
-                losses[s:s + b] = loss
+                losses[s:s + b] = loss[:b]       # (the padding's losses are dropped)
                 if match is not None:
-                    match[s:s + b] = hit.to(torch.float32)
+                    match[s:s + b] = hit[:b].to(torch.float32)
                 del x, kv, logits
                 s += b
             except Exception as e:

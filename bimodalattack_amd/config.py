@@ -137,6 +137,11 @@ class EngineOptions:
     fuse_pgd_only: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
+    # Padded scoring (no ragged rows: Gemma-3's layout, fp32 models) runs chunks whose candidate count is a
+    # multiple of this -- a short last chunk is padded with copies of its last candidate, whose losses are
+    # dropped -- so a decaying search width (reference :919-923) meets a handful of GEMM shapes, not hundreds.
+    # 1 switches it off.  Ignored when config.batch_size fixes the chunk.
+    chunk_quantum: int = 8
     # Measurement only: the candidate count of loop step i (bench.py samples the dynamic-width schedule of a
     # 600-step run, reference :919-923, at evenly spaced points of a handful of timed steps).  None: the
     # reference's schedule of this run's own num_steps.
@@ -194,6 +199,8 @@ class EngineOptions:
             opts.gemm_tuning = env["BMA_GEMM_TUNING"]
         if "BMA_FUSE_PGD_ONLY" in env:
             opts.fuse_pgd_only = env["BMA_FUSE_PGD_ONLY"] not in ("0", "false", "False")
+        if "BMA_CHUNK_QUANTUM" in env:
+            opts.chunk_quantum = max(1, int(env["BMA_CHUNK_QUANTUM"]))
         if "BMA_CHUNK" in env:
             opts.chunk = int(env["BMA_CHUNK"])
         if "BMA_STRICT" in env:

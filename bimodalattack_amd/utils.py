@@ -109,14 +109,19 @@ def is_oom(exc: BaseException) -> bool:
 
 def plan_chunk(n_candidates: int, new_tokens: int, prefix_tokens: int, kv_bytes_per_token: int,
                act_bytes_per_token: int, free_bytes: int, user_batch: Optional[int] = None,
-               token_budget: int = 49152) -> int:
+               token_budget: int = 49152, quantum: int = 1) -> int:
     """Candidates per forward.  ``user_batch`` (config.batch_size) wins when given, as in
     the reference (:521-523).  Otherwise bound (a) the new tokens in flight and (b) the
     memory of activations plus the per-candidate copy of the shared-prefix keys/values,
-    using at most half of the free HBM."""
+    using at most half of the free HBM; a bound of `quantum` candidates or more is rounded down
+    to a multiple of it (the engine pads a short last chunk up to one: GEMM shapes then come
+    from a small set whatever the search width, which a lookup-only GEMM selection can cover)."""
     if user_batch is not None:
         return max(1, min(n_candidates, int(user_batch)))
     per_cand = new_tokens * act_bytes_per_token + (prefix_tokens + new_tokens) * kv_bytes_per_token
     by_mem = max(1, int(free_bytes * 0.5) // max(per_cand, 1))
     by_tok = max(1, token_budget // max(new_tokens, 1))
-    return max(1, min(n_candidates, by_mem, by_tok))
+    cap = min(by_mem, by_tok)
+    if quantum > 1 and cap >= quantum:
+        cap -= cap % quantum
+    return max(1, min(n_candidates, cap))
