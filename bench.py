@@ -393,14 +393,21 @@ def main() -> None:
         torch.cuda.synchronize(device)
         return t
 
+    def marker() -> None:
+        """A float64 reduction no step launches: tools/trace_by_grid.py --between-markers keeps what lies between."""
+        torch.zeros(12345, device=device, dtype=torch.float64).sum()
+        torch.cuda.synchronize(device)
+
     def hook(i: int) -> None:
         log(f"step {i}/{total}" + (" (profiled, outside the timed region)" if timed_end <= i < total else ""))
         if i == args.warmup:
             for k_ in attack.score_stats:
                 attack.score_stats[k_] = 0
+            marker()                             # outside the clock: a kernel trace can be cut to the timed steps
             marks["t0"] = barrier_clock()
         if i == timed_end:
             marks["t1"] = barrier_clock()
+            marker()
             marks["stats"] = dict(attack.score_stats)
             if n_prof:
                 native.profile_enable(True)      # event brackets cost a few us per launch: kept OUT of the timing

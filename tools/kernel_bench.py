@@ -134,6 +134,15 @@ def cases():
         cl = torch.full((B,), L, dtype=torch.int32, device=DEV)
         return lambda: ops.ragged_attention(q, k, v, pk, pv, cs, cf, cl, L, Dh ** -0.5)
 
+    def gemm(M, N, K):
+        # a library product of the candidate forward (hipBLASLt / rocBLAS through torch, with the shipped GEMM
+        # selection when its validators match): not a bma kernel -- timed with torch events, PMC'd like the rest
+        from bimodalattack_amd import gemm_tuning
+        gemm_tuning.enable("auto", torch.device(DEV))
+        x = torch.randn((1, M, K), generator=g, device=DEV).to(bf)
+        w = (torch.randn((N, K), generator=g, device=DEV) * 0.02).to(bf)
+        return lambda: torch.nn.functional.linear(x, w)
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -173,6 +182,10 @@ def cases():
         "linf/llava_3x336x336": ("linf", lambda: linf(3 * 336 * 336)),
         "linf/gemma_3x896x896": ("linf", lambda: linf(3 * 896 * 896)),
         "sample_scatter/B512": ("sample_scatter", lambda: scatter(512)),
+        # the dominant kernel of a step: the fused gate/up product of the C3 ragged candidate forward
+        "gemm/gate_up_17152x22016x4096": (None, lambda: gemm(17152, 22016, 4096)),
+        "gemm/down_17152x4096x11008": (None, lambda: gemm(17152, 4096, 11008)),
+        "gemm/qkv_17152x12288x4096": (None, lambda: gemm(17152, 12288, 4096)),
     }
 
 
@@ -193,6 +206,24 @@ def main():
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize()
+        if kid is None:                       # a library GEMM: torch events on the current stream, flops not bytes
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.iters
+            M, N, K = (int(v) for v in name.rsplit("_", 1)[1].split("x"))
+            tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+            mb = 2.0 * (M * K + N * K + M * N) / 1e6
+            results[name] = dict(symbol="library GEMM", launches=args.iters, avg_us=us, algorithmic_MB=mb,
+                                 algorithmic_GFLOP=2e-9 * M * N * K, achieved_TFLOPs=tf, frac_of_2500TFLOPs=tf / 2500.0,
+                                 achieved_GBps=mb * 1e6 / (us * 1e-6) / 1e9, frac_of_8TBps=mb * 1e6 / (us * 1e-6) / 8e12)
+            print(f"{name:40s} {us:9.1f} us  {mb:9.2f} MB  {tf:8.0f} TFLOP/s  {100 * tf / 2500.0:5.1f}% of 2.5 PFLOP/s", flush=True)
+            del fn
+            torch.cuda.empty_cache()
+            continue
         native.profile_enable(True)
         for _ in range(args.iters):
             fn()

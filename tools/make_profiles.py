@@ -14,15 +14,30 @@ out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
 
 shutil.copyfile(os.path.join(src, "kernel_bench.json"), os.path.join(out, f"{tag}_kernel_bench.json"))
-for w in ("gcg", "joint"):
+for w in ("gcg", "joint", "gemma_joint"):
     for a, b in ((f"kt_{w}_kernel_stats.csv", f"{tag}_bench_{w}_kernel_stats.csv"),
                  (f"kt_{w}_by_grid.txt", f"{tag}_bench_{w}_kernel_by_grid.txt"),
                  (f"bench_{w}_under_rocprof.json", f"{tag}_bench_{w}_under_rocprof.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copyfile(os.path.join(src, a), os.path.join(out, b))
+for w in ("gcg", "joint"):                 # the batch-1 gradient pass alone (tools/grad_pass_profile.py)
+    for a, b in ((f"gp_{w}_by_grid.txt", f"{tag}_gradient_pass_{w}_by_grid.txt"), (f"gp_{w}.txt", None)):
+        pa = os.path.join(src, a)
+        if os.path.exists(pa) and b:
+            shutil.copyfile(pa, os.path.join(out, b))
+            note = os.path.join(src, f"gp_{w}.txt")
+            if os.path.exists(note):
+                last = [l for l in open(note).read().splitlines() if "gradient pass" in l][-1:]
+                with open(os.path.join(out, b), "a") as f:
+                    f.write("# " + (last[0] if last else "") + "\n")
+for extra in ("bench_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
+              "bench_gemma_joint.json", "bench_default.json"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
 for c in ("fetch", "write"):
     rows = list(csv.DictReader(open(os.path.join(src, f"{c}_counter_collection.csv"))))
-    keep = [r for r in rows if "anonymous namespace" in r["Kernel_Name"] and "at::native" not in r["Kernel_Name"]]
+    keep = [r for r in rows if ("anonymous namespace" in r["Kernel_Name"] and "at::native" not in r["Kernel_Name"])
+            or "Cijk_" in r["Kernel_Name"]]
     if len(keep) > 1500:                       # keep the committed raw rows small: every case, first 8 dispatches
         seen, small = {}, []
         for r in keep:
@@ -45,29 +60,40 @@ kb = json.load(open(os.path.join(src, "kernel_bench.json")))
 # kernel_bench case -> (bench kernel name, PMC key = "<symbol><template>/threads<total threads>")
 CASES = [
     ("rmsnorm/c3r_17152x4096", "rmsnorm", "rmsnorm_kernel<1, 2, false>/threads4390912", "17152 x 4096 bf16 (C3 ragged candidate forward)"),
-    ("swiglu/c3r_17152x11008", "swiglu", "swiglu_kernel<1, 0>/threads5900288", "17152 x 11008 bf16 (C3 ragged candidate forward)"),
+    ("swiglu/c3r_17152x11008", "swiglu", "swiglu_kernel<1, 0, false>/threads5900288", "17152 x 11008 bf16 (C3 ragged candidate forward)"),
     ("rope/c3r_N17152_H32_Dh128", "rope", "rope_kernel<1>/threads4390912", "17152 rows, H=32 Dh=128 bf16 (C3 ragged)"),
     ("ragged_attn/c3r_sw512_P21_L44_H32_Dh128", "ragged_attn", "ragged_attn_kernel<1, 3, 128>/threads92160", "17152 rows, 480 candidates x 32 heads, 21 prefix keys (C3 ragged)"),
+    ("ragged_attn/gemma_B164_L303_P20_H8_Hk4_Dh256", "ragged_attn", "ragged_attn_kernel<1, 4, 256>/threads41984", "Gemma-3 joint blocks: 164 x 303 tokens, 8 heads on 4, 256 wide, 20 prefix keys"),
+    ("ragged_attn/c4_B512_L45_P0_H32_Dh128", "ragged_attn", "ragged_attn_kernel<1, 3, 128>/threads98304", "C4 padded blocks 512 x 45, no prefix"),
     ("attn_merge/c3r_N17152_B481_L44", "attn_merge", "attn_merge_kernel<1>/threads4390912", "17152 rows vs padded 481 x 44, H=32 Dh=128 bf16 (library-attention route)"),
     ("gather_rows/c3r_21164_of_17152x4096", "gather_rows", "gather_rows_kernel/threads5417984", "21164 padded slots from 17152 rows of 8 KiB (library-attention route)"),
     ("ce_rows/llava_B512_T20_V32064", "ce_rows", "ce_rows_kernel<1, true, false>/threads2621440", "B=512 T=20 V=32064 bf16 (C3/C4 scoring, one chunk)"),
+    ("ce_rows/gemma_B64_T20_V262208", "ce_rows", "ce_rows_kernel<1, true, false>/threads327680", "B=64 T=20 V=262208 bf16 (Gemma-3 scoring)"),
     ("ce_dlogits/llava_T20_V32064", "ce_dlogits", "ce_dlogits_kernel<1, true>/threads5120", "B=1 T=20 V=32064 bf16 (gradient pass)"),
     ("splice/c3_tail_B512_S44_D4096", "splice", "splice_kernel<1>/threads720896", "C3 tail: B=512, 19 gathered + 25 shared rows, D=4096 bf16"),
     ("splice/c3_full_B512_S65_D4096", "splice", "splice_kernel<1>/threads532480", "C3 full: B=512 S=65 D=4096 bf16"),
     ("splice/c4_full_B512_S643_D4096", "splice", "splice_kernel<1>/threads5267456", "C4 full: B=512 S=643 D=4096 bf16"),
     ("linf/gemma_3x896x896", "linf", "linf_step_vec4/threads524288", "Gemma image 3x896x896 fp32"),
     ("linf/llava_3x336x336", "linf", "linf_step_vec4/threads84736", "LLaVA image 3x336x336 fp32"),
-    ("mask_topk/llava_19x32064_f32", "mask_topk", "mask_topk_kernel<0, true>/threads19456", "19 x 32064 fp32"),
+    ("mask_topk/llava_19x32064_bf16", "mask_topk", "topk_slice_kernel<1, true>/threads38912", "19 x 32064 bf16, stage 1 (slice select)"),
+    ("mask_topk/gemma_19x262208_bf16", "mask_topk", "topk_slice_kernel<1, true>/threads316160", "19 x 262208 bf16, stage 1 (slice select)"),
     ("rmsnorm/c3_22528x4096", "rmsnorm", "rmsnorm_kernel<1, 2, false>/threads5767168", "22528 x 4096 bf16 (C3 candidate forward)"),
-    ("swiglu/c3_22528x11008", "swiglu", "swiglu_kernel<1, 0>/threads7749632", "22528 x 11008 bf16 (C3 candidate forward)"),
+    ("swiglu/c3_22528x11008", "swiglu", "swiglu_kernel<1, 0, false>/threads7749632", "22528 x 11008 bf16 (C3 candidate forward)"),
     ("rope/c3_B512_L44_H32_Dh128", "rope", "rope_kernel<1>/threads5767168", "B=512 L=44 H=32 Dh=128 bf16"),
     ("attn_merge/c4_B512_L45_H32_Dh128", "attn_merge", "attn_merge_kernel<1>/threads5898240", "B=512 L=45 H=32 Dh=128 bf16 (C4)"),
+    # library GEMMs (keys are matched by symbol prefix: the kernel name depends on the selection table)
+    ("gemm/gate_up_17152x22016x4096", "gemm_gate_up_proj", "Cijk", "fused gate/up product of the C3 ragged candidate forward, 17152 x 22016 x 4096 bf16"),
+    ("gemm/down_17152x4096x11008", "gemm_down_proj", "Cijk", "down_proj, 17152 x 4096 x 11008 bf16"),
+    ("gemm/qkv_17152x12288x4096", "gemm_qkv_proj", "Cijk", "fused q/k/v product, 17152 x 12288 x 4096 bf16"),
 ]
 entries = []
 for case, kernel, key, shape in CASES:
     if case not in kb:
         continue
-    cands = [k for k in folded if k.rsplit("/run", 1)[0] == key] or [k for k in folded if k.split("/")[0] == key.split("/")[0]]
+    if key == "Cijk":
+        cands = [k for k in folded if "Cijk_" in k.split("/")[0]]
+    else:
+        cands = [k for k in folded if k.rsplit("/run", 1)[0] == key] or [k for k in folded if k.split("/")[0] == key.split("/")[0]]
     # several shapes can share a symbol: take the launch whose traffic is closest to the algorithmic bytes
     algo = kb[case]["algorithmic_MB"] * 1e6
     if not cands:
@@ -77,7 +103,8 @@ for case, kernel, key, shape in CASES:
     entries.append(dict(kernel=kernel, shape=shape, pmc_key=best, algorithmic_bytes=algo,
                         hbm_bytes_per_launch=v["hbm_bytes_per_launch"], fetch_bytes_corrected=v["fetch_bytes_per_launch_corrected"],
                         write_bytes=v["write_bytes_per_launch"], ratio_to_algorithmic=v["hbm_bytes_per_launch"] / algo,
-                        avg_us=kb[case]["avg_us"], achieved_GBps=kb[case]["achieved_GBps"]))
+                        avg_us=kb[case]["avg_us"], achieved_GBps=kb[case]["achieved_GBps"],
+                        achieved_TFLOPs=kb[case].get("achieved_TFLOPs")))
 json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes with --kernel-trace only, of "
                       "tools/kernel_bench.py --iters 5 on MI355X; raw rows in *_kernel_bench_pmc_*.csv",
                corrections="counters are KiB; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM); WRITE_SIZE x1",
