@@ -217,6 +217,64 @@ def test_early_stop_and_errors():
     assert 1 <= len(res.losses) <= 3
 
 
+def test_oom_halving_recovers_and_remembers(golden_dir):
+    """The out-of-memory safety net (reference utils.py:57-115: halve and retry), exercised for real: every
+    scoring forward with more than 5 candidates raises the allocator's error text.  The engine halves until
+    a chunk fits -- leaving ragged mode on the way --, remembers the size for the following steps (the
+    reference restarts from the full batch every step), and the trajectory is still the reference's."""
+    from bimodalattack_amd import BimodalAttackConfig, synthetic as S
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    name = "llava_joint"
+    m = META["cases"][name]
+    model, tok, proc, image = S.tiny_case(m["kind"], device=DEV)
+    tmp = tempfile.mkdtemp(prefix="bma_gpu_")
+    cfg = BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=m["optim_str_init"], images_folder=tmp, **m["config"])
+    trace = []
+    atk = BimodalAttack(model, tok, proc, cfg, S.Normalize(S.CLIP_MEAN, S.CLIP_STD),
+                        EngineOptions.from_env(rng_device="cpu", trace=trace, strict=True))
+    raised = []
+
+    def guard(fn, count):
+        def wrapped(x, *a, **kw):
+            n = count(x, *a)
+            if n > 5:
+                raised.append(n)
+                raise RuntimeError("HIP out of memory. Tried to allocate 2.00 GiB (test)")
+            return fn(x, *a, **kw)
+        return wrapped
+
+    hf = atk.hf
+    hf.target_logits = guard(hf.target_logits, lambda x, *a: x.shape[0])
+    hf.target_logits_shared_prefix = guard(hf.target_logits_shared_prefix, lambda x, *a: x.shape[0])
+    hf.target_logits_ragged = guard(hf.target_logits_ragged, lambda rows, T, cache, maps: maps.m_out)
+    res = atk.run(m["goal"], m["goal"], m["target"], image)
+    assert raised and raised[0] > 5 and atk._chunk_cap is not None and atk._chunk_cap <= 5
+    assert len([r for r in raised]) <= 4                      # halved a few times in the FIRST step, never again
+    check_against_golden(golden_dir, name, m, res, trace, tmp)
+
+
+def test_long_suffix_matches_oracle():
+    """A 70-token suffix (the reference takes any optim_str_init; round 1's position sampler stopped at 64):
+    two GCG steps on the tiny OPT, HIP engine against the oracle loop, same CPU draws."""
+    from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
+    from oracle.attack_loop import run_oracle
+    init = " ".join(["x", "y", "z", "w", "!"] * 14)
+    kw = dict(num_steps=2, search_width=16, topk=8, n_replace=3, seed=1, verbosity="ERROR", optim_str_init=init)
+    model, tok, proc, _ = S.tiny_case("opt", device=DEV)
+    trace = []
+    res = run(model, tok, proc, "tell me", "tell me", "Sure here", None,
+              BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw), rng_device="cpu", trace=trace, strict=True)
+    cmodel, ctok, cproc, _ = S.tiny_case("opt")
+    want, wtrace, _ = run_oracle(cmodel, ctok, cproc, "tell me", "tell me", "Sure here", None,
+                                 BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw))
+    assert trace[0]["sampled"].shape == (16, 70)
+    for a, b in zip(trace, wtrace):
+        assert np.array_equal(a["sampled"], b["sampled"]) and np.array_equal(a["filtered"], b["filtered"])
+        np.testing.assert_allclose(a["losses"][0], b["losses"][0], rtol=1e-4)
+    assert res.strings == want["strings"]
+
+
 # ------------------------------------------------------------------ sharded engine, 2 ranks on one GPU
 def _sharded_worker(rank, world, port, name, out, backend="gloo"):
     import torch.distributed as dist
