@@ -483,17 +483,19 @@ class BimodalAttack:
         dealt = None           # (order over distinct candidates, inverse map, distinct count, first positions) when dealing
         emulate = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else 0
         world = emulate or self.shard.world
-        want_ragged = bool(parent is not None and allow_prefix and self.opt.ragged_suffix and hf.ragged_ok is not False
-                           and hf.shared_ok is not False and n > 1 and self.opt.prefix_reuse and self.opt.target_rows_only
-                           and self.opt.shared_prefix_attention and hf.shared_prefix_configs())
+        # `plan_ok` depends on options and the model family only -- never on what one rank learnt at run time --
+        # because it also decides HOW candidates are partitioned over ranks, which every rank must decide alike
+        plan_ok = bool(parent is not None and allow_prefix and self.opt.ragged_suffix and n > 1 and self.opt.prefix_reuse
+                       and self.opt.target_rows_only and self.opt.shared_prefix_attention and hf.shared_prefix_configs())
+        want_ragged = bool(plan_ok and hf.ragged_ok is not False and hf.shared_ok is not False)
         host_mine = host_par = inv_mine = None
-        if want_ragged:
+        if plan_ok:
             # ONE device-to-host copy (ids + parent) and ONE exact dedup per step feed both the partition over
             # ranks and the ragged plan
             both_h = torch.cat([sampled, parent.reshape(1, -1).to(sampled.device)], dim=0).cpu().numpy()
             host_all, host_par = both_h[:n], both_h[n]
             uniq, inv = unique_rows(host_all)
-        if want_ragged and (self.shard.enabled or emulate) and n > world:
+        if plan_ok and (self.shard.enabled or emulate) and n > world:
             # Ragged scoring on several GPUs: every rank sees the same ids, so each can drop the
             # duplicates, sort the distinct candidates by first replaced position and take every
             # world-th one -- all ranks then compute (almost) the same number of rows, and the fixed
@@ -509,7 +511,7 @@ class BimodalAttack:
         else:
             lo, hi = self.shard.bounds(n)
             mine = sampled[lo:hi].contiguous()
-            if want_ragged:
+            if plan_ok:
                 if (lo, hi) == (0, n):
                     host_mine, inv_mine = uniq, inv
                 else:

@@ -120,6 +120,7 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_ATTN_MERGE: return "attn_merge_kernel";
     case BMA_K_GATHER_ROWS: return "gather_rows_kernel";
     case BMA_K_RAGGED_ATTN: return "ragged_attn_kernel";
+    case BMA_K_PREFIX_ATTN: return "prefix_attn_kernel";
     default: return "?";
   }
 }

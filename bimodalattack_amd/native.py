@@ -74,6 +74,8 @@ PROTOTYPES = {
                                      c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
+    "bma_prefix_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                     c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bma_profile_enable": (c_int, [c_int]),
     "bma_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "bma_profile_kernel_name": (c_char_p, [c_int]),
@@ -81,7 +83,7 @@ PROTOTYPES = {
 
 KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5,
               "ce_rows_grad": 6, "rmsnorm": 7, "swiglu": 8, "rope": 9, "attn_merge": 10, "gather_rows": 11,
-              "ragged_attn": 12}
+              "ragged_attn": 12, "prefix_attn": 13}
 
 
 def profile_enable(on: bool) -> None:

@@ -449,6 +449,33 @@ def ragged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor
     return out
 
 
+def prefix_attention_ok(query: torch.Tensor, key: torch.Tensor) -> bool:
+    """Can bma_prefix_attention take these (.,H,N,Dh) queries / (1,Hk,P,Dh) prefix keys?"""
+    return (query.is_cuda and query.dtype in (torch.bfloat16, torch.float16) and key.dtype == query.dtype
+            and query.shape[-1] in (64, 128) and query.shape[1] % key.shape[1] == 0 and key.shape[2] >= 1)
+
+
+def prefix_attention(query: torch.Tensor, prefix_k: torch.Tensor, prefix_v: torch.Tensor, scale: float):
+    """All rows against the shared prefix, no mask (include/bma.h: bma_prefix_attention).  query (1,H,N,Dh),
+    prefix_k/prefix_v (1,Hk,P,Dh): any row/head strides with a contiguous last dim.  Returns (o1 (N,H,Dh) in the
+    query dtype, lse1 (H,N) fp32 natural log): the partial bma_ragged_attention merges."""
+    dev = _need_gpu(query, prefix_k, prefix_v)
+    if query.dim() != 4 or query.shape[0] != 1 or query.stride(3) != 1:
+        raise ValueError("query must be (1,H,N,Dh) with a contiguous last dim")
+    _, H, N, Dh = query.shape
+    Hk, P = prefix_k.shape[1], prefix_k.shape[2]
+    for t in (prefix_k, prefix_v):
+        if t.shape != (1, Hk, P, Dh) or t.stride(3) != 1 or t.dtype != query.dtype:
+            raise ValueError("prefix_k/prefix_v must be (1,Hk,P,Dh) of the query dtype with a contiguous last dim")
+    out = torch.empty((N, H, Dh), dtype=query.dtype, device=dev)
+    lse = torch.empty((H, N), dtype=torch.float32, device=dev)
+    check("bma_prefix_attention", lib.bma_prefix_attention(
+        query.data_ptr(), query.stride(2), query.stride(1), prefix_k.data_ptr(), prefix_k.stride(2), prefix_k.stride(1),
+        prefix_v.data_ptr(), prefix_v.stride(2), prefix_v.stride(1), P, N, H, Hk, Dh, _dt(query), float(scale),
+        out.data_ptr(), lse.data_ptr(), _stream(dev)))
+    return out, lse
+
+
 class FrozenLinearFn(torch.autograd.Function):
     """y = x W^T for a weight that is a constant of the attack; the input gradient dX = dY W is
     computed as ``linear(dY, W^T-copy)``.  Both products then run in the library's "weight rows along

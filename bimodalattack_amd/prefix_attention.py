@@ -39,9 +39,11 @@ import torch
 from . import ops
 
 # ragged scoring: attention in one MFMA launch (csrc/ragged_attention.hip) instead of the five-launch
-# library route; prefixes longer than FUSED_PREFIX_MAX keys stay with the library flash kernel
+# library route; prefixes longer than FUSED_PREFIX_MAX keys (the image of joint mode) are a separate partial
 FUSED_RAGGED_ATTENTION = os.environ.get("BMA_FUSED_RAGGED_ATTENTION", "1") not in ("0", "false", "False")
 FUSED_PREFIX_MAX = int(os.environ.get("BMA_FUSED_PREFIX_MAX", "128"))
+# ... whose part is the hand-written flash kernel csrc/prefix_attention.hip (BMA_PREFIX_ATTENTION=0: the library's)
+PREFIX_ATTENTION_KERNEL = os.environ.get("BMA_PREFIX_ATTENTION", "1") not in ("0", "false", "False")
 NAME = "bma_shared_prefix"
 _FAMILIES = ("modeling_llama", "modeling_mistral", "modeling_qwen2", "modeling_gemma3")
 _ACTIVE: List["SharedPrefixKV"] = []
@@ -110,6 +112,7 @@ class SharedPrefixKV(_CacheBase):
         self._rep = {}
         self.ragged: Optional["RaggedMaps"] = None     # set for a ragged scoring forward
         self.fused_ok = True                           # padded blocks through the one-launch MFMA kernel
+        self.prefix_kernel_ok = True                   # long prefixes through csrc/prefix_attention.hip
 
     @property
     def is_sliding(self):                          # read-only property on the HF base class
@@ -243,18 +246,18 @@ def shared_prefix_attention(module, query, key, value, attention_mask=None, drop
         out = _fused_block_attention(kv, module.layer_idx, query, key, value, scale)
         if out is not None:
             return out, None
+    n_rep_prefix = n_rep
     if n_rep > 1:
         key, value = key.repeat_interleave(n_rep, dim=1), value.repeat_interleave(n_rep, dim=1)
-    Kp, Vp = kv.prefix(module.layer_idx, n_rep)
     qm = query.transpose(1, 2)                      # (B,L,H,Dh): the projection's own memory order
     if not qm.is_contiguous():
         qm = qm.contiguous()
     q1 = qm.view(1, B * L, H, Dh).transpose(1, 2)   # (1,H,B*L,Dh) view, no copy
-    o1, l1 = _partial_attention(q1, Kp, Vp, False, scale)
+    o1, l1 = _prefix_partial(kv, module.layer_idx, q1, n_rep_prefix, scale)
     o2, l2 = _partial_attention(qm.transpose(1, 2), key, value, True, scale)
-    o1 = o1.transpose(1, 2).reshape(B, L, H, Dh).contiguous()
+    o1 = o1.view(B, L, H, Dh)
     o2 = o2.transpose(1, 2).contiguous()
-    out = ops.attn_merge(o1, o2, l1.reshape(H, B * L).contiguous(), l2.contiguous())
+    out = ops.attn_merge(o1, o2, l1, l2.contiguous())
     return out, None
 
 
@@ -298,6 +301,20 @@ def _fused_block_attention(kv: "SharedPrefixKV", layer_idx: int, query, key, val
     return out.view(B, L, H, Dh)
 
 
+def _prefix_partial(kv: "SharedPrefixKV", layer_idx: int, query, n_rep: int, scale: float):
+    """(o1 (N,H,Dh), lse1 (H,N)) of every row of `query` (1,H,N,Dh) against the shared prefix, no mask: the
+    hand-written flash kernel (grouped heads in place, output already in row-list order), else the library's
+    efficient attention + a transpose copy."""
+    _, H, N, Dh = query.shape
+    if PREFIX_ATTENTION_KERNEL and kv.prefix_kernel_ok:
+        Kp, Vp = kv.prefix(layer_idx, 1)
+        if ops.prefix_attention_ok(query, Kp):
+            return ops.prefix_attention(query, Kp, Vp, scale)
+    Kp, Vp = kv.prefix(layer_idx, n_rep)
+    o1, l1 = _partial_attention(query, Kp, Vp, False, scale)
+    return o1.transpose(1, 2).reshape(N, H, Dh).contiguous(), l1.reshape(H, N).contiguous()
+
+
 def _rows(t: torch.Tensor) -> torch.Tensor:
     """(1,H,N,Dh) view of a projection's (1,N,H,Dh) output -> the contiguous (N,H,Dh) row list."""
     r = t.transpose(1, 2)
@@ -320,11 +337,9 @@ def _ragged_attention(kv: SharedPrefixKV, layer_idx: int, query, key, value, n_r
             Kp, Vp = kv.prefix(layer_idx, 1)
             out = ops.ragged_attention(query, key, value, Kp, Vp, rg.cstart, rg.cfirst, rg.clen, rg.L, scale)
         else:
-            Kp, Vp = kv.prefix(layer_idx, n_rep)
-            o1, l1 = _partial_attention(query, Kp, Vp, False, scale)
-            o1 = o1.transpose(1, 2).reshape(N, H, Dh).contiguous()
+            o1, l1 = _prefix_partial(kv, layer_idx, query, n_rep, scale)
             out = ops.ragged_attention(query, key, value, None, None, rg.cstart, rg.cfirst, rg.clen, rg.L, scale,
-                                       o1=o1, lse1=l1.reshape(H, N).contiguous())
+                                       o1=o1, lse1=l1)
         return out.unsqueeze(0)
     if rg.q_src is None:
         raise RuntimeError("ragged maps were built without the padded-block maps the library attention route needs")

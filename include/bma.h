@@ -202,6 +202,15 @@ int bma_attn_merge_rows(const void* o1, const void* o2, const float* lse1, const
 int bma_gather_rows(const void* src, const int* idx, int64_t n_out, int64_t n_src, int64_t row_bytes,
                     void* out, void* stream);
 
+/* bma_prefix_attention: N rows (q [N][H][Dh] through row/head strides) against the P keys/values of the SHARED
+ *   prefix (pk/pv [P][Hk][Dh] through strides; grouped heads in place), no mask: out [N][H][Dh] contiguous of
+ *   `dtype` and lse [H][N] fp32 (natural log) -- the partial that bma_ragged_attention merges (o1, lse1).  A
+ *   flash-attention forward on the matrix cores (bf16 / f16, Dh 64 or 128): 4*N*P*Dh*H flops per launch. */
+int bma_prefix_attention(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* pk,
+                         int64_t pk_row_stride, int64_t pk_head_stride, const void* pv, int64_t pv_row_stride,
+                         int64_t pv_head_stride, int P, int64_t N, int H, int Hk, int Dh, int dtype, float scale,
+                         void* out, float* lse, void* stream);
+
 /* bma_ragged_attention: the attention of a ragged scoring forward in one launch (bf16 / f16, MFMA).
  *   Candidate i (0 <= i < B2) owns rows start[i] .. start[i]+len[i]-1 of the row list: its tokens at
  *   positions first[i] .. first[i]+len[i]-1 behind the shared prefix (len[i] <= max_len <= 64).  A query
@@ -230,7 +239,7 @@ enum {
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
   BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11,
-  BMA_K_RAGGED_ATTN = 12, BMA_K_COUNT = 13
+  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_COUNT = 14
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

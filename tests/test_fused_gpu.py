@@ -396,6 +396,32 @@ def test_fused_block_attention_equals_sdpa(dtype, B, H, Hk, L, Dh, P):
     assert pa._fused_block_attention(kv, 0, q.contiguous(), k, v, scale) is None or H == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,P,H,Hk,Dh", [(300, 599, 8, 8, 128), (129, 70, 8, 4, 128), (17, 1, 4, 2, 64), (1000, 33, 16, 16, 64),
+                                         (128, 32, 3, 3, 128)])
+def test_prefix_attention_vs_fp32(dtype, N, P, H, Hk, Dh):
+    """All rows against the shared prefix (no mask) on the matrix cores: output and natural-log LSE against
+    fp32 softmax attention; row counts off the 128-row workgroup, prefix lengths off the 32-key chunk, grouped
+    heads, a head count that is not a multiple of the XCD count."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(N + P)
+    q = torch.randn((1, N, H, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2)          # (1,H,N,Dh) view
+    pk, pv = (torch.randn((1, P, Hk, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2) for _ in range(2))
+    scale = Dh ** -0.5
+    o, lse = ops.prefix_attention(q, pk, pv, scale)
+    rep = H // Hk
+    s_ = (q[0].float() @ pk[0].float().repeat_interleave(rep, 0).transpose(-1, -2)) * scale     # (H,N,P)
+    want = (torch.softmax(s_, -1) @ pv[0].float().repeat_interleave(rep, 0)).transpose(0, 1)   # (N,H,Dh)
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert o.shape == (N, H, Dh) and float((o.float() - want).abs().max()) < tol
+    np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(s_, -1).cpu().numpy(), rtol=2e-3, atol=2e-3)
+    # the pair (o, lse) is what bma_ragged_attention merges: against the library's partial
+    from bimodalattack_amd import prefix_attention as pa
+    o_lib, lse_lib = pa._partial_attention(q, pk.repeat_interleave(rep, 1), pv.repeat_interleave(rep, 1), False, scale)
+    assert float((o.float() - o_lib.transpose(1, 2)[0].float()).abs().max()) < 2 * tol
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_lib[0].cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_ragged_forward_equals_padded_forward(dtype):
     """Whole-model check on a small Llama: candidates that differ from a parent suffix from

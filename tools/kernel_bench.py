@@ -143,6 +143,18 @@ def cases():
         w = (torch.randn((N, K), generator=g, device=DEV) * 0.02).to(bf)
         return lambda: torch.nn.functional.linear(x, w)
 
+    def prefix_attn(N, P, H, Dh):
+        q = torch.randn((1, N, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2)
+        pk, pv = (torch.randn((1, P, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2) for _ in range(2))
+        return lambda: ops.prefix_attention(q, pk, pv, Dh ** -0.5)
+
+    def prefix_attn_lib(N, P, H, Dh):
+        # the library kernel the hand-written one replaces (aten efficient attention, no mask, with LSE)
+        from bimodalattack_amd import prefix_attention as pa
+        q = torch.randn((1, N, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2)
+        pk, pv = (torch.randn((1, P, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2) for _ in range(2))
+        return lambda: pa._partial_attention(q, pk, pv, False, Dh ** -0.5)
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -160,6 +172,9 @@ def cases():
         "ragged_attn/c3r_sw512_P21_L44_H32_Dh128": ("ragged_attn", lambda: ragged_attn(512, 19, 44, 20, 21, 32, 128)),
         "ragged_attn/gemma_B164_L303_P20_H8_Hk4_Dh256": ("ragged_attn", lambda: block_attn(164, 303, 20, 8, 4, 256)),
         "ragged_attn/c4_B512_L45_P0_H32_Dh128": ("ragged_attn", lambda: block_attn(512, 45, 0, 32, 32, 128)),
+        # joint scoring: every computed row against the 599 shared prefix keys (168 GFLOP per launch)
+        "prefix_attn/c4_N17152_P599_H32_Dh128": ("prefix_attn", lambda: prefix_attn(17152, 599, 32, 128)),
+        "libattn/c4_17152x599x32x128": (None, lambda: prefix_attn_lib(17152, 599, 32, 128)),
         "gather_rows/c3r_21164_of_17152x4096": ("gather_rows", lambda: gather(17152, 481 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),
         "swiglu/c3_22528x11008": ("swiglu", lambda: swiglu(22528, 11008)),
@@ -214,9 +229,14 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = 1e3 * e0.elapsed_time(e1) / args.iters
-            M, N, K = (int(v) for v in name.rsplit("_", 1)[1].split("x"))
+            dims = [int(v) for v in name.rsplit("_", 1)[1].split("x")]
+            if len(dims) == 4:                # attention: rows x keys x heads x head dim
+                M, N, K = dims[0] * dims[2], dims[1], 2 * dims[3]            # 4*N*P*Dh*H flops = 2*M*N*K
+                mb = 2.0 * 2 * dims[0] * dims[2] * dims[3] / 1e6
+            else:
+                M, N, K = dims
+                mb = 2.0 * (M * K + N * K + M * N) / 1e6
             tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-            mb = 2.0 * (M * K + N * K + M * N) / 1e6
             results[name] = dict(symbol="library GEMM", launches=args.iters, avg_us=us, algorithmic_MB=mb,
                                  algorithmic_GFLOP=2e-9 * M * N * K, achieved_TFLOPs=tf, frac_of_2500TFLOPs=tf / 2500.0,
                                  achieved_GBps=mb * 1e6 / (us * 1e-6) / 1e9, frac_of_8TBps=mb * 1e6 / (us * 1e-6) / 8e12)
