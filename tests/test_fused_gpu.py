@@ -212,8 +212,10 @@ def test_fused_context_patches_and_restores(kind, dtype):
         assert y.requires_grad
         gf, = torch.autograd.grad(y.float().square().mean(), xf)
     if kind == "llama" and dtype != torch.float32:
-        # 72 rows: the transposed-weight backward ran -- q/k/v as one fused projection per layer, o/gate/up/down each
-        assert len(fused.qkv) == 2 and len(fused._wqkv) == 2 and len(fused._wt) == 2 * 5 and len(fused.linears) == 2 * 7
+        # 72 rows: the transposed-weight backward ran -- q/k/v as one fused projection per layer, gate/up as one
+        # (chunk-interleaved) projection, o and down each
+        assert len(fused.qkv) == 2 and len(fused._wqkv) == 2 and len(fused._wgu) == 2 and len(fused._wt) == 2 * 4 \
+            and len(fused.linears) == 2 * 7
     gtol = 1e-4 if dtype == torch.float32 else 8e-2
     assert float((gf.float() - ge.float()).abs().max()) <= gtol * float(ge.float().abs().max())
     assert not any("forward" in m.__dict__ for m in model.modules())
