@@ -162,6 +162,7 @@ class BimodalAttack:
         self._feat_graph = None                    # image -> image features (no autograd)
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
+        self.opt_b1_min = int(os.environ.get("BMA_B1_MIN_TOKENS", "2"))
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
@@ -299,7 +300,7 @@ class BimodalAttack:
         else:
             parts = [self.seg["before"], emb, self.seg["after"], self.seg["target"]]
         x = torch.cat(parts, dim=1)
-        with self.fused:
+        with self.fused, self._b1_attention(x.shape[1]):
             if self.opt.target_rows_only:
                 logits = self.hf.target_logits(x[:, :-1], self.T, rows_only=True)
             else:
@@ -314,6 +315,17 @@ class BimodalAttack:
                 g_tok = (g_emb @ E.t()).unsqueeze(0)      # (1, n_opt, V), model dtype
         g_img = grads.pop(0) if cfg.pgd_attack else None
         return g_tok, g_img, loss.detach()
+
+    def _b1_attention(self, seq_len: int):
+        """Context for the batch-1 gradient pass: mask-free causal attention for the text layers of the model
+        families the shared-prefix scheme knows (plain causal attention; a sliding window at least as long as
+        the sequence), nothing otherwise."""
+        import contextlib
+        cfgs = self.hf.shared_prefix_configs(seq_len) if (self.opt.maskless_b1_attention and seq_len >= self.opt_b1_min) else []
+        if not cfgs:
+            return contextlib.nullcontext()
+        from . import prefix_attention as pa
+        return pa.causal_b1(cfgs)
 
     def perform_pgd_step(self, image: Tensor, eps: float, alpha: float, image_grad: Tensor,
                          image_original: Tensor) -> Tensor:
@@ -428,7 +440,9 @@ class BimodalAttack:
         hf = self.hf
 
         def build(f):
-            return hf.build_prefix_recording(cat_prefix(f))
+            x = cat_prefix(f)
+            with self._b1_attention(x.shape[1]):          # one sequence, nothing cached in front of it: plain causal
+                return hf.build_prefix_recording(x)
 
         if feats is None or not self.opt.graph_prefix or self._prefix_graphs.get(key) is False:
             return build(feats)

@@ -109,6 +109,10 @@ class EngineOptions:
     # q_proj/k_proj/v_proj of an attention block as one GEMM against the concatenated weight (16-bit
     # models; one more copy of those matrices): fewer partly filled tile rounds, one weight stream.
     fuse_qkv: bool = True
+    # Gradient pass: ask the library attention for `is_causal` instead of handing it the (1,1,S,S) mask tensor
+    # HuggingFace builds for inputs_embeds calls (the causal flash kernels instead of the masked ones: -3 ms per
+    # pass at the 643 tokens of the image prompt).  Model families with plain causal text attention only.
+    maskless_b1_attention: bool = True
     # gate_proj / up_proj of a gated MLP as one GEMM against their chunk-interleaved weights (16-bit models; one
     # more copy of those two matrices, two in the gradient pass): see fused.py.
     fuse_gate_up: bool = True
@@ -187,6 +191,8 @@ class EngineOptions:
             opts.joint_winner_from_batch = env["BMA_JOINT_WINNER_FROM_BATCH"] not in ("0", "false", "False")
         if "BMA_FUSE_QKV" in env:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
+        if "BMA_MASKLESS_B1_ATTENTION" in env:
+            opts.maskless_b1_attention = env["BMA_MASKLESS_B1_ATTENTION"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:

@@ -358,6 +358,26 @@ def _ragged_attention(kv: SharedPrefixKV, layer_idx: int, query, key, value, n_r
     return out.unsqueeze(0)                         # (1,N,H,Dh)
 
 
+NAME_B1 = "bma_causal_b1"
+
+
+def causal_b1_attention(module, query, key, value, attention_mask=None, dropout: float = 0.0,
+                        scaling: Optional[float] = None, **kwargs):
+    """HF attention-interface function for the batch-1 GRADIENT pass (no cache, plain causal): the library's
+    attention asked for `is_causal` instead of being handed a mask tensor.  HuggingFace's sdpa path builds a
+    (1,1,S,S) mask for `inputs_embeds` calls, which routes the 643-token image prompt to the masked
+    efficient-attention kernels; the causal flash variant does the same maths 3.1 ms per pass faster (forward
+    + backward, 32 layers).  Measured against it and dropped: explicit scores (library batched products with
+    fp32 scores + hand-written causal-softmax row kernels), 1.8 ms slower than this per pass."""
+    B, H, S, Dh = query.shape
+    scale = float(scaling) if scaling is not None else Dh ** -0.5
+    n_rep = H // key.shape[1]
+    if n_rep > 1:
+        key, value = key.repeat_interleave(n_rep, dim=1), value.repeat_interleave(n_rep, dim=1)
+    out = torch.nn.functional.scaled_dot_product_attention(query, key, value, is_causal=S > 1, scale=scale)
+    return out.transpose(1, 2).contiguous(), None
+
+
 def _no_mask(*args, **kwargs):
     return None
 
@@ -370,6 +390,8 @@ def register() -> bool:
         from transformers.modeling_utils import AttentionInterface
         AttentionInterface.register(NAME, shared_prefix_attention)
         AttentionMaskInterface.register(NAME, _no_mask)
+        AttentionInterface.register(NAME_B1, causal_b1_attention)
+        AttentionMaskInterface.register(NAME_B1, _no_mask)
         _REGISTERED["done"] = True
     except Exception:
         return False
@@ -420,5 +442,18 @@ def active(configs: list, kv: SharedPrefixKV):
         yield
     finally:
         _ACTIVE.pop()
+        for c, o in zip(configs, old):
+            c._attn_implementation = o
+
+
+@contextlib.contextmanager
+def causal_b1(configs: list):
+    """Switch the text layers to the mask-free causal attention for one batch-1 forward (no cache)."""
+    old = [getattr(c, "_attn_implementation", None) for c in configs]
+    try:
+        for c in configs:
+            c._attn_implementation = NAME_B1
+        yield
+    finally:
         for c, o in zip(configs, old):
             c._attn_implementation = o

@@ -534,6 +534,41 @@ def test_gemma3_4b_scoring_equals_reference_call_shape():
         assert int(got.argmin()) == int(want32.argmin())
 
 
+def test_maskless_b1_attention_gradient_matches_masked():
+    """The gradient pass of the image prompt (643 rows, LLaVA-1.5-7B width, 2 layers here) with the library
+    attention asked for `is_causal` against the same pass handed HuggingFace's mask tensor: token and pixel
+    gradients agree to bf16 noise (same maths, different library kernels)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig, prefix_attention as pa
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("joint", dev, torch.bfloat16, 2)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=True,
+                              joint_eval=True, images_folder=tempfile.mkdtemp())
+    out, calls = {}, []
+    orig = pa.causal_b1_attention
+    for maskless in (True, False):
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, graph_gradient=False,
+                                                                                maskless_b1_attention=maskless, strict=True))
+        atk._prepare_prompt(messages, target)
+        ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+        img = image.detach().clone().requires_grad_()
+        g_tok, g_img, loss = atk._gradient_eager(ids, img)
+        out[maskless] = (g_tok.float(), g_img.float(), float(loss))
+        calls.append(len(atk.hf.shared_prefix_configs(643)) > 0)
+    assert all(calls) and callable(orig)
+    (t1, i1, l1), (t0, i0, l0) = out[True], out[False]
+    assert abs(l1 - l0) <= 2e-2 * abs(l0)
+    assert float((t1 - t0).abs().max()) <= 5e-2 * float(t0.abs().max())
+    assert float((i1 - i0).abs().max()) <= 5e-2 * float(i0.abs().max())
+    big = i0.abs() > 0.05 * i0.abs().max()
+    assert float((torch.sign(i1[big]) == torch.sign(i0[big])).float().mean()) > 0.98
+
+
 def test_run_experiment_writes_reference_artifacts(tmp_path):
     """The harness loop (reference experiments.py:54-285) on this engine: two prompts, PNGs per
     step under images_<run>/, the seven artefact files, losses.csv consistent with the result."""
