@@ -147,6 +147,7 @@ class BimodalAttack:
                 f"bimodalattack_amd runs on an AMD GPU only (model is on {model.device}); there is no CPU path. "
                 "Move the model to the device first.")
         self.hf = HFAdapter(model, processor, normalize)
+        self.hf.pad_vision_heads = bool(self.opt.pad_vision_heads)
         self.embedding_layer = self.hf.embedding
         self.not_allowed_ids = None if config.allow_non_ascii else get_nonascii_toks(tokenizer, device=model.device)
         self.mask_bits = ops.build_mask_bits(self.not_allowed_ids, self.embedding_layer.num_embeddings, model.device)

@@ -113,6 +113,9 @@ class EngineOptions:
     # HuggingFace builds for inputs_embeds calls (the causal flash kernels instead of the masked ones: -3 ms per
     # pass at the 643 tokens of the image prompt).  Model families with plain causal text attention only.
     maskless_b1_attention: bool = True
+    # vision towers whose head width is not a multiple of 32 (SigLIP: 72): zero-pad q/k/v to a width the library's
+    # attention kernels are built for (prefix_attention.padded_heads_attention); same attention, faster kernels
+    pad_vision_heads: bool = True
     # gate_proj / up_proj of a gated MLP as one GEMM against their chunk-interleaved weights (16-bit models; one
     # more copy of those two matrices, two in the gradient pass): see fused.py.
     fuse_gate_up: bool = True
@@ -193,6 +196,8 @@ class EngineOptions:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
         if "BMA_MASKLESS_B1_ATTENTION" in env:
             opts.maskless_b1_attention = env["BMA_MASKLESS_B1_ATTENTION"] not in ("0", "false", "False")
+        if "BMA_PAD_VISION_HEADS" in env:
+            opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:

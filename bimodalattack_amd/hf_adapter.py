@@ -15,6 +15,7 @@ exercised by CPU tests as well.
 from __future__ import annotations
 
 import copy
+import contextlib
 import inspect
 from typing import Optional
 
@@ -100,15 +101,33 @@ class HFAdapter:
         self.shared_window: Optional[int] = None
         self.shared_ok: Optional[bool] = None
         self.ragged_ok: Optional[bool] = None
+        self.pad_vision_heads = True            # EngineOptions.pad_vision_heads, set by the attack object
+        self._vision_cfgs = None
 
     # ------------------------------------------------------------ vision
+    def vision_configs(self) -> list:
+        """Vision-tower attention configs to switch to the padded-head attention (prefix_attention.py), [] when
+        the tower's head width is one the library handles as is (CLIP: 64) or the option is off."""
+        if self._vision_cfgs is None:
+            from . import prefix_attention as pa
+            ok = self.device.type == "cuda" and pa.register()
+            self._vision_cfgs = pa.vision_configs(self.model) if ok else []
+        return self._vision_cfgs if self.pad_vision_heads else []
+
     def image_features(self, image: torch.Tensor) -> torch.Tensor:
         px = self.normalize(image)
-        if self.is_gemma_processor:
-            out = self.model.get_image_features(pixel_values=px)
+        cfgs = self.vision_configs()
+        if cfgs:
+            from . import prefix_attention as pa
+            ctx = pa.causal_b1(cfgs, pa.NAME_VIS)
         else:
-            out = self.model.get_image_features(pixel_values=px, vision_feature_layer=-2,
-                                                vision_feature_select_strategy="default")
+            ctx = contextlib.nullcontext()
+        with ctx:
+            if self.is_gemma_processor:
+                out = self.model.get_image_features(pixel_values=px)
+            else:
+                out = self.model.get_image_features(pixel_values=px, vision_feature_layer=-2,
+                                                    vision_feature_select_strategy="default")
         return features_tensor(out)
 
     # ------------------------------------------------------------ language model

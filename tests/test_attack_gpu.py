@@ -711,3 +711,47 @@ def test_16bit_engine_paths_agree(dtype):
         np.testing.assert_allclose(st["grad_tok"][-1], base["grad_tok"][-1], rtol=0.2,
                                    atol=0.05 * float(np.abs(base["grad_tok"][-1]).max()), err_msg=str(eng))
     assert sum(np.array_equal(st["sampled"], base["sampled"]) for st in out[1:]) >= 3
+
+
+def test_padded_vision_heads_same_features_and_pixel_gradient():
+    """SigLIP-So400m-shaped tower (4096 patches, 16 heads x 72; 3 layers here): image features and the pixel
+    gradient through the padded-head attention (72 -> 96 forward-only, -> 128 with a backward) against the
+    library's own 72-wide route -- same attention, different kernels, bf16 noise apart."""
+    from bimodalattack_amd import prefix_attention as pa, synthetic as S
+    from bimodalattack_amd.hf_adapter import HFAdapter
+
+    dev = torch.device(DEV)
+    model = S._gemma3(1024, 256, 512, 1, 4, 2, 64, 1152, 4304, 3, 16, 896, 14, 256, 1024, torch.bfloat16, dev, 0, "sdpa")
+    tok = S.build_tokenizer(256, 0, 0)
+    hf = HFAdapter(model, S.Gemma3Processor(tok, S.GEMMA_TEMPLATE), S.Normalize((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)))
+    assert len(hf.vision_configs()) == 1 and pa.padded_width(72, True) == 128
+    image = S.synthetic_image(896, 896, seed=0, device=dev)
+    w = torch.randn(256, 256, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=DEV).manual_seed(1))
+    seen = []
+    orig = torch.nn.functional.scaled_dot_product_attention
+
+    def spy(q, *a, **k):
+        seen.append(int(q.shape[-1]))
+        return orig(q, *a, **k)
+
+    out = {}
+    torch.nn.functional.scaled_dot_product_attention = spy
+    try:
+        for pad in (True, False):
+            hf.pad_vision_heads = pad
+            seen.clear()
+            img = image.clone().requires_grad_()
+            feats = hf.image_features(img)
+            (g,) = torch.autograd.grad((feats[0].to(torch.bfloat16) * w).sum().float(), img)
+            with torch.no_grad():
+                f2 = hf.image_features(image)
+            out[pad] = (feats.detach().float(), g.float(), f2.float(), list(seen))
+    finally:
+        torch.nn.functional.scaled_dot_product_attention = orig
+    assert out[True][3] == [128] * 3 + [96] * 3 and out[False][3] == [72] * 6
+    assert model.config.vision_config._attn_implementation == "sdpa"            # restored
+    (f1, g1, n1, _), (f0, g0, n0, _) = out[True], out[False]
+    for a, b in ((f1, f0), (n1, n0), (g1, g0)):
+        assert float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
+    big = g0.abs() > 0.1 * g0.abs().max()
+    assert float((torch.sign(g1[big]) == torch.sign(g0[big])).float().mean()) > 0.98

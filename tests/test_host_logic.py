@@ -303,3 +303,32 @@ def test_unique_rows_is_exact_and_ordered_by_first_appearance(monkeypatch):
     a = rng.integers(0, 5, (40, 6))
     u, inv = layout.unique_rows(a)
     assert np.array_equal(u[inv], a) and len(u) == len(np.unique(a, axis=0))
+
+
+def test_padded_heads_attention_is_the_same_attention():
+    """Zero columns appended to q, k, v up to a library-friendly head width, dropped from the output: the same
+    attention and the same gradients (fp32 on the CPU here; the GPU twin checks bf16 at SigLIP's size)."""
+    import torch
+    from bimodalattack_amd import prefix_attention as pa
+    assert pa.padded_width(72, True) == 128 and pa.padded_width(72, False) == 96
+    assert pa.padded_width(64, True) == 64 and pa.padded_width(128, False) == 128 and pa.padded_width(160, True) == 160
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(2, 3, 40, 24, generator=g, requires_grad=True) for _ in range(3))
+    old = pa.PAD_HEADS_MIN_TOKENS
+    outs = []
+    try:
+        for thr in (0, 10 ** 9):
+            pa.PAD_HEADS_MIN_TOKENS = thr
+            o, w = pa.padded_heads_attention(None, q, k, v, None, scaling=24 ** -0.5)
+            assert w is None and o.shape == (2, 40, 3, 24)
+            grads = torch.autograd.grad(o.square().sum(), (q, k, v))
+            outs.append((o.detach(), grads))
+            with torch.no_grad():
+                o2, _ = pa.padded_heads_attention(None, q, k, v, None, scaling=24 ** -0.5)
+            assert torch.allclose(o2, o, atol=1e-6)
+    finally:
+        pa.PAD_HEADS_MIN_TOKENS = old
+    (o1, g1), (o0, g0) = outs
+    assert torch.allclose(o1, o0, atol=1e-6)
+    for a, b in zip(g1, g0):
+        assert torch.allclose(a, b, atol=1e-5)

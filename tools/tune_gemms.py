@@ -2,6 +2,7 @@
 """Offline GEMM selection for the attack's shapes (run on an MI355X):
 
     python tools/tune_gemms.py            # ~15 GPU-minutes; writes bimodalattack_amd/tuning/<arch>.csv
+    BMA_TUNE_WORLDS=1 python tools/tune_gemms.py gemma_joint    # one workload, one world size
 
 Runs bench.py under PyTorch TunableOp in tuning mode for the per-rank shapes of 1/2/4/8 GPUs
 (one process emulating rank 0 of each world size) on the GCG-only and joint workloads.  The gradient pass is run eagerly here (tuning cannot happen inside a
@@ -31,7 +32,7 @@ def main():
     if os.path.exists(dst) and not os.path.exists(src):
         shutil.copyfile(dst, src)            # keep what is already tuned: only new shapes are searched
     for wl in workloads:
-        for world in (1, 2, 4, 8):
+        for world in [int(w) for w in os.environ.get("BMA_TUNE_WORLDS", "1,2,4,8").split(",")]:
             # rank 0's share of a `world`-GPU run, in one process (EngineOptions.emulate_world): the shapes
             # candidate dealing produces, not those of a smaller search width
             print(f"== tuning {wl} as rank 0 of {world}", flush=True)
