@@ -360,7 +360,7 @@ class BimodalAttack:
         sampled = ops.sample_scatter(ids, topk_idx, pos, rank)
         self.shard.sync_state(*([sampled] if image is None else [sampled, image]))
         self._last = dict(topk_idx=topk_idx, pos=pos, rank=rank, sampled=sampled)
-        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids)
+        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids, threaded=self.opt.threaded_filter)
 
     # ------------------------------------------------------------ scoring
     def _segments(self, order, feats):
@@ -461,6 +461,12 @@ class BimodalAttack:
             self.graphs_captured.append("prefix:" + "|".join(key))
         return g(feats)
 
+    def _upload(self, host: np.ndarray) -> Tensor:
+        """Host array -> device without holding the host: through a pinned block of torch's caching host allocator
+        (which keeps the block from being reused until the copy has run) and a non-blocking copy.  A `.to(device)`
+        from pageable memory waits for the stream on ROCm."""
+        return torch.from_numpy(np.ascontiguousarray(host)).pin_memory().to(self.model.device, non_blocking=True)
+
     def _ragged_logits(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
                        n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None) -> Optional[Tensor]:
         """Target logits (m_out,T,V) through the ragged forward, or None when this draw does not fit the row
@@ -495,7 +501,7 @@ class BimodalAttack:
                           allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
-        dealt = None           # (order over distinct candidates, inverse map, distinct count, first positions) when dealing
+        dealt = None           # (order over distinct candidates, device index candidate -> gathered slot, distinct count, first positions) when dealing
         emulate = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else 0
         world = emulate or self.shard.world
         # `plan_ok` depends on options and the model family only -- never on what one rank learnt at run time --
@@ -519,10 +525,19 @@ class BimodalAttack:
             diff = uniq != host_par[None, :]
             first = np.where(diff.any(1), diff.argmax(1), uniq.shape[1] - 1)
             by_cost = np.argsort(first, kind="stable")
-            dealt = (by_cost, inv, uniq.shape[0], first)
             take = by_cost[0::world] if emulate else self.shard.deal(by_cost)
             host_mine = np.ascontiguousarray(uniq[take])
-            mine = torch.from_numpy(host_mine).to(sampled.device)
+            mine = self._upload(host_mine)
+            # where each of the n candidates' loss will sit in the gathered buffer: uploaded NOW, while the stream
+            # is idle -- behind the forward the same pageable copy would hold the host until the GPU had finished,
+            # and the retokenisation filter would run after the forward instead of beside it (dist.dealt_index)
+            if emulate:
+                slot = np.full((uniq.shape[0],), take.shape[0], dtype=np.int64)      # unscored: the padding slot
+                slot[take] = np.arange(take.shape[0])
+                sel = slot[inv]
+            else:
+                sel = self.shard.dealt_index(by_cost, inv)
+            dealt = (by_cost, self._upload(sel), uniq.shape[0], first)
         else:
             lo, hi = self.shard.bounds(n)
             mine = sampled[lo:hi].contiguous()
@@ -629,17 +644,14 @@ class BimodalAttack:
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
         if dealt is not None:
-            by_cost, inv, n_u, _ = dealt
-            inv_t = torch.from_numpy(inv).to(losses.device)
+            by_cost, sel_t, n_u, _ = dealt
             if emulate:        # GEMM tuning only: rank 0's shapes of an `emulate`-rank run, the other ranks' shares unscored
-                take_t = torch.from_numpy(np.ascontiguousarray(by_cost[0::world])).to(losses.device)
-                full = torch.full((n_u,), float("inf"), device=losses.device).index_put_((take_t,), losses)[inv_t]
-                self._match = None if match is None else torch.zeros(n_u, device=losses.device).index_put_((take_t,), match)[inv_t]
+                full = torch.cat([losses.to(torch.float32), losses.new_full((1,), float("inf"), dtype=torch.float32)])[sel_t]
+                self._match = None if match is None else torch.cat([match.to(torch.float32), match.new_zeros((1,), dtype=torch.float32)])[sel_t]
             elif match is None:
-                full, self._match = self.shard.gather_dealt(losses, by_cost)[inv_t], None
+                full, self._match = self.shard.gather_dealt(losses, by_cost, at=sel_t), None
             else:
-                full, hits = self.shard.gather_dealt(losses, by_cost, extra=match)
-                full, self._match = full[inv_t], hits[inv_t]
+                full, self._match = self.shard.gather_dealt(losses, by_cost, extra=match, at=sel_t)
         else:
             full, self._match = self.shard.gather2(losses, match, n)
         if self.opt.loss_in_model_dtype:
@@ -848,7 +860,7 @@ class BimodalAttack:
                             idx = None
                             out = loss_all, sampled_all
                         else:
-                            idx = torch.tensor(keep, device=loss_all.device)
+                            idx = self._upload(np.asarray(keep, dtype=np.int64))
                             out = loss_all[idx], sampled_all[idx]
                         if cfg.early_stop and self._match is not None:
                             hit = self._match if idx is None else self._match[idx]
@@ -925,9 +937,10 @@ class BimodalAttack:
                         st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
                 loss_time = max(self._sync() - t0 - prefetch_s, 0.0)   # a prefetched gradient pass is booked as gradient time
                 if cfg.gcg_attack:
-                    # the reference books the filter under "sampling"; it ran inside this section
-                    samp_time += job.seconds
-                    loss_time = max(loss_time - job.seconds, 0.0)
+                    # the reference books the filter under "sampling"; here it ran beside the forward, so what it
+                    # cost this section is the time result() was blocked on it
+                    samp_time += job.waited
+                    loss_time = max(loss_time - job.waited, 0.0)
                     t_samp.append(samp_time)
                 t_loss.append(loss_time)
                 logger.info(f"[Iteration {i}] Current loss: {current_loss:.4f} | Best loss: {buffer.get_lowest_loss():.4f} | ")

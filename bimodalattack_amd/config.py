@@ -113,6 +113,10 @@ class EngineOptions:
     # HuggingFace builds for inputs_embeds calls (the causal flash kernels instead of the masked ones: -3 ms per
     # pass at the 643 tokens of the image prompt).  Model families with plain causal text attention only.
     maskless_b1_attention: bool = True
+    # retokenisation filter on a worker thread beside the forward's enqueue (utils.FilterJob) instead of on the main
+    # thread right after it.  Measured neutral to slightly slower (the two threads share the interpreter lock while
+    # the main one enqueues), so off; what mattered was keeping the host from blocking behind the forward at all.
+    threaded_filter: bool = False
     # vision towers whose head width is not a multiple of 32 (SigLIP: 72): zero-pad q/k/v to a width the library's
     # attention kernels are built for (prefix_attention.padded_heads_attention); same attention, faster kernels
     pad_vision_heads: bool = True
@@ -196,6 +200,8 @@ class EngineOptions:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
         if "BMA_MASKLESS_B1_ATTENTION" in env:
             opts.maskless_b1_attention = env["BMA_MASKLESS_B1_ATTENTION"] not in ("0", "false", "False")
+        if "BMA_THREADED_FILTER" in env:
+            opts.threaded_filter = env["BMA_THREADED_FILTER"] not in ("0", "false", "False")
         if "BMA_PAD_VISION_HEADS" in env:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:

@@ -90,24 +90,45 @@ class CandidateSharder:
         r = self.rank if rank is None else rank
         return order[r::self.world]
 
+    def dealt_index(self, order, inverse=None, world: Optional[int] = None):
+        """Host index vector for ``gather_dealt(..., at=)``: position of every candidate's value in the gathered
+        buffer (rank r's k-th dealt entry sits at r*per + k), composed with `inverse` (candidate -> distinct
+        candidate) when given.  Built -- and uploaded by the caller -- BEFORE the forward is enqueued: a host-to-
+        device copy from pageable memory issued behind it blocks the host until the stream has drained (ROCm),
+        which put the whole retokenisation filter behind the forward instead of beside it."""
+        import numpy as np
+        order = np.asarray(order)
+        n = int(order.shape[0])
+        w = self.world if world is None else world
+        per = -(-n // w)
+        src = np.empty((n,), dtype=np.int64)
+        for r in range(w):
+            idx = order[r::w]
+            src[idx] = r * per + np.arange(idx.shape[0])
+        return src if inverse is None else src[np.asarray(inverse)]
+
     def gather_dealt(self, local: torch.Tensor, order, pad: float = float("inf"),
-                     extra: Optional[torch.Tensor] = None):
+                     extra: Optional[torch.Tensor] = None, at: Optional[torch.Tensor] = None):
         """Inverse of ``deal``: `local` holds this rank's values for ``deal(order)``, in that order;
         returns the len(order) values indexed by candidate (order's entries) on every rank (and, with
-        `extra`, a second vector gathered in the same collective: a pair is returned)."""
+        `extra`, a second vector gathered in the same collective: a pair is returned).  `at`: the device copy
+        of ``dealt_index(order[, inverse])`` uploaded earlier (then len(at) values come back)."""
         import numpy as np
         order = np.asarray(order)
         n = int(order.shape[0])
         if not self.enabled:
-            at = torch.from_numpy(order).to(local.device)
-            outs = []
-            for v in (local, extra):
-                if v is None:
-                    outs.append(None)
-                    continue
-                o = torch.empty((n,), dtype=torch.float32, device=local.device)
-                o[at] = v.to(torch.float32)
-                outs.append(o)
+            if at is None:
+                at = torch.from_numpy(order).to(local.device)
+                outs = []
+                for v in (local, extra):
+                    if v is None:
+                        outs.append(None)
+                        continue
+                    o = torch.empty((n,), dtype=torch.float32, device=local.device)
+                    o[at] = v.to(torch.float32)
+                    outs.append(o)
+                return outs[0] if extra is None else tuple(outs)
+            outs = [None if v is None else v.to(torch.float32)[at] for v in (local, extra)]   # world 1: per = n
             return outs[0] if extra is None else tuple(outs)
         per = self.per_rank(n)
         if per:
@@ -115,11 +136,8 @@ class CandidateSharder:
         else:
             recv = local.new_empty((0,), dtype=torch.float32)
             recv2 = None if extra is None else recv
-        src = np.empty((n,), dtype=np.int64)
-        for r in range(self.world):
-            idx = order[r::self.world]
-            src[idx] = r * per + np.arange(idx.shape[0])
-        at = torch.from_numpy(src).to(recv.device)
+        if at is None:
+            at = torch.from_numpy(self.dealt_index(order)).to(recv.device)
         return recv[at] if extra is None else (recv[at], recv2[at])
 
     def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:

@@ -70,31 +70,57 @@ class FilterJob:
     """The retokenisation filter taken off the critical path: the candidate ids start
     their way to the host (pinned buffer, non-blocking copy) right after sampling, the
     GPU goes on to score EVERY sampled candidate, and the host runs the tokenizer round
-    trip meanwhile.  ``result()`` returns the surviving indices; the caller masks the
-    losses with them -- the same candidates win as if they had been filtered first."""
+    trip meanwhile: in ``result()``, called once the forward is enqueued (nothing on the
+    way there may block the host behind the stream -- see dist.dealt_index), or with
+    ``threaded`` on a worker thread from the start (measured no faster: both threads want
+    the interpreter lock while the main one enqueues).
+    ``result()`` returns the surviving indices; the caller masks the losses with them --
+    the same candidates win as if they had been filtered first.  ``seconds`` is the round
+    trip's own duration, ``waited`` what the caller actually spent blocked in ``result()``."""
 
-    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool):
+    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool, threaded: bool = False):
         self.n = ids.shape[0]
         self.tokenizer = tokenizer
         self.enabled = enabled
         self.seconds = 0.0
+        self.waited = 0.0
         self._keep: Optional[List[int]] = None
+        self._error: Optional[BaseException] = None
+        self._thread = None
         if enabled:
             self.host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
             self.host.copy_(ids, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(ids.device))
+            if threaded:
+                import threading
+                self._thread = threading.Thread(target=self._run, name="bma-filter", daemon=True)
+                self._thread.start()
+
+    def _run(self) -> None:
+        import time
+        try:
+            self.event.synchronize()
+            t0 = time.perf_counter()
+            self._keep = roundtrip_keep(self.host.tolist(), self.tokenizer)
+            self.seconds = time.perf_counter() - t0
+        except BaseException as e:          # handed to the caller of result(), reference behaviour (:183-186)
+            self._error = e
 
     def result(self) -> List[int]:
-        if self._keep is None:
+        if self._keep is None and self._error is None:
             if not self.enabled:
                 self._keep = list(range(self.n))
             else:
                 import time
-                self.event.synchronize()
                 t0 = time.perf_counter()
-                self._keep = roundtrip_keep(self.host.tolist(), self.tokenizer)
-                self.seconds = time.perf_counter() - t0
+                if self._thread is not None:
+                    self._thread.join()
+                else:
+                    self._run()
+                self.waited = time.perf_counter() - t0
+        if self._error is not None:
+            raise self._error
         return self._keep
 
 

@@ -755,3 +755,28 @@ def test_padded_vision_heads_same_features_and_pixel_gradient():
         assert float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
     big = g0.abs() > 0.1 * g0.abs().max()
     assert float((torch.sign(g1[big]) == torch.sign(g0[big])).float().mean()) > 0.98
+
+
+def test_filter_job_on_a_worker_thread_matches_inline():
+    """The retokenisation filter beside the forward (worker thread) keeps exactly what the inline one keeps, and
+    hands the reference's "nothing survives" error to the caller of result()."""
+    from bimodalattack_amd import synthetic as S
+    from bimodalattack_amd.utils import FilterJob, roundtrip_keep
+    tok = S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, S.TINY_UNRT)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, len(tok), (64, 8), generator=g).to(DEV)
+    want = None
+    try:
+        want = roundtrip_keep(ids.tolist(), tok)
+    except RuntimeError:
+        pass
+    assert want is not None and 0 < len(want) < 64           # the tiny vocabulary has words that do not round-trip
+    for threaded in (True, False):
+        job = FilterJob(ids, tok, True, threaded=threaded)
+        assert job.result() == want and job.result() is job.result() and job.seconds > 0
+    bad = ids[[i for i in range(64) if i not in want]][:4]
+    for threaded in (True, False):
+        job = FilterJob(bad, tok, True, threaded=threaded)
+        with pytest.raises(RuntimeError, match="No token sequences are the same"):
+            job.result()
+    assert FilterJob(ids, tok, False).result() == list(range(64))

@@ -54,6 +54,14 @@ def _worker(rank, world, port, out):
             assert torch.equal(full, truth) and torch.equal(neg, -truth)
             # every candidate is dealt exactly once
             assert sorted(np.concatenate([sh.deal(order, r) for r in range(world)]).tolist()) == list(range(n))
+            # the index uploaded before the forward (attack._score_candidates): composed with a duplicate map,
+            # one gather hands back one value per ORIGINAL candidate
+            if n:
+                inverse = torch.randint(0, n, (n + 3,), generator=g).numpy()
+                at = torch.from_numpy(sh.dealt_index(order, inverse))
+                assert torch.equal(sh.gather_dealt(truth[mine].clone(), order, at=at), truth[torch.from_numpy(inverse)])
+                a, b = sh.gather_dealt(truth[mine].clone(), order, extra=-truth[mine], at=at)
+                assert torch.equal(a, truth[torch.from_numpy(inverse)]) and torch.equal(b, -truth[torch.from_numpy(inverse)])
         # rank 0's ids and image overwrite a drifted rank's, in one packed broadcast
         ids = torch.arange(12, dtype=torch.int64).view(4, 3) + (0 if rank == 0 else 100 * rank)
         img = torch.full((1, 3, 4, 4), float(rank) + 0.25).requires_grad_()
