@@ -42,7 +42,7 @@ struct Args {
   uint16_t* out;
   const int *start, *first, *len;
   int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, pk_rs, pk_hs, pv_rs, pv_hs;
-  int B2, H, Hk, P, N;
+  int B2, H, Hk, P, N, nz;
   float scale_log2e;
 };
 
@@ -64,8 +64,13 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return bma::pack
 // list / Gemma-3 blocks / C4 blocks): two image pairs with one barrier per chunk 164 / 363 / 176 us, every chunk
 // resident in LDS with a single barrier 284 / 367 / 196 us, against 157 / 344 / 166 us for this scheme: the
 // kernel is bound by how many workgroups a CU holds, not by its barriers.
+// (waves per SIMD asked of the register allocator at 256-wide heads: 164 registers instead of 240 is a third wave per
+// SIMD, no spills, and the long Gemma-3 blocks -- a chain of one memory latency per 32-key chunk -- ran 11 % faster,
+// 318 -> 282 us.  At 128 the same request, 119 registers instead of 144 and a fourth wave, measured 3-10 % SLOWER on
+// the C3 row list and the C4 blocks, so nothing is asked there.)
 template <int DT, int QT, int DH>
-__global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
+__global__ __launch_bounds__(64 * QT) __attribute__((amdgpu_waves_per_eu(DH == 256 ? 2 : 1)))
+void ragged_attn_kernel(const Args a) {
   constexpr int KS = DH / 32;      // k-steps of the QK product
   constexpr int NT = DH / 16;      // 16-dim tiles of the output
   constexpr int PITCH = DH + 16;   // elements per LDS row (row + 32 B: conflict-free transposing reads)
@@ -76,9 +81,21 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, qt = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int i = blockIdx.x, h = blockIdx.y;
-  const int q0 = 16 * QT * blockIdx.z;                    // first query of this workgroup inside the block
-  const int hk = h / (a.H / a.Hk);
+  // Workgroup -> (candidate i, head h, stretch z).  The workgroups that read the same key/value rows from HBM --
+  // the H/Hk query heads on one key/value head, times the nz 64-query stretches of a long block -- get linear ids
+  // 8 apart, back to back: same XCD (workgroups go round the eight XCDs by linear id), hence the same L2, and
+  // dispatched within a few dozen ids of each other, so the rows are still there.  With (i, h, z) on the grid axes
+  // the sharers were a whole launch apart and on two XCDs: Gemma-3 blocks (303 tokens, 8 heads on 4) moved 2.85x
+  // their algorithmic bytes through HBM.  One stretch and H = Hk (the LLaVA row list) is the old order: i fastest.
+  const int rep = a.H / a.Hk;
+  const int S = rep * a.nz;
+  const int lin = blockIdx.x, t = lin >> 3;
+  const int grp = (t / S) * 8 + (lin & 7);                // (candidate, key/value head), candidate fastest
+  if (grp >= a.B2 * a.Hk) return;                         // uniform over the workgroup
+  const int sh = t % S;
+  const int i = grp % a.B2, hk = grp / a.B2;
+  const int h = hk * rep + sh % rep;
+  const int q0 = 16 * QT * (a.nz - 1 - sh / rep);         // longest stretch first
   const int st = a.start[i], p0 = a.first[i], ln = a.len[i];
   if (q0 >= ln) return;                                   // uniform over the workgroup
   const int P = a.P;
@@ -257,13 +274,17 @@ __global__ __launch_bounds__(64 * QT) void ragged_attn_kernel(const Args a) {
 template <int DT, int DH>
 int launch_dh(const Args& a, int max_len, hipStream_t st) {
   const int qt = max_len >= 64 ? 4 : (max_len + 15) / 16;
-  const dim3 grid(static_cast<unsigned>(a.B2), static_cast<unsigned>(a.H),
-                  static_cast<unsigned>((max_len + 16 * qt - 1) / (16 * qt)));
+  Args b = a;
+  b.nz = (max_len + 16 * qt - 1) / (16 * qt);
+  const int64_t groups = static_cast<int64_t>(a.B2) * a.Hk, sharers = static_cast<int64_t>(a.H / a.Hk) * b.nz;
+  const int64_t blocks = (groups + 7) / 8 * sharers * 8;
+  if (blocks > 0x7fffffffLL) return BMA_ELIMIT;
+  const dim3 grid(static_cast<unsigned>(blocks));
   switch (qt) {
-    case 1: hipLaunchKernelGGL((ragged_attn_kernel<DT, 1, DH>), grid, dim3(64), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((ragged_attn_kernel<DT, 2, DH>), grid, dim3(128), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((ragged_attn_kernel<DT, 3, DH>), grid, dim3(192), 0, st, a); break;
-    default: hipLaunchKernelGGL((ragged_attn_kernel<DT, 4, DH>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((ragged_attn_kernel<DT, 1, DH>), grid, dim3(64), 0, st, b); break;
+    case 2: hipLaunchKernelGGL((ragged_attn_kernel<DT, 2, DH>), grid, dim3(128), 0, st, b); break;
+    case 3: hipLaunchKernelGGL((ragged_attn_kernel<DT, 3, DH>), grid, dim3(192), 0, st, b); break;
+    default: hipLaunchKernelGGL((ragged_attn_kernel<DT, 4, DH>), grid, dim3(256), 0, st, b); break;
   }
   return BMA_OK;
 }

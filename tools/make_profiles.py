@@ -20,7 +20,7 @@ for w in ("gcg", "joint", "gemma_joint"):
                  (f"bench_{w}_under_rocprof.json", f"{tag}_bench_{w}_under_rocprof.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copyfile(os.path.join(src, a), os.path.join(out, b))
-for w in ("gcg", "joint"):                 # the batch-1 gradient pass alone (tools/grad_pass_profile.py)
+for w in ("gcg", "joint", "gemma_joint"):  # the batch-1 gradient pass alone (tools/grad_pass_profile.py)
     for a, b in ((f"gp_{w}_by_grid.txt", f"{tag}_gradient_pass_{w}_by_grid.txt"), (f"gp_{w}.txt", None)):
         pa = os.path.join(src, a)
         if os.path.exists(pa) and b:
@@ -30,7 +30,7 @@ for w in ("gcg", "joint"):                 # the batch-1 gradient pass alone (to
                 last = [l for l in open(note).read().splitlines() if "gradient pass" in l][-1:]
                 with open(os.path.join(out, b), "a") as f:
                     f.write("# " + (last[0] if last else "") + "\n")
-for extra in ("bench_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
+for extra in ("bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
               "bench_gemma_joint.json", "bench_default.json"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))

@@ -8,7 +8,7 @@ D=gpurun_out/${1:-round}
 mkdir -p "$D"
 export TMPDIR=/tmp
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke
-for w in gcg joint; do
+for w in gcg joint gemma_joint; do
   timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$D" -o gp_$w -- python3 tools/grad_pass_profile.py --workload $w > "$D/gp_$w.txt" 2>&1; tail -1 "$D/gp_$w.txt"
   python3 tools/trace_by_grid.py "$D/gp_${w}_kernel_trace.csv" "$D/gp_${w}_by_grid.txt" 40 --between-markers; rm -f "$D/gp_${w}_kernel_trace.csv"
 done
@@ -23,6 +23,9 @@ rm -f "$D"/*_kernel_trace.csv
 for w in joint pgd_gcg pgd gemma_joint; do
   timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > "$D/bench_$w.json" 2> /dev/null; echo "$w-rc=$?"
 done
-BMA_EMULATE_WORLD=8 timeout -k 10 300 python bench.py --no-cpu-baseline > "$D/bench_em8.json" 2> /dev/null; echo "em8-rc=$?"
+for n in 2 4 8; do
+  BMA_EMULATE_WORLD=$n timeout -k 10 300 python bench.py --no-cpu-baseline > "$D/bench_em$n.json" 2> /dev/null; echo "em$n-rc=$?"
+done
+BMA_EMULATE_WORLD=8 timeout -k 10 300 python bench.py --workload joint --no-cpu-baseline > "$D/bench_joint_em8.json" 2> /dev/null; echo "joint-em8-rc=$?"
 timeout -k 10 300 python bench.py --workload opt125m > "$D/bench_opt125m.json" 2> "$D/bench_opt125m.err"; echo "opt125m-rc=$?"
 timeout -k 10 300 python bench.py > "$D/bench_default.json" 2> "$D/bench_default.err"; echo "default-rc=$?"
