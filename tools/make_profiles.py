@@ -31,7 +31,7 @@ for w in ("gcg", "joint", "gemma_joint"):  # the batch-1 gradient pass alone (to
                 with open(os.path.join(out, b), "a") as f:
                     f.write("# " + (last[0] if last else "") + "\n")
 for extra in ("bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
-              "bench_gemma_joint.json", "bench_default.json"):
+              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
 for c in ("fetch", "write"):

@@ -29,3 +29,4 @@ done
 BMA_EMULATE_WORLD=8 timeout -k 10 300 python bench.py --workload joint --no-cpu-baseline > "$D/bench_joint_em8.json" 2> /dev/null; echo "joint-em8-rc=$?"
 timeout -k 10 300 python bench.py --workload opt125m > "$D/bench_opt125m.json" 2> "$D/bench_opt125m.err"; echo "opt125m-rc=$?"
 timeout -k 10 300 python bench.py > "$D/bench_default.json" 2> "$D/bench_default.err"; echo "default-rc=$?"
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > "$D/bench_driver.json" 2> /dev/null; echo "driver-rc=$?"   # the driver's own command line
