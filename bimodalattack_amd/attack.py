@@ -160,6 +160,8 @@ class BimodalAttack:
         # through the model behind the shared prefix for `candidates` candidates; bench.py reads this
         self.score_stats = dict(candidates=0, rows=0, rows_needed=0, ragged_calls=0, padded_calls=0)
         self._rescore_graphs: Dict[tuple, object] = {}
+        self._gp = None                            # _GradPrefix: scoring prefix reused by the gradient pass (joint mode)
+        self._gp_flag: Optional[bool] = None
         self._feat_graph = None                    # image -> image features (no autograd)
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
@@ -273,6 +275,15 @@ class BimodalAttack:
         change during an attack, so the whole forward+backward is captured into a hipGraph
         on the first call (after one eager run) and replayed afterwards; results are the
         eager ones (same kernels, same order)."""
+        if image is not None and self._gp_enabled():
+            try:
+                if self._gp is None:
+                    self._gp = _GradPrefix(self)
+                return self._gp.gradient(optim_ids, image)
+            except Exception as e:            # not workable with this model: the full pass below
+                self._fallback("grad_prefix_reuse", e, "gradient pass does not reuse the scoring prefix; running the full pass")
+                self._gp = False
+                torch.cuda.synchronize(self.model.device)
         if not self.opt.graph_gradient or self._grad_graph is False:
             return self._gradient_eager(optim_ids, image)
         if self._grad_graph is None:           # first call of the attack: warm up eagerly, capture, replay
@@ -285,6 +296,26 @@ class BimodalAttack:
                 torch.cuda.synchronize(self.model.device)
                 return self._gradient_eager(optim_ids, image)
         return self._grad_graph(optim_ids, image)
+
+    _GRAD_ORDER = ["before_img", "image", "before_suffix", "optim", "after", "target"]
+
+    def _gp_enabled(self) -> bool:
+        """Joint mode with the image in FRONT of the suffix (LLaVA layout): the prefix pass candidate scoring runs
+        on the image a PGD step has just produced -- vision tower + prompt up to the suffix, batch 1 -- is the
+        first 599 of the 644 rows of the NEXT step's gradient pass.  Run with autograd it serves both
+        (``_GradPrefix``): the gradient pass then runs 44 rows forward instead of 644.  Needs the gradient pass
+        and the scoring call to be the same function of the same segments (:968, :981-991 against :1142,
+        :1150-1163: true for the llava order and an unscaled embedding table)."""
+        if self._gp is False:
+            return False
+        if self._gp_flag is None:
+            cfg, hf, opt = self.config, self.hf, self.opt
+            ok = bool(opt.grad_prefix_reuse and cfg.pgd_attack and cfg.gcg_attack and cfg.joint_eval and opt.prefix_reuse
+                      and opt.shared_prefix_attention and opt.target_rows_only and hf.emb_scale == 1.0
+                      and hf.shared_ok is not False and hf.prefix_ok is not False
+                      and segment_order("pgd", hf.model_type, single=True) == self._GRAD_ORDER)
+            self._gp_flag = bool(ok and hf.shared_prefix_configs())
+        return self._gp_flag
 
     def _gradient_eager(self, optim_ids: Tensor, image: Optional[Tensor] = None):
         """One forward/backward at batch 1.  The one-hot is never built: its gradient is
@@ -385,6 +416,13 @@ class BimodalAttack:
     def scoring_features(self, image: Tensor) -> Tensor:
         """Image features for scoring (no autograd): the vision tower at batch 1 is launch-bound,
         so it is replayed from a hipGraph after the first call."""
+        if self._gp_enabled() and self._gp is not None:
+            try:
+                return self._gp.features(image)
+            except Exception as e:
+                self._fallback("grad_prefix_reuse", e, "gradient pass does not reuse the scoring prefix; running the full pass")
+                self._gp = False
+                torch.cuda.synchronize(self.model.device)
         if not self.opt.graph_prefix or self._feat_graph is False:
             return self.hf.image_features(image)
         if self._feat_graph is None:
@@ -413,6 +451,10 @@ class BimodalAttack:
         key = tuple(prefix_names)
         if "image" not in prefix_names and key in self._prefix_cache:
             return self._prefix_cache[key]
+        gp = self._gp
+        if gp not in (None, False) and feats is not None and gp.serves(key, feats):
+            hf.prefix_ok = True
+            return gp.cache(), gp.P
         def cat_prefix(f):
             return torch.cat([f if p == "image" else self.seg[p] for p in prefix_names], dim=1)
 
@@ -985,6 +1027,126 @@ class BimodalAttack:
         text = self.tokenizer.decode(out[0], skip_special_tokens=True)
         logger.info(f"Output generated: {text}")
         return text
+
+
+class _GradPrefix:
+    """The prefix pass of joint-mode candidate scoring, run WITH autograd so that it is also the first 599 rows of
+    the next gradient pass (``BimodalAttack._gp_enabled``).
+
+    ``features(image)``  -- scoring, step t: vision tower + prompt up to the suffix at batch 1; the recorded keys/
+                            values keep their history; scoring gets detached views.
+    ``gradient(ids, image)`` -- step t+1: the 44 tokens behind the prefix run forward against those keys/values
+                            (prefix_attention.tail_grad_attention), the loss back-propagates through both parts.
+
+    With hipGraphs (options graph_gradient and graph_prefix): two captures sharing one autograd graph, as
+    torch.cuda.make_graphed_callables does for a forward and its backward -- G1 = the prefix forward, G2 = the tail
+    forward + the whole backward.  Each keeps its own memory pool, so what G1's replay writes (saved activations,
+    keys/values) is read by G2's replay and by scoring and touched by nobody else.  The same maths as the full pass up
+    to the rounding of different GEMM shapes and of attention over [prefix ; tail] keys in one library call."""
+
+    def __init__(self, attack: "BimodalAttack"):
+        import weakref
+        # a proxy, not a reference: attack -> _GradPrefix -> attack would be a cycle, and a cycle holding hipGraphs and
+        # their memory pools is freed by the garbage collector whenever it happens to run -- e.g. in the middle of
+        # some later capture, which aborts the process
+        self.a = weakref.proxy(attack)
+        self.names = ("before_img", "image", "before_suffix")
+        self.image: Optional[Tensor] = None        # leaf the prefix was computed from (static under graphs)
+        self.ids: Optional[Tensor] = None
+        self.feats = self.rec = self.out = None
+        self.current = None                        # the caller's image tensor the prefix state belongs to
+        self.g1 = self.g2 = None
+        self.graphs = bool(attack.opt.graph_gradient and attack.opt.graph_prefix)
+        self.P = 0
+        self._cache = None
+
+    # -- the two halves ---------------------------------------------------------------------------
+    def _prefix_fn(self):
+        a = self.a
+        with torch.enable_grad():
+            feats = a.hf.image_features(self.image)
+            x = torch.cat([a.seg["before_img"], feats.to(a.model.dtype), a.seg["before_suffix"]], dim=1)
+            with a.fused, a._b1_attention(x.shape[1]):
+                rec = a.hf.build_prefix_recording(x)
+        return feats, rec
+
+    def _tail_fn(self):
+        a = self.a
+        E = a.embedding_layer.weight
+        emb = E[self.ids[0]].unsqueeze(0).detach().requires_grad_()
+        tail = torch.cat([emb, a.seg["after"], a.seg["target_in"]], dim=1)
+        with torch.enable_grad(), a.fused:
+            logits = a.hf.target_logits_behind_grad_prefix(tail, a.T, self.rec)
+            loss = ops.TargetCrossEntropy.apply(logits[0], a.labels)
+        g_emb, g_img = torch.autograd.grad(loss, [emb, self.image])
+        with torch.no_grad():
+            g_tok = (g_emb[0] @ E.t()).unsqueeze(0)
+        return g_tok, g_img, loss.detach()
+
+    def _set(self, feats, rec) -> None:
+        from .prefix_attention import RecordingKV
+        self.feats, self.rec = feats, rec
+        self.P = int(rec.k[0].shape[2])
+        det = RecordingKV(len(rec.k))
+        det.k, det.v = [t.detach() for t in rec.k], [t.detach() for t in rec.v]
+        self._cache = det
+        self._feats_out = feats.detach()
+
+    # -- what the engine calls ----------------------------------------------------------------------
+    def features(self, image: Tensor) -> Tensor:
+        """Make the prefix state current for `image`; the image features for scoring (no history)."""
+        if self.g1 is not None:
+            with torch.no_grad():
+                self.image.copy_(image)
+            self.g1.replay()
+        else:
+            self.image = image.detach().clone().requires_grad_()
+            self._set(*self._prefix_fn())
+        self.current = image
+        return self._feats_out
+
+    def serves(self, key: tuple, feats: Tensor) -> bool:
+        return key == self.names and feats is self._feats_out and self._cache is not None
+
+    def cache(self):
+        return self._cache
+
+    def gradient(self, optim_ids: Tensor, image: Tensor):
+        if self.graphs and self.g2 is None:
+            self._capture(optim_ids, image)
+        if self.current is not image:
+            self.features(image)
+        if self.g2 is not None:
+            with torch.no_grad():
+                self.ids.copy_(optim_ids)
+            self.g2.replay()
+            return self.out
+        self.ids = optim_ids
+        out = self._tail_fn()
+        self.current = None                        # eager: the history was consumed by this backward
+        return out
+
+    def _capture(self, optim_ids: Tensor, image: Tensor) -> None:
+        a, dev = self.a, self.a.model.device
+        self.image = image.detach().clone().requires_grad_()
+        self.ids = optim_ids.detach().clone()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):              # lazy initialisations must not land in a capture
+            self._set(*self._prefix_fn())
+            self._tail_fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            feats, rec = self._prefix_fn()
+        self._set(feats, rec)
+        with torch.cuda.graph(g2):
+            self.out = self._tail_fn()
+        self.g1, self.g2 = g1, g2
+        self.current = None
+        a.graphs_captured.append("grad_prefix")
+        a.graphs_captured.append("grad_tail")
 
 
 class _GradientGraph:

@@ -113,6 +113,9 @@ class EngineOptions:
     # HuggingFace builds for inputs_embeds calls (the causal flash kernels instead of the masked ones: -3 ms per
     # pass at the 643 tokens of the image prompt).  Model families with plain causal text attention only.
     maskless_b1_attention: bool = True
+    # joint mode, image in front of the suffix: the scoring prefix pass runs with autograd and serves as the first
+    # 599 rows of the next gradient pass, which then runs 44 rows forward instead of 644 (attack._GradPrefix)
+    grad_prefix_reuse: bool = True
     # retokenisation filter on a worker thread beside the forward's enqueue (utils.FilterJob) instead of on the main
     # thread right after it.  Measured neutral to slightly slower (the two threads share the interpreter lock while
     # the main one enqueues), so off; what mattered was keeping the host from blocking behind the forward at all.
@@ -200,6 +203,8 @@ class EngineOptions:
             opts.fuse_qkv = env["BMA_FUSE_QKV"] not in ("0", "false", "False")
         if "BMA_MASKLESS_B1_ATTENTION" in env:
             opts.maskless_b1_attention = env["BMA_MASKLESS_B1_ATTENTION"] not in ("0", "false", "False")
+        if "BMA_GRAD_PREFIX_REUSE" in env:
+            opts.grad_prefix_reuse = env["BMA_GRAD_PREFIX_REUSE"] not in ("0", "false", "False")
         if "BMA_THREADED_FILTER" in env:
             opts.threaded_filter = env["BMA_THREADED_FILTER"] not in ("0", "false", "False")
         if "BMA_PAD_VISION_HEADS" in env:

@@ -205,6 +205,16 @@ class HFAdapter:
         with pa.active(self.shared_prefix_configs(), kv):
             return self.model(inputs_embeds=embeds, past_key_values=kv, logits_to_keep=keep).logits
 
+    def target_logits_behind_grad_prefix(self, embeds: torch.Tensor, T: int, rec) -> torch.Tensor:
+        """Gradient pass with the prefix reused: `embeds` (1,L,D) are the tokens behind a prefix whose recorded
+        keys/values (`rec`, a RecordingKV filled under autograd) stay differentiable; returns the (1,T,V) logits
+        of the target-predicting rows."""
+        from . import prefix_attention as pa
+        kv = pa.GradPrefixKV(rec)
+        keep = self._keep_index(embeds.shape[1], T, embeds.device)
+        with pa.active(self.shared_prefix_configs(), kv, pa.NAME_TAIL):
+            return self.model(inputs_embeds=embeds, past_key_values=kv, logits_to_keep=keep).logits
+
     def target_logits_ragged(self, rows: torch.Tensor, T: int, cache, maps) -> torch.Tensor:
         """Ragged scoring (layout.ragged_plan): `rows` (1,N,D) holds, per candidate, only the tokens
         from its first replaced suffix position on (and the parent suffix in front); returns the

@@ -387,6 +387,73 @@ def causal_b1_attention(module, query, key, value, attention_mask=None, dropout:
     return out.transpose(1, 2).contiguous(), None
 
 
+NAME_TAIL = "bma_tail_grad"
+
+
+class GradPrefixKV(_CacheBase):
+    """The prefix keys/values of every layer WITH their autograd history (a RecordingKV filled under
+    `torch.enable_grad()`), handed to the forward of the tokens behind the prefix in the gradient pass: the
+    loss then back-propagates through them into whatever the prefix was computed from (the image)."""
+
+    def __init__(self, rec: RecordingKV):
+        try:
+            super().__init__(layers=[])
+        except Exception:
+            pass
+        self.k, self.v = list(rec.k), list(rec.v)
+        self.P = int(self.k[0].shape[2])
+        self._sliding = [False] * len(self.k)
+        self._bias = {}
+
+    @property
+    def is_sliding(self):
+        return self._sliding
+
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        return key_states, value_states            # the new tokens only: the attention function concatenates
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.P
+
+    def get_mask_sizes(self, q, layer_idx: int = 0):
+        q_len = int(q) if isinstance(q, int) else int(q.shape[0])
+        return self.P + q_len, 0
+
+    def get_max_cache_shape(self, layer_idx: int = 0) -> int:
+        return -1
+
+    def __len__(self):
+        return len(self.k)
+
+    def bias(self, L: int, dtype, device) -> torch.Tensor:
+        """(1,1,L,P+L) additive mask: every prefix key, causal among the L new tokens."""
+        key = (L, dtype, str(device))
+        if key not in self._bias:
+            b = torch.zeros((L, self.P + L), dtype=dtype, device=device)
+            b[:, self.P:] = torch.full((L, L), float("-inf"), dtype=dtype, device=device).triu(1)
+            self._bias[key] = b.view(1, 1, L, self.P + L)
+        return self._bias[key]
+
+
+def tail_grad_attention(module, query, key, value, attention_mask=None, dropout: float = 0.0,
+                        scaling: Optional[float] = None, **kwargs):
+    """HF attention-interface function for the tokens behind a prefix whose keys/values carry autograd history
+    (gradient pass with the scoring prefix reused, attack.py): library attention over [prefix ; new] keys, every
+    operand differentiable.  45 queries against 644 keys: the cost is in the launches, not the arithmetic."""
+    kv: GradPrefixKV = _ACTIVE[-1]
+    B, H, L, Dh = query.shape
+    scale = float(scaling) if scaling is not None else Dh ** -0.5
+    pk, pv = kv.k[module.layer_idx], kv.v[module.layer_idx]
+    K = torch.cat([pk.expand(B, -1, -1, -1), key], dim=2)
+    V = torch.cat([pv.expand(B, -1, -1, -1), value], dim=2)
+    n_rep = H // K.shape[1]
+    if n_rep > 1:
+        K, V = K.repeat_interleave(n_rep, dim=1), V.repeat_interleave(n_rep, dim=1)
+    out = torch.nn.functional.scaled_dot_product_attention(query, K, V, attn_mask=kv.bias(L, query.dtype, query.device),
+                                                           scale=scale)
+    return out.transpose(1, 2).contiguous(), None
+
+
 NAME_VIS = "bma_padded_heads"
 PAD_HEADS_MIN_TOKENS = int(os.environ.get("BMA_PAD_HEADS_MIN_TOKENS", "1024"))
 
@@ -456,6 +523,8 @@ def register() -> bool:
         AttentionInterface.register(NAME_B1, causal_b1_attention)
         AttentionMaskInterface.register(NAME_B1, _no_mask)
         AttentionInterface.register(NAME_VIS, padded_heads_attention)
+        AttentionInterface.register(NAME_TAIL, tail_grad_attention)
+        AttentionMaskInterface.register(NAME_TAIL, _no_mask)
         _REGISTERED["done"] = True
     except Exception:
         return False
@@ -496,13 +565,14 @@ def min_sliding_window(model) -> Optional[int]:
 
 
 @contextlib.contextmanager
-def active(configs: list, kv: SharedPrefixKV):
-    """Switch the text layers to the shared-prefix attention for one forward."""
+def active(configs: list, kv, name: str = NAME):
+    """Switch the text layers to the shared-prefix attention (or, with ``name=NAME_TAIL`` and a GradPrefixKV, to the
+    differentiable prefix + new-token attention of the gradient pass) for one forward."""
     old = [getattr(c, "_attn_implementation", None) for c in configs]
     _ACTIVE.append(kv)
     try:
         for c in configs:
-            c._attn_implementation = NAME
+            c._attn_implementation = name
         yield
     finally:
         _ACTIVE.pop()

@@ -144,6 +144,8 @@ def test_trajectory_matches_reference(golden_dir, name):
                                     dict(ragged_suffix=False),
                                     # the reference's separate batch-1 re-score of the joint winner
                                     dict(joint_winner_from_batch=False),
+                                    # the full 1-sequence gradient pass instead of scoring prefix + tail (joint mode)
+                                    dict(grad_prefix_reuse=False),
                                     # everything eager and unfused
                                     dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
                                          fused_elementwise=False, gemm_tuning="off")])
@@ -159,6 +161,7 @@ def test_restructurings_do_not_change_results(golden_dir, name, engine):
 @pytest.mark.parametrize("engine", [dict(graph_rescore=False, graph_gradient=False, graph_prefix=False),
                                     dict(joint_winner_from_batch=False),
                                     dict(fuse_pgd_only=False),
+                                    dict(grad_prefix_reuse=False),
                                     dict(ragged_suffix=False, chunk=7)])
 def test_early_stop_and_gemma_orders_under_restructurings(golden_dir, name, engine):
     """early_stop runs that stop mid-run (reference :1300-1306, :785-787) and the Gemma-3 segment orders
@@ -646,14 +649,16 @@ print("rccl-ok")
     assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stderr[-2000:]
 
 
-def test_graphs_are_really_captured_with_a_list_style_normalize():
+@pytest.mark.parametrize("reuse", [True, False])
+def test_graphs_are_really_captured_with_a_list_style_normalize(reuse):
     """The hipGraph paths must not silently fall back to eager: with a torchvision-style normalize
     (mean/std as Python lists, rebuilt as tensors on every call -- a host-to-device copy that aborts a
     capture) the engine still captures the gradient pass, the vision tower, the prefix pass and the
-    winner re-score, and the run equals the all-eager run."""
+    winner re-score -- or, with the scoring prefix reused by the gradient pass (the default in joint mode), the
+    prefix-with-history and tail+backward pair -- and the run equals the all-eager run."""
     from bimodalattack_amd import BimodalAttackConfig, synthetic as S
     from bimodalattack_amd.config import EngineOptions
-    from bimodalattack_amd.attack import BimodalAttack, _GradientGraph, _ReplayGraph
+    from bimodalattack_amd.attack import BimodalAttack, _GradientGraph, _GradPrefix, _ReplayGraph
 
     class ListNormalize:
         mean, std = list(S.CLIP_MEAN), list(S.CLIP_STD)
@@ -671,13 +676,20 @@ def test_graphs_are_really_captured_with_a_list_style_normalize():
                                   images_folder=tempfile.mkdtemp())
         kw = dict(graph_gradient=False, graph_prefix=False, graph_rescore=False) if eager else {}
         kw["joint_winner_from_batch"] = False           # keep the batch-1 winner re-score (and its graph) in play
-        attack = BimodalAttack(model, tok, proc, cfg, ListNormalize(), EngineOptions.from_env(rng_device="cpu", **kw))
+        attack = BimodalAttack(model, tok, proc, cfg, ListNormalize(),
+                               EngineOptions.from_env(rng_device="cpu", grad_prefix_reuse=reuse, strict=True, **kw))
         res = attack.run("tell me a story", "tell me a story", "Sure here is a story", image)
         out[eager] = res
+        assert attack.fallbacks == {}
+        assert isinstance(attack._gp, _GradPrefix) == reuse
         if not eager:
-            assert isinstance(attack._grad_graph, _GradientGraph)
-            assert isinstance(attack._feat_graph, _ReplayGraph)
-            assert attack._prefix_graphs and all(isinstance(g, _ReplayGraph) for g in attack._prefix_graphs.values())
+            if reuse:
+                assert isinstance(attack._gp.g1, torch.cuda.CUDAGraph) and isinstance(attack._gp.g2, torch.cuda.CUDAGraph)
+                assert attack._grad_graph is None        # (the buffer initialisation, before step 0, still scores through the plain prefix graph)
+            else:
+                assert isinstance(attack._grad_graph, _GradientGraph)
+                assert isinstance(attack._feat_graph, _ReplayGraph)
+                assert attack._prefix_graphs and all(isinstance(g, _ReplayGraph) for g in attack._prefix_graphs.values())
             assert attack._rescore_graphs and all(isinstance(g, _ReplayGraph) for g in attack._rescore_graphs.values())
             assert attack.hf.normalize.ok is True
     np.testing.assert_allclose(out[False].losses, out[True].losses, rtol=1e-5)
@@ -690,8 +702,14 @@ def test_16bit_engine_paths_agree(dtype):
     attention where the head size allows) against the plainer paths of the same engine on a 16-bit
     model: same candidates (CPU draws), first-step candidate losses equal to 16-bit rounding noise."""
     from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
-    variants = [dict(), dict(ragged_suffix=False), dict(shared_prefix_attention=False), dict(prefix_reuse=False),
-                dict(fuse_qkv=False, fuse_gate_up=False, backward_weight_copies=False, graph_gradient=False)]
+    # one gradient pass for all (the full 1-sequence pass): the prefix-reusing pass of joint mode rounds differently in
+    # 16 bits and two of the variants switch it off by construction, which would change the top-k picks under
+    # comparison; it rides along as the last variant, where its gradient is held to the same tolerance
+    full = dict(grad_prefix_reuse=False)
+    variants = [dict(full), dict(full, ragged_suffix=False), dict(full, shared_prefix_attention=False),
+                dict(full, prefix_reuse=False),
+                dict(full, fuse_qkv=False, fuse_gate_up=False, backward_weight_copies=False, graph_gradient=False),
+                dict()]
     out = []
     for eng in variants:
         model, tok, proc, image = S.tiny_case("llava", dtype=dtype, device=DEV)
@@ -710,7 +728,7 @@ def test_16bit_engine_paths_agree(dtype):
             np.testing.assert_allclose(st["losses"][0], base["losses"][0], rtol=tol, err_msg=str(eng))
         np.testing.assert_allclose(st["grad_tok"][-1], base["grad_tok"][-1], rtol=0.2,
                                    atol=0.05 * float(np.abs(base["grad_tok"][-1]).max()), err_msg=str(eng))
-    assert sum(np.array_equal(st["sampled"], base["sampled"]) for st in out[1:]) >= 3
+    assert sum(np.array_equal(st["sampled"], base["sampled"]) for st in out[1:5]) >= 3
 
 
 def test_padded_vision_heads_same_features_and_pixel_gradient():
@@ -780,3 +798,73 @@ def test_filter_job_on_a_worker_thread_matches_inline():
         with pytest.raises(RuntimeError, match="No token sequences are the same"):
             job.result()
     assert FilterJob(ids, tok, False).result() == list(range(64))
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_gradient_pass_reusing_the_scoring_prefix_equals_the_full_pass(graphs):
+    """Joint mode, LLaVA layout: the prefix pass of candidate scoring run with autograd + the 44 tokens behind it
+    (attack._GradPrefix) against the full 1-sequence forward/backward -- token gradients, pixel gradients and loss;
+    eagerly and as two hipGraphs sharing one autograd graph, over three images and suffixes in a row (a replay must
+    see the new image, not the captured one).  fp32 tiny model: the two are the same maths."""
+    from bimodalattack_amd import BimodalAttackConfig, synthetic as S
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    model, tok, proc, image = S.tiny_case("llava", device=DEV)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=8, topk=16, seed=1, verbosity="ERROR", pgd_attack=True,
+                              gcg_attack=True, joint_eval=True, optim_str_init=S.TINY_OPTIM_INIT,
+                              images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, S.Normalize(S.CLIP_MEAN, S.CLIP_STD),
+                        EngineOptions.from_env(save_images=False, graph_gradient=graphs, graph_prefix=graphs, strict=True))
+    atk._prepare_prompt("tell me a story", "Sure here is")
+    assert atk._gp_enabled()
+    g = torch.Generator().manual_seed(3)
+    ids0 = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(DEV)
+    for it in range(3):
+        ids = ids0.clone()
+        ids[0, it] = 17 + it
+        img = (image.to(DEV) + 0.05 * it * torch.rand(image.shape, generator=g).to(DEV)).clamp(0, 1)
+        want_tok, want_img, want_loss = atk._gradient_eager(ids, img.detach().clone().requires_grad_())
+        got_tok, got_img, got_loss = atk.compute_gradient(ids, img)
+        assert atk._gp not in (None, False) and (atk._gp.g2 is not None) == graphs
+        assert abs(float(got_loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
+        for got, want in ((got_tok, want_tok), (got_img, want_img)):        # fp32 sums in another order: 1e-5 of the scale
+            assert float((got.float() - want.float()).abs().max()) <= 1e-4 * float(want.float().abs().max())
+        # scoring on the next image goes through the same object and serves the prefix of the pass after it
+        nxt = (img + 0.01).clamp(0, 1)
+        feats = atk.scoring_features(nxt)
+        assert atk._gp.serves(("before_img", "image", "before_suffix"), feats) and atk._gp.current is nxt
+        with torch.no_grad():
+            assert torch.allclose(feats, atk.hf.image_features(nxt), rtol=1e-5, atol=1e-6)
+    assert atk.fallbacks == {}
+    assert ("grad_tail" in atk.graphs_captured) == graphs
+
+
+def test_prefix_reusing_gradient_pass_at_7b_width_bf16():
+    """LLaVA-1.5-7B width, 2 layers, bf16, the 643-token image prompt: scoring prefix (599 rows, with history) + the
+    44 tokens behind it against the full pass -- same function, other GEMM shapes and one library attention over
+    [prefix ; tail] keys: loss, token gradient and pixel gradient agree to bf16 noise, as two hipGraphs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("joint", dev, torch.bfloat16, 2)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=True,
+                              joint_eval=True, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True))
+    atk._prepare_prompt(messages, target)
+    assert atk._gp_enabled()
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    t0, i0, l0 = atk._gradient_eager(ids, image.detach().clone().requires_grad_())
+    for _ in range(2):                                        # capture, then a replay
+        t1, i1, l1 = atk.compute_gradient(ids, image)
+    assert atk._gp.g2 is not None and atk._gp.P == 599 and atk.fallbacks == {}
+    t0, i0, t1, i1 = t0.float(), i0.float(), t1.float(), i1.float()
+    assert abs(float(l1) - float(l0)) <= 2e-2 * abs(float(l0))
+    assert float((t1 - t0).abs().max()) <= 5e-2 * float(t0.abs().max())
+    assert float((i1 - i0).abs().max()) <= 5e-2 * float(i0.abs().max())
+    big = i0.abs() > 0.05 * i0.abs().max()
+    assert float((torch.sign(i1[big]) == torch.sign(i0[big])).float().mean()) > 0.98
