@@ -1029,6 +1029,12 @@ class BimodalAttack:
         return text
 
 
+# hipGraph captures police the capturing THREAD only: the process has other threads that talk to the runtime while a
+# capture is open -- RCCL's watchdog polling events of earlier collectives, the PNG writer copying an image to the
+# host -- and in the default ("global") mode any such call from any thread invalidates the capture.
+_CAPTURE_MODE = os.environ.get("BMA_CAPTURE_MODE", "thread_local")
+
+
 class _GradPrefix:
     """The prefix pass of joint-mode candidate scoring, run WITH autograd so that it is also the first 599 rows of
     the next gradient pass (``BimodalAttack._gp_enabled``).
@@ -1138,10 +1144,10 @@ class _GradPrefix:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
+        with torch.cuda.graph(g1, capture_error_mode=_CAPTURE_MODE):
             feats, rec = self._prefix_fn()
         self._set(feats, rec)
-        with torch.cuda.graph(g2):
+        with torch.cuda.graph(g2, capture_error_mode=_CAPTURE_MODE):
             self.out = self._tail_fn()
         self.g1, self.g2 = g1, g2
         self.current = None
@@ -1165,7 +1171,7 @@ class _GradientGraph:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.out = attack._gradient_eager(self.ids, self.image)
 
     def __call__(self, optim_ids: Tensor, image: Optional[Tensor]):
@@ -1191,7 +1197,7 @@ class _ReplayGraph:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.out = fn(*self.inputs)
 
     def __call__(self, *inputs: Tensor):
