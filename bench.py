@@ -34,6 +34,9 @@ if REPO not in sys.path:
 # the CLIP patch-embedding convolution would otherwise trigger MIOpen's exhaustive kernel search on a
 # fresh machine (~2 minutes before the first PGD step); must be set before MIOpen initialises
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the
+# launcher usually exports it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 _T0 = time.perf_counter()
 
