@@ -270,7 +270,7 @@ class BimodalAttack:
         return rnd.contiguous(), rank.contiguous()
 
     # ------------------------------------------------------------ gradient pass
-    def compute_gradient(self, optim_ids: Tensor, image: Optional[Tensor] = None):
+    def compute_gradient(self, optim_ids: Tensor, image: Optional[Tensor] = None, tokens_only: bool = False):
         """d(mean target CE)/d(one-hot suffix) and /d(image) (:953-1028).  Shapes never
         change during an attack, so the whole forward+backward is captured into a hipGraph
         on the first call (after one eager run) and replayed afterwards; results are the
@@ -279,7 +279,7 @@ class BimodalAttack:
             try:
                 if self._gp is None:
                     self._gp = _GradPrefix(self)
-                return self._gp.gradient(optim_ids, image)
+                return self._gp.gradient(optim_ids, image, tokens_only)
             except Exception as e:            # not workable with this model: the full pass below
                 self._fallback("grad_prefix_reuse", e, "gradient pass does not reuse the scoring prefix; running the full pass")
                 self._gp = False
@@ -300,17 +300,20 @@ class BimodalAttack:
     _GRAD_ORDER = ["before_img", "image", "before_suffix", "optim", "after", "target"]
 
     def _gp_enabled(self) -> bool:
-        """Joint mode with the image in FRONT of the suffix (LLaVA layout): the prefix pass candidate scoring runs
-        on the image a PGD step has just produced -- vision tower + prompt up to the suffix, batch 1 -- is the
-        first 599 of the 644 rows of the NEXT step's gradient pass.  Run with autograd it serves both
-        (``_GradPrefix``): the gradient pass then runs 44 rows forward instead of 644.  Needs the gradient pass
+        """PGD + GCG with the image in FRONT of the suffix (LLaVA layout).  Joint mode: the prefix pass candidate
+        scoring runs on the image a PGD step has just produced -- vision tower + prompt up to the suffix, batch 1 --
+        is the first 599 of the 644 rows of the NEXT step's gradient pass; run with autograd it serves both
+        (``_GradPrefix``) and the gradient pass runs 44 rows forward instead of 644.  Without joint_eval the step has
+        two gradient passes on the same image (:481): the second only feeds the token gradient, which does not reach
+        the prefix at all -- 44 rows forward and backward against the prefix's detached keys/values -- and the first
+        pass of the next step back-propagates through the history that prefix pass kept.  Needs the gradient pass
         and the scoring call to be the same function of the same segments (:968, :981-991 against :1142,
         :1150-1163: true for the llava order and an unscaled embedding table)."""
         if self._gp is False:
             return False
         if self._gp_flag is None:
             cfg, hf, opt = self.config, self.hf, self.opt
-            ok = bool(opt.grad_prefix_reuse and cfg.pgd_attack and cfg.gcg_attack and cfg.joint_eval and opt.prefix_reuse
+            ok = bool(opt.grad_prefix_reuse and cfg.pgd_attack and cfg.gcg_attack and opt.prefix_reuse
                       and opt.shared_prefix_attention and opt.target_rows_only and hf.emb_scale == 1.0
                       and hf.shared_ok is not False and hf.prefix_ok is not False
                       and segment_order("pgd", hf.model_type, single=True) == self._GRAD_ORDER)
@@ -851,9 +854,9 @@ class BimodalAttack:
                         if g[1] is not None:
                             st["grad_img"].append(g[1].cpu().numpy())
 
-                def grad_pass(record: bool = True):
+                def grad_pass(record: bool = True, tokens_only: bool = False):
                     t0 = self._sync()
-                    g = self.compute_gradient(optim_ids, image if cfg.pgd_attack else None)
+                    g = self.compute_gradient(optim_ids, image if cfg.pgd_attack else None, tokens_only)
                     dt = self._sync() - t0
                     t_grad.append(dt)
                     if record:
@@ -877,7 +880,8 @@ class BimodalAttack:
                     if st is not None:
                         st["image_after_pgd"] = image.detach().cpu().numpy()
                     if cfg.gcg_attack and not cfg.joint_eval:
-                        (g_tok, g_img, _), grad_time = grad_pass()
+                        # only the token gradient of this pass is used (the image has just been stepped)
+                        (g_tok, g_img, _), grad_time = grad_pass(tokens_only=True)
 
                 # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
@@ -1061,7 +1065,9 @@ class _GradPrefix:
         self.ids: Optional[Tensor] = None
         self.feats = self.rec = self.out = None
         self.current = None                        # the caller's image tensor the prefix state belongs to
-        self.g1 = self.g2 = None
+        self.g1 = self.g2 = self.g3 = None
+        self.ids3 = self.out3 = None
+        self._feats_out = None
         self.graphs = bool(attack.opt.graph_gradient and attack.opt.graph_prefix)
         self.P = 0
         self._cache = None
@@ -1101,6 +1107,8 @@ class _GradPrefix:
     # -- what the engine calls ----------------------------------------------------------------------
     def features(self, image: Tensor) -> Tensor:
         """Make the prefix state current for `image`; the image features for scoring (no history)."""
+        if self.current is image and self._cache is not None:
+            return self._feats_out
         if self.g1 is not None:
             with torch.no_grad():
                 self.image.copy_(image)
@@ -1117,11 +1125,50 @@ class _GradPrefix:
     def cache(self):
         return self._cache
 
-    def gradient(self, optim_ids: Tensor, image: Tensor):
+    def _tokens_fn(self):
+        """Token gradient only: the prefix is a constant of the suffix, so its detached keys/values do."""
+        a = self.a
+        E = a.embedding_layer.weight
+        emb = E[self.ids3[0]].unsqueeze(0).detach().requires_grad_()
+        tail = torch.cat([emb, a.seg["after"], a.seg["target_in"]], dim=1)
+        with torch.enable_grad(), a.fused:
+            logits = a.hf.target_logits_behind_grad_prefix(tail, a.T, self._cache)
+            loss = ops.TargetCrossEntropy.apply(logits[0], a.labels)
+        (g_emb,) = torch.autograd.grad(loss, [emb])
+        with torch.no_grad():
+            g_tok = (g_emb[0] @ E.t()).unsqueeze(0)
+        return g_tok, None, loss.detach()
+
+    def _tokens(self, optim_ids: Tensor):
+        if self.g1 is None:                        # eager: the history stays for the pass that wants the pixels
+            self.ids3 = optim_ids
+            return self._tokens_fn()
+        if self.g3 is None:
+            dev = self.a.model.device
+            self.ids3 = optim_ids.detach().clone()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._tokens_fn()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3, capture_error_mode=_CAPTURE_MODE):
+                self.out3 = self._tokens_fn()
+            self.g3 = g3
+            self.a.graphs_captured.append("grad_tail_tokens")
+        with torch.no_grad():
+            self.ids3.copy_(optim_ids)
+        self.g3.replay()
+        return self.out3
+
+    def gradient(self, optim_ids: Tensor, image: Tensor, tokens_only: bool = False):
         if self.graphs and self.g2 is None:
             self._capture(optim_ids, image)
         if self.current is not image:
             self.features(image)
+        if tokens_only:
+            return self._tokens(optim_ids)
         if self.g2 is not None:
             with torch.no_grad():
                 self.ids.copy_(optim_ids)

@@ -829,6 +829,11 @@ def test_gradient_pass_reusing_the_scoring_prefix_equals_the_full_pass(graphs):
         assert abs(float(got_loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
         for got, want in ((got_tok, want_tok), (got_img, want_img)):        # fp32 sums in another order: 1e-5 of the scale
             assert float((got.float() - want.float()).abs().max()) <= 1e-4 * float(want.float().abs().max())
+        # the token gradient alone (second pass of a non-joint step): prefix detached, same numbers
+        tok_only, none_img, loss_only = atk.compute_gradient(ids, img, tokens_only=True)
+        assert none_img is None and abs(float(loss_only) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
+        assert float((tok_only.float() - want_tok.float()).abs().max()) <= 1e-4 * float(want_tok.float().abs().max())
+        assert (atk._gp.g3 is not None) == graphs
         # scoring on the next image goes through the same object and serves the prefix of the pass after it
         nxt = (img + 0.01).clamp(0, 1)
         feats = atk.scoring_features(nxt)
