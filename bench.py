@@ -3,6 +3,7 @@
 LLaVA-1.5-7B (bf16), search_width = 512.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gcg|joint|pgd|pgd_gcg|gemma_joint|opt125m]
+                    [--extra-workloads joint,pgd,gemma_joint | none]
 
 A "step" is one full pass of the hot path: gradient pass -> (PGD projection) ->
 mask/top-k/scatter sampling -> retokenisation filter -> candidate splice + forward +
@@ -17,6 +18,16 @@ per-kernel HIP-event brackets behind `roofline`, `gemms` and `kernels` run in
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `value` is whole-step
 candidate forwards per second (all ranks, wall clock, max over ranks); the per-phase
 rate the reference's tables quote (search_width / loss-phase seconds) is given beside it.
+
+The line's `value` / `config` are the --workload run (default: BASELINE configs[2], GCG-only).  On one GPU the
+other single-GPU BASELINE configurations -- joint (configs[3]) and PGD-only (configs[1]) on the SAME LLaVA model,
+Gemma-3 joint with the dynamic width schedule (configs[4]) on its own model -- run after it, --extra-steps timed
+steps each, and land under `workloads`: {name: {ms_per_step, value, phase_s_per_step, roofline, gradient_pass,
+engine}}.  Every workload's batch-1 gradient pass (replayed from hipGraphs in the timed steps, where neither Python
+hooks nor the in-library event brackets can see it) is profiled once more EAGERLY after the timed region: every
+library GEMM it issues is recorded (aten.mm / addmm / bmm, forward and backward) and each distinct product is timed
+back to back over the layers' own weights with HIP events -- `gradient_pass.gemms`, with FLOPs, bytes, us and both
+roofline fractions; for PGD-only its dominant product IS the step's `roofline`.
 """
 
 from __future__ import annotations
@@ -95,18 +106,42 @@ def wl_segments(workload: str, attack) -> dict:
             "target": seg["target"]}
 
 
-def build_plugins(workload: str, device, dtype, layers: int):
+_MODELS: dict = {}
+
+
+def build_model(kind: str, device, dtype, layers: int, share: bool = False):
+    """Random-weight model of a public config shape ("llava", "gemma", "opt"); with `share` built once per process
+    and kind (bench.py's workloads on one model shape run on ONE model object)."""
+    from bimodalattack_amd import synthetic as S
+    key = (kind, str(device), dtype, layers)
+    if not share or key not in _MODELS:
+        if kind == "gemma":
+            log("building Gemma-3-4b-shaped model on the device")
+            model = S.gemma3_4b_shaped(dtype=dtype, device=device, seed=0)
+        elif kind == "opt":
+            model = S.opt_125m_shaped(50272, dtype=dtype, device=device, seed=0)
+        else:
+            log("building LLaVA-1.5-7B-shaped model on the device")
+            model = S.llava_15_7b_shaped(dtype=dtype, device=device, seed=0, text_layers=layers)
+        log(f"model ready on {model.device} ({sum(p.numel() for p in model.parameters()) / 1e9:.2f} B parameters)")
+        if not share:
+            return model
+        _MODELS[key] = model
+    return _MODELS[key]
+
+
+def build_plugins(workload: str, device, dtype, layers: int, share: bool = False):
     """Synthetic tokenizer (32000 printable-ASCII words; embedding table has 32064 rows),
-    LLaVA-1.5-7B-shaped random-weight model, prompt strings of the fixed segment lengths."""
+    LLaVA-1.5-7B-shaped random-weight model, prompt strings of the fixed segment lengths.  Workloads on one model
+    shape share the model object (and the engine's derived weight copies with it); tokenizer, processor and
+    prompt are built per workload (the PGD workloads write their own chat template)."""
     from bimodalattack_amd import synthetic as S
     if workload == "gemma_joint":
         # Gemma-3 layout 20|19|3|256|6|20 (SURVEY.md 8): suffix in FRONT of the image
         tok = S.build_tokenizer(262144, 0, 0)
         tok.chat_template = S.GEMMA_TEMPLATE
         proc = S.Gemma3Processor(tok, S.GEMMA_TEMPLATE)
-        log("tokenizer built; building Gemma-3-4b-shaped model on the device")
-        model = S.gemma3_4b_shaped(dtype=dtype, device=device, seed=0)
-        log(f"model ready on {model.device} ({sum(p.numel() for p in model.parameters()) / 1e9:.2f} B parameters)")
+        model = build_model("gemma", device, dtype, layers, share)
         goal, target = S.synthetic_prompt(tok, 18, 20, seed=0)        # <start_of_turn>user + 18 + BOS = 20
         image = S.synthetic_image(896, 896, seed=0, device=device)
         return model, tok, proc, goal, goal, target, image, S.Normalize((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
@@ -114,16 +149,13 @@ def build_plugins(workload: str, device, dtype, layers: int):
         # OPT-125M shape (768 / 12 layers / 12 heads / 3072), fp32, vocabulary = the tokenizer's 50272 words
         tok = S.build_tokenizer(50272, 0, 0)
         proc = S.SyntheticProcessor(tok)
-        model = S.opt_125m_shaped(50272, dtype=dtype, device=device, seed=0)
-        log(f"OPT-125M-shaped model ready on {model.device} ({sum(p.numel() for p in model.parameters()) / 1e6:.0f} M parameters)")
+        model = build_model("opt", device, dtype, layers, share)
         goal, target = S.synthetic_prompt(tok, SEG["gcg"]["before"] - 1, SEG["gcg"]["target"], seed=0)
         after, _ = S.synthetic_prompt(tok, SEG["gcg"]["after"], 1, seed=1)
         return model, tok, proc, f"{goal} {{optim_str}} {after}", goal, target, None, None
     tok = S.build_tokenizer(32000, 0, 0)
     proc = S.SyntheticProcessor(tok)
-    log("tokenizer built; building LLaVA-1.5-7B-shaped model on the device")
-    model = S.llava_15_7b_shaped(dtype=dtype, device=device, seed=0, text_layers=layers)
-    log(f"model ready on {model.device} ({sum(p.numel() for p in model.parameters()) / 1e9:.2f} B parameters)")
+    model = build_model("llava", device, dtype, layers, share)
     if workload == "gcg":
         # GCG-only template renders the bare content: before = BOS + goal tokens
         n_goal, after_txt = SEG["gcg"]["before"] - 1, SEG["gcg"]["after"]
@@ -221,6 +253,16 @@ class GemmTimer:
     passes (those are replayed from hipGraphs and run no Python anyway)."""
 
     ROLES = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj", "lm_head")
+    _BY_MODEL: dict = {}
+
+    @classmethod
+    def for_model(cls, model, fused_qkv_blocks):
+        """One timer (one set of module hooks) per model object: the workloads of a run share the model."""
+        t = cls._BY_MODEL.get(id(model))
+        if t is None:
+            t = cls._BY_MODEL[id(model)] = cls(model, fused_qkv_blocks)
+        t.on, t.rec = False, []
+        return t
 
     def __init__(self, model, fused_qkv_blocks, min_rows: int = 1024):
         import torch
@@ -284,6 +326,127 @@ class GemmTimer:
         return out
 
 
+class GradPassProfile:
+    """The library GEMMs of ONE batch-1 gradient pass, measured outside the timed region.
+
+    The timed steps replay the pass from hipGraphs: no Python runs, so neither module hooks nor the in-library event
+    brackets see it (and GemmTimer deliberately ignores products under 1024 rows).  Here the same work runs once
+    EAGERLY under a dispatch mode that records every aten.mm / addmm / bmm -- forward and backward, the autograd
+    engine's thread included -- with its operand tensors; then each distinct product (op, shapes, strides) is
+    timed: its recorded calls, which walk the layers' own weights, so every launch streams a different weight from
+    HBM as in the real pass, are captured into one hipGraph and replayed between two HIP events on the stream they
+    run on.  Per product: FLOPs 2MNK, operand bytes, us, TFLOP/s against the dense MFMA peak, GB/s against HBM."""
+
+    OPS = ("mm", "addmm", "bmm")
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.calls = []
+
+    def record(self, fn):
+        torch = self.torch
+        from torch.utils._python_dispatch import TorchDispatchMode
+        outer = self
+
+        class Rec(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                name = getattr(getattr(func, "overloadpacket", None), "__name__", "")
+                if name in outer.OPS and all(torch.is_tensor(a) and a.is_cuda for a in args[-2:]):
+                    outer.calls.append((name, func, args, dict(kwargs or {})))
+                return func(*args, **(kwargs or {}))
+
+        with Rec():
+            out = fn()
+        torch.cuda.synchronize()
+        return out
+
+    @staticmethod
+    def _mnk(name, args):
+        a, b = args[-2], args[-1]
+        if name == "bmm":
+            return a.shape[0], a.shape[1], b.shape[2], a.shape[2]
+        return 1, a.shape[0], b.shape[1], a.shape[1]
+
+    def table(self, roles: dict, max_launches: int = 96) -> list:
+        """One entry per distinct product, in order of summed time."""
+        torch = self.torch
+        groups = {}
+        for name, func, args, kw in self.calls:
+            a, b = args[-2], args[-1]
+            key = (name, tuple(a.shape), tuple(b.shape), tuple(a.stride()), tuple(b.stride()), str(a.dtype))
+            groups.setdefault(key, []).append((func, args, kw))
+        out = []
+        for key, calls in groups.items():
+            name = key[0]
+            batch, M, N, K = self._mnk(name, calls[0][1])
+            run = calls[:max_launches]
+            for func, args, kw in run[:2]:
+                func(*args, **kw)
+            torch.cuda.synchronize()
+            how = "hipGraph of the recorded calls"
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    keep = [func(*args, **kw) for func, args, kw in run]
+                g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                del keep, g
+            except Exception:
+                torch.cuda.synchronize()
+                how = "eager loop over the recorded calls"
+                e0.record()
+                for func, args, kw in run:
+                    func(*args, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / len(run)
+            es = calls[0][1][-1].element_size()
+            flops = 2.0 * batch * M * N * K
+            nbytes = float(es * batch * (M * K + K * N + M * N))
+            b_shape = key[2]
+            # a linear layer's weight is the (K,N) operand, a transposed view of the stored (N,K) matrix -- or, for the
+            # input gradients through the transposed copies, of the stored (K,N) one
+            role = roles.get((N, K)) if name != "bmm" else None
+            out.append(dict(op=name, role=role or f"{name} {tuple(key[1])} x {tuple(b_shape)}", batch=batch, M=M, N=N, K=K,
+                            dtype=key[5].replace("torch.", ""), launches_per_pass=len(calls), avg_us=us,
+                            total_ms_per_pass=us * len(calls) / 1e3, flops_per_launch=flops, bytes_per_launch=nbytes,
+                            achieved_TFLOPs=flops / (us * 1e-6) / 1e12, frac_of_mfma_peak=flops / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS,
+                            achieved_GBps=nbytes / (us * 1e-6) / 1e9, frac_of_8TBps=nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            timed_as=how))
+        out.sort(key=lambda d: -d["total_ms_per_pass"])
+        return out
+
+
+def gemm_roles(tc, vocab_rows: int) -> dict:
+    """(N, K) of a product -> which decoder projection it is (forward: y = x W^T; `dX`: the input gradient)."""
+    D = tc.hidden_size
+    inter = getattr(tc, "intermediate_size", None) or getattr(tc, "ffn_dim")
+    heads = tc.num_attention_heads
+    hd = getattr(tc, "head_dim", None) or D // heads
+    kvh = getattr(tc, "num_key_value_heads", None) or heads
+    q, kv = heads * hd, kvh * hd
+    r = {}
+
+    def put(n, k, name):
+        r.setdefault((n, k), name)
+        r.setdefault((k, n), name + " dX")
+
+    put(2 * inter, D, "gate_up_proj (fused)")
+    put(q + 2 * kv, D, "qkv_proj (fused)")
+    put(D, inter, "down_proj")
+    put(D, q, "o_proj")
+    put(inter, D, "gate_proj / up_proj")
+    put(q, D, "q_proj")
+    put(kv, D, "k_proj / v_proj")
+    put(vocab_rows, D, "lm_head / token scores")
+    return r
+
+
 def self_launch(args) -> None:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes
     (python -m torch.distributed.run, rendezvous on 127.0.0.1) before this process has touched the GPU, pass
@@ -303,16 +466,356 @@ def self_launch(args) -> None:
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+_PMC = {}
+
+
+def committed_profile(name: str):
+    """A committed measurement file under profiles/ (the newest round that has one), parsed; (None, None) when absent."""
+    if name not in _PMC:
+        hit = (None, None)
+        for tag in ("r3", "r2"):
+            path = os.path.join(REPO, "profiles", f"{tag}_{name}")
+            try:
+                with open(path) as f:
+                    hit = (json.load(f), f"profiles/{tag}_{name}")
+                break
+            except Exception:
+                continue
+        _PMC[name] = hit
+    return _PMC[name]
+
+
+def pmc_traffic(kernel: str, live_bytes: float):
+    """(HBM bytes per launch, source) from the COMMITTED rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE over
+    tools/kernel_bench.py -- not measured in this run): the entry of this kernel whose launch shape is within 6 % of
+    this run's algorithmic bytes, scaled by its measured traffic / algorithmic ratio.  (None, None) without one."""
+    pmc, src = committed_profile("pmc_traffic.json")
+    near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == kernel
+            and abs(e["algorithmic_bytes"] - live_bytes) <= 0.06 * e["algorithmic_bytes"]]
+    if not near:
+        return None, None
+    e = min(near, key=lambda e: abs(e["algorithmic_bytes"] - live_bytes))
+    at = (pmc or {}).get("generated_at_commit")
+    return e["ratio_to_algorithmic"] * live_bytes, f"{src}{'@' + at if at else ''} ({e['pmc_key']}), committed file, not measured in this run"
+
+
+COPY_CEILING_GBS = 6290.0     # measured streaming-copy ceiling of the part (MI355X_MICROARCH.md)
+
+
+def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, world: int, rank: int, primary: bool):
+    """One workload: construct the engine on the (shared) model, run warmup + steps + n_prof attack steps with the clock
+    around the `steps`, then profile.  Returns (result dict, what cpu_baseline needs)."""
+    import torch
+    import torch.distributed as dist
+    from bimodalattack_amd import BimodalAttackConfig, native
+    from bimodalattack_amd.attack import BimodalAttack, logger as gcg_logger
+    from bimodalattack_amd.config import EngineOptions
+
+    wl = WORKLOADS[workload]
+    dtype = torch.float32 if wl.get("fp32") else torch.bfloat16
+    sw = args.search_width if (args.search_width is not None and primary) else wl.get("search_width", 512)
+    log(f"=== workload {workload}: {wl['name']}")
+    model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, device, dtype, args.layers, share=True)
+    cfg_kw = dict(search_width=sw, topk=wl.get("topk", 256), n_replace=1, seed=1, verbosity="ERROR",
+                  pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
+                  eps=64 / 255, alpha=4 / 255)
+    timed_end = warmup + steps
+    total = timed_end + n_prof
+    width_of = None
+    if wl.get("gemma"):
+        # BASELINE configs[4]: dynamic_search 512 -> 128 over 600 steps (reference :919-923).  K timed steps sample
+        # that schedule at evenly spaced points (mean width 271 at K = 5; the 600-step mean is 272); warm-up runs
+        # the widest step, the profiled steps the middle one.
+        from bimodalattack_amd.layout import dynamic_width
+        cfg_kw.update(dynamic_search=True, min_search_width=128)
+        SCHED = 600
+
+        def width_of(i: int) -> int:
+            if i < warmup:
+                v = 0
+            elif i < timed_end:
+                v = int(round((i - warmup + 0.5) * SCHED / steps))
+            else:
+                v = SCHED // 2
+            return dynamic_width(min(v, SCHED - 1), sw, SCHED, 128, True)
+    cfg = BimodalAttackConfig(num_steps=total, images_folder=tempfile.mkdtemp(prefix="bma_bench_"), **cfg_kw)
+
+    marks = {}
+
+    def barrier_clock():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t = time.perf_counter()
+        torch.cuda.synchronize(device)
+        return t
+
+    def marker() -> None:
+        """A float64 reduction no step launches: tools/trace_by_grid.py --between-markers keeps what lies between."""
+        torch.zeros(12345, device=device, dtype=torch.float64).sum()
+        torch.cuda.synchronize(device)
+
+    def hook(i: int) -> None:
+        log(f"{workload}: step {i}/{total}" + (" (profiled, outside the timed region)" if timed_end <= i < total else ""))
+        if i == warmup:
+            for k_ in attack.score_stats:
+                attack.score_stats[k_] = 0
+            if primary:
+                marker()                         # outside the clock: a kernel trace can be cut to the timed steps
+            marks["t0"] = barrier_clock()
+        if i == timed_end:
+            marks["t1"] = barrier_clock()
+            if primary:
+                marker()
+            marks["stats"] = dict(attack.score_stats)
+            marks["ids"] = attack._last["sampled"][:1].clone() if getattr(attack, "_last", None) else None
+            if n_prof:
+                native.profile_enable(True)      # event brackets cost a few us per launch: kept OUT of the timing (resets the tallies)
+                gemms.on = True
+        if i == total and n_prof:
+            torch.cuda.synchronize(device)
+            gemms.on = False
+
+    gcg_logger.setLevel("ERROR")
+    attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(
+        step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse, width_override=width_of))
+    gemms = GemmTimer.for_model(model, attack.fused.qkv if attack.fused.enabled else [])
+    gemms.rec = []
+    attack.fused.gemm_probe = gemms
+    log(f"{workload}: engine constructed; running")
+    res = attack.run(messages, goal, target, image)
+    log(f"{workload}: run finished")
+    prof = native.profile_read()
+    native.profile_enable(False)
+
+    elapsed = marks["t1"] - marks["t0"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timed = attack.n_scored[warmup:timed_end]
+    n_cand = sum(timed)
+    emulate = attack.opt.emulate_world if (attack.opt.emulate_world > 1 and world == 1) else 0
+    ss = marks.get("stats", attack.score_stats)
+    # with BMA_EMULATE_WORLD=W this process scores rank 0's share only: `value` counts the candidates ACTUALLY scored,
+    # the whole-job figure a W-GPU run would print is a projection and is labelled as one
+    n_done = ss["candidates"] if (emulate and ss["candidates"]) else n_cand
+    loss_s = sum(res.loss_times[warmup:timed_end])
+    grad_per_step = len(res.gradient_times) // total
+    grad_s = sum(res.gradient_times[warmup * grad_per_step:timed_end * grad_per_step])
+    samp_s = sum(res.sampling_times[warmup:timed_end]) if res.sampling_times else 0.0
+    pgd_s = sum(res.pgd_times[warmup:timed_end]) if res.pgd_times else 0.0
+
+    # ---- per-kernel rooflines from the in-library HIP events (profiled steps after the timed region) ----
+    kb, kb_src = committed_profile("kernel_bench.json")
+    kernels = {}
+    for name, p in prof.items():
+        if p["launches"] == 0:
+            continue
+        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None
+        k = dict(symbol=p["symbol"], launches=p["launches"], avg_us=1e3 * p["ms"] / p["launches"],
+                 algorithmic_MB_per_launch=p["bytes"] / p["launches"] / 1e6,
+                 achieved_GBps=gbs, frac_of_8TBps=None if gbs is None else gbs / HBM_PEAK_GBS, total_ms=p["ms"])
+        if gbs is not None and gbs > COPY_CEILING_GBS:
+            # faster than a streaming copy can move data through HBM: part of this launch's bytes never left the
+            # 256 MB Infinity Cache (its input was just written by the producer, or its output is consumed at once).
+            # The HBM-honest figure is the standalone one (tools/kernel_bench.py, cold operands).
+            mb = k["algorithmic_MB_per_launch"]
+            alone = [v for c, v in (kb or {}).items() if isinstance(v, dict) and c.split("/")[0] == name
+                     and abs(v.get("algorithmic_MB", 0) - mb) <= 0.1 * mb]
+            k["cache_resident"] = True
+            k["live_frac_exceeds_copy_ceiling"] = gbs / COPY_CEILING_GBS
+            if alone:
+                a = min(alone, key=lambda v: abs(v["algorithmic_MB"] - mb))
+                k["standalone"] = dict(avg_us=a["avg_us"], achieved_GBps=a["achieved_GBps"],
+                                       frac_of_8TBps=a["achieved_GBps"] / HBM_PEAK_GBS, source=kb_src)
+                k["frac_of_8TBps_hbm"] = a["achieved_GBps"] / HBM_PEAK_GBS
+        kernels[name] = k
+    gemm_table = gemms.table()
+
+    # ---- the batch-1 gradient pass, eagerly, GEMM by GEMM (see GradPassProfile) ------------------------
+    tc = getattr(model.config, "text_config", None) or model.config
+    grad_profile = None
+    if n_prof and not args.no_gradient_profile and (wl["pgd_attack"] or wl["gcg_attack"]):
+        try:
+            log(f"{workload}: profiling one eager gradient pass")
+            ids = marks.get("ids")
+            if ids is None:
+                ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(device)
+            gp = GradPassProfile(torch)
+            img = attack.final_image if wl["pgd_attack"] else None
+            with torch.enable_grad():
+                attack.gradient_pass_eager(ids, img)            # lazy initialisations out of the recording
+                gp.record(lambda: attack.gradient_pass_eager(ids, img))
+            rows = gp.table(gemm_roles(tc, attack.embedding_layer.num_embeddings))
+            timed_passes = res.gradient_times[warmup * grad_per_step:timed_end * grad_per_step]
+            pass_ms = 1e3 * sum(timed_passes) / max(1, len(timed_passes))
+            gemm_ms = sum(r["total_ms_per_pass"] for r in rows)
+            flops = sum(r["flops_per_launch"] * r["launches_per_pass"] for r in rows)
+            nbytes = sum(r["bytes_per_launch"] * r["launches_per_pass"] for r in rows)
+            grad_profile = dict(
+                replayed_pass_ms=pass_ms, passes_per_step=grad_per_step, gemm_ms_per_pass=gemm_ms,
+                gemm_share_of_pass=gemm_ms / pass_ms if pass_ms else None, gemm_launches_per_pass=len(gp.calls),
+                gemm_TFLOP_per_pass=flops / 1e12, gemm_GB_per_pass=nbytes / 1e9,
+                gemms_achieved_TFLOPs=flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None,
+                gemms_frac_of_mfma_peak=flops / (gemm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if gemm_ms else None,
+                gemms_achieved_GBps=nbytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms else None,
+                gemms_frac_of_8TBps=nbytes / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if gemm_ms else None,
+                gemms=rows[:14],
+                note="one gradient pass run eagerly AFTER the timed region; every aten.mm/addmm/bmm it issues (forward and "
+                     "backward) recorded, each distinct product timed over its recorded calls (the layers' own weights, so "
+                     "every launch streams from HBM) as one hipGraph between two HIP events; replayed_pass_ms is the "
+                     "hipGraph replay of the whole pass in the timed steps")
+            del gp
+        except Exception as e:
+            grad_profile = dict(error=f"{type(e).__name__}: {e}")
+            torch.cuda.synchronize(device)
+
+    # ---- the dominant kernel of a step BY DEVICE TIME, hand-written or library: the headline roofline ----
+    es = 2 if dtype != torch.float32 else 4
+    by_time = [("hip:" + k, v["total_ms"] / max(1, n_prof)) for k, v in kernels.items()] + \
+              [("gemm:" + k, v["total_ms"] / max(1, n_prof)) for k, v in gemm_table.items()]
+    if grad_profile and "gemms" in grad_profile:
+        by_time += [(f"grad:{i}", r["total_ms_per_pass"] * grad_per_step) for i, r in enumerate(grad_profile["gemms"])]
+    roofline = None
+    if by_time:
+        top = max(by_time, key=lambda kv: kv[1])[0]
+        if top.startswith("gemm:"):
+            gk = gemm_table[top[5:]]
+            traffic, tsrc = pmc_traffic("gemm_" + gk["role"], es * (gk["M"] * gk["K"] + gk["N"] * gk["K"] + gk["M"] * gk["N"]))
+            roofline = dict(bound="mfma", kernel=f"hipBLASLt/rocBLAS GEMM {top[5:]} (decoder {gk['role']}, {('bf16' if es == 2 else 'f32')})",
+                            achieved=gk["achieved_TFLOPs"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=gk["frac_of_peak"],
+                            traffic=traffic, traffic_source=tsrc,
+                            algorithmic_flops_per_launch=gk["flops_per_launch"], avg_launch_us=gk["avg_us"], launches=gk["launches"],
+                            note="dominant kernel of the step by summed device time; achieved = 2*M*N*K / HIP-event time around "
+                                 "the library call on torch's current stream, over the profiled steps that follow the timed "
+                                 "region; the rocprofv3 kernel-trace line of the same launch shape is in "
+                                 "profiles/r3_bench_*_kernel_by_grid.txt; peak = 2.5 PFLOP/s dense bf16; traffic = HBM bytes "
+                                 "of this launch shape from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)")
+        elif top.startswith("grad:"):
+            r = grad_profile["gemms"][int(top[5:])]
+            mfma_bound = r["frac_of_mfma_peak"] >= r["frac_of_8TBps"]
+            roofline = dict(bound="mfma" if mfma_bound else "hbm",
+                            kernel=f"hipBLASLt/rocBLAS GEMM of the batch-1 gradient pass: {r['role']}, M={r['M']} N={r['N']} K={r['K']} {r['dtype']}",
+                            achieved=r["achieved_TFLOPs"] if mfma_bound else r["achieved_GBps"],
+                            peak=MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS, unit="TFLOP/s" if mfma_bound else "GB/s",
+                            frac=r["frac_of_mfma_peak"] if mfma_bound else r["frac_of_8TBps"],
+                            frac_of_mfma_peak=r["frac_of_mfma_peak"], frac_of_8TBps=r["frac_of_8TBps"], traffic=None,
+                            algorithmic_flops_per_launch=r["flops_per_launch"], algorithmic_bytes_per_launch=r["bytes_per_launch"],
+                            avg_launch_us=r["avg_us"], launches=r["launches_per_pass"] * grad_per_step,
+                            note="dominant kernel of the step by summed device time: a product of the gradient pass (which the "
+                                 "timed steps replay from a hipGraph); measured by GradPassProfile after the timed region -- the "
+                                 "product's recorded calls over the layers' own weights, one hipGraph between two HIP events; "
+                                 "both fractions given, `bound` names the larger")
+        else:
+            k = kernels[top[4:]]
+            live = k["algorithmic_MB_per_launch"] * 1e6
+            traffic, tsrc = pmc_traffic(top[4:], live)
+            roofline = dict(bound="hbm", kernel=k["symbol"], achieved=k["achieved_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=k.get("frac_of_8TBps_hbm", k["frac_of_8TBps"]), traffic=traffic, traffic_source=tsrc,
+                            algorithmic_bytes_per_launch=live,
+                            avg_launch_us=k["avg_us"], launches=k["launches"],
+                            note="dominant kernel of the step by summed device time; achieved = algorithmic bytes / HIP-event "
+                                 "time on the launch stream (bma_profile_*) over the profiled steps that follow the timed region; "
+                                 "traffic = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes (committed file)")
+
+    # ---- the candidate forward: MFMA-bound, algorithmic FLOPs with prefix reuse ----------
+    inter = getattr(tc, "intermediate_size", None) or getattr(tc, "ffn_dim")
+    heads = tc.num_attention_heads
+    head_dim = getattr(tc, "head_dim", None) or tc.hidden_size // heads
+    kv_heads = getattr(tc, "num_key_value_heads", None) or heads
+    n_mlp = 3 if hasattr(tc, "intermediate_size") else 2
+    p_layer = tc.hidden_size * head_dim * (2 * heads + 2 * kv_heads) + n_mlp * tc.hidden_size * inter
+    p_lm = tc.num_hidden_layers * p_layer
+    seg = wl_segments(workload, attack)
+    full_tok = sum(seg.values())
+    new_tok = full_tok - seg["shared_prefix"] - 1
+    need_tok = ss["rows_needed"] / ss["candidates"] if ss["candidates"] else float(new_tok)
+    done_tok = ss["rows"] / ss["candidates"] if ss["candidates"] else float(new_tok)
+    flops_cand = 2 * p_lm * need_tok + 2 * tc.hidden_size * tc.vocab_size * seg["target"]
+    fwd = None
+    if loss_s > 0 and n_done and wl["gcg_attack"]:
+        ach = flops_cand * n_done / loss_s / 1e12
+        fwd = dict(bound="mfma", achieved=ach, peak=MFMA_PEAK_TFLOPS * world, unit="TFLOP/s",
+                   frac=ach / (MFMA_PEAK_TFLOPS * world),
+                   algorithmic_flops_per_candidate=flops_cand, rows_needed_per_candidate=need_tok,
+                   rows_computed_per_candidate=done_tok, new_tokens_per_candidate=new_tok,
+                   full_recompute_tokens_per_candidate=full_tok,
+                   ragged_calls=ss["ragged_calls"], padded_calls=ss["padded_calls"],
+                   note="scoring phase (splice + forward + CE + all-gather + argmin) over the timed steps, the candidates "
+                        "ACTUALLY scored against all ranks' peak; flops count the rows the ragged forward NEEDS (tokens from "
+                        "the first replaced suffix position on), not the padded block; GEMMs are hipBLASLt/rocBLAS "
+                        "inside the HuggingFace model")
+
+    out = {
+        "metric": "candidate_forwards_per_sec", "value": n_done / elapsed, "unit": "candidate_forwards/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if dtype == torch.float32 else "bf16", "data": "synthetic",
+        "config": {"workload": wl["name"], "search_width": sw, "topk": cfg_kw["topk"], "n_optim": 19,
+                   "target_tokens": seg["target"], "seq_len": full_tok, "candidates_per_step_after_filter":
+                   n_cand / max(1, len(timed)), "sharding": f"candidates/{world}" if world > 1 else "none",
+                   "text_layers": tc.num_hidden_layers, "prefix_reuse": not args.no_prefix_reuse,
+                   "width_schedule": None if width_of is None else
+                   {"of": "600-step dynamic_search 512->128, sampled evenly", "timed_widths": [width_of(i) for i in range(warmup, timed_end)]}},
+        "attack_steps_per_sec": steps / elapsed,
+        "scoring_phase_candidate_forwards_per_sec": n_done / loss_s if loss_s else None,
+        "phase_s_per_step": {"gradient": grad_s / steps, "pgd": pgd_s / steps,
+                             "sampling_incl_filter": samp_s / steps, "scoring": loss_s / steps},
+        "roofline": roofline, "forward_roofline": fwd, "gradient_pass": grad_profile, "gemms": gemm_table, "kernels": kernels,
+        "profiled_steps_after_timed_region": n_prof,
+        "engine": attack.engine_state(),
+        "final_loss": res.losses[timed_end - 1],
+        "gradient_pass_ms_each": [round(1e3 * t, 2) for t in res.gradient_times[:timed_end * grad_per_step]],
+    }
+    if emulate:
+        # a single process doing rank 0's share of an `emulate`-rank run (GEMM tuning aid): NOT a multi-GPU measurement
+        out["config"]["emulate_world"] = emulate
+        out["config"]["sharding"] = f"EMULATED: rank 0's share of candidates/{emulate}, in one process on one GPU"
+        out["config"]["candidates_scored_per_step"] = n_done / max(1, len(timed))
+        out["projected_value"] = n_cand / elapsed
+        out["projection"] = (f"what {emulate} GPUs WOULD print as `value` if every rank took this rank's time and the "
+                             "collectives cost nothing: an upper bound from one process, not a measurement")
+    keep = dict(model=model, tok=tok, proc=proc, messages=messages, goal=goal, target=target, image=image, norm=norm,
+                cfg_kw=cfg_kw, wl=wl, collectives=attack.shard.n_collectives, total_steps=total)
+    del attack
+    return out, keep
+
+
+def rccl_info(torch, dist, device, world: int, keep: dict) -> dict:
+    """What a multi-rank line needs to be believed: backend, world, every rank's device, the collectives of a step."""
+    names = [None] * world
+    mine = f"rank {dist.get_rank()}: {torch.cuda.get_device_name(device)} (cuda:{device.index}, " \
+           f"{torch.cuda.get_device_properties(device).total_memory / 2**30:.0f} GiB)"
+    dist.all_gather_object(names, mine)
+    sw = keep["cfg_kw"]["search_width"]
+    per = -(-sw // world)
+    img = keep["image"]
+    sync_bytes = sw * 19 * 8 + (0 if img is None else img.numel() * 4)
+    return dict(backend=dist.get_backend(), world=world, device_names=names,
+                rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                collectives_per_step=round((keep["collectives"] - 1) / max(1, keep["total_steps"]), 2),
+                allgather_bytes_per_step=4 * per * world, allgather_bytes_per_rank=4 * per,
+                state_broadcast_bytes_per_step=sync_bytes,
+                what="per step: one broadcast of rank 0's packed sampled ids (+ PGD image), one all_gather_into_tensor of "
+                     "ceil(N/W) fp32 losses per rank (+inf padded); plus one loss gather for the initial suffix")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 5; 8 for opt125m: 2 + 8 = its 10 steps)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="gcg", choices=sorted(WORKLOADS))
+    ap.add_argument("--extra-workloads", default=None,
+                    help="comma list of further workloads measured after --workload and reported under `workloads` "
+                         "(default: joint,pgd,gemma_joint when --workload gcg runs on one GPU; 'none' to skip)")
+    ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of each extra workload (2 warm-up steps)")
     ap.add_argument("--search-width", type=int, default=None)
     ap.add_argument("--layers", type=int, default=32, help="debug only: fewer layers is NOT the benchmark")
     ap.add_argument("--profile-steps", type=int, default=2,
                     help="extra steps AFTER the timed region with HIP-event brackets around kernels (rooflines)")
+    ap.add_argument("--no-gradient-profile", action="store_true", help="skip the eager per-GEMM profile of the gradient pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-width", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -352,206 +855,45 @@ def main() -> None:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from bimodalattack_amd import BimodalAttackConfig, native
-    from bimodalattack_amd.attack import BimodalAttack, logger as gcg_logger
-    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd import native
     native.check_single_hip_runtime()
 
-    wl = WORKLOADS[args.workload]
-    dtype = torch.float32 if wl.get("fp32") else torch.bfloat16
-    sw = args.search_width if args.search_width is not None else wl.get("search_width", 512)
-    model, tok, proc, messages, goal, target, image, norm = build_plugins(args.workload, device, dtype, args.layers)
-    cfg_kw = dict(search_width=sw, topk=wl.get("topk", 256), n_replace=1, seed=1, verbosity="ERROR",
-                  pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
-                  eps=64 / 255, alpha=4 / 255)
     n_prof = max(0, args.profile_steps)
-    timed_end = args.warmup + args.steps
-    total = timed_end + n_prof
-    width_of = None
-    if wl.get("gemma"):
-        # BASELINE configs[4]: dynamic_search 512 -> 128 over 600 steps (reference :919-923).  K timed steps sample
-        # that schedule at evenly spaced points (mean width 271 at K = 5; the 600-step mean is 272); warm-up runs
-        # the widest step, the profiled steps the middle one.
-        from bimodalattack_amd.layout import dynamic_width
-        cfg_kw.update(dynamic_search=True, min_search_width=128)
-        SCHED = 600
-
-        def width_of(i: int) -> int:
-            if i < args.warmup:
-                v = 0
-            elif i < timed_end:
-                v = int(round((i - args.warmup + 0.5) * SCHED / args.steps))
-            else:
-                v = SCHED // 2
-            return dynamic_width(min(v, SCHED - 1), sw, SCHED, 128, True)
-    cfg = BimodalAttackConfig(num_steps=total, images_folder=tempfile.mkdtemp(prefix="bma_bench_"), **cfg_kw)
-
-    marks = {}
-
-    def barrier_clock():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        t = time.perf_counter()
-        torch.cuda.synchronize(device)
-        return t
-
-    def marker() -> None:
-        """A float64 reduction no step launches: tools/trace_by_grid.py --between-markers keeps what lies between."""
-        torch.zeros(12345, device=device, dtype=torch.float64).sum()
-        torch.cuda.synchronize(device)
-
-    def hook(i: int) -> None:
-        log(f"step {i}/{total}" + (" (profiled, outside the timed region)" if timed_end <= i < total else ""))
-        if i == args.warmup:
-            for k_ in attack.score_stats:
-                attack.score_stats[k_] = 0
-            marker()                             # outside the clock: a kernel trace can be cut to the timed steps
-            marks["t0"] = barrier_clock()
-        if i == timed_end:
-            marks["t1"] = barrier_clock()
-            marker()
-            marks["stats"] = dict(attack.score_stats)
-            if n_prof:
-                native.profile_enable(True)      # event brackets cost a few us per launch: kept OUT of the timing
-                gemms.on = True
-        if i == total and n_prof:
-            torch.cuda.synchronize(device)
-            gemms.on = False
-
-    gcg_logger.setLevel("ERROR")
-    attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(
-        step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse, width_override=width_of))
-    gemms = GemmTimer(model, attack.fused.qkv if attack.fused.enabled else [])
-    attack.fused.gemm_probe = gemms
-    log("engine constructed; running")
-    res = attack.run(messages, goal, target, image)
-    log("run finished")
-    prof = native.profile_read()
-    native.profile_enable(False)
-
-    elapsed = marks["t1"] - marks["t0"]
+    out, keep = measure(args, args.workload, args.steps, args.warmup, n_prof, device, world, rank, primary=True)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    timed = attack.n_scored[args.warmup:timed_end]
-    n_cand = sum(timed)
-    loss_s = sum(res.loss_times[args.warmup:timed_end])
-    grad_per_step = len(res.gradient_times) // total
-    grad_s = sum(res.gradient_times[args.warmup * grad_per_step:timed_end * grad_per_step])
-    samp_s = sum(res.sampling_times[args.warmup:timed_end]) if res.sampling_times else 0.0
-    pgd_s = sum(res.pgd_times[args.warmup:timed_end]) if res.pgd_times else 0.0
+        out["rccl"] = rccl_info(torch, dist, device, world, keep)
 
-    # ---- per-kernel rooflines from the in-library HIP events (profiled steps after the timed region) ----
-    kernels = {}
-    for name, p in prof.items():
-        if p["launches"] == 0:
-            continue
-        gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else None
-        kernels[name] = dict(symbol=p["symbol"], launches=p["launches"], avg_us=1e3 * p["ms"] / p["launches"],
-                             algorithmic_MB_per_launch=p["bytes"] / p["launches"] / 1e6,
-                             achieved_GBps=gbs, frac_of_8TBps=None if gbs is None else gbs / HBM_PEAK_GBS,
-                             total_ms=p["ms"])
-    gemm_table = gemms.table()
-    pmc = None
-    try:
-        with open(os.path.join(REPO, "profiles", "r2_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-    except Exception:
-        pass
+    # ---- the other single-GPU BASELINE configurations, on the same models, under `workloads` ----------
+    if args.extra_workloads is None:
+        emulating = int(os.environ.get("BMA_EMULATE_WORLD", "0") or 0) > 1
+        extra = ["joint", "pgd", "gemma_joint"] if (args.workload == "gcg" and world == 1 and args.layers == 32
+                                                     and args.search_width is None and not emulating) else []
+    else:
+        extra = [w for w in args.extra_workloads.split(",") if w and w != "none"]
+    if extra:
+        out["workloads"] = {}
+        short = ("ms_per_step", "value", "unit", "steps", "warmup", "attack_steps_per_sec",
+                 "scoring_phase_candidate_forwards_per_sec", "phase_s_per_step", "roofline", "forward_roofline",
+                 "gradient_pass", "engine", "config", "final_loss")
+        for w in extra:
+            if w not in WORKLOADS or w == args.workload:
+                continue
+            try:
+                r, _ = measure(args, w, args.extra_steps, 2, n_prof, device, world, rank, primary=False)
+                out["workloads"][w] = {k: r[k] for k in short}
+                if w == "pgd":
+                    out["workloads"][w]["note"] = ("PGD-only scores no candidates: `value` counts one forward per step, "
+                                                   "i.e. it IS attack steps per second")
+            except Exception as e:       # the headline line stands on its own
+                out["workloads"][w] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.synchronize(device)
+            log(f"workload {w} done")
 
-    def pmc_traffic(kernel: str, live_bytes: float):
-        """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE): the entry
-        of this kernel whose launch shape is within 6 % of this run's algorithmic bytes, scaled by its measured
-        traffic / algorithmic ratio.  None when no such pass is committed."""
-        near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == kernel
-                and abs(e["algorithmic_bytes"] - live_bytes) <= 0.06 * e["algorithmic_bytes"]]
-        if not near:
-            return None
-        e = min(near, key=lambda e: abs(e["algorithmic_bytes"] - live_bytes))
-        return e["ratio_to_algorithmic"] * live_bytes
-
-    # the dominant kernel of a step BY DEVICE TIME, hand-written or library: that is the headline roofline
-    by_time = [("hip:" + k, v["total_ms"]) for k, v in kernels.items()] + [("gemm:" + k, v["total_ms"]) for k, v in gemm_table.items()]
-    roofline = None
-    if by_time:
-        top = max(by_time, key=lambda kv: kv[1])[0]
-        if top.startswith("gemm:"):
-            gk = gemm_table[top[5:]]
-            es = 2 if dtype != torch.float32 else 4
-            roofline = dict(bound="mfma", kernel=f"hipBLASLt/rocBLAS GEMM {top[5:]} (decoder {gk['role']}, {('bf16' if es == 2 else 'f32')})",
-                            achieved=gk["achieved_TFLOPs"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=gk["frac_of_peak"],
-                            traffic=pmc_traffic("gemm_" + gk["role"], es * (gk["M"] * gk["K"] + gk["N"] * gk["K"] + gk["M"] * gk["N"])),
-                            algorithmic_flops_per_launch=gk["flops_per_launch"], avg_launch_us=gk["avg_us"], launches=gk["launches"],
-                            note="dominant kernel of the step by summed device time; achieved = 2*M*N*K / HIP-event time around "
-                                 "the library call on torch's current stream, over the profiled steps that follow the timed "
-                                 "region; the rocprofv3 kernel-trace line of the same launch shape is in "
-                                 "profiles/r2_bench_*_kernel_by_grid.txt (top line); peak = 2.5 PFLOP/s dense bf16")
-        else:
-            k = kernels[top[4:]]
-            live = k["algorithmic_MB_per_launch"] * 1e6
-            roofline = dict(bound="hbm", kernel=k["symbol"], achieved=k["achieved_GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=k["frac_of_8TBps"], traffic=pmc_traffic(top[4:], live), algorithmic_bytes_per_launch=live,
-                            avg_launch_us=k["avg_us"], launches=k["launches"],
-                            note="dominant kernel of the step by summed device time; achieved = algorithmic bytes / HIP-event "
-                                 "time on the launch stream (bma_profile_*) over the profiled steps that follow the timed region; "
-                                 "traffic = FETCH_SIZE*2 + WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json)")
-
-    # ---- the candidate forward: MFMA-bound, algorithmic FLOPs with prefix reuse ----------
-    tc = getattr(model.config, "text_config", None) or model.config
-    inter = getattr(tc, "intermediate_size", None) or getattr(tc, "ffn_dim")
-    heads = tc.num_attention_heads
-    head_dim = getattr(tc, "head_dim", None) or tc.hidden_size // heads
-    kv_heads = getattr(tc, "num_key_value_heads", None) or heads
-    n_mlp = 3 if hasattr(tc, "intermediate_size") else 2
-    p_layer = tc.hidden_size * head_dim * (2 * heads + 2 * kv_heads) + n_mlp * tc.hidden_size * inter
-    p_lm = tc.num_hidden_layers * p_layer
-    seg = wl_segments(args.workload, attack)
-    full_tok = sum(seg.values())
-    new_tok = full_tok - seg["shared_prefix"] - 1
-    ss = marks.get("stats", attack.score_stats)
-    need_tok = ss["rows_needed"] / ss["candidates"] if ss["candidates"] else float(new_tok)
-    done_tok = ss["rows"] / ss["candidates"] if ss["candidates"] else float(new_tok)
-    flops_cand = 2 * p_lm * need_tok + 2 * tc.hidden_size * tc.vocab_size * seg["target"]
-    fwd = None
-    if loss_s > 0 and n_cand:
-        ach = flops_cand * n_cand / loss_s / 1e12
-        fwd = dict(bound="mfma", achieved=ach, peak=MFMA_PEAK_TFLOPS * world, unit="TFLOP/s",
-                   frac=ach / (MFMA_PEAK_TFLOPS * world),
-                   algorithmic_flops_per_candidate=flops_cand, rows_needed_per_candidate=need_tok,
-                   rows_computed_per_candidate=done_tok, new_tokens_per_candidate=new_tok,
-                   full_recompute_tokens_per_candidate=full_tok,
-                   ragged_calls=ss["ragged_calls"], padded_calls=ss["padded_calls"],
-                   note="scoring phase (splice + forward + CE + all-gather + argmin) over the timed steps, all ranks' "
-                        "candidates against all ranks' peak; flops count the rows the ragged forward NEEDS (tokens from "
-                        "the first replaced suffix position on), not the padded block; GEMMs are hipBLASLt/rocBLAS "
-                        "inside the HuggingFace model")
-
-    out = {
-        "metric": "candidate_forwards_per_sec", "value": n_cand / elapsed, "unit": "candidate_forwards/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if dtype == torch.float32 else "bf16", "data": "synthetic",
-        "config": {"workload": wl["name"], "search_width": sw, "topk": cfg_kw["topk"], "n_optim": 19,
-                   "target_tokens": seg["target"], "seq_len": full_tok, "candidates_per_step_after_filter":
-                   n_cand / max(1, len(timed)), "sharding": f"candidates/{world}" if world > 1 else "none",
-                   "text_layers": tc.num_hidden_layers, "prefix_reuse": not args.no_prefix_reuse,
-                   "width_schedule": None if width_of is None else
-                   {"of": "600-step dynamic_search 512->128, sampled evenly", "timed_widths": [width_of(i) for i in range(args.warmup, timed_end)]}},
-        "attack_steps_per_sec": args.steps / elapsed,
-        "scoring_phase_candidate_forwards_per_sec": n_cand / loss_s if loss_s else None,
-        "phase_s_per_step": {"gradient": grad_s / args.steps, "pgd": pgd_s / args.steps,
-                             "sampling_incl_filter": samp_s / args.steps, "scoring": loss_s / args.steps},
-        "roofline": roofline, "forward_roofline": fwd, "gemms": gemm_table, "kernels": kernels,
-        "profiled_steps_after_timed_region": n_prof,
-        "engine": attack.engine_state(),
-        "final_loss": res.losses[timed_end - 1],
-        "gradient_pass_ms_each": [round(1e3 * t, 2) for t in res.gradient_times[:timed_end * grad_per_step]],
-    }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args, wl, model, tok, proc, messages, goal, target, image, norm, cfg_kw)
+            _MODELS.clear()
+            out["cpu_baseline"] = cpu_baseline(args, keep["wl"], keep["model"], keep["tok"], keep["proc"], keep["messages"],
+                                               keep["goal"], keep["target"], keep["image"], keep["norm"], keep["cfg_kw"])
         except Exception as e:  # the GPU numbers stand on their own
             out["cpu_baseline"] = {"value": None, "unit": "candidate_forwards/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}

@@ -351,6 +351,19 @@ class BimodalAttack:
         g_img = grads.pop(0) if cfg.pgd_attack else None
         return g_tok, g_img, loss.detach()
 
+    def gradient_pass_eager(self, optim_ids: Tensor, image: Optional[Tensor] = None):
+        """What ONE gradient pass of this attack computes, run eagerly on fresh leaves -- the work the hipGraphs replay,
+        without the graphs (measurement only: bench.py records the library GEMMs of this call; a replay runs no Python
+        and the in-library event brackets cannot see inside it)."""
+        img = None if image is None else image.detach().clone().requires_grad_()
+        if img is not None and self._gp_enabled() and self._gp not in (None, False):
+            gp = _GradPrefix(self)                 # scoring prefix with history + the tail forward + the backward through both
+            gp.graphs = False
+            gp.image, gp.ids = img, optim_ids
+            gp._set(*gp._prefix_fn())
+            return gp._tail_fn()
+        return self._gradient_eager(optim_ids, img)
+
     def _b1_attention(self, seq_len: int):
         """Context for the batch-1 gradient pass: mask-free causal attention for the text layers of the model
         families the shared-prefix scheme knows (plain causal attention; a sliding window at least as long as
@@ -455,7 +468,9 @@ class BimodalAttack:
         if "image" not in prefix_names and key in self._prefix_cache:
             return self._prefix_cache[key]
         gp = self._gp
-        if gp not in (None, False) and feats is not None and gp.serves(key, feats):
+        # ... from the gradient pass's recorded prefix only while the shared-prefix attention will consume it (a
+        # RecordingKV is not an HF cache: the KV-concat route cannot expand it)
+        if gp not in (None, False) and feats is not None and gp.serves(key, feats) and self._wants_shared(gp.P, total_len):
             hf.prefix_ok = True
             return gp.cache(), gp.P
         def cat_prefix(f):
@@ -518,12 +533,14 @@ class BimodalAttack:
         count asked for (then the caller scores the padded block).  host_ids: this rank's DISTINCT candidates
         (host copy); inverse: which of them each candidate to report is (None: one each, in order)."""
         hf, dev = self.hf, self.model.device
-        fused = bool(self.model.dtype in (torch.bfloat16, torch.float16) and hf.head_dim in (32, 64, 128, 256))
+        from .prefix_attention import RaggedMaps, fused_ragged_route
+        # the same predicate the attention function evaluates on the tensors: the library route needs the padded-block
+        # maps (BMA_FUSED_RAGGED_ATTENTION=0, fp32 models, head sizes the kernel does not take), the kernel route not
+        fused = fused_ragged_route(self.model.dtype, hf.head_dim, hf.heads, hf.kv_heads, L)
         plan = ragged_plan(host_ids, host_parent, L, self.T, P, n_rows, dedup=False, padded_maps=not fused,
                            inverse=inverse)
         if plan is None:
             return None
-        from .prefix_attention import RaggedMaps
         mu = int(plan["m"])           # distinct candidates, in the plan's order: duplicates are computed once
         maps = RaggedMaps(plan, dev, ids=np.concatenate([plan["cand"], host_parent.reshape(1, -1)]), stage=self._stage)
         x = ops.splice(segs, mu + 1, self.embedding_layer.weight, maps.ids, hf.emb_scale)
@@ -666,13 +683,15 @@ class BimodalAttack:
                             raise
                         self._fallback("shared_prefix_attention", e, "shared-prefix attention disabled")
                         hf.shared_ok, shared = False, False
+                        self._gp, self._gp_flag = False, False      # its recorded prefix only serves the shared-prefix route
                         self._prefix_cache.clear()                  # rebuild the prefix as an HF cache
                         cache, P = self._prefix(prefix_names, feats, total_len)
                         use_prefix = cache is not None
                         if not use_prefix:
                             raise
                 if logits is None:
-                    kv = hf.expand_prefix(cache, b) if use_prefix else None
+                    # the padded chunk's row count, not b: a short last chunk carries copies of its last candidate
+                    kv = hf.expand_prefix(cache, x.shape[0]) if use_prefix else None
                     logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
                 loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
                 losses[s:s + b] = loss[:b]       # (the padding's losses are dropped)
@@ -872,6 +891,7 @@ class BimodalAttack:
 
                 # ---- phase B: PGD update; phase C: second gradient pass -------------------
                 pgd_time = 0.0
+                image_synced = False
                 if cfg.pgd_attack:
                     t0 = self._sync()
                     image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
@@ -880,13 +900,20 @@ class BimodalAttack:
                     if st is not None:
                         st["image_after_pgd"] = image.detach().cpu().numpy()
                     if cfg.gcg_attack and not cfg.joint_eval:
+                        # several GPUs: rank 0's image overwrites everybody's HERE, before its first consumer -- the
+                        # pass below caches what it derives from the image by tensor identity (_GradPrefix), so an
+                        # in-place overwrite behind it (the packed broadcast of the sampling phase) would leave the
+                        # winner re-score and the next token gradient on the pre-sync pixels
+                        self.shard.sync_state(image)
+                        image_synced = True
                         # only the token gradient of this pass is used (the image has just been stepped)
                         (g_tok, g_img, _), grad_time = grad_pass(tokens_only=True)
 
                 # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
                 t0 = self._sync()
-                sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, image if cfg.pgd_attack else None)
+                sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok,
+                                                           image if (cfg.pgd_attack and not image_synced) else None)
                 if cfg.gcg_attack:
                     samp_time = self._sync() - t0
                     if st is not None:

@@ -46,6 +46,41 @@ def _eps_of(m):
 
 SKINNY_ROWS = 1024     # rows up to which the gradient pass takes its input gradients through transposed weight copies
 
+# Derived weight copies (transposed, concatenated q/k/v, interleaved gate/up) belong to the MODEL, not to one attack
+# object: a second attack on the same model (the next prompt of an experiment, bench.py's other workloads) finds them
+# instead of building another 30 GB.  Every copy remembers the (data_ptr, _version) of the tensors it was made from
+# and is rebuilt when a caller has changed the weights in between (``_CopyCache.get``).
+import weakref
+
+_COPY_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+class _CopyCache:
+    def __init__(self):
+        self.d = {}
+
+    @staticmethod
+    def _stamp(srcs):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in srcs)
+
+    def get(self, key, srcs=None):
+        """The cached copy under `key`, or None when there is none or its sources changed since it was made."""
+        hit = self.d.get(key)
+        if hit is None:
+            return None
+        val, stamp = hit
+        if srcs is not None and stamp != self._stamp(srcs):
+            del self.d[key]
+            return None
+        return val
+
+    def put(self, key, val, srcs):
+        self.d[key] = (val, self._stamp(srcs))
+        return val
+
+    def __len__(self):
+        return len(self.d)
+
 
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
@@ -54,15 +89,17 @@ class FusedInference:
         self.weight_copies = weight_copies
         self.fuse_gate_up = fuse_gate_up
         self.gemm_probe = None                       # measurement hook for products no nn.Linear module owns
-        self._wgu = {}                               # MLP -> chunk-interleaved [gate_proj; up_proj] weight
+        cache = _COPY_CACHES.get(model)
+        if cache is None:
+            cache = _COPY_CACHES[model] = _CopyCache()
+        self._copies: _CopyCache = cache             # ("wt"|"wqkv"|"wgu"|"gu_t", id(module)) -> derived weight copy
         self.qkv: List[torch.nn.Module] = []        # attention blocks whose q/k/v projections run as one GEMM
-        self._wqkv = {}
         self.norms: List[Tuple[torch.nn.Module, float, bool]] = []
         self.mlps: List[torch.nn.Module] = []
         self.linears: List[torch.nn.Module] = []
         self.rope_modules = []
         self._saved_rope = {}
-        self._wt = {}
+        self._gu_ok = {}
         self.depth = 0
         if not enabled:
             return
@@ -145,13 +182,12 @@ class FusedInference:
             if not (self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                     and x.numel() // x.shape[-1] <= SKINNY_ROWS):
                 return orig(x)
-            wt = self._wt.get(id(m))
+            wt = self._copies.get(("wt", id(m)), (w,))
             if wt is None:
                 if torch.cuda.is_current_stream_capturing():
                     return orig(x)
                 with torch.no_grad():
-                    wt = w.detach().t().contiguous()
-                self._wt[id(m)] = wt
+                    wt = self._copies.put(("wt", id(m)), w.detach().t().contiguous(), (w,))
             return ops.FrozenLinearFn.apply(x, w, wt)
         return forward
 
@@ -167,14 +203,15 @@ class FusedInference:
         sizes = [m.out_features for m in mods]
         slot = {}
 
+        srcs = tuple(m.weight for m in mods)
+
         def fused_weight():
-            w = self._wqkv.get(id(attn))
+            w = self._copies.get(("wqkv", id(attn)), srcs)
             if w is None:
                 if torch.cuda.is_current_stream_capturing():
                     return None
                 with torch.no_grad():
-                    w = torch.cat([m.weight.detach() for m in mods], dim=0).contiguous()
-                self._wqkv[id(attn)] = w
+                    w = self._copies.put(("wqkv", id(attn)), torch.cat([m.weight.detach() for m in mods], dim=0).contiguous(), srcs)
             return w
 
         def first(x):
@@ -189,13 +226,12 @@ class FusedInference:
                 if not self.weight_copies or x.numel() // x.shape[-1] > SKINNY_ROWS:
                     y = torch.nn.functional.linear(x, w)
                 else:
-                    wt = self._wt.get(id(attn))
+                    wt = self._copies.get(("wqkv_t", id(attn)), srcs)
                     if wt is None:
                         if torch.cuda.is_current_stream_capturing():
                             return origs[0](x)
                         with torch.no_grad():
-                            wt = w.t().contiguous()
-                        self._wt[id(attn)] = wt
+                            wt = self._copies.put(("wqkv_t", id(attn)), w.t().contiguous(), srcs)
                     y = ops.FrozenLinearFn.apply(x, w, wt)
             else:
                 y = torch.nn.functional.linear(x, w)
@@ -223,21 +259,23 @@ class FusedInference:
         the block does not qualify (or a capture is running and the copy does not exist yet)."""
         if not self.fuse_gate_up:
             return None
-        w = self._wgu.get(id(m))
-        if w is None:
-            g, u = m.gate_proj, m.up_proj
+        g, u = m.gate_proj, m.up_proj
+        ok = self._gu_ok.get(id(m))
+        if ok is None:
             ok = all(type(l) is torch.nn.Linear and l.bias is None for l in (g, u)) \
                 and g.weight.shape == u.weight.shape and g.weight.dtype == u.weight.dtype \
                 and g.weight.dtype in (torch.bfloat16, torch.float16) and g.out_features % 8 == 0
-            if not ok:
-                self._wgu[id(m)] = False
-                return None
+            self._gu_ok[id(m)] = ok
+        if not ok:
+            return None
+        srcs = (g.weight, u.weight)
+        w = self._copies.get(("wgu", id(m)), srcs)
+        if w is None:
             if torch.cuda.is_current_stream_capturing():
                 return None
             with torch.no_grad():
-                w = ops.interleave_gate_up(g.weight.detach(), u.weight.detach())
-            self._wgu[id(m)] = w
-        return w if w is not False else None
+                w = self._copies.put(("wgu", id(m)), ops.interleave_gate_up(g.weight.detach(), u.weight.detach()), srcs)
+        return w
 
     def _mlp_forward(self, m, orig):
         act = self._act_code(m.act_fn)
@@ -253,11 +291,11 @@ class FusedInference:
                 # input-gradient product in the ~70-row gradient pass; the gate kernel reads the alternating chunks
                 if self._tracking(x):
                     if self.weight_copies and x.numel() // x.shape[-1] <= SKINNY_ROWS:
-                        wt = self._wt.get(("gu", id(m)))
+                        srcs = (m.gate_proj.weight, m.up_proj.weight)
+                        wt = self._copies.get(("wgu_t", id(m)), srcs)
                         if wt is None and not torch.cuda.is_current_stream_capturing():
                             with torch.no_grad():
-                                wt = w.t().contiguous()
-                            self._wt[("gu", id(m))] = wt
+                                wt = self._copies.put(("wgu_t", id(m)), w.t().contiguous(), srcs)
                         y = ops.FrozenLinearFn.apply(x, w, wt) if wt is not None else torch.nn.functional.linear(x, w)
                     else:
                         y = torch.nn.functional.linear(x, w)

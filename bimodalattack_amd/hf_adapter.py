@@ -91,7 +91,7 @@ class HFAdapter:
         hidden = int(getattr(tc, "hidden_size", 0) or 0)
         head_dim = int(getattr(tc, "head_dim", None) or (hidden // heads if heads else 0))
         inter = int(getattr(tc, "intermediate_size", None) or getattr(tc, "ffn_dim", None) or 4 * hidden)
-        self.head_dim = head_dim
+        self.head_dim, self.heads, self.kv_heads = head_dim, heads, kv_heads
         es = torch.empty((), dtype=self.dtype).element_size()
         self.kv_bytes_per_token = 2 * self.n_layers * kv_heads * head_dim * es
         self.act_bytes_per_token = (16 * hidden + 4 * inter) * es

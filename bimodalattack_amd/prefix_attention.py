@@ -55,6 +55,14 @@ except Exception:  # pragma: no cover
     _CacheBase = object
 
 
+def fused_ragged_route(dtype, head_dim: int, heads: int, kv_heads: int, max_len: int) -> bool:
+    """Will ``_ragged_attention`` take the one-launch MFMA kernel for these text layers?  The planner asks this BEFORE
+    the forward (the library route needs the padded-block maps, the kernel route does not), with the very conditions
+    ``ops.ragged_attention_ok`` checks on the tensors at run time plus the module switch."""
+    return bool(FUSED_RAGGED_ATTENTION and dtype in (torch.bfloat16, torch.float16) and head_dim in (32, 64, 128, 256)
+                and 0 < max_len <= ops.RAGGED_ATTN_MAX_LEN and kv_heads > 0 and heads % kv_heads == 0)
+
+
 class RecordingKV(_CacheBase):
     """The cache handed to the model for the PREFIX pass: it keeps a reference to every
     layer's keys/values (after rotary embedding) and hands them straight back -- nothing is
@@ -197,7 +205,7 @@ class RaggedMaps:
         self.keep = view("keep")
         self.cstart, self.cfirst, self.clen = view("cstart"), view("cfirst"), view("clen")
         self.ids = None if ids is None else view("ids").view(-1, int(plan["n_opt"]))
-        self.fused_ok = True           # cleared if the one-launch attention kernel refuses the shapes
+        self.fused_ok = True           # a caller may clear it to force the library route (needs the padded-block maps)
 
 
 _BIAS = {}

@@ -213,11 +213,11 @@ int bma_prefix_attention(const void* q, int64_t q_row_stride, int64_t q_head_str
 
 /* bma_ragged_attention: the attention of a ragged scoring forward in one launch (bf16 / f16, MFMA).
  *   Candidate i (0 <= i < B2) owns rows start[i] .. start[i]+len[i]-1 of the row list: its tokens at
- *   positions first[i] .. first[i]+len[i]-1 behind the shared prefix (len[i] <= max_len <= 64).  A query
+ *   positions first[i] .. first[i]+len[i]-1 behind the shared prefix (len[i] <= max_len <= 4096).  A query
  *   at position j attends to the P prefix keys (pk/pv), to rows t of the row list for positions
  *   t < first[i] (its parent's keys/values) and to its own rows for first[i] <= t <= j.
  *   q/k/v: row-list tensors addressed as base + row*rs + head*hs (elements; multiples of 8);
- *   pk/pv likewise with P rows; H query heads, Hk key/value heads (H % Hk == 0), Dh in {32,64,128}.
+ *   pk/pv likewise with P rows; H query heads, Hk key/value heads (H % Hk == 0), Dh in {32,64,128,256}.
  *   out: [N][H][Dh] contiguous.  If o1/lse1 are given (o1 [N][H][Dh], lse1 [H][N] fp32: a prefix
  *   partial computed elsewhere, then pass P = 0) the result is merged with it as bma_attn_merge does. */
 int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,

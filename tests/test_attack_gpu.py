@@ -278,6 +278,134 @@ def test_long_suffix_matches_oracle():
     assert res.strings == want["strings"]
 
 
+@pytest.mark.parametrize("name", ["llava_joint_dyn", "gemma3_joint_dyn"])
+def test_hf_cache_route_with_padded_last_chunk(golden_dir, name):
+    """Decaying widths that are not a multiple of the chunk quantum (24, 18, 12, 8; 24, 19, 14, 9, 8) through the
+    HF-cache route (KV concat, shared_prefix_attention=False): the last chunk is padded to the quantum and the
+    prefix cache must be expanded to the PADDED row count (it was expanded to b and the concat failed)."""
+    m, res, trace, tmp = run_case(name, shared_prefix_attention=False)
+    check_against_golden(golden_dir, name, m, res, trace, tmp)
+
+
+def test_hf_cache_route_odd_width_matches_oracle():
+    """A model outside the shared-prefix families (OPT) at search_width 13: 13 > quantum 8 and 13 % 8 != 0, so the
+    one chunk is padded to 16 rows on the HF-cache route; against the oracle loop, same CPU draws."""
+    from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
+    from oracle.attack_loop import run_oracle
+    kw = dict(num_steps=3, search_width=13, topk=8, seed=1, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT)
+    model, tok, proc, _ = S.tiny_case("opt", device=DEV)
+    trace = []
+    res = run(model, tok, proc, "tell me", "tell me", "Sure here", None,
+              BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw), rng_device="cpu", trace=trace, strict=True)
+    cmodel, ctok, cproc, _ = S.tiny_case("opt")
+    want, wtrace, _ = run_oracle(cmodel, ctok, cproc, "tell me", "tell me", "Sure here", None,
+                                 BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw))
+    assert trace[0]["sampled"].shape[0] == 13
+    for a, b in zip(trace, wtrace):
+        assert np.array_equal(a["sampled"], b["sampled"]) and np.array_equal(a["filtered"], b["filtered"])
+        np.testing.assert_allclose(a["losses"][0], b["losses"][0], rtol=1e-4)
+    assert res.strings == want["strings"]
+
+
+def test_library_ragged_route_on_a_16bit_model(monkeypatch):
+    """BMA_FUSED_RAGGED_ATTENTION=0 (the documented A/B switch) on a bf16 model: the planner builds the padded-block
+    maps the library attention route needs (it decided from dtype/head size alone, the route then raised
+    and ragged scoring was disabled), ragged scoring stays ON, and the losses agree with the kernel route."""
+    from bimodalattack_amd import BimodalAttackConfig, prefix_attention as pa, synthetic as S
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(pa, "FUSED_RAGGED_ATTENTION", fused)
+        model, tok, proc, image = S.tiny_case("llava", dtype=torch.bfloat16, device=DEV)
+        trace = []
+        cfg = BimodalAttackConfig(num_steps=2, search_width=24, topk=16, pgd_attack=False, gcg_attack=True, seed=5,
+                                  verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT, images_folder=tempfile.mkdtemp())
+        atk = BimodalAttack(model, tok, proc, cfg, None, EngineOptions.from_env(rng_device="cpu", trace=trace, strict=True,
+                                                                                  loss_in_model_dtype=False))
+        atk.run("tell me a story", "tell me a story", "Sure here is a story", None)
+        assert atk.fallbacks == {} and atk.hf.ragged_ok is True and atk.score_stats["ragged_calls"] == 2
+        out[fused] = trace
+    a, b = out[True][0], out[False][0]
+    assert np.array_equal(a["sampled"], b["sampled"])
+    np.testing.assert_allclose(a["losses"][0], b["losses"][0], rtol=2e-2)      # bf16: two attention implementations
+
+
+def test_list_form_optim_str_init_matches_oracle():
+    """optim_str_init as a LIST of strings (reference :857-866: one buffer entry per string, a warning when the count
+    differs from buffer_size): HIP engine against the oracle loop."""
+    from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
+    from oracle.attack_loop import run_oracle
+    inits = ["x x x x x x x x", "y x y x y x y x", "! ! x x ! ! x x"]
+    kw = dict(num_steps=2, search_width=16, topk=8, buffer_size=3, seed=1, verbosity="ERROR", optim_str_init=inits,
+              pgd_attack=True, gcg_attack=True, joint_eval=True, eps=64 / 255, alpha=4 / 255)
+    norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
+    model, tok, proc, image = S.tiny_case("llava", device=DEV)
+    trace = []
+    res = run(model, tok, proc, "tell me", "tell me", "Sure here", image,
+              BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw), normalize=norm, rng_device="cpu", trace=trace,
+              strict=True)
+    cmodel, ctok, cproc, cimage = S.tiny_case("llava")
+    want, wtrace, orc = run_oracle(cmodel, ctok, cproc, "tell me", "tell me", "Sure here", cimage,
+                                   BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw), normalize=norm)
+    for a, b in zip(trace, wtrace):
+        assert np.array_equal(a["optim_ids_in"], b["optim_ids_in"]) and np.array_equal(a["sampled"], b["sampled"])
+        np.testing.assert_allclose(a["losses"][0], b["losses"][0], rtol=1e-4)
+    np.testing.assert_allclose(res.losses, want["losses"], rtol=1e-4)
+    assert res.strings == want["strings"]
+
+
+def test_debug_output_generates_every_tenth_step():
+    """debug_output=True (reference :745-777): a greedy generation from the first candidate's prompt at steps 0, 10, ...;
+    model_outputs carries the decoded text there and "" elsewhere; the trajectory is the one without it."""
+    from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
+    norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
+    out = {}
+    for dbg in (False, True):
+        model, tok, proc, image = S.tiny_case("llava", device=DEV)
+        cfg = BimodalAttackConfig(num_steps=11, search_width=8, topk=8, seed=2, verbosity="ERROR", debug_output=dbg,
+                                  pgd_attack=True, gcg_attack=True, joint_eval=True, eps=64 / 255, alpha=4 / 255,
+                                  optim_str_init=S.TINY_OPTIM_INIT, images_folder=tempfile.mkdtemp())
+        out[dbg] = run(model, tok, proc, "tell me", "tell me", "Sure here", image, cfg, normalize=norm, rng_device="cpu",
+                       strict=True)
+    assert out[True].losses == out[False].losses and out[True].strings == out[False].strings
+    mo = out[True].model_outputs
+    assert len(mo) == 11 and all(isinstance(t, str) for t in mo)
+    assert all(mo[i] == "" for i in range(11) if i % 10) and out[False].model_outputs == [""] * 11
+
+
+def test_weights_changed_between_runs_are_picked_up():
+    """The engine keeps derived copies of the decoder weights per MODEL (transposed, concatenated q/k/v, interleaved
+    gate/up: fused._CopyCache).  A caller who changes the weights between two run() calls -- in place -- must get the
+    attack on the NEW weights: every copy is stamped with its sources' version counters and rebuilt when they moved."""
+    from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
+    norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
+
+    def attack(model, tok, proc, image):
+        cfg = BimodalAttackConfig(num_steps=2, search_width=16, topk=8, seed=4, verbosity="ERROR", pgd_attack=True,
+                                  gcg_attack=True, joint_eval=True, eps=64 / 255, alpha=4 / 255,
+                                  optim_str_init=S.TINY_OPTIM_INIT, images_folder=tempfile.mkdtemp())
+        return run(model, tok, proc, "tell me", "tell me", "Sure here", image.clone(), cfg, normalize=norm, rng_device="cpu",
+                   strict=True)
+
+    def perturb(model):
+        g = torch.Generator(device=DEV).manual_seed(99)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if p.dim() == 2 and "proj" in name:
+                    p.mul_(1.0 + 0.2 * torch.rand(p.shape, generator=g, device=DEV).to(p.dtype))
+
+    model, tok, proc, image = S.tiny_case("llava", dtype=torch.bfloat16, device=DEV)
+    first = attack(model, tok, proc, image)
+    perturb(model)
+    second = attack(model, tok, proc, image)
+    fresh, tok2, proc2, image2 = S.tiny_case("llava", dtype=torch.bfloat16, device=DEV)
+    perturb(fresh)
+    want = attack(fresh, tok2, proc2, image2)
+    assert second.losses == want.losses and second.strings == want.strings
+    assert first.losses != second.losses
+
+
 # ------------------------------------------------------------------ sharded engine, 2 ranks on one GPU
 def _sharded_worker(rank, world, port, name, out, backend="gloo"):
     import torch.distributed as dist
@@ -454,8 +582,24 @@ def test_7b_scoring_equals_reference_call_shape(workload, n):
             assert distinct < n - 5                          # the draw has duplicates to remove
             assert (st["rows"] - n * L) % 256 == 0 and 0 <= (st["rows"] - n * L) - need < 256     # coarse grid
         want = _reference_call_shape_losses(model, atk, cand, order, feats)
+        # the yardstick for "bf16 rounding noise" on THIS model, measured instead of assumed: the same reference call
+        # shape in fp32 on the same weights (first 48 candidates).  The engine -- prefix reuse, ragged rows, the two MFMA
+        # attention kernels, fused elementwise kernels -- must be as close to fp32 as the reference's own bf16 forward is.
+        ny = min(n, 48)
+        segs16 = atk.seg
+        model.float()
+        atk.seg = {k_: v_.float() for k_, v_ in segs16.items()}
+        want32 = _reference_call_shape_losses(model, atk, cand[:ny], order, None if feats is None else feats.float())
+        atk.seg = segs16
     rel = np.abs(got - want) / np.abs(want)
     rel_r = np.abs(ragged - want) / np.abs(want)
+    noise = (np.abs(want[:ny] - want32) / np.abs(want32)).max()
+    err = (np.abs(got[:ny] - want32) / np.abs(want32)).max()
+    err_r = (np.abs(ragged[:ny] - want32) / np.abs(want32)).max()
+    print(f"{workload} n={n}: vs fp32 (first {ny}): reference-bf16 {noise:.2e}, engine padded {err:.2e}, engine ragged {err_r:.2e}")
+    assert noise < 1e-2, noise                              # the reference's own bf16 computation
+    assert err <= 1.5 * noise + 2e-3, (err, noise)
+    assert err_r <= 1.5 * noise + 2e-3, (err_r, noise)
     # bf16 has 8 significand bits; 32 layers of rounding noise land well under 1 %
     assert rel.max() < 1e-2, rel.max()
     assert rel_r.max() < 1e-2, rel_r.max()
@@ -473,6 +617,68 @@ def test_7b_scoring_equals_reference_call_shape(workload, n):
         assert int(ragged.argmin()) == int(want.argmin())
     print(f"{workload} n={n}: max rel diff {rel.max():.2e} (ragged {rel_r.max():.2e}), mean {rel.mean():.2e} "
           f"(ragged {rel_r.mean():.2e}), loss range [{want.min():.4f}, {want.max():.4f}], {distinct} distinct")
+
+
+@pytest.mark.parametrize("workload", ["gcg", "joint"])
+def test_7b_scoring_fp32_within_1e_4(workload):
+    """north_star's "fp32 losses within 1e-4" at BASELINE width: LLaVA-1.5-7B width (D = 4096, 32 heads x 128, FFN 11008,
+    V = 32064; the 576-token CLIP image prefix in joint mode, S = 644), fp32, 4 decoder layers, search_width 512 drawn
+    like the sampler draws it.  The engine's scoring -- prefix keys/values reused, ragged rows with duplicates computed
+    once, target rows only, the padded shared-prefix path, and padded chunks of 100 -- against the reference's call
+    shape (:1112-1225, :1282-1299: emb(ids) + repeated segments, full-sequence forward, full (B,S,V) logits, torch
+    cross-entropy): every per-candidate loss within 1e-4 relative, same argmin."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import segment_order
+
+    dev = torch.device(DEV)
+    n = 512
+    model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, dev, torch.float32, 4)
+    tc = model.config.text_config
+    assert (tc.hidden_size, tc.num_attention_heads, tc.intermediate_size, tc.num_hidden_layers) == (4096, 32, 11008, 4)
+    assert model.get_input_embeddings().num_embeddings == 32064 and model.dtype == torch.float32
+    joint = workload == "joint"
+    cfg = BimodalAttackConfig(num_steps=1, search_width=n, seed=1, verbosity="ERROR", pgd_attack=joint,
+                              gcg_attack=True, joint_eval=joint, images_folder=tempfile.mkdtemp())
+    order = segment_order("pgd", "llava", single=True) if joint else segment_order("gcg", "llava", no_joint_eval=True)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    n_opt = ids.shape[1]
+    cand = ids.repeat(n, 1)
+    pos = torch.randint(0, n_opt, (n,), generator=g, device=DEV)
+    pool = torch.randint(5, 32000, (n_opt, 256), generator=g, device=DEV)      # a "top-k" table per position
+    cand[torch.arange(n, device=DEV), pos] = pool[pos, torch.randint(0, 256, (n,), generator=g, device=DEV)]
+    cand[7] = cand[3]                                       # an exact duplicate and a copy of the parent
+    cand[11] = ids[0]
+    cand = cand.contiguous()
+    got = {}
+    for name, kw in (("ragged", {}), ("padded", dict(ragged_suffix=False)), ("chunks of 100", dict(ragged_suffix=False, chunk=100))):
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False,
+                                                                                strict=True, **kw))
+        atk._prepare_prompt(messages, target)
+        with torch.no_grad():
+            feats = atk.hf.image_features(image) if joint else None
+            got[name] = atk.score_candidates(cand, order, feats, parent=ids).float().cpu().numpy()
+        assert not atk.fallbacks, atk.fallbacks
+        st = atk.score_stats
+        assert (st["ragged_calls"], st["padded_calls"]) == {"ragged": (1, 0), "padded": (0, 1), "chunks of 100": (0, 6)}[name]
+        assert feats is None or feats.shape[1] == 576
+    with torch.no_grad():
+        want = _reference_call_shape_losses(model, atk, cand, order, feats, chunk=8)
+    seq = sum((n_opt if nm == "optim" else (576 if nm == "image" else atk.seg[nm].shape[1])) for nm in order)
+    assert atk.T == 20 and seq == (644 if joint else 66)                        # SURVEY.md 8: the BASELINE sequence lengths
+    for name, v in got.items():
+        rel = np.abs(v - want) / np.abs(want)
+        print(f"fp32 {workload} {name}: max rel {rel.max():.2e} mean {rel.mean():.2e}; loss range [{want.min():.5f}, {want.max():.5f}]")
+        np.testing.assert_allclose(v, want, rtol=1e-4, atol=0)                  # north_star's bar
+        gap = np.sort(want)[1] - np.sort(want)[0]
+        if gap > 4 * np.abs(v - want).max():
+            assert int(v.argmin()) == int(want.argmin())
+    assert got["ragged"][7] == got["ragged"][3]
 
 
 def test_gemma3_4b_scoring_equals_reference_call_shape():

@@ -214,8 +214,19 @@ def test_fused_context_patches_and_restores(kind, dtype):
     if kind == "llama" and dtype != torch.float32:
         # 72 rows: the transposed-weight backward ran -- q/k/v as one fused projection per layer, gate/up as one
         # (chunk-interleaved) projection, o and down each
-        assert len(fused.qkv) == 2 and len(fused._wqkv) == 2 and len(fused._wgu) == 2 and len(fused._wt) == 2 * 4 \
-            and len(fused.linears) == 2 * 7
+        kinds = [k[0] for k in fused._copies.d]
+        assert len(fused.qkv) == 2 and len(fused.linears) == 2 * 7 and \
+            {k: kinds.count(k) for k in set(kinds)} == {"wqkv": 2, "wqkv_t": 2, "wgu": 2, "wgu_t": 2, "wt": 4}
+        # the copies belong to the model: a second context object on it finds them, and a changed weight drops its copy
+        again = FusedInference(model)
+        assert again._copies is fused._copies
+        lin = fused.linears[0]
+        key = next(k for k in fused._copies.d if k[0] == "wt")
+        owner = next(m for m in fused.linears if id(m) == key[1])
+        old = fused._copies.get(key, (owner.weight,))
+        with torch.no_grad():
+            owner.weight.mul_(1.0)                      # an in-place write bumps the version counter
+        assert old is not None and fused._copies.get(key, (owner.weight,)) is None
     gtol = 1e-4 if dtype == torch.float32 else 8e-2
     assert float((gf.float() - ge.float()).abs().max()) <= gtol * float(ge.float().abs().max())
     assert not any("forward" in m.__dict__ for m in model.modules())

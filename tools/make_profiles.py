@@ -4,6 +4,7 @@ summaries under profiles/:  python tools/make_profiles.py gpurun_out/r1b r1"""
 import csv
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -92,7 +93,19 @@ for case, kernel, key, shape in CASES:
     if case not in kb:
         continue
     if key == "Cijk":
-        cands = [k for k in folded if "Cijk_" in k.split("/")[0]]
+        # library GEMMs share one symbol family: the launch of THIS product is the one whose grid is the product's tile
+        # count (macro-tile MTaxb from the kernel name, 256 threads per workgroup) -- round 2 took the launch whose
+        # traffic was nearest to the operand bytes, which gave all three products the smallest one's row
+        Mg, Ng = (int(v) for v in case.rsplit("_", 1)[1].split("x")[:2])
+        cands = []
+        for k in folded:
+            sym = k.split("/")[0]
+            mt = re.search(r"_MT(\d+)x(\d+)x", sym)
+            th = re.search(r"/threads(\d+)/", k)
+            if "Cijk_" in sym and mt and th:
+                tiles = -(-Mg // int(mt.group(1))) * -(-Ng // int(mt.group(2)))
+                if int(th.group(1)) in (tiles * 256, tiles * 512, tiles * 128):
+                    cands.append(k)
     else:
         cands = [k for k in folded if k.rsplit("/run", 1)[0] == key] or [k for k in folded if k.split("/")[0] == key.split("/")[0]]
     # several shapes can share a symbol: take the launch whose traffic is closest to the algorithmic bytes
@@ -101,14 +114,22 @@ for case, kernel, key, shape in CASES:
         continue
     best = min(cands, key=lambda k: abs(folded[k]["hbm_bytes_per_launch"] - algo))
     v = folded[best]
-    entries.append(dict(kernel=kernel, shape=shape, pmc_key=best, algorithmic_bytes=algo,
+    entries.append(dict(kernel=kernel, shape=shape, pmc_key=best, algorithmic_bytes=algo, fetch_bytes_uncorrected=v["fetch_bytes_per_launch_corrected"] / 2 if v["fetch_bytes_per_launch_corrected"] else None,
                         hbm_bytes_per_launch=v["hbm_bytes_per_launch"], fetch_bytes_corrected=v["fetch_bytes_per_launch_corrected"],
                         write_bytes=v["write_bytes_per_launch"], ratio_to_algorithmic=v["hbm_bytes_per_launch"] / algo,
                         avg_us=kb[case]["avg_us"], achieved_GBps=kb[case]["achieved_GBps"],
                         achieved_TFLOPs=kb[case].get("achieved_TFLOPs")))
+try:
+    commit = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
 json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes with --kernel-trace only, of "
                       "tools/kernel_bench.py --iters 5 on MI355X; raw rows in *_kernel_bench_pmc_*.csv",
-               corrections="counters are KiB; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM); WRITE_SIZE x1",
+               generated_at_commit=commit,
+               corrections="counters are KiB; FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM); WRITE_SIZE x1.  "
+                           "The counters sit on the L2's memory side: Infinity-Cache hits are counted, so for a library GEMM "
+                           "(tiles re-read operand panels; 16-byte-per-lane buffer loads assumed for the x2) the figure is L2-miss "
+                           "traffic, an upper bound on HBM bytes; without the x2 it would be fetch/2 + write",
                entries=entries), open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 for e in entries:
     print(f"{e['kernel']:11s} {e['shape'][:52]:52s} {e['avg_us']:8.1f} us {e['achieved_GBps']:7.0f} GB/s  traffic/algorithmic = {e['ratio_to_algorithmic']:.3f}")
