@@ -170,7 +170,7 @@ class BimodalAttack:
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
-                                    self.opt.fuse_gate_up)
+                                    self.opt.fuse_gate_up, self.opt.fuse_add_norm)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
@@ -543,9 +543,8 @@ class BimodalAttack:
             return None
         mu = int(plan["m"])           # distinct candidates, in the plan's order: duplicates are computed once
         maps = RaggedMaps(plan, dev, ids=np.concatenate([plan["cand"], host_parent.reshape(1, -1)]), stage=self._stage)
-        x = ops.splice(segs, mu + 1, self.embedding_layer.weight, maps.ids, hf.emb_scale)
-        rows = ops.gather_rows(x.view((mu + 1) * L, x.shape[-1]), maps.flat).unsqueeze(0)
-        del x
+        # the row list straight from the segments and the table: the padded (mu+1, L, D) block is never built
+        rows = ops.splice(segs, mu + 1, self.embedding_layer.weight, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
         st = self.score_stats
         st["ragged_calls"] += 1
         st["rows"] += int(plan["N"])

@@ -126,6 +126,9 @@ class EngineOptions:
     # gate_proj / up_proj of a gated MLP as one GEMM against their chunk-interleaved weights (16-bit models; one
     # more copy of those two matrices, two in the gradient pass): see fused.py.
     fuse_gate_up: bool = True
+    # every residual add of a decoder layer fused into the RMSNorm that follows it (also across the layer boundary) and
+    # q/k rotary as one launch: see fused.py (_layer_forward); known llama- / gemma3-style layer structures only.
+    fuse_add_norm: bool = True
     # joint_eval: the step's loss is the winner's row of the candidate batch (scored with the image, in the
     # re-score's own segment order) instead of a second, batch-1 forward of the same sequence (:605-612).
     joint_winner_from_batch: bool = True
@@ -211,6 +214,8 @@ class EngineOptions:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
+        if "BMA_FUSE_ADD_NORM" in env:
+            opts.fuse_add_norm = env["BMA_FUSE_ADD_NORM"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:
             opts.backward_weight_copies = env["BMA_BACKWARD_WEIGHT_COPIES"] not in ("0", "false", "False")
         if "BMA_SHARED_PREFIX_ATTENTION" in env:

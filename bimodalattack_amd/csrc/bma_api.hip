@@ -121,6 +121,8 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_GATHER_ROWS: return "gather_rows_kernel";
     case BMA_K_RAGGED_ATTN: return "ragged_attn_kernel";
     case BMA_K_PREFIX_ATTN: return "prefix_attn_kernel";
+    case BMA_K_ADD_RMSNORM: return "add_rmsnorm_kernel";
+    case BMA_K_GEMM_NT: return "gemm_nt_kernel";
     default: return "?";
   }
 }

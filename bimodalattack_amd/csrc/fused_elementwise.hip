@@ -114,6 +114,94 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(const uint4_t* __
   }
 }
 
+// Residual add + RMSNorm in one pass (HF decoder layer: `h = residual + h` followed by a norm of the sum):
+//   s = dt(res + a)           a = h, or with PRE the Gemma-3 sandwich norm of h:  a = dt(h * rstd(h) * (1 + wp))
+//   y = rmsnorm(s; w)         same arithmetic and rounding points as rmsnorm_kernel on s
+// Both s (the next residual) and y are written: 2 reads + 2 writes per row instead of the 3 + 2 (+2 with PRE) of
+// the separate launches.  Bit-identical to aten's add followed by rmsnorm_kernel (same reduction order).
+template <int DT, int NCH, bool GEMMA, bool PRE>
+__global__ __launch_bounds__(kNormThreads) void add_rmsnorm_kernel(const uint4_t* __restrict__ res,
+                                                                   const uint4_t* __restrict__ h,
+                                                                   const uint4_t* __restrict__ wp, float eps_pre,
+                                                                   const uint4_t* __restrict__ w, float eps, int cpr,
+                                                                   int D, uint4_t* __restrict__ s_out,
+                                                                   uint4_t* __restrict__ y) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ float part[2][kNormThreads / 64];
+  float v[NCH][NE];
+  if (PRE) {
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = tid + c * kNormThreads;
+      if (i < cpr) {
+        Chunk<DT>::unpack(h[row * cpr + i], v[c]);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) ss += v[c][j] * v[c][j];
+      }
+    }
+    ss = bma::wave_sum(ss);
+    if ((tid & 63) == 0) part[0][tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kNormThreads / 64; ++i) tot += part[0][i];
+    const float rstd = 1.0f / sqrtf(tot / static_cast<float>(D) + eps_pre);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = tid + c * kNormThreads;
+      if (i < cpr) {
+        float wf[NE];
+        Chunk<DT>::unpack(wp[i], wf);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          if (GEMMA) v[c][j] = rnd<DT>(v[c][j] * rstd * (1.0f + wf[j]));
+          else v[c][j] = rnd<DT>(wf[j] * rnd<DT>(v[c][j] * rstd));
+        }
+      }
+    }
+  }
+  float ss = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float r[NE];
+      Chunk<DT>::unpack(res[row * cpr + i], r);
+      if (!PRE) Chunk<DT>::unpack(h[row * cpr + i], v[c]);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        v[c][j] = rnd<DT>(r[j] + v[c][j]);            // the sum as the eager add leaves it in the model dtype
+        ss += v[c][j] * v[c][j];
+      }
+      s_out[row * cpr + i] = Chunk<DT>::pack(v[c]);
+    }
+  }
+  ss = bma::wave_sum(ss);
+  if ((tid & 63) == 0) part[1][tid >> 6] = ss;
+  __syncthreads();
+  float tot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kNormThreads / 64; ++i) tot += part[1][i];
+  const float rstd = 1.0f / sqrtf(tot / static_cast<float>(D) + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float wf[NE], o[NE];
+      Chunk<DT>::unpack(w[i], wf);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (GEMMA) o[j] = v[c][j] * rstd * (1.0f + wf[j]);
+        else o[j] = wf[j] * rnd<DT>(v[c][j] * rstd);
+      }
+      y[row * cpr + i] = Chunk<DT>::pack(o);
+    }
+  }
+}
+
 // Short rows (per-head q/k norms: D = 128 or 256): LPR lanes per row, 256/LPR rows per workgroup,
 // one chunk per lane, the sum of squares reduced inside the LPR-lane group with xor shuffles.
 template <int DT, int LPR, bool GEMMA>
@@ -221,10 +309,10 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
 // output), and the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
 // Requires cph = Dh*es/16 to be a power of two <= 64 (Dh = 64..512 for 16-bit dtypes).
 template <int DT>
-__global__ __launch_bounds__(256) void rope_kernel(const void* q, int64_t sb, int64_t sh, int64_t sl, void* dst,
-                                                   int64_t db, int64_t dh, int64_t dl, int B, int H, int L, int Dh,
-                                                   const void* __restrict__ cosp, const void* __restrict__ sinp,
-                                                   int cos_batch, int cph_log2, float sin_sign) {
+__device__ __forceinline__ void rope_row(const void* q, int64_t sb, int64_t sh, int64_t sl, void* dst,
+                                         int64_t db, int64_t dh, int64_t dl, int B, int H, int L, int Dh,
+                                         const void* __restrict__ cosp, const void* __restrict__ sinp,
+                                         int cos_batch, int cph_log2, float sin_sign) {
   constexpr int NE = Chunk<DT>::NE;
   constexpr int ES = bma::elem_bytes<DT>::value;
   const int cph = 1 << cph_log2;               // chunks per head vector
@@ -261,6 +349,31 @@ __global__ __launch_bounds__(256) void rope_kernel(const void* q, int64_t sb, in
     for (int j = 0; j < NE; ++j) o[j] = rnd<DT>(rnd<DT>(x[j] * cf[j]) + rnd<DT>(sign * p[j] * sf[j]));
     *pd = Chunk<DT>::pack(o);
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void rope_kernel(const void* q, int64_t sb, int64_t sh, int64_t sl, void* dst,
+                                                   int64_t db, int64_t dh, int64_t dl, int B, int H, int L, int Dh,
+                                                   const void* __restrict__ cosp, const void* __restrict__ sinp,
+                                                   int cos_batch, int cph_log2, float sin_sign) {
+  rope_row<DT>(q, sb, sh, sl, dst, db, dh, dl, B, H, L, Dh, cosp, sinp, cos_batch, cph_log2, sin_sign);
+}
+
+// q AND k of one attention block in ONE launch (blockIdx.y picks the tensor): they share cos/sin, B, L and Dh and
+// differ in base pointer, strides and head count (grouped key/value heads).
+struct RopeTensor {
+  const void* src;
+  void* dst;
+  int64_t sb, sh, sl, db, dh, dl;
+  int H;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void rope2_kernel(RopeTensor tq, RopeTensor tk, int B, int L, int Dh,
+                                                    const void* __restrict__ cosp, const void* __restrict__ sinp,
+                                                    int cos_batch, int cph_log2, float sin_sign) {
+  const RopeTensor& t = blockIdx.y ? tk : tq;
+  rope_row<DT>(t.src, t.sb, t.sh, t.sl, t.dst, t.db, t.dh, t.dl, B, t.H, L, Dh, cosp, sinp, cos_batch, cph_log2, sin_sign);
 }
 
 template <int DT>
@@ -323,6 +436,62 @@ extern "C" int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t
     case BMA_F32: return launch_rmsnorm<BMA_F32>(x, weight, eps, rows, D, gemma_style, out, st);
     case BMA_BF16: return launch_rmsnorm<BMA_BF16>(x, weight, eps, rows, D, gemma_style, out, st);
     case BMA_F16: return launch_rmsnorm<BMA_F16>(x, weight, eps, rows, D, gemma_style, out, st);
+    default: return BMA_EDTYPE;
+  }
+}
+
+namespace {
+template <int DT>
+int launch_add_rmsnorm(const void* res, const void* h, const void* wp, float eps_pre, const void* w, float eps,
+                       int64_t rows, int D, int gemma, void* s_out, void* y, hipStream_t st) {
+  constexpr int ES = bma::elem_bytes<DT>::value;
+  const int cpr = static_cast<int>(static_cast<int64_t>(D) * ES / 16);
+  const int nch = (cpr + kNormThreads - 1) / kNormThreads;
+  if (nch > kNormMaxChunks) return BMA_ELIMIT;
+  const dim3 grid(static_cast<unsigned>(rows)), block(kNormThreads);
+  const uint4_t* rp = static_cast<const uint4_t*>(res);
+  const uint4_t* hp = static_cast<const uint4_t*>(h);
+  const uint4_t* pp = static_cast<const uint4_t*>(wp);
+  const uint4_t* wq = static_cast<const uint4_t*>(w);
+  uint4_t* sp = static_cast<uint4_t*>(s_out);
+  uint4_t* yp = static_cast<uint4_t*>(y);
+  BMA_PROF_BEGIN(BMA_K_ADD_RMSNORM, st, 4.0 * static_cast<double>(rows) * D * ES);
+#define BMA_AN_GO(N)                                                                                                      \
+  do {                                                                                                                    \
+    if (gemma && wp) hipLaunchKernelGGL((add_rmsnorm_kernel<DT, N, true, true>), grid, block, 0, st, rp, hp, pp, eps_pre, wq, eps, cpr, D, sp, yp);   \
+    else if (gemma) hipLaunchKernelGGL((add_rmsnorm_kernel<DT, N, true, false>), grid, block, 0, st, rp, hp, pp, eps_pre, wq, eps, cpr, D, sp, yp);   \
+    else if (wp) hipLaunchKernelGGL((add_rmsnorm_kernel<DT, N, false, true>), grid, block, 0, st, rp, hp, pp, eps_pre, wq, eps, cpr, D, sp, yp);      \
+    else hipLaunchKernelGGL((add_rmsnorm_kernel<DT, N, false, false>), grid, block, 0, st, rp, hp, pp, eps_pre, wq, eps, cpr, D, sp, yp);             \
+  } while (0)
+  switch (nch) {
+    case 1: BMA_AN_GO(1); break;
+    case 2: BMA_AN_GO(2); break;
+    case 3: BMA_AN_GO(3); break;
+    default: BMA_AN_GO(4); break;
+  }
+#undef BMA_AN_GO
+  BMA_PROF_END(BMA_K_ADD_RMSNORM, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+}  // namespace
+
+extern "C" int bma_add_rmsnorm(const void* residual, const void* h, const void* pre_weight, float pre_eps,
+                               const void* weight, float eps, int64_t rows, int D, int dtype, int gemma_style,
+                               void* sum_out, void* out, void* stream) {
+  if (rows < 0 || D <= 0 || rows > 0x7fffffffLL) return BMA_EINVAL;
+  if (rows == 0) return BMA_OK;
+  if (!residual || !h || !weight || !sum_out || !out) return BMA_EINVAL;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((static_cast<int64_t>(D) * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(pre_weight) |
+       reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(sum_out) | reinterpret_cast<uintptr_t>(out)) % 16)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BMA_F32: return launch_add_rmsnorm<BMA_F32>(residual, h, pre_weight, pre_eps, weight, eps, rows, D, gemma_style, sum_out, out, st);
+    case BMA_BF16: return launch_add_rmsnorm<BMA_BF16>(residual, h, pre_weight, pre_eps, weight, eps, rows, D, gemma_style, sum_out, out, st);
+    case BMA_F16: return launch_add_rmsnorm<BMA_F16>(residual, h, pre_weight, pre_eps, weight, eps, rows, D, gemma_style, sum_out, out, st);
     default: return BMA_EDTYPE;
   }
 }
@@ -412,6 +581,46 @@ extern "C" int bma_rope(const void* q, int64_t stride_b, int64_t stride_h, int64
   else if (dtype == BMA_BF16) BMA_ROPE_GO(BMA_BF16);
   else BMA_ROPE_GO(BMA_F16);
 #undef BMA_ROPE_GO
+  BMA_PROF_END(BMA_K_ROPE, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+extern "C" int bma_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, void* qd, int64_t qd_b, int64_t qd_h,
+                         int64_t qd_l, int Hq, const void* k, int64_t k_b, int64_t k_h, int64_t k_l, void* kd,
+                         int64_t kd_b, int64_t kd_h, int64_t kd_l, int Hk, int B, int L, int Dh, const void* cos,
+                         const void* sin, int cos_batch, float sin_sign, int dtype, void* stream) {
+  if (B < 0 || Hq <= 0 || Hk <= 0 || L < 0 || Dh <= 0 || (cos_batch != 1 && cos_batch != B)) return BMA_EINVAL;
+  if (sin_sign != 1.0f && sin_sign != -1.0f) return BMA_EINVAL;
+  if (B == 0 || L == 0) return BMA_OK;
+  if (!q || !qd || !k || !kd || !cos || !sin) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  const int ne = 16 / es;
+  if (Dh % (2 * ne)) return BMA_EALIGN;
+  const int cph_host = Dh / ne;
+  if (cph_host > 64 || (cph_host & (cph_host - 1))) return BMA_ELIMIT;
+  const int64_t strides[12] = {q_b, q_h, q_l, qd_b, qd_h, qd_l, k_b, k_h, k_l, kd_b, kd_h, kd_l};
+  for (int i = 0; i < 12; ++i)
+    if ((strides[i] * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(qd) | reinterpret_cast<uintptr_t>(k) |
+       reinterpret_cast<uintptr_t>(kd) | reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin)) % 16)
+    return BMA_EALIGN;
+  int cph_log2 = 0;
+  while ((1 << cph_log2) < cph_host) ++cph_log2;
+  const int64_t rows = static_cast<int64_t>(B) * L;
+  if (rows > 0x7fffffffLL) return BMA_ELIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(rows), 2), block(256);
+  const RopeTensor tq{q, qd, q_b, q_h, q_l, qd_b, qd_h, qd_l, Hq};
+  const RopeTensor tk{k, kd, k_b, k_h, k_l, kd_b, kd_h, kd_l, Hk};
+  BMA_PROF_BEGIN(BMA_K_ROPE, st, 2.0 * static_cast<double>(B) * (Hq + Hk) * L * Dh * es);
+#define BMA_ROPE2_GO(DT_) \
+  hipLaunchKernelGGL((rope2_kernel<DT_>), grid, block, 0, st, tq, tk, B, L, Dh, cos, sin, cos_batch, cph_log2, sin_sign)
+  if (dtype == BMA_F32) BMA_ROPE2_GO(BMA_F32);
+  else if (dtype == BMA_BF16) BMA_ROPE2_GO(BMA_BF16);
+  else BMA_ROPE2_GO(BMA_F16);
+#undef BMA_ROPE2_GO
   BMA_PROF_END(BMA_K_ROPE, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
@@ -546,10 +755,13 @@ extern "C" int bma_gather_rows(const void* src, const int* idx, int64_t n_out, i
 //   rope bwd    : the rotation is orthogonal -- backward is the forward kernel with -sin.
 namespace {
 
+// `add` (optional): a gradient arriving at x by another path (the residual stream past a fused add + norm):
+// dx = rnd(add + rnd(dx_norm)) -- the sum autograd's accumulation would form with one more launch.
 template <int DT, int NCH, bool GEMMA>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint4_t* __restrict__ x,
                                                                    const uint4_t* __restrict__ w,
-                                                                   const uint4_t* __restrict__ dy, float eps, int cpr,
+                                                                   const uint4_t* __restrict__ dy,
+                                                                   const uint4_t* __restrict__ add, float eps, int cpr,
                                                                    int D, uint4_t* __restrict__ dx) {
   constexpr int NE = Chunk<DT>::NE;
   const int64_t row = blockIdx.x;
@@ -589,6 +801,12 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_bwd_kernel(const uint4_t
       float o[NE];
 #pragma unroll
       for (int j = 0; j < NE; ++j) o[j] = r * gv[c][j] - xv[c][j] * k;
+      if (add) {
+        float af[NE];
+        Chunk<DT>::unpack(add[row * cpr + i], af);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) o[j] = af[j] + rnd<DT>(o[j]);
+      }
       dx[row * cpr + i] = Chunk<DT>::pack(o);
     }
   }
@@ -628,8 +846,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint4_t* __restri
 }
 
 template <int DT>
-int launch_rmsnorm_bwd(const void* x, const void* w, const void* dy, float eps, int64_t rows, int D, int gemma,
-                       void* dx, hipStream_t st) {
+int launch_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* add, float eps, int64_t rows, int D,
+                       int gemma, void* dx, hipStream_t st) {
   constexpr int ES = bma::elem_bytes<DT>::value;
   const int cpr = static_cast<int>(static_cast<int64_t>(D) * ES / 16);
   const int nch = (cpr + kNormThreads - 1) / kNormThreads;
@@ -638,11 +856,12 @@ int launch_rmsnorm_bwd(const void* x, const void* w, const void* dy, float eps, 
   const uint4_t* xp = static_cast<const uint4_t*>(x);
   const uint4_t* wp = static_cast<const uint4_t*>(w);
   const uint4_t* dp = static_cast<const uint4_t*>(dy);
+  const uint4_t* ap = static_cast<const uint4_t*>(add);
   uint4_t* op = static_cast<uint4_t*>(dx);
-#define BMA_NB_GO(N)                                                                                                \
-  do {                                                                                                              \
-    if (gemma) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, N, true>), grid, block, 0, st, xp, wp, dp, eps, cpr, D, op); \
-    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, N, false>), grid, block, 0, st, xp, wp, dp, eps, cpr, D, op);      \
+#define BMA_NB_GO(N)                                                                                                    \
+  do {                                                                                                                  \
+    if (gemma) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, N, true>), grid, block, 0, st, xp, wp, dp, ap, eps, cpr, D, op); \
+    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DT, N, false>), grid, block, 0, st, xp, wp, dp, ap, eps, cpr, D, op);      \
   } while (0)
   switch (nch) {
     case 1: BMA_NB_GO(1); break;
@@ -657,23 +876,28 @@ int launch_rmsnorm_bwd(const void* x, const void* w, const void* dy, float eps, 
 
 }  // namespace
 
-extern "C" int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy, float eps, int64_t rows, int D,
-                               int dtype, int gemma_style, void* dx, void* stream) {
+extern "C" int bma_add_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* dsum, float eps,
+                                   int64_t rows, int D, int dtype, int gemma_style, void* dx, void* stream) {
   if (rows < 0 || D <= 0 || rows > 0x7fffffffLL) return BMA_EINVAL;
   if (rows == 0) return BMA_OK;
   if (!x || !weight || !dy || !dx) return BMA_EINVAL;
   const int es = dtype == BMA_F32 ? 4 : 2;
   if ((static_cast<int64_t>(D) * es) % 16) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(dy) |
-       reinterpret_cast<uintptr_t>(dx)) % 16)
+       reinterpret_cast<uintptr_t>(dsum) | reinterpret_cast<uintptr_t>(dx)) % 16)
     return BMA_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case BMA_F32: return launch_rmsnorm_bwd<BMA_F32>(x, weight, dy, eps, rows, D, gemma_style, dx, st);
-    case BMA_BF16: return launch_rmsnorm_bwd<BMA_BF16>(x, weight, dy, eps, rows, D, gemma_style, dx, st);
-    case BMA_F16: return launch_rmsnorm_bwd<BMA_F16>(x, weight, dy, eps, rows, D, gemma_style, dx, st);
+    case BMA_F32: return launch_rmsnorm_bwd<BMA_F32>(x, weight, dy, dsum, eps, rows, D, gemma_style, dx, st);
+    case BMA_BF16: return launch_rmsnorm_bwd<BMA_BF16>(x, weight, dy, dsum, eps, rows, D, gemma_style, dx, st);
+    case BMA_F16: return launch_rmsnorm_bwd<BMA_F16>(x, weight, dy, dsum, eps, rows, D, gemma_style, dx, st);
     default: return BMA_EDTYPE;
   }
+}
+
+extern "C" int bma_rmsnorm_bwd(const void* x, const void* weight, const void* dy, float eps, int64_t rows, int D,
+                               int dtype, int gemma_style, void* dx, void* stream) {
+  return bma_add_rmsnorm_bwd(x, weight, dy, nullptr, eps, rows, D, dtype, gemma_style, dx, stream);
 }
 
 static int gated_act_bwd_launch(const void* gate, const void* up, bool interleaved, const void* dy, int64_t n, int dtype,

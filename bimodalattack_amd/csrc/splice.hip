@@ -92,7 +92,111 @@ __global__ __launch_bounds__(256) void splice_kernel(SpliceArgs a, const void* _
   }
 }
 
+// Row-list form (ragged scoring, layout.ragged_plan): output row n is row slot[n] = b*S + s of the padded [B][S][D]
+// block bma_splice would build -- written directly, one workgroup per output row, so the block itself (of which ragged
+// scoring needs ~3/4 of the rows) is never materialised and never read back by a gather.
+template <int DT>
+__global__ __launch_bounds__(256) void splice_rows_kernel(SpliceArgs a, const void* __restrict__ emb, int V,
+                                                          const int64_t* __restrict__ ids, int B, int n_opt, int S,
+                                                          int cpr, float emb_scale, const int* __restrict__ slot,
+                                                          uint4_t* __restrict__ out) {
+  const int64_t n = blockIdx.x;
+  int64_t sl = slot[n];
+  const int64_t total = static_cast<int64_t>(B) * S;
+  sl = sl < 0 ? 0 : (sl >= total ? total - 1 : sl);        // never read outside the sources
+  const int b = static_cast<int>(sl / S);
+  const int s = static_cast<int>(sl - static_cast<int64_t>(b) * S);
+  int seg = 0;
+#pragma unroll
+  for (int i = 1; i < BMA_MAX_SEGS; ++i)
+    if (i < a.n && s >= a.start[i]) seg = i;
+  const int r = s - a.start[seg];
+  const int len = a.start[seg + 1] - a.start[seg];
+  const int kind = a.kind[seg];
+  const uint4_t* sp;
+  bool scale = false;
+  if (kind == BMA_SEG_SHARED) {
+    sp = static_cast<const uint4_t*>(a.ptr[seg]) + static_cast<int64_t>(r) * cpr;
+  } else if (kind == BMA_SEG_PERCAND) {
+    sp = static_cast<const uint4_t*>(a.ptr[seg]) + (static_cast<int64_t>(b) * len + r) * cpr;
+  } else {
+    int64_t id = ids[static_cast<int64_t>(b) * n_opt + r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    sp = static_cast<const uint4_t*>(emb) + id * cpr;
+    scale = emb_scale != 1.0f;
+  }
+  uint4_t* dst = out + n * cpr;
+  if (scale) {
+    for (int c = threadIdx.x; c < cpr; c += 256) dst[c] = scale_chunk<DT>(sp[c], emb_scale);
+  } else {
+    for (int c = threadIdx.x; c < cpr; c += 256) dst[c] = sp[c];
+  }
+}
+
+int fill_args(const bma_segment* segs_host, int n_segs, const void* emb, int V, const int64_t* ids, int B, int n_opt,
+              SpliceArgs& a, int& S) {
+  S = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const bma_segment& sg = segs_host[i];
+    if (sg.len < 0) return BMA_EINVAL;
+    a.start[i] = S;
+    a.kind[i] = sg.kind;
+    a.ptr[i] = sg.ptr;
+    if (sg.kind == BMA_SEG_GATHER) {
+      if (sg.len != n_opt || n_opt <= 0 || V <= 0) return BMA_EINVAL;
+      if (B > 0 && (!emb || !ids)) return BMA_EINVAL;
+      if (reinterpret_cast<uintptr_t>(emb) % 16) return BMA_EALIGN;
+    } else if (sg.kind == BMA_SEG_SHARED || sg.kind == BMA_SEG_PERCAND) {
+      if (sg.len > 0 && B > 0 && !sg.ptr) return BMA_EINVAL;
+      if (reinterpret_cast<uintptr_t>(sg.ptr) % 16) return BMA_EALIGN;
+    } else {
+      return BMA_EINVAL;
+    }
+    S += sg.len;
+  }
+  for (int i = n_segs; i <= BMA_MAX_SEGS; ++i) a.start[i] = S;
+  for (int i = n_segs; i < BMA_MAX_SEGS; ++i) { a.kind[i] = BMA_SEG_SHARED; a.ptr[i] = nullptr; }
+  a.n = n_segs;
+  return BMA_OK;
+}
+
 }  // namespace
+
+extern "C" int bma_splice_rows(const bma_segment* segs_host, int n_segs, const void* emb, int V, const int64_t* ids,
+                               int B, int n_opt, int D, int dtype, float emb_scale, const int* slot, int64_t n_rows,
+                               void* out, void* stream) {
+  if (!segs_host || n_segs <= 0 || n_segs > BMA_MAX_SEGS || B <= 0 || D <= 0 || n_rows < 0) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((static_cast<int64_t>(D) * es) % 16 != 0) return BMA_EALIGN;
+  SpliceArgs a;
+  int S = 0;
+  const int rc = fill_args(segs_host, n_segs, emb, V, ids, B, n_opt, a, S);
+  if (rc != BMA_OK) return rc;
+  if (n_rows == 0) return BMA_OK;
+  if (S == 0 || !slot || !out) return BMA_EINVAL;
+  if (reinterpret_cast<uintptr_t>(out) % 16) return BMA_EALIGN;
+  if (n_rows > 0x7fffffffLL) return BMA_ELIMIT;
+  const int cpr = static_cast<int>(static_cast<int64_t>(D) * es / 16);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(n_rows)), block(256);
+  uint4_t* o = static_cast<uint4_t*>(out);
+  BMA_PROF_BEGIN(BMA_K_SPLICE, st, 2.0 * static_cast<double>(n_rows) * D * es);   // every row read once, written once
+  switch (dtype) {
+    case BMA_F32:
+      hipLaunchKernelGGL((splice_rows_kernel<BMA_F32>), grid, block, 0, st, a, emb, V, ids, B, n_opt, S, cpr, emb_scale, slot, o);
+      break;
+    case BMA_BF16:
+      hipLaunchKernelGGL((splice_rows_kernel<BMA_BF16>), grid, block, 0, st, a, emb, V, ids, B, n_opt, S, cpr, emb_scale, slot, o);
+      break;
+    default:
+      hipLaunchKernelGGL((splice_rows_kernel<BMA_F16>), grid, block, 0, st, a, emb, V, ids, B, n_opt, S, cpr, emb_scale, slot, o);
+      break;
+  }
+  BMA_PROF_END(BMA_K_SPLICE, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
 
 extern "C" int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V, const int64_t* ids,
                           int B, int n_opt, int D, int dtype, float emb_scale, void* out, void* stream) {

@@ -82,12 +82,76 @@ class _CopyCache:
         return len(self.d)
 
 
+_LLAMA_BODY = ["residual = hidden_states", "hidden_states = self.input_layernorm(hidden_states)",
+               "hidden_states, _ = self.self_attn(", "hidden_states = residual + hidden_states", "residual = hidden_states",
+               "hidden_states = self.post_attention_layernorm(hidden_states)", "hidden_states = self.mlp(hidden_states)",
+               "hidden_states = residual + hidden_states", "return hidden_states"]
+_GEMMA_BODY = ["residual = hidden_states", "hidden_states = self.input_layernorm(hidden_states)",
+               "hidden_states, _ = self.self_attn(", "hidden_states = self.post_attention_layernorm(hidden_states)",
+               "hidden_states = residual + hidden_states", "residual = hidden_states",
+               "hidden_states = self.pre_feedforward_layernorm(hidden_states)", "hidden_states = self.mlp(hidden_states)",
+               "hidden_states = self.post_feedforward_layernorm(hidden_states)", "hidden_states = residual + hidden_states",
+               "return hidden_states"]
+
+
+def _layer_kind(layer):
+    """"llama" / "gemma" when the decoder layer's forward is, statement for statement, the residual structure the
+    fused forward restates (read from its source: every line that touches `self.`, `residual` or returns), else None."""
+    import inspect
+    try:
+        src = inspect.getsource(type(layer).forward)
+    except (OSError, TypeError):
+        return None
+    lines = []
+    for ln in src.splitlines():
+        t = ln.strip()
+        if t.startswith("#") or t.startswith("def ") or t.startswith("self,") or not t:
+            continue
+        if "self." in t or t.startswith("residual") or t.startswith("return") or "residual +" in t:
+            lines.append(t)
+    for kind, want in (("llama", _LLAMA_BODY), ("gemma", _GEMMA_BODY)):
+        if len(lines) == len(want) and all(l.startswith(w) if w.endswith("(") else l == w for l, w in zip(lines, want)):
+            return kind
+    return None
+
+
+def _decoder_layers(model, norm_info):
+    """[(layer, kind, next norm)] for every decoder stack -- a module with a ``layers`` ModuleList and a final ``norm``
+    -- whose layers all have a known residual structure and whose norms are ones the fused kernels replace."""
+    out = []
+    for parent in model.modules():
+        layers = getattr(parent, "layers", None)
+        final = getattr(parent, "norm", None)
+        if not isinstance(layers, torch.nn.ModuleList) or len(layers) == 0 or final is None or id(final) not in norm_info:
+            continue
+        n_used = getattr(getattr(parent, "config", None), "num_hidden_layers", len(layers))
+        if n_used != len(layers):
+            continue                                 # the stack runs a prefix of its layers: the hand-over would miss
+        kinds = [_layer_kind(l) for l in layers]
+        if any(k is None for k in kinds) or len(set(kinds)) != 1:
+            continue
+        names = ["input_layernorm", "post_attention_layernorm"] + \
+            (["pre_feedforward_layernorm", "post_feedforward_layernorm"] if kinds[0] == "gemma" else [])
+        if not all(id(getattr(l, n, None)) in norm_info for l in layers for n in names):
+            continue
+        if not all(hasattr(l, "self_attn") and hasattr(l, "mlp") for l in layers):
+            continue
+        for i, l in enumerate(layers):
+            nxt = layers[i + 1].input_layernorm if i + 1 < len(layers) else final
+            out.append((l, kinds[0], nxt))
+    return out
+
+
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
-                 fuse_qkv: bool = True, fuse_gate_up: bool = True):
+                 fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True):
         self.enabled = enabled
         self.weight_copies = weight_copies
         self.fuse_gate_up = fuse_gate_up
+        self.fuse_add_norm = fuse_add_norm
+        self.layers: List[Tuple[torch.nn.Module, str, torch.nn.Module]] = []   # (decoder layer, kind, the norm that reads its output)
+        self._norm_info = {}                         # id(norm module) -> (eps, gemma)
+        self._stash = {}                             # id(norm module) -> (sum tensor, its norm): handed over by the layer in front
         self.gemm_probe = None                       # measurement hook for products no nn.Linear module owns
         cache = _COPY_CACHES.get(model)
         if cache is None:
@@ -125,6 +189,9 @@ class FusedInference:
                     self._act_code(m.act_fn) is not None:
                 self.mlps.append(m)
             files.add(type(m).__module__)
+        self._norm_info = {id(m): (eps, gemma) for m, eps, gemma in self.norms}
+        if fuse_add_norm:
+            self.layers = _decoder_layers(model, self._norm_info)
         for f in files:
             mod = sys.modules.get(f)
             if mod is not None and f.rsplit(".", 1)[-1] in _ROPE_FILES and hasattr(mod, "apply_rotary_pos_emb"):
@@ -159,6 +226,9 @@ class FusedInference:
 
     def _norm_forward(self, m, eps, gemma, orig):
         def forward(x):
+            hit = self._stash.pop(id(m), None)
+            if hit is not None and hit[0] is x:
+                return hit[1]                        # computed by the fused add + norm of the layer in front
             D = x.shape[-1]
             if not self._usable(x) or (D * x.element_size()) % 16 or D * x.element_size() > 16384 \
                     or m.weight.dtype != x.dtype:
@@ -316,6 +386,53 @@ class FusedInference:
             return m.down_proj(ops.swiglu(g, u, act))
         return forward
 
+    def _add_norm(self, residual, h, norm, pre=None):
+        """(residual + h', norm(residual + h')) with h' = h, or pre(h) for Gemma-3's sandwich norm -- one launch when
+        the tensors qualify, the eager add and the (patched) norm modules otherwise."""
+        eps, gemma = self._norm_info[id(norm)]
+        w = norm.weight
+        ok = (h.shape == residual.shape and h.dtype == residual.dtype and ops.add_rmsnorm_ok(h, w)
+              and h.is_contiguous() and residual.is_contiguous())
+        if ok and self._tracking(residual, h):
+            if pre is not None:
+                h = pre(h)                           # (its own fused forward/backward; the add + norm pair below)
+            return ops.AddRMSNormFn.apply(residual, h, w, eps, gemma)
+        if ok and not torch.is_grad_enabled():
+            if pre is None:
+                return ops.add_rmsnorm(residual, h, w, eps, gemma)
+            peps, pgemma = self._norm_info[id(pre)]
+            if pgemma == gemma and pre.weight.dtype == h.dtype:
+                return ops.add_rmsnorm(residual, h, w, eps, gemma, pre_weight=pre.weight, pre_eps=peps)
+            return ops.add_rmsnorm(residual, pre(h), w, eps, gemma)
+        s = residual + (h if pre is None else pre(h))
+        return s, norm(s)
+
+    def _layer_forward(self, layer, kind, next_norm):
+        """The decoder layer's forward with each residual add fused into the norm that follows it -- the layer's own
+        post-attention norm, and across the layer boundary the NEXT layer's input norm (or the stack's final norm),
+        whose result is handed over through ``_stash`` and picked up by that norm's patched forward when it is called
+        on the very tensor this layer returned.  Same statements as HuggingFace's forward (checked structurally when
+        the layer was admitted, ``_decoder_layers``), same rounding points."""
+        gem = kind == "gemma"
+
+        def forward(hidden_states, *args, **kwargs):
+            if args:                                  # HF calls its layers with keywords; anything else: their code
+                return type(layer).forward(layer, hidden_states, *args, **kwargs)
+            residual = hidden_states
+            h = layer.input_layernorm(hidden_states)
+            h, _ = layer.self_attn(hidden_states=h, **kwargs)
+            if gem:
+                residual, h = self._add_norm(residual, h, layer.pre_feedforward_layernorm, pre=layer.post_attention_layernorm)
+            else:
+                residual, h = self._add_norm(residual, h, layer.post_attention_layernorm)
+            h = layer.mlp(h)
+            if next_norm is None:
+                return residual + (layer.post_feedforward_layernorm(h) if gem else h)
+            out, normed = self._add_norm(residual, h, next_norm, pre=layer.post_feedforward_layernorm if gem else None)
+            self._stash[id(next_norm)] = (out, normed)
+            return out
+        return forward
+
     def _rope(self, orig):
         def apply_rotary_pos_emb(q, k, cos, sin, *args, unsqueeze_dim=1, **kw):
             ok = (self._usable(q) and not args and not kw and unsqueeze_dim == 1 and q.dim() == 4 and k.dim() == 4
@@ -327,10 +444,15 @@ class FusedInference:
                   and all((s * q.element_size()) % 16 == 0 for s in q.stride()[:3] + k.stride()[:3]))
             if not ok:
                 return orig(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kw)
+            same = q.shape[0] == k.shape[0] and q.shape[2] == k.shape[2] and q.shape[3] == k.shape[3]
             if self._tracking(q, k):
                 if cos.requires_grad or sin.requires_grad:
                     return orig(q, k, cos, sin, *args, unsqueeze_dim=unsqueeze_dim, **kw)
+                if same and self.fuse_add_norm:
+                    return ops.RoPE2Fn.apply(q, k, cos, sin)          # q and k in one launch, forward and backward
                 return ops.RoPEFn.apply(q, cos, sin), ops.RoPEFn.apply(k, cos, sin)
+            if same and self.fuse_add_norm:
+                return ops.rope2(q, k, cos, sin, inplace=True)
             ops.rope_(q, cos, sin)
             ops.rope_(k, cos, sin)
             return q, k
@@ -349,6 +471,8 @@ class FusedInference:
             m.forward = self._linear_forward(m, type(m).forward.__get__(m))
         for attn in self.qkv:                      # after the per-projection patches: these win for q/k/v
             attn.q_proj.forward, attn.k_proj.forward, attn.v_proj.forward = self._qkv_forwards(attn)
+        for layer, kind, nxt in self.layers:
+            layer.forward = self._layer_forward(layer, kind, nxt)
         for mod in self.rope_modules:
             self._saved_rope[mod] = mod.apply_rotary_pos_emb
             mod.apply_rotary_pos_emb = self._rope(mod.apply_rotary_pos_emb)
@@ -367,6 +491,9 @@ class FusedInference:
         for attn in self.qkv:
             for m in (attn.q_proj, attn.k_proj, attn.v_proj):
                 m.__dict__.pop("forward", None)
+        for layer, _, _ in self.layers:
+            layer.__dict__.pop("forward", None)
+        self._stash.clear()
         for mod, fn in self._saved_rope.items():
             mod.apply_rotary_pos_emb = fn
         self._saved_rope.clear()

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 101
+ABI_VERSION = 102
 
 
 class BmaSegment(Structure):
@@ -53,6 +53,15 @@ PROTOTYPES = {
                                    c_void_p, c_void_p]),
     "bma_splice": (c_int, [POINTER(BmaSegment), c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                            c_float, c_void_p, c_void_p]),
+    "bma_splice_rows": (c_int, [POINTER(BmaSegment), c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                c_float, c_void_p, c_int64, c_void_p, c_void_p]),
+    "bma_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_int64, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p]),
+    "bma_add_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p,
+                                    c_void_p]),
+    "bma_rope2": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                          c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                          c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
     "bma_rmsnorm": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bma_swiglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bma_gated_act": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
@@ -83,7 +92,7 @@ PROTOTYPES = {
 
 KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5,
               "ce_rows_grad": 6, "rmsnorm": 7, "swiglu": 8, "rope": 9, "attn_merge": 10, "gather_rows": 11,
-              "ragged_attn": 12, "prefix_attn": 13}
+              "ragged_attn": 12, "prefix_attn": 13, "add_rmsnorm": 14, "gemm_nt": 15}
 
 
 def profile_enable(on: bool) -> None:

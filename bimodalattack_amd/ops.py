@@ -183,11 +183,14 @@ Segment = Tuple[str, Optional[torch.Tensor]]   # ("shared"|"percand"|"gather", t
 
 def splice(segments: Sequence[Segment], B: int, emb_weight: Optional[torch.Tensor] = None,
            ids: Optional[torch.Tensor] = None, emb_scale: float = 1.0,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Build (B,S,D) candidate embeddings -- reference :1112-1225.
 
     ``("shared", t)``: t is (L,D) or (1,L,D), broadcast to every candidate;
     ``("percand", t)``: t is (B,L,D); ``("gather", None)``: rows emb_weight[ids[b]] * emb_scale.
+
+    With ``rows`` (int32 (N,): slots b*S + s of that block) only those rows are built, as an (N,D) row list
+    (``bma_splice_rows``: ragged scoring never materialises the block).
     """
     if not segments or len(segments) > native.BMA_MAX_SEGS:
         raise ValueError(f"1..{native.BMA_MAX_SEGS} segments")
@@ -232,6 +235,21 @@ def splice(segments: Sequence[Segment], B: int, emb_weight: Optional[torch.Tenso
         keep.append(t)
         arr[i] = BmaSegment(t.data_ptr() if L else None, L, code)
         S += L
+    if rows is not None:
+        if rows.dtype != torch.int32 or rows.dim() != 1 or not rows.is_contiguous() or rows.device != dev:
+            raise ValueError("rows must be a contiguous int32 vector on the segments' device")
+        if B <= 0 or S <= 0:
+            raise ValueError("row-list splice of an empty block")
+        N = rows.shape[0]
+        if out is None:
+            out = torch.empty((N, D), dtype=dtype, device=dev)
+        elif out.shape != (N, D) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+            raise ValueError("bad out tensor")
+        check("bma_splice_rows", lib.bma_splice_rows(
+            arr, len(segments), emb_weight.data_ptr() if emb_weight is not None else None, V,
+            ids.data_ptr() if ids is not None else None, B, n_opt, D, _DT[dtype], float(emb_scale), rows.data_ptr(), N,
+            out.data_ptr(), _stream(dev)))
+        return out
     if out is None:
         out = torch.empty((B, S, D), dtype=dtype, device=dev)
     elif out.shape != (B, S, D) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
@@ -254,6 +272,58 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, gemma_style: bool
     check("bma_rmsnorm", lib.bma_rmsnorm(x.data_ptr(), weight.data_ptr(), float(eps), x.numel() // D, D, _dt(x),
                                          1 if gemma_style else 0, out.data_ptr(), _stream(dev)))
     return out
+
+
+def add_rmsnorm(residual: torch.Tensor, h: torch.Tensor, weight: torch.Tensor, eps: float, gemma_style: bool = False,
+                pre_weight: Optional[torch.Tensor] = None, pre_eps: float = 0.0):
+    """(sum, y): sum = dt(residual + a), y = rmsnorm(sum; weight) with a = h or, given ``pre_weight``, the RMSNorm of h
+    under it (Gemma-3's norm on the branch output) -- one pass (include/bma.h: bma_add_rmsnorm)."""
+    dev = _need_gpu(residual, h, weight)
+    D = h.shape[-1]
+    if residual.shape != h.shape or residual.dtype != h.dtype or weight.shape != (D,) or weight.dtype != h.dtype \
+            or not weight.is_contiguous():
+        raise ValueError("residual and h must agree in shape and dtype; weight a contiguous (D,) tensor of that dtype")
+    if pre_weight is not None and (pre_weight.shape != (D,) or pre_weight.dtype != h.dtype or not pre_weight.is_contiguous()):
+        raise ValueError("pre_weight must be a contiguous (D,) tensor of h's dtype")
+    residual, h = residual.contiguous(), h.contiguous()
+    s_out, y = torch.empty_like(h), torch.empty_like(h)
+    check("bma_add_rmsnorm", lib.bma_add_rmsnorm(
+        residual.data_ptr(), h.data_ptr(), pre_weight.data_ptr() if pre_weight is not None else None, float(pre_eps),
+        weight.data_ptr(), float(eps), h.numel() // D, D, _dt(h), 1 if gemma_style else 0, s_out.data_ptr(), y.data_ptr(),
+        _stream(dev)))
+    return s_out, y
+
+
+def add_rmsnorm_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes bma_add_rmsnorm / bma_rmsnorm take: 16-byte rows of at most 16 KiB in one of the three dtypes."""
+    rb = x.shape[-1] * x.element_size()
+    return bool(x.is_cuda and x.dtype in _DT and weight.dtype == x.dtype and rb % 16 == 0 and rb <= 16384)
+
+
+class AddRMSNormFn(torch.autograd.Function):
+    """(residual, h) -> (residual + h, rmsnorm(residual + h)) under autograd (the gradient pass): the backward folds
+    the gradient arriving at the sum through the residual stream into the norm's backward launch."""
+
+    @staticmethod
+    def forward(ctx, residual, h, weight, eps, gemma_style):
+        s_out, y = add_rmsnorm(residual, h, weight, eps, gemma_style)
+        ctx.save_for_backward(s_out, weight)
+        ctx.eps, ctx.gemma = float(eps), bool(gemma_style)
+        return s_out, y
+
+    @staticmethod
+    def backward(ctx, d_sum, d_y):
+        x, w = ctx.saved_tensors
+        if d_y is None:
+            return d_sum, d_sum, None, None, None
+        d_y = d_y.contiguous()
+        d_sum = None if d_sum is None else d_sum.contiguous()
+        dx = torch.empty_like(x)
+        D = x.shape[-1]
+        check("bma_add_rmsnorm_bwd", lib.bma_add_rmsnorm_bwd(
+            x.data_ptr(), w.data_ptr(), d_y.data_ptr(), d_sum.data_ptr() if d_sum is not None else None, ctx.eps,
+            x.numel() // D, D, _dt(x), 1 if ctx.gemma else 0, dx.data_ptr(), _stream(x.device)))
+        return dx, dx, None, None, None
 
 
 ACT_SILU, ACT_GELU_TANH = 0, 1
@@ -342,6 +412,49 @@ def rope(q: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, inverse: bool = 
                                    out.stride(1), out.stride(2), B, H, L, Dh, cos.data_ptr(), sin.data_ptr(), cos.shape[0],
                                    -1.0 if inverse else 1.0, _dt(q), _stream(dev)))
     return out
+
+
+def rope2(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, inverse: bool = False,
+          inplace: bool = False):
+    """Rotary embedding of q (B,H,L,Dh) and k (B,Hk,L,Dh) in ONE launch (bma_rope2); out of place by default (outputs in
+    the projections' (B,L,heads,Dh) memory order), ``inplace`` rotates the given tensors."""
+    dev = _need_gpu(q, k, cos, sin)
+    if q.dim() != 4 or k.dim() != 4 or q.stride(3) != 1 or k.stride(3) != 1 or cos.shape != sin.shape or cos.dim() != 3:
+        raise ValueError("q/k must be (B,heads,L,Dh) with a contiguous last dim; cos/sin (1|B,L,Dh)")
+    B, H, L, Dh = q.shape
+    Hk = k.shape[1]
+    if k.shape != (B, Hk, L, Dh) or k.dtype != q.dtype or cos.shape[1] != L or cos.shape[2] != Dh \
+            or cos.shape[0] not in (1, B) or cos.dtype != q.dtype:
+        raise ValueError("k / cos / sin do not match q")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    if inplace:
+        qo, ko = q, k
+    else:
+        qo = torch.empty((B, L, H, Dh), dtype=q.dtype, device=dev).transpose(1, 2)
+        ko = torch.empty((B, L, Hk, Dh), dtype=q.dtype, device=dev).transpose(1, 2)
+    check("bma_rope2", lib.bma_rope2(
+        q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), qo.data_ptr(), qo.stride(0), qo.stride(1), qo.stride(2), H,
+        k.data_ptr(), k.stride(0), k.stride(1), k.stride(2), ko.data_ptr(), ko.stride(0), ko.stride(1), ko.stride(2), Hk,
+        B, L, Dh, cos.data_ptr(), sin.data_ptr(), cos.shape[0], -1.0 if inverse else 1.0, _dt(q), _stream(dev)))
+    return qo, ko
+
+
+class RoPE2Fn(torch.autograd.Function):
+    """q and k rotated by one launch; the backward is the inverse rotation of (dq, dk), one launch again."""
+
+    @staticmethod
+    def forward(ctx, q, k, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        return rope2(q, k, cos, sin)
+
+    @staticmethod
+    def backward(ctx, dq, dk):
+        cos, sin = ctx.saved_tensors
+        if dq is None or dk is None:            # one side unused: the one-tensor kernel
+            return (None if dq is None else rope(dq, cos, sin, inverse=True),
+                    None if dk is None else rope(dk, cos, sin, inverse=True), None, None)
+        gq, gk = rope2(dq, dk, cos, sin, inverse=True)
+        return gq, gk, None, None
 
 
 def attn_merge(o1: torch.Tensor, o2: torch.Tensor, lse1: torch.Tensor, lse2: torch.Tensor) -> torch.Tensor:

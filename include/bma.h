@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 101 /* 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 102 /* 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -140,6 +140,13 @@ typedef struct bma_segment {
 int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
                const int64_t* ids, int B, int n_opt, int D, int dtype,
                float emb_scale, void* out, void* stream);
+/* bma_splice_rows: the ROW-LIST form for ragged scoring (a candidate is computed from its first replaced suffix
+ *   position on): out[n][D] = row slot[n] of the [B][S][D] block bma_splice would build from the same arguments
+ *   (slot[n] = b*S + s, int32, clamped into the block), for n < n_rows; the block itself is never materialised.
+ *   Replaces bma_splice + bma_gather_rows (one pass over the rows instead of a write, a read and a write). */
+int bma_splice_rows(const bma_segment* segs_host, int n_segs, const void* emb, int V,
+                    const int64_t* ids, int B, int n_opt, int D, int dtype, float emb_scale,
+                    const int* slot, int64_t n_rows, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * a6  the elementwise tail of a Llama-family decoder layer during candidate scoring
@@ -155,6 +162,18 @@ int bma_splice(const bma_segment* segs_host, int n_segs, const void* emb, int V,
  * ------------------------------------------------------------------------- */
 int bma_rmsnorm(const void* x, const void* weight, float eps, int64_t rows, int D,
                 int dtype, int gemma_style, void* out, void* stream);
+/* bma_add_rmsnorm: the residual add of a decoder layer and the norm that follows it, in one pass (2 reads + 2 writes
+ *   per row instead of 3 + 2):   sum_out = dt(residual + a),   out = rmsnorm(sum_out; weight, eps)   as bma_rmsnorm,
+ *   where a = h, or, with pre_weight != NULL, a = rmsnorm(h; pre_weight, pre_eps) rounded to `dtype` first (Gemma-3's
+ *   sandwich norm on the branch output: HF Gemma3DecoderLayer.forward).  Bit-identical to the eager add followed by
+ *   bma_rmsnorm.  All of residual, h, sum_out, out: rows x D contiguous; limits as bma_rmsnorm.
+ * bma_add_rmsnorm_bwd: dx = dsum + rmsnorm_bwd(x, weight, dy) (dsum may be NULL: then == bma_rmsnorm_bwd): the
+ *   gradient of both inputs of the fused add (x is the forward's sum_out). */
+int bma_add_rmsnorm(const void* residual, const void* h, const void* pre_weight, float pre_eps,
+                    const void* weight, float eps, int64_t rows, int D, int dtype, int gemma_style,
+                    void* sum_out, void* out, void* stream);
+int bma_add_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* dsum, float eps,
+                        int64_t rows, int D, int dtype, int gemma_style, void* dx, void* stream);
 int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream);
 /* bma_gated_act: out = dt(dt(act(gate)) * up); act 0 = SiLU (== bma_swiglu), 1 = GELU-tanh as
  *   aten evaluates gelu(x, approximate="tanh") (Gemma's gated MLP). */
@@ -171,6 +190,12 @@ int bma_rope_inplace(void* q, int64_t stride_b, int64_t stride_h, int64_t stride
 int bma_rope(const void* q, int64_t stride_b, int64_t stride_h, int64_t stride_l, void* dst, int64_t dst_b,
              int64_t dst_h, int64_t dst_l, int B, int H, int L, int Dh, const void* cos, const void* sin,
              int cos_batch, float sin_sign, int dtype, void* stream);
+/* bma_rope2: q AND k of one attention block in one launch (same cos/sin, B, L, Dh; own base pointers, strides, head
+ *   counts and destinations, each as in bma_rope; qd == q / kd == k is the in-place form). */
+int bma_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, void* qd, int64_t qd_b, int64_t qd_h,
+              int64_t qd_l, int Hq, const void* k, int64_t k_b, int64_t k_h, int64_t k_l, void* kd,
+              int64_t kd_b, int64_t kd_h, int64_t kd_l, int Hk, int B, int L, int Dh, const void* cos,
+              const void* sin, int cos_batch, float sin_sign, int dtype, void* stream);
 /* Backward halves, used by the gradient pass (autograd at batch 1; weights are constants, so no
  * weight gradients): bma_rmsnorm_bwd: dx from x, weight, dy (D*es <= 16 KiB);
  * bma_swiglu_bwd: dgate, dup from gate, up, dy.  RoPE's backward is bma_rope_inplace with -sin. */
@@ -239,7 +264,7 @@ enum {
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
   BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11,
-  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_COUNT = 14
+  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_COUNT = 16
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

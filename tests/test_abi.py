@@ -54,6 +54,18 @@ def test_argument_validation_launches_nothing():
     assert lib.bma_splice(segs, 1, None, 0, None, 0, 0, 8, 1, 1.0, None, None) == 0
     bad = (BmaSegment * 1)(BmaSegment(16, 4, 7))
     assert lib.bma_splice(bad, 1, None, 0, None, 2, 0, 8, 1, 1.0, 16, None) == -1
+    # round 3 entry points
+    assert lib.bma_splice_rows(segs, 1, None, 0, None, 2, 0, 8, 1, 1.0, 16, 0, None, None) == 0        # no rows: nothing to do
+    assert lib.bma_splice_rows(segs, 1, None, 0, None, 2, 0, 8, 1, 1.0, None, 5, 16, None) == -1       # no slot map
+    assert lib.bma_splice_rows(segs, 1, None, 0, None, 0, 0, 8, 1, 1.0, 16, 5, 16, None) == -1         # an empty block has no rows
+    assert lib.bma_add_rmsnorm(None, 16, None, 0.0, 16, 1e-5, 4, 4096, 1, 0, 16, 16, None) == -1
+    assert lib.bma_add_rmsnorm(16, 16, None, 0.0, 16, 1e-5, 4, 4100, 1, 0, 16, 16, None) == -3         # row bytes not 16-byte multiples
+    assert lib.bma_add_rmsnorm(16, 16, None, 0.0, 16, 1e-5, 0, 4096, 1, 0, 16, 16, None) == 0
+    assert lib.bma_add_rmsnorm(16, 16, None, 0.0, 16, 1e-5, 4, 16384, 1, 0, 16, 16, None) == -5        # row longer than 16 KiB
+    assert lib.bma_add_rmsnorm_bwd(16, 16, None, None, 1e-5, 4, 4096, 1, 0, 16, None) == -1
+    assert lib.bma_rope2(16, 8, 8, 8, 16, 8, 8, 8, 4, 16, 8, 8, 8, 16, 8, 8, 8, 2, 0, 5, 64, 16, 16, 1, 1.0, 1, None) == 0   # B == 0
+    assert lib.bma_rope2(16, 8, 8, 8, 16, 8, 8, 8, 4, 16, 8, 8, 8, 16, 8, 8, 8, 2, 1, 5, 64, 16, 16, 1, 0.5, 1, None) == -1  # sin_sign
+    assert lib.bma_rope2(16, 8, 8, 8, 16, 8, 8, 8, 4, 16, 8, 4, 8, 16, 8, 8, 8, 2, 1, 5, 64, 16, 16, 1, 1.0, 1, None) == -3  # stride
 
 
 def test_no_cpu_fallback():

@@ -146,6 +146,8 @@ def test_trajectory_matches_reference(golden_dir, name):
                                     dict(joint_winner_from_batch=False),
                                     # the full 1-sequence gradient pass instead of scoring prefix + tail (joint mode)
                                     dict(grad_prefix_reuse=False),
+                                    # HuggingFace's own decoder-layer forward (aten residual adds, one rotary launch per tensor)
+                                    dict(fuse_add_norm=False),
                                     # everything eager and unfused
                                     dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
                                          fused_elementwise=False, gemm_tuning="off")])

@@ -477,6 +477,97 @@ def test_ragged_forward_equals_padded_forward(dtype):
     assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
 
 
+# ------------------------------------------------------------------ round 3: add + norm, q/k rotary, row-list splice
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gemma", [False, True])
+def test_add_rmsnorm_is_the_add_followed_by_the_norm(dtype, gemma):
+    """bma_add_rmsnorm against the two launches it replaces -- aten's add, then bma_rmsnorm -- BIT for bit (sum and
+    normed output), with and without the Gemma-3 sandwich norm on the addend; its autograd form against autograd
+    through the separate Functions, bit for bit as well (the fused backward rounds where the accumulation would)."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(31)
+    for rows, D in ((65, 4096), (1000, 2560), (3, 128), (17, 8192 if dtype != torch.float32 else 4096)):
+        res = (torch.randn((1, rows, D), generator=g, device=DEV) * 3).to(dtype)
+        h = (torch.randn((1, rows, D), generator=g, device=DEV) * 2).to(dtype)
+        w = (torch.randn(D, generator=g, device=DEV) * 0.3 + (0.0 if gemma else 1.0)).to(dtype)
+        wp = (torch.randn(D, generator=g, device=DEV) * 0.3 + (0.0 if gemma else 1.0)).to(dtype)
+        s, y = ops.add_rmsnorm(res, h, w, 1e-6, gemma)
+        s0 = res + h
+        assert torch.equal(s, s0) and torch.equal(y, ops.rmsnorm(s0, w, 1e-6, gemma))
+        s2, y2 = ops.add_rmsnorm(res, h, w, 1e-6, gemma, pre_weight=wp, pre_eps=1e-5)
+        s3 = res + ops.rmsnorm(h, wp, 1e-5, gemma)
+        assert torch.equal(s2, s3) and torch.equal(y2, ops.rmsnorm(s3, w, 1e-6, gemma))
+        # under autograd: d(res), d(h) with gradients arriving at BOTH outputs
+        ds = torch.randn((1, rows, D), generator=g, device=DEV).to(dtype)
+        dy = torch.randn((1, rows, D), generator=g, device=DEV).to(dtype)
+        ra, ha = res.clone().requires_grad_(), h.clone().requires_grad_()
+        sa, ya = ops.AddRMSNormFn.apply(ra, ha, w, 1e-6, gemma)
+        ga = torch.autograd.grad([sa, ya], [ra, ha], [ds, dy])
+        rb, hb = res.clone().requires_grad_(), h.clone().requires_grad_()
+        sb = rb + hb
+        yb = ops.RMSNormFn.apply(sb, w, 1e-6, gemma)
+        gb = torch.autograd.grad([sb, yb], [rb, hb], [ds, dy])
+        assert torch.equal(sa, sb) and torch.equal(ya, yb)
+        for a_, b_ in zip(ga, gb):
+            assert torch.equal(a_, b_)
+        # only the normed output used downstream
+        ra, ha = res.clone().requires_grad_(), h.clone().requires_grad_()
+        (g1,) = torch.autograd.grad(ops.AddRMSNormFn.apply(ra, ha, w, 1e-6, gemma)[1], ra, dy)
+        rb = res.clone().requires_grad_()
+        (g2,) = torch.autograd.grad(ops.RMSNormFn.apply(rb + h, w, 1e-6, gemma), rb, dy)
+        assert torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_rope2_is_two_ropes(dtype):
+    """q and k rotated by one launch == the two one-tensor launches, bit for bit: grouped heads, the strided views of a
+    fused q/k/v product, in place and out of place, forward and inverse."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for B, L, H, Hk, Dh in ((1, 65, 32, 32, 128), (3, 7, 8, 4, 256), (2, 44, 4, 2, 64)):
+        qkv = torch.randn((B, L, (H + 2 * Hk) * Dh), generator=g, device=DEV).to(dtype)
+        q = qkv[..., :H * Dh].view(B, L, H, Dh).transpose(1, 2)
+        k = qkv[..., H * Dh:(H + Hk) * Dh].view(B, L, Hk, Dh).transpose(1, 2)
+        ang = torch.randn((1, L, Dh // 2), generator=g, device=DEV)
+        cos, sin = torch.cat([ang.cos()] * 2, -1).to(dtype), torch.cat([ang.sin()] * 2, -1).to(dtype)
+        for inv in (False, True):
+            q2, k2 = ops.rope2(q, k, cos, sin, inverse=inv)
+            assert torch.equal(q2, ops.rope(q, cos, sin, inverse=inv)) and torch.equal(k2, ops.rope(k, cos, sin, inverse=inv))
+        qa, ka = qkv.clone(), qkv.clone()
+        q_in = qa[..., :H * Dh].view(B, L, H, Dh).transpose(1, 2)
+        k_in = qa[..., H * Dh:(H + Hk) * Dh].view(B, L, Hk, Dh).transpose(1, 2)
+        ops.rope2(q_in, k_in, cos, sin, inplace=True)
+        ops.rope_(ka[..., :H * Dh].view(B, L, H, Dh).transpose(1, 2), cos, sin)
+        ops.rope_(ka[..., H * Dh:(H + Hk) * Dh].view(B, L, Hk, Dh).transpose(1, 2), cos, sin)
+        assert torch.equal(qa, ka)
+        # autograd pair
+        qg, kg = q.clone().requires_grad_(), k.clone().requires_grad_()
+        dq, dk = torch.randn_like(q), torch.randn_like(k)
+        a = torch.autograd.grad(ops.RoPE2Fn.apply(qg, kg, cos, sin), [qg, kg], [dq, dk])
+        b = (torch.autograd.grad(ops.RoPEFn.apply(qg, cos, sin), qg, dq)[0], torch.autograd.grad(ops.RoPEFn.apply(kg, cos, sin), kg, dk)[0])
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float32, 1.0), (torch.bfloat16, 50.5)])
+def test_splice_rows_is_splice_then_gather(dtype, scale):
+    """bma_splice_rows (the ragged row list straight from the segments) == bma_splice + bma_gather_rows, byte for byte:
+    shared, per-candidate and gathered segments, scaled embeddings, repeated and out-of-order slots."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(17)
+    B, n_opt, D, V = 37, 19, 512, 1000
+    table = torch.randn((V, D), generator=g, device=DEV).to(dtype)
+    ids = torch.randint(0, V, (B, n_opt), generator=g, device=DEV)
+    segs = [("shared", torch.randn((1, 5, D), generator=g, device=DEV).to(dtype)), ("gather", None),
+            ("percand", torch.randn((B, 3, D), generator=g, device=DEV).to(dtype)),
+            ("shared", torch.randn((1, 20, D), generator=g, device=DEV).to(dtype))]
+    S = 5 + n_opt + 3 + 20
+    slot = torch.randint(0, B * S, (4000,), generator=g, device=DEV).to(torch.int32)
+    slot[:S] = torch.arange(S, device=DEV, dtype=torch.int32) + (B - 1) * S          # the whole last block, in order
+    want = ops.gather_rows(ops.splice(segs, B, table, ids, scale).view(B * S, D), slot)
+    got = ops.splice(segs, B, table, ids, scale, rows=slot)
+    assert got.shape == (4000, D) and torch.equal(got, want)
+
+
 # ------------------------------------------------------------------ fused ops under autograd
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_backward_matches_eager_autograd(dtype):
