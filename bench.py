@@ -327,7 +327,8 @@ class GemmTimer:
 
 
 class GradPassProfile:
-    """The library GEMMs of ONE batch-1 gradient pass, measured outside the timed region.
+    """The GEMMs of ONE batch-1 gradient pass (library products, and those on the engine's own bma_gemm_nt), measured
+    outside the timed region.
 
     The timed steps replay the pass from hipGraphs: no Python runs, so neither module hooks nor the in-library event
     brackets see it (and GemmTimer deliberately ignores products under 1024 rows).  Here the same work runs once
@@ -355,8 +356,17 @@ class GradPassProfile:
                     outer.calls.append((name, func, args, dict(kwargs or {})))
                 return func(*args, **(kwargs or {}))
 
-        with Rec():
-            out = fn()
+        from bimodalattack_amd import ops
+
+        def nt_hook(x, w):          # products the engine routes to its own skinny kernel never reach aten
+            outer.calls.append(("gemm_nt", ops.gemm_nt, (x, w), {}))
+
+        ops.GEMM_NT_HOOK = nt_hook
+        try:
+            with Rec():
+                out = fn()
+        finally:
+            ops.GEMM_NT_HOOK = None
         torch.cuda.synchronize()
         return out
 
@@ -365,6 +375,8 @@ class GradPassProfile:
         a, b = args[-2], args[-1]
         if name == "bmm":
             return a.shape[0], a.shape[1], b.shape[2], a.shape[2]
+        if name == "gemm_nt":                       # (x (..., K), w (N, K))
+            return 1, a.numel() // a.shape[-1], b.shape[0], b.shape[1]
         return 1, a.shape[0], b.shape[1], a.shape[1]
 
     def table(self, roles: dict, max_launches: int = 96) -> list:
@@ -412,6 +424,8 @@ class GradPassProfile:
             # a linear layer's weight is the (K,N) operand, a transposed view of the stored (N,K) matrix -- or, for the
             # input gradients through the transposed copies, of the stored (K,N) one
             role = roles.get((N, K)) if name != "bmm" else None
+            if role and name == "gemm_nt":
+                role += " [bma_gemm_nt]"
             out.append(dict(op=name, role=role or f"{name} {tuple(key[1])} x {tuple(b_shape)}", batch=batch, M=M, N=N, K=K,
                             dtype=key[5].replace("torch.", ""), launches_per_pass=len(calls), avg_us=us,
                             total_ms_per_pass=us * len(calls) / 1e3, flops_per_launch=flops, bytes_per_launch=nbytes,

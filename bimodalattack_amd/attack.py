@@ -169,6 +169,7 @@ class BimodalAttack:
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
+        ops.SKINNY_GEMM = bool(self.opt.skinny_gemm)
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
                                     self.opt.fuse_gate_up, self.opt.fuse_add_norm)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)

@@ -129,6 +129,10 @@ class EngineOptions:
     # every residual add of a decoder layer fused into the RMSNorm that follows it (also across the layer boundary) and
     # q/k rotary as one launch: see fused.py (_layer_forward); known llama- / gemma3-style layer structures only.
     fuse_add_norm: bool = True
+    # batch-1 gradient pass: products with at most 96 rows (16-bit, bias-free decoder projections and their input
+    # gradients through the transposed copies) on the hand-written weight-streaming kernel bma_gemm_nt instead of the
+    # library (process-wide switch: ops.SKINNY_GEMM).
+    skinny_gemm: bool = True
     # joint_eval: the step's loss is the winner's row of the candidate batch (scored with the image, in the
     # re-score's own segment order) instead of a second, batch-1 forward of the same sequence (:605-612).
     joint_winner_from_batch: bool = True
@@ -214,6 +218,8 @@ class EngineOptions:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
+        if "BMA_SKINNY_GEMM" in env:
+            opts.skinny_gemm = env["BMA_SKINNY_GEMM"] not in ("0", "false", "False")
         if "BMA_FUSE_ADD_NORM" in env:
             opts.fuse_add_norm = env["BMA_FUSE_ADD_NORM"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:

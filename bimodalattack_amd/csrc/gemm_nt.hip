@@ -1,0 +1,314 @@
+// a1 (gradient pass) -- the skinny products of the batch-1 forward/backward:  y[M][N] = x[M][K] . W[N][K]^T
+//
+// The reference's compute_gradient (bimodal_attack.py:953-1028) runs the language model at batch 1: every linear layer
+// is a product of a handful of activation rows (65 at S = 66, 44 behind a reused prefix) with a 34-180 MB weight that is
+// streamed from HBM exactly once.  Such a product is bound by how many bytes of W each CU keeps in flight, not by the
+// matrix cores (M = 96 padded rows cost 6 us of MFMA time against a 22 us HBM floor for the 180 MB gate/up weight);
+// the library's kernels reach 0.27-0.49 of 8 TB/s on these shapes inside the pass (bench.py, gradient_pass.gemms).
+//
+// Design (gfx950 only):
+//   * one workgroup = 4 waves owns a 128-row slab of W (BN) x a K range x all M rows (M <= 16*MT); grid = slabs x splits,
+//     with the split count chosen on the host so that the workgroups fill the 256 CUs in whole rounds;
+//   * W and x tiles of BK = 64 (128-byte rows) go HBM/L2 -> LDS by `global_load_lds_dwordx4` (1 KiB = 8 rows x 128 B per
+//     wave instruction, every byte of every line used), a ring of ST stages with ST-1 in flight (>= 48 KiB of W per CU),
+//     counted `s_waitcnt vmcnt(N)` + ONE raw `s_barrier` per stage, a single LDS array (cdna_hip_programming.md 5:
+//     "Pipelining across barriers", "Projection GEMM at M = 256" items 3-4);
+//   * LDS image: linear rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7) -- applied to the SOURCE address of
+//     the DMA and to the fragment read (rule 21) -- so the `ds_read_b128` of an MFMA fragment (16 rows x 16 B per
+//     k-group) is conflict-free;
+//   * `v_mfma_f32_16x16x32`: A = 16 rows of W, B = 16 rows of x (both K-contiguous, the same read shape), so a lane ends
+//     up with 4 consecutive n of one m: 8-byte output stores;
+//   * split-K: partials as fp32 in the accumulator's own register order (1 KiB per wave instruction), an agent-scope
+//     release + ticket per tile, and the last arriver sums the S partials IN SPLIT ORDER (its own from registers) --
+//     bitwise reproducible whichever workgroup arrives last -- then resets the ticket for the next launch.
+//
+// Algorithmic bytes per launch: (M*K + N*K + M*N) * es.
+
+#include "bma_common.h"
+#include "bma_profile.h"
+
+namespace {
+
+using bma::uint4_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBN = 128;          // W rows per workgroup
+constexpr int kBK = 64;           // k per stage
+constexpr int kRowB = kBK * 2;    // bytes per LDS row (16-bit types only)
+
+struct GemmArgs {
+  const char* x;
+  const char* w;
+  char* y;
+  float* ws;
+  int* cnt;
+  int64_t ldx, ldw, ldy;   // elements
+  int M, N, K, S, m_tiles;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const uint4_t& a, const uint4_t& b, const f32x4& c) {
+  if (DT == BMA_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DT, int MT, int NW, int ST>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int BM = 16 * MT;
+  constexpr int NTW = (kBN / 16) / NW;              // n-tiles per wave
+  constexpr int PIECES = (BM + kBN) / 8;            // 1 KiB pieces per stage
+  constexpr int PW = PIECES / NW;                   // ... issued by each wave
+  constexpr int STAGE = (BM + kBN) * kRowB;
+  static_assert((kBN / 16) % NW == 0 && PIECES % NW == 0, "tile does not divide over the waves");
+  static_assert(PW * (ST - 2) <= 63, "vmcnt is six bits");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[ST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = blockIdx.x;
+  const int split = bid % a.S;
+  const int tile = bid / a.S;
+  const int m0 = (tile % a.m_tiles) * BM;
+  const int n0 = (tile / a.m_tiles) * kBN;
+  const int T = a.K / kBK;
+  const int t0 = static_cast<int>(static_cast<int64_t>(T) * split / a.S);
+  const int t1 = static_cast<int>(static_cast<int64_t>(T) * (split + 1) / a.S);
+
+  // ---- per-wave DMA pieces: piece p covers tile rows 8p .. 8p+7 (x rows first, then W rows) -------------------
+  const int prow = lane >> 3;                                  // row inside the piece == (tile row & 7)
+  const int pchunk = (lane & 7) ^ prow;                        // source chunk that lands at LDS position lane & 7
+  const char* src[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) {
+    const int p = wave * PW + i;
+    const int r = p * 8 + prow;
+    if (r < BM) {
+      int m = m0 + r;
+      m = m < a.M ? m : a.M - 1;                               // rows past M repeat the last one (never stored)
+      src[i] = a.x + (static_cast<int64_t>(m) * a.ldx) * 2 + pchunk * 16;
+    } else {
+      int n = n0 + (r - BM);
+      n = n < a.N ? n : a.N - 1;
+      src[i] = a.w + (static_cast<int64_t>(n) * a.ldw) * 2 + pchunk * 16;
+    }
+  }
+  auto issue = [&](int t, int slot) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      unsigned char* dst = lds + slot * STAGE + (wave * PW + i) * 1024;     // wave-uniform; the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + static_cast<int64_t>(t) * kRowB),
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[NTW][MT];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // fragment read offsets inside a stage: row (lane & 15) of a 16-row tile, chunk (4*kk + (lane >> 4)) ^ (row & 7)
+  const int frow = lane & 15, fg = lane >> 4;
+  const int foff0 = frow * kRowB + ((fg) ^ (frow & 7)) * 16;          // kk = 0
+  const int foff1 = frow * kRowB + ((4 + fg) ^ (frow & 7)) * 16;      // kk = 1
+
+  // ---- prologue: ST-1 stages in flight ---------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (t0 + s < t1) issue(t0 + s, s);
+
+  int slot = 0;
+  for (int t = t0; t < t1; ++t) {
+    const int rem = t1 - 1 - t;                                  // stages behind t already issued: min(rem, ST-2)
+    if (rem >= ST - 2) wait_vm<PW * (ST - 2)>();
+    else if (ST > 3 && rem == ST - 3 && ST - 3 > 0) wait_vm<PW * (ST - 3 > 0 ? ST - 3 : 0)>();
+    else if (ST > 4 && rem == ST - 4 && ST - 4 > 0) wait_vm<PW * (ST - 4 > 0 ? ST - 4 : 0)>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                                // everybody's pieces of stage t landed; slot t-1 is free
+    if (t + ST - 1 < t1) {
+      int ns = slot + ST - 1;
+      ns = ns >= ST ? ns - ST : ns;
+      issue(t + ST - 1, ns);
+    }
+    const unsigned char* xs = lds + slot * STAGE;
+    const unsigned char* wsm = xs + BM * kRowB + wave * (NTW * 16) * kRowB;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int fo = kk ? foff1 : foff0;
+      uint4_t wf[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) wf[j] = *reinterpret_cast<const uint4_t*>(wsm + j * 16 * kRowB + fo);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const uint4_t xf = *reinterpret_cast<const uint4_t*>(xs + m * 16 * kRowB + fo);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j][m] = mfma16<DT>(wf[j], xf, acc[j][m]);
+      }
+    }
+    slot = slot + 1 == ST ? 0 : slot + 1;
+  }
+
+  // ---- split-K: publish the partial, the last arriver of a tile sums them in split order ---------------------------
+  if (a.S > 1) {
+    f32x4* wsv = reinterpret_cast<f32x4*>(a.ws);
+    const int64_t per = static_cast<int64_t>(NW) * NTW * MT * 64;         // float4 per (tile, split)
+    f32x4* mine = wsv + (static_cast<int64_t>(tile) * a.S + split) * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mine[(j * MT + m) * 64] = acc[j][m];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                            // (also: every wave is done with the stage ring)
+    int* flag = reinterpret_cast<int*>(lds);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int last = ticket == a.S - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;
+    // every partial -- this workgroup's own too -- is read back in split order: all loads of a split are independent
+    // (a per-element "own registers or load" select would serialise them behind one wait each)
+    const f32x4* base = wsv + static_cast<int64_t>(tile) * a.S * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < a.S; ++s) {
+      f32x4 v[NTW][MT];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) v[j][m] = base[static_cast<int64_t>(s) * per + (j * MT + m) * 64];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] += v[j][m];
+    }
+  }
+
+  // ---- epilogue: a lane holds y[m][n .. n+3] for each of its tiles -------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int n = n0 + (wave * NTW + j) * 16 + fg * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = m0 + m * 16 + frow;
+      if (row < a.M && n < a.N) {
+        char* dst = a.y + (static_cast<int64_t>(row) * a.ldy + n) * 2;
+        const f32x4 v = acc[j][m];
+        if (n + 3 < a.N) {
+          bma::uint2_t o;
+          o.x = bma::pack16<DT>(v.x, v.y);
+          o.y = bma::pack16<DT>(v.z, v.w);
+          *reinterpret_cast<bma::uint2_t*>(dst) = o;
+        } else {                                                 // N not a multiple of 4: element by element
+          const float e[4] = {v.x, v.y, v.z, v.w};
+          for (int r = 0; r < 4 && n + r < a.N; ++r)
+            reinterpret_cast<uint16_t*>(dst)[r] = static_cast<uint16_t>(bma::pack16<DT>(e[r], 0.0f) & 0xffffu);
+        }
+      }
+    }
+  }
+}
+
+constexpr int kMaxSplit = 16;
+
+// Split count: fill the 256 CUs in whole rounds.  cost = rounds x k-steps per workgroup (+ a little per split for the
+// partial traffic and the reducer's serial reads).
+int choose_split(int tiles, int T, int cus) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= kMaxSplit && s <= T; ++s) {
+    const int wgs = tiles * s;
+    const int rounds = (wgs + cus - 1) / cus;
+    const double steps = static_cast<double>((T + s - 1) / s);
+    const double cost = rounds * (steps + 6.0) + (s > 1 ? 1.5 * s : 0.0);     // 6: pipeline fill + epilogue, in k-steps
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
+struct Plan {
+  int mt, m_tiles, slabs, S;
+};
+
+bool make_plan(int M, int N, int K, Plan& p) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % kBK) return false;
+  p.mt = M <= 64 ? 4 : 6;                      // 64- or 96-row tiles
+  const int bm = 16 * p.mt;
+  p.m_tiles = (M + bm - 1) / bm;
+  p.slabs = (N + kBN - 1) / kBN;
+  p.S = choose_split(p.slabs * p.m_tiles, K / kBK, 256);
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t bma_gemm_nt_ws_bytes(int M, int N, int K) {
+  Plan p;
+  if (!make_plan(M, N, K, p) || p.S == 1) return 0;
+  return static_cast<size_t>(p.slabs) * p.m_tiles * p.S * (16 * p.mt) * kBN * sizeof(float);
+}
+
+extern "C" int bma_gemm_nt_tiles(int M, int N, int K) {
+  Plan p;
+  if (!make_plan(M, N, K, p)) return 0;
+  return p.slabs * p.m_tiles;
+}
+
+extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N,
+                           int K, int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream) {
+  if (M < 0 || N < 0 || K <= 0 || ldx < K || ldw < K || ldy < N) return BMA_EINVAL;
+  if (M == 0 || N == 0) return BMA_OK;
+  if (!x || !w || !y) return BMA_EINVAL;
+  if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  if (K % kBK) return BMA_ELIMIT;
+  if ((ldx * 2) % 16 || (ldw * 2) % 16 || (ldy * 2) % 8) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16 || reinterpret_cast<uintptr_t>(y) % 8 ||
+      reinterpret_cast<uintptr_t>(ws) % 16)
+    return BMA_EALIGN;
+  Plan p;
+  if (!make_plan(M, N, K, p)) return BMA_EINVAL;
+  const int tiles = p.slabs * p.m_tiles;
+  if (p.S > 1) {
+    if (!ws || !counters || ws_bytes < bma_gemm_nt_ws_bytes(M, N, K) || n_counters < tiles) return BMA_EINVAL;
+  }
+  GemmArgs a;
+  a.x = static_cast<const char*>(x);
+  a.w = static_cast<const char*>(w);
+  a.y = static_cast<char*>(y);
+  a.ws = static_cast<float*>(ws);
+  a.cnt = counters;
+  a.ldx = ldx; a.ldw = ldw; a.ldy = ldy;
+  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(tiles * p.S)), block(256);
+  BMA_PROF_BEGIN(BMA_K_GEMM_NT, st, 2.0 * (static_cast<double>(M) * K + static_cast<double>(N) * K + static_cast<double>(M) * N));
+#define BMA_GEMM_GO(DT_)                                                                      \
+  do {                                                                                        \
+    if (p.mt == 4) hipLaunchKernelGGL((gemm_nt_kernel<DT_, 4, 4, 4>), grid, block, 0, st, a);  \
+    else hipLaunchKernelGGL((gemm_nt_kernel<DT_, 6, 4, 4>), grid, block, 0, st, a);            \
+  } while (0)
+  if (dtype == BMA_BF16) BMA_GEMM_GO(BMA_BF16);
+  else BMA_GEMM_GO(BMA_F16);
+#undef BMA_GEMM_GO
+  BMA_PROF_END(BMA_K_GEMM_NT, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}

@@ -189,6 +189,8 @@ class FusedInference:
                     self._act_code(m.act_fn) is not None:
                 self.mlps.append(m)
             files.add(type(m).__module__)
+        if next((True for p in model.parameters() if p.is_cuda), False):
+            ops.gemm_workspace(next(p for p in model.parameters() if p.is_cuda).device)   # before any capture needs it
         self._norm_info = {id(m): (eps, gemma) for m, eps, gemma in self.norms}
         if fuse_add_norm:
             self.layers = _decoder_layers(model, self._norm_info)

@@ -85,6 +85,10 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p]),
     "bma_prefix_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                      c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "bma_gemm_nt_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "bma_gemm_nt_tiles": (c_int, [c_int, c_int, c_int]),
+    "bma_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                            c_size_t, c_void_p, c_int, c_void_p]),
     "bma_profile_enable": (c_int, [c_int]),
     "bma_profile_read": (c_int, [c_int, POINTER(c_int64), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "bma_profile_kernel_name": (c_char_p, [c_int]),

@@ -589,6 +589,67 @@ def prefix_attention(query: torch.Tensor, prefix_k: torch.Tensor, prefix_v: torc
     return out, lse
 
 
+# ---------------------------------------------------------------------------
+# skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
+SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
+GEMM_NT_MAX_ROWS = 96           # one 64- or 96-row tile: the shapes the kernel is built and measured for
+_GEMM_WS_BYTES = 64 << 20
+_GEMM_COUNTERS = 4096
+_GEMM_WS = {}
+GEMM_NT_HOOK = None             # measurement: called as hook(x, w) for every product routed to the kernel (bench.py)
+
+
+def gemm_workspace(dev: torch.device):
+    """(partial-sum workspace, zeroed tile tickets) of the split-K reduction, one pair per device for the life of the
+    process: captured hipGraphs hold their addresses, so they are never freed or reallocated.  None while a capture is
+    running and the pair does not exist yet (allocate it beforehand: ``FusedInference`` does at construction)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ws = (torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=dev), torch.zeros(_GEMM_COUNTERS, dtype=torch.int32, device=dev))
+        _GEMM_WS[key] = ws
+    return ws
+
+
+def gemm_nt_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Can bma_gemm_nt compute linear(x, w)?  16-bit, K a multiple of 64, at most GEMM_NT_MAX_ROWS rows, rows 16-byte
+    aligned, workspace within the fixed budget."""
+    if not (SKINNY_GEMM and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and w.dim() == 2
+            and x.dim() >= 2 and x.shape[-1] == w.shape[1] and w.is_contiguous() and x.stride(-1) == 1):
+        return False
+    K, N = w.shape[1], w.shape[0]
+    M = x.numel() // K if K else 0
+    if K % 64 or N % 4 or not (0 < M <= GEMM_NT_MAX_ROWS) or not x.is_contiguous():
+        return False
+    return lib.bma_gemm_nt_ws_bytes(M, N, K) <= _GEMM_WS_BYTES and lib.bma_gemm_nt_tiles(M, N, K) <= _GEMM_COUNTERS
+
+
+def gemm_nt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """linear(x, w) = x @ w^T through bma_gemm_nt (include/bma.h); x (..., K) contiguous, w (N, K) contiguous."""
+    dev = _need_gpu(x, w)
+    K, N = w.shape[1], w.shape[0]
+    M = x.numel() // K
+    pair = gemm_workspace(dev)
+    if pair is None:
+        raise RuntimeError("bma_gemm_nt workspace requested inside a graph capture before it was allocated")
+    ws, cnt = pair
+    if GEMM_NT_HOOK is not None:
+        GEMM_NT_HOOK(x, w)
+    y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=dev)
+    check("bma_gemm_nt", lib.bma_gemm_nt(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws.data_ptr(),
+                                         ws.numel(), cnt.data_ptr(), cnt.numel(), _stream(dev)))
+    return y
+
+
+def linear_b1(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x @ w^T for a bias-free weight: the hand-written skinny kernel where it applies, the library otherwise."""
+    if gemm_nt_ok(x, w) and (gemm_workspace(x.device) is not None):
+        return gemm_nt(x, w)
+    return torch.nn.functional.linear(x, w)
+
+
 class FrozenLinearFn(torch.autograd.Function):
     """y = x W^T for a weight that is a constant of the attack; the input gradient dX = dY W is
     computed as ``linear(dY, W^T-copy)``.  Both products then run in the library's "weight rows along
@@ -598,11 +659,11 @@ class FrozenLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, weight_t):
         ctx.weight_t = weight_t
-        return torch.nn.functional.linear(x, weight)
+        return linear_b1(x, weight)
 
     @staticmethod
     def backward(ctx, dy):
-        return torch.nn.functional.linear(dy, ctx.weight_t), None, None
+        return linear_b1(dy.contiguous(), ctx.weight_t), None, None
 
 
 # ---------------------------------------------------------------------------

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 102 /* 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 102 /* 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -226,6 +226,21 @@ int bma_attn_merge_rows(const void* o1, const void* o2, const float* lse1, const
                         void* stream);
 int bma_gather_rows(const void* src, const int* idx, int64_t n_out, int64_t n_src, int64_t row_bytes,
                     void* out, void* stream);
+
+/* bma_gemm_nt: y[M][N] = x[M][K] . w[N][K]^T for the SKINNY products of the batch-1 gradient pass (a1, :953-1028: every
+ *   linear layer of the language model applied to a handful of rows): bf16 / f16 operands with K contiguous, fp32
+ *   accumulation on the matrix cores, one rounding to `dtype`.  Leading dimensions ldx/ldw/ldy in elements (multiples
+ *   of 8 / 8 / 4); K a multiple of 64; any M (tiles of 64 or 96 rows), any N.  The weight is streamed once; the grid is
+ *   (128-row slabs of w) x (splits of K), the split count chosen so that the workgroups fill the CUs in whole rounds.
+ *   With more than one split the partial sums pass through `ws` (bma_gemm_nt_ws_bytes(M,N,K) bytes, 16-byte aligned)
+ *   and a ticket per tile in `counters` (bma_gemm_nt_tiles(M,N,K) ints, ZERO before the first launch; every launch
+ *   leaves them zero); the last workgroup of a tile adds the partials in split order, so the result does not depend on
+ *   arrival order.  ws/counters may be NULL when bma_gemm_nt_ws_bytes returns 0.  Launches that share ws/counters
+ *   must be ordered on one stream. */
+size_t bma_gemm_nt_ws_bytes(int M, int N, int K);
+int bma_gemm_nt_tiles(int M, int N, int K);
+int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
+                int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream);
 
 /* bma_prefix_attention: N rows (q [N][H][Dh] through row/head strides) against the P keys/values of the SHARED
  *   prefix (pk/pv [P][Hk][Dh] through strides; grouped heads in place), no mask: out [N][H][Dh] contiguous of

@@ -358,3 +358,82 @@ def test_splice_clamps_bad_ids(ops):
     ids = torch.tensor([[-3, 99]], device=DEV)
     y = ops.splice([("gather", None)], 1, table, ids)
     assert torch.equal(y[0, 0], table[0]) and torch.equal(y[0, 1], table[9])
+
+
+# ------------------------------------------------------------------ bma_gemm_nt (round 3)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_nt_matches_fp32_reference(dtype):
+    """y = x W^T on the hand-written skinny kernel against the product in fp32 (one rounding of the fp32 sum to the
+    16-bit type: at most 1 ulp from the rounded fp32 reference): the gradient pass's shapes (65 and 44 rows; forward
+    and transposed-copy input-gradient shapes, 3- to 16-way split-K), one row, N off the 128-row slab and off 16,
+    row counts on and off the 64- and 96-row tiles; bitwise equal over repeated launches (the split-K reducer adds
+    in split order whichever workgroup arrives last) and the tile tickets are zero again after every launch."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    g = torch.Generator(device=DEV).manual_seed(123)
+    shapes = [(65, 4096, 4096), (65, 22016, 4096), (44, 4096, 22016), (65, 12288, 4096), (45, 4096, 11008), (1, 128, 64),
+              (96, 132, 128), (17, 32064, 4096), (64, 4096, 11008), (33, 260, 192), (96, 1024, 4096), (7, 8, 64)]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    splits = set()
+    for M, N, K in shapes:
+        x = (torch.randn((M, K), generator=g, device=DEV)).to(dtype)
+        w = (torch.randn((N, K), generator=g, device=DEV) * 0.05).to(dtype)
+        assert ops.gemm_nt_ok(x, w)
+        y = ops.gemm_nt(x, w)
+        ref = x.float() @ w.float().t()
+        err = (y.float() - ref).abs()
+        tol = 1.01 * eps * ref.abs() + 1e-30 + (2.0 ** -24 if dtype == torch.float16 else 0.0)
+        assert y.shape == (M, N) and bool((err <= tol + 3e-3 * ref.abs().max() * eps).all()), (M, N, K, float(err.max()))
+        for _ in range(4):
+            assert torch.equal(ops.gemm_nt(x, w), y)
+        ws, cnt = ops.gemm_workspace(torch.device(DEV))
+        assert int(cnt.sum()) == 0
+        splits.add(lib.bma_gemm_nt_ws_bytes(M, N, K) > 0)
+        # against the library on the same operands: both are one rounding of (almost) the same fp32 sum
+        lib_y = torch.nn.functional.linear(x, w)
+        assert float((y.float() - lib_y.float()).abs().max()) <= 2.5 * eps * float(ref.abs().max())
+    assert splits == {True, False}                              # both the direct and the split-K epilogue ran
+    # a 3-D activation, as the decoder hands it over
+    x = torch.randn((1, 65, 4096), generator=g, device=DEV).to(dtype)
+    w = (torch.randn((4096, 4096), generator=g, device=DEV) * 0.05).to(dtype)
+    assert ops.linear_b1(x, w).shape == (1, 65, 4096)
+    assert torch.equal(ops.linear_b1(x, w)[0], ops.gemm_nt(x[0], w))
+    # shapes it does not take go to the library
+    assert not ops.gemm_nt_ok(torch.zeros((97, 4096), device=DEV, dtype=dtype), w)
+    assert not ops.gemm_nt_ok(torch.zeros((8, 100), device=DEV, dtype=dtype), torch.zeros((16, 100), device=DEV, dtype=dtype))
+    assert not ops.gemm_nt_ok(torch.zeros((8, 4096), device=DEV), w.float())
+
+
+def test_gemm_nt_under_autograd_and_in_a_graph():
+    """FrozenLinearFn on the skinny kernel (forward and the input gradient through the transposed copy) against autograd
+    through the library, and the same pair captured into a hipGraph and replayed."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn((1, 65, 4096), generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn((11008, 4096), generator=g, device=DEV) * 0.02).to(torch.bfloat16)
+    wt = w.t().contiguous()
+    dy = torch.randn((1, 65, 11008), generator=g, device=DEV).to(torch.bfloat16)
+    xa = x.clone().requires_grad_()
+    ya = ops.FrozenLinearFn.apply(xa, w, wt)
+    (ga,) = torch.autograd.grad(ya, xa, dy)
+    xb = x.clone().requires_grad_()
+    yb = torch.nn.functional.linear(xb, w)
+    (gb,) = torch.autograd.grad(yb, xb, dy)
+    assert float((ya.float() - yb.float()).abs().max()) <= 2 ** -7 * float(yb.float().abs().max())
+    assert float((ga.float() - gb.float()).abs().max()) <= 2 ** -7 * float(gb.float().abs().max())
+    xs = x.clone()
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gemm_nt(xs, w)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.gemm_nt(xs, w)
+        out2 = ops.gemm_nt(out, wt)
+    for k in range(3):
+        xs.copy_(x * (k + 1))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ops.gemm_nt(xs, w)) and torch.equal(out2, ops.gemm_nt(out, wt))
