@@ -160,6 +160,9 @@ class BimodalAttack:
         # through the model behind the shared prefix for `candidates` candidates; bench.py reads this
         self.score_stats = dict(candidates=0, rows=0, rows_needed=0, ragged_calls=0, padded_calls=0)
         self._rescore_graphs: Dict[tuple, object] = {}
+        self._score_graphs: Dict[tuple, object] = {}    # ragged candidate forward per row-count grid point (LRU, insertion-ordered)
+        self._score_pool = None                         # one memory pool for all of them (never replayed concurrently)
+        self._score_seen: Dict[tuple, int] = {}
         self._gp = None                            # _GradPrefix: scoring prefix reused by the gradient pass (joint mode)
         self._gp_flag: Optional[bool] = None
         self._feat_graph = None                    # image -> image features (no autograd)
@@ -528,12 +531,14 @@ class BimodalAttack:
         from pageable memory waits for the stream on ROCm."""
         return torch.from_numpy(np.ascontiguousarray(host)).pin_memory().to(self.model.device, non_blocking=True)
 
-    def _ragged_logits(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
-                       n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None) -> Optional[Tensor]:
-        """Target logits (m_out,T,V) through the ragged forward, or None when this draw does not fit the row
-        count asked for (then the caller scores the padded block).  host_ids: this rank's DISTINCT candidates
-        (host copy); inverse: which of them each candidate to report is (None: one each, in order)."""
-        hf, dev = self.hf, self.model.device
+    def _ragged_score(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
+                      n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None, m_cap: Optional[int] = None):
+        """(loss (m_out,) fp32, early-stop hit or None) of this rank's candidates through the ragged forward, or None
+        when this draw does not fit the row count asked for (then the caller scores the padded block).  host_ids: this
+        rank's DISTINCT candidates (host copy); inverse: which of them each candidate to report is (None: one each, in
+        order).  From the second step that meets a row count on, the whole forward -- row-list splice, model, target
+        cross-entropy -- is ONE hipGraph replay (``_ScoreGraph``); the host only plans and uploads the index maps."""
+        hf, dev, cfg = self.hf, self.model.device, self.config
         from .prefix_attention import RaggedMaps, fused_ragged_route
         # the same predicate the attention function evaluates on the tensors: the library route needs the padded-block
         # maps (BMA_FUSED_RAGGED_ATTENTION=0, fp32 models, head sizes the kernel does not take), the kernel route not
@@ -543,14 +548,51 @@ class BimodalAttack:
         if plan is None:
             return None
         mu = int(plan["m"])           # distinct candidates, in the plan's order: duplicates are computed once
-        maps = RaggedMaps(plan, dev, ids=np.concatenate([plan["cand"], host_parent.reshape(1, -1)]), stage=self._stage)
-        # the row list straight from the segments and the table: the padded (mu+1, L, D) block is never built
-        rows = ops.splice(segs, mu + 1, self.embedding_layer.weight, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
         st = self.score_stats
         st["ragged_calls"] += 1
         st["rows"] += int(plan["N"])
         st["rows_needed"] += int(plan["needed"])
-        return hf.target_logits_ragged(rows, self.T, cache, maps)
+        m_out = int(plan.get("m_out", mu))
+        ids = np.concatenate([plan["cand"], host_parent.reshape(1, -1)])
+        E = self.embedding_layer.weight
+
+        def forward(maps, blocks):
+            # the row list straight from the segments and the table: the padded (blocks, L, D) block is never built
+            rows = ops.splice(segs, blocks, E, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
+            logits = hf.target_logits_ragged(rows, self.T, cache, maps)
+            loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
+            return loss, hit
+
+        graphs_on = bool(self.opt.score_graphs > 0 and fused and hf.ragged_ok)      # (the first forward of an attack runs eagerly)
+        if graphs_on:
+            cap_m = max(m_out, m_cap or 0)
+            cap_b2 = max(host_ids.shape[0], cap_m) + 1
+            kptr = cache.k[0].data_ptr() if hasattr(cache, "k") else 0
+            key = (int(plan["N"]), cap_b2, cap_m, int(plan["n_opt"]), L, P, kptr, bool(cfg.early_stop))
+            g = self._score_graphs.get(key)
+            if g is None and self._score_graphs.get(("failed",)) is None:
+                seen = self._score_seen.get(key, 0) + 1
+                self._score_seen[key] = seen
+                if seen >= 2:                       # a row count met twice will be met again: worth a capture
+                    try:
+                        g = _ScoreGraph(self, key, plan, ids, forward, cap_b2, cap_m)
+                        while len(self._score_graphs) >= self.opt.score_graphs:
+                            old = next(iter(self._score_graphs))
+                            del self._score_graphs[old]
+                            self.graphs_captured = [n for n in self.graphs_captured if n != f"score:{old[0]}"]
+                        self._score_graphs[key] = g
+                        self.graphs_captured.append(f"score:{key[0]}")
+                    except Exception as e:
+                        self._fallback("graph_score", e, "ragged scoring forward not captured into a graph; running eager")
+                        self._score_graphs[("failed",)] = False
+                        torch.cuda.synchronize(dev)
+                        g = None
+            if g is not None:
+                self._score_graphs[key] = self._score_graphs.pop(key)          # most recently used last
+                loss, hit = g(plan, ids, self._stage)
+                return loss[:m_out], (None if hit is None else hit[:m_out])
+        maps = RaggedMaps(plan, dev, ids=ids, stage=self._stage)
+        return forward(maps, mu + 1)
 
     @staticmethod
     def _dealt_rows(dealt, world: int, L: int, n_opt: int) -> int:
@@ -644,15 +686,16 @@ class BimodalAttack:
         while s < m:
             b = min(chunk, m - s)
             try:
-                kv, x, logits = None, None, None
+                kv, x, logits, scored = None, None, None, None
                 if ragged:
                     try:
-                        n_rows = None
+                        n_rows, m_cap = None, None
                         if dealt is not None:
                             # every rank builds the row count of the rank with the most rows (they differ by
                             # a few rows after dealing): one set of GEMM shapes per step on all ranks
                             n_rows = self._dealt_rows(dealt, world, L, mine.shape[1])
-                        logits = self._ragged_logits(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine)
+                            m_cap = -(-n // world)      # most candidates a rank can be dealt: the captured forward's fixed size
+                        scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, m_cap)
                         hf.ragged_ok = True
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):
@@ -661,7 +704,7 @@ class BimodalAttack:
                         hf.ragged_ok, ragged = False, False
                 if m > 1:
                     self.score_stats["candidates"] += b
-                if logits is None:
+                if logits is None and scored is None:
                     ids_b = mine[s:s + b]
                     pad = (-b) % quantum if not self._chunk_cap else 0
                     if pad:                      # a short last chunk: up to the next multiple, with copies of its last candidate
@@ -672,7 +715,7 @@ class BimodalAttack:
                         st["padded_calls"] += 1
                         st["rows"] += (b + pad) * L
                         st["rows_needed"] += b * L
-                if logits is not None:
+                if logits is not None or scored is not None:
                     pass
                 elif shared:
                     try:
@@ -689,11 +732,14 @@ class BimodalAttack:
                         use_prefix = cache is not None
                         if not use_prefix:
                             raise
-                if logits is None:
+                if logits is None and scored is None:
                     # the padded chunk's row count, not b: a short last chunk carries copies of its last candidate
                     kv = hf.expand_prefix(cache, x.shape[0]) if use_prefix else None
                     logits = hf.target_logits(x, self.T, rows_only=rows_only, cache=kv)
-                loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
+                if scored is not None:
+                    loss, hit = scored
+                else:
+                    loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
                 losses[s:s + b] = loss[:b]       # (the padding's losses are dropped)
                 if match is not None:
                     match[s:s + b] = hit[:b].to(torch.float32)
@@ -1227,6 +1273,35 @@ class _GradPrefix:
         self.current = None
         a.graphs_captured.append("grad_prefix")
         a.graphs_captured.append("grad_tail")
+
+
+class _ScoreGraph:
+    """The ragged candidate forward of one row count -- row-list splice, the model on the row list, target cross-entropy
+    -- as one hipGraph.  What changes from step to step is data, not shape: the index maps of the step's plan go into a
+    static device buffer of a fixed byte layout (``RaggedMaps`` with caps), the prefix keys/values and the prompt
+    segments are the attack's own long-lived tensors (the key holds the prefix's address: another prefix, another
+    capture), the losses come back in a static output."""
+
+    def __init__(self, attack: "BimodalAttack", key, plan, ids, forward, cap_b2: int, cap_m: int):
+        from .prefix_attention import RaggedMaps
+        dev = attack.model.device
+        probe = RaggedMaps(plan, dev, ids=ids, stage=attack._stage, b2_cap=cap_b2, m_cap=cap_m)
+        self.buf = torch.empty(probe.nbytes, dtype=torch.uint8, device=dev)
+        self.cap_b2, self.cap_m = cap_b2, cap_m
+        maps = RaggedMaps(plan, dev, ids=ids, stage=attack._stage, b2_cap=cap_b2, m_cap=cap_m, out=self.buf)
+        self.maps = maps                       # views into self.buf: what the captured kernels read
+        if attack._score_pool is None:
+            attack._score_pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, pool=attack._score_pool, capture_error_mode=_CAPTURE_MODE):
+            self.loss, self.hit = forward(maps, cap_b2)
+
+    def __call__(self, plan, ids, stage):
+        from .prefix_attention import RaggedMaps
+        RaggedMaps(plan, self.buf.device, ids=ids, stage=stage, b2_cap=self.cap_b2, m_cap=self.cap_m, out=self.buf)
+        self.graph.replay()
+        return self.loss, self.hit
 
 
 class _GradientGraph:

@@ -99,6 +99,11 @@ class EngineOptions:
     # ... and for the per-step image-features + shared-prefix pass of joint scoring (vision tower
     # forward, then the prompt+image prefix through the LM with a recording cache).
     graph_prefix: bool = True
+    # ... and for the ragged candidate forward itself (splice of the row list, the model, the target cross-entropy): one
+    # hipGraph per row-count grid point (two at BASELINE's width), the step's index maps uploaded into a static buffer.
+    # The eager forward costs the host ~9 ms of enqueue per step: hidden behind 165 ms of GPU work on one GPU, a third
+    # of the scoring phase on eight.  At most `score_graphs` captures are kept (0: off).
+    score_graphs: int = 4
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
@@ -198,6 +203,8 @@ class EngineOptions:
             opts.graph_rescore = env["BMA_GRAPH_RESCORE"] not in ("0", "false", "False")
         if "BMA_GRAPH_PREFIX" in env:
             opts.graph_prefix = env["BMA_GRAPH_PREFIX"] not in ("0", "false", "False")
+        if "BMA_SCORE_GRAPHS" in env:
+            opts.score_graphs = max(0, int(env["BMA_SCORE_GRAPHS"]))
         if "BMA_GRAPH_GRADIENT" in env:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:

@@ -19,8 +19,19 @@
 //   * `v_mfma_f32_16x16x32`: A = 16 rows of W, B = 16 rows of x (both K-contiguous, the same read shape), so a lane ends
 //     up with 4 consecutive n of one m: 8-byte output stores;
 //   * split-K: partials as fp32 in the accumulator's own register order (1 KiB per wave instruction), an agent-scope
-//     release + ticket per tile, and the last arriver sums the S partials IN SPLIT ORDER (its own from registers) --
-//     bitwise reproducible whichever workgroup arrives last -- then resets the ticket for the next launch.
+//     release + ticket per tile, and the last arriver sums the S partials IN SPLIT ORDER -- bitwise reproducible
+//     whichever workgroup arrives last -- then resets the ticket for the next launch.
+//
+// Measured against the tuned library kernels, each shape over 32 different weights from one hipGraph (tools/
+// gemm_bench.py; profiles/r3_gemm_bench.txt): it wins where the library has to split K itself -- the input-gradient
+// products through the transposed copies, N = 4096 with K = 12288 / 22016: 1.09-1.27x at 65 rows -- ties on down_proj
+// and loses 7-27 % on the wide forward products (whose 172 / 96 / 86 slabs do not fill 256 CUs in whole rounds),
+// so ops.gemm_nt_ok routes only K >= 3N to it.  What was tried on top and measured WORSE or no better: a stream-K
+// decomposition (every CU the same number of k-steps, partial tiles summed by the last arriver: the 2 x 48-98 KB of
+// partials per workgroup cost more than the balance gains, 0.65-0.94x), 3 or 5 LDS stages instead of 4 (+-1 %: the
+// pipeline is not latency-bound), W addressed as if pre-tiled per stage (contiguous 16 KiB per stage: +3-14 %), and the
+// same kernel at 599-643 rows (0.5-0.8x of the library: a 96 x 128 tile moves 28 KB per stage through a load path
+// that fills ~28 B/clk per CU, i.e. ~1000 cycles against 384 cycles of MFMA).
 //
 // Algorithmic bytes per launch: (M*K + N*K + M*N) * es.
 
@@ -129,8 +140,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
   for (int t = t0; t < t1; ++t) {
     const int rem = t1 - 1 - t;                                  // stages behind t already issued: min(rem, ST-2)
     if (rem >= ST - 2) wait_vm<PW * (ST - 2)>();
-    else if (ST > 3 && rem == ST - 3 && ST - 3 > 0) wait_vm<PW * (ST - 3 > 0 ? ST - 3 : 0)>();
-    else if (ST > 4 && rem == ST - 4 && ST - 4 > 0) wait_vm<PW * (ST - 4 > 0 ? ST - 4 : 0)>();
+    else if (ST > 3 && rem == 2) wait_vm<PW * 2>();
+    else if (ST > 2 && rem == 1) wait_vm<PW>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();                                // everybody's pieces of stage t landed; slot t-1 is free
     if (t + ST - 1 < t1) {

@@ -49,12 +49,14 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="comma list of shape names")
     args = ap.parse_args()
+    ops.GEMM_NT_MIN_K_OVER_N = 0.0                 # time the kernel on every shape, routed or not
     gemm_tuning.enable("auto", DEV)
     ops.gemm_workspace(DEV)
     out = {}
     gen = torch.Generator(device=DEV).manual_seed(0)
-    for name, N, K in SHAPES:
+    for name, N, K in [s_ for s_ in SHAPES if args.only is None or s_[0] in args.only.split(",")]:
         ws = [(torch.randn((N, K), generator=gen, device=DEV) * 0.02).to(torch.bfloat16) for _ in range(args.layers)]
         for M in [int(r) for r in args.rows.split(",")]:
             x = torch.randn((1, M, K), generator=gen, device=DEV).to(torch.bfloat16)
