@@ -573,7 +573,7 @@ class BimodalAttack:
             if g is None and self._score_graphs.get(("failed",)) is None:
                 seen = self._score_seen.get(key, 0) + 1
                 self._score_seen[key] = seen
-                if seen >= 2:                       # a row count met twice will be met again: worth a capture
+                if seen >= self.opt.score_graph_after:      # (1: capture at first sight -- a capture runs no kernel, the replay that follows does)
                     try:
                         g = _ScoreGraph(self, key, plan, ids, forward, cap_b2, cap_m)
                         while len(self._score_graphs) >= self.opt.score_graphs:

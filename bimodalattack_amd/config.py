@@ -104,6 +104,7 @@ class EngineOptions:
     # The eager forward costs the host ~9 ms of enqueue per step: hidden behind 165 ms of GPU work on one GPU, a third
     # of the scoring phase on eight.  At most `score_graphs` captures are kept (0: off).
     score_graphs: int = 4
+    score_graph_after: int = 1          # capture a row count when it has been met this many times
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True

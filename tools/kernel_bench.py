@@ -155,6 +155,40 @@ def cases():
         pk, pv = (torch.randn((1, P, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2) for _ in range(2))
         return lambda: pa._partial_attention(q, pk, pv, False, Dh ** -0.5)
 
+    def add_rmsnorm(rows, D):
+        r = torch.randn((rows, D), generator=g, device=DEV).to(bf)
+        h = torch.randn((rows, D), generator=g, device=DEV).to(bf)
+        w = torch.randn((D,), generator=g, device=DEV).to(bf)
+        return lambda: ops.add_rmsnorm(r, h, w, 1e-5)
+
+    def splice_rows(m, n_opt, L, T, P, D, V=32064):
+        # the ragged row list of C3 straight from the segments and the table (no padded block, no gather)
+        import numpy as np
+        from bimodalattack_amd.layout import ragged_plan
+        rng = np.random.default_rng(0)
+        parent = rng.integers(0, 32000, n_opt)
+        cand = np.tile(parent, (m, 1))
+        cand[np.arange(m), rng.integers(0, n_opt, m)] = rng.integers(0, 256, m) + 20000
+        plan = ragged_plan(cand, parent, L, T, P)
+        table = torch.randn((V, D), generator=g, device=DEV).to(bf)
+        ids = torch.from_numpy(np.concatenate([plan["cand"], parent[None]])).to(DEV)
+        flat = torch.from_numpy(plan["flat"]).to(DEV)
+        segs = [("gather", None), ("shared", torch.randn((1, L - n_opt, D), generator=g, device=DEV).to(bf))]
+        return lambda: ops.splice(segs, ids.shape[0], table, ids, 1.0, rows=flat)
+
+    def gemm_nt(M, N, K, layers=8):
+        # the skinny kernel over `layers` different weights (each launch streams its weight from HBM)
+        ops.GEMM_NT_MIN_K_OVER_N = 0.0
+        ops.gemm_workspace(torch.device(DEV))
+        x = torch.randn((1, M, K), generator=g, device=DEV).to(bf)
+        ws = [(torch.randn((N, K), generator=g, device=DEV) * 0.02).to(bf) for _ in range(layers)]
+        state = {"i": 0}
+
+        def go():
+            state["i"] = (state["i"] + 1) % layers
+            return ops.gemm_nt(x, ws[state["i"]])
+        return go
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -197,6 +231,13 @@ def cases():
         "linf/llava_3x336x336": ("linf", lambda: linf(3 * 336 * 336)),
         "linf/gemma_3x896x896": ("linf", lambda: linf(3 * 896 * 896)),
         "sample_scatter/B512": ("sample_scatter", lambda: scatter(512)),
+        # round 3: residual add + norm in one pass, the row list straight from the segments, the skinny weight-streaming product
+        "add_rmsnorm/c3r_17152x4096": ("add_rmsnorm", lambda: add_rmsnorm(17152, 4096)),
+        "add_rmsnorm/n8_2816x4096": ("add_rmsnorm", lambda: add_rmsnorm(2816, 4096)),
+        "splice/c3r_rows_17152_D4096": ("splice", lambda: splice_rows(512, 19, 44, 20, 21, 4096)),
+        "gemm_nt/gate_up_dX_65x4096x22016": ("gemm_nt", lambda: gemm_nt(65, 4096, 22016)),
+        "gemm_nt/qkv_dX_65x4096x12288": ("gemm_nt", lambda: gemm_nt(65, 4096, 12288)),
+        "gemm_nt/gate_up_65x22016x4096": ("gemm_nt", lambda: gemm_nt(65, 22016, 4096)),
         # the dominant kernel of a step: the fused gate/up product of the C3 ragged candidate forward
         "gemm/gate_up_17152x22016x4096": (None, lambda: gemm(17152, 22016, 4096)),
         "gemm/down_17152x4096x11008": (None, lambda: gemm(17152, 4096, 11008)),

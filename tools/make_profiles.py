@@ -15,13 +15,13 @@ out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
 
 shutil.copyfile(os.path.join(src, "kernel_bench.json"), os.path.join(out, f"{tag}_kernel_bench.json"))
-for w in ("gcg", "joint", "gemma_joint"):
+for w in ("gcg", "joint", "pgd", "gemma_joint"):
     for a, b in ((f"kt_{w}_kernel_stats.csv", f"{tag}_bench_{w}_kernel_stats.csv"),
                  (f"kt_{w}_by_grid.txt", f"{tag}_bench_{w}_kernel_by_grid.txt"),
                  (f"bench_{w}_under_rocprof.json", f"{tag}_bench_{w}_under_rocprof.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copyfile(os.path.join(src, a), os.path.join(out, b))
-for w in ("gcg", "joint", "gemma_joint"):  # the batch-1 gradient pass alone (tools/grad_pass_profile.py)
+for w in ("gcg", "joint", "pgd", "gemma_joint"):  # the batch-1 gradient pass alone (tools/grad_pass_profile.py)
     for a, b in ((f"gp_{w}_by_grid.txt", f"{tag}_gradient_pass_{w}_by_grid.txt"), (f"gp_{w}.txt", None)):
         pa = os.path.join(src, a)
         if os.path.exists(pa) and b:
@@ -32,7 +32,7 @@ for w in ("gcg", "joint", "gemma_joint"):  # the batch-1 gradient pass alone (to
                 with open(os.path.join(out, b), "a") as f:
                     f.write("# " + (last[0] if last else "") + "\n")
 for extra in ("bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
-              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json"):
+              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json", "gemm_bench.json", "gemm_bench.txt", "kernel_bench.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
 for c in ("fetch", "write"):
@@ -83,6 +83,10 @@ CASES = [
     ("swiglu/c3_22528x11008", "swiglu", "swiglu_kernel<1, 0, false>/threads7749632", "22528 x 11008 bf16 (C3 candidate forward)"),
     ("rope/c3_B512_L44_H32_Dh128", "rope", "rope_kernel<1>/threads5767168", "B=512 L=44 H=32 Dh=128 bf16"),
     ("attn_merge/c4_B512_L45_H32_Dh128", "attn_merge", "attn_merge_kernel<1>/threads5898240", "B=512 L=45 H=32 Dh=128 bf16 (C4)"),
+    ("add_rmsnorm/c3r_17152x4096", "add_rmsnorm", "add_rmsnorm_kernel<1, 2, false, false>/threads4390912", "17152 x 4096 bf16: residual add + RMSNorm in one pass (C3 ragged candidate forward)"),
+    ("splice/c3r_rows_17152_D4096", "splice", "splice_rows_kernel<1>/threads4390912", "C3 ragged row list: 17152 rows of 8 KiB straight from the segments and the table"),
+    ("gemm_nt/gate_up_dX_65x4096x22016", "gemm_nt", "gemm_nt_kernel<1, 6, 4, 4>/threads65536", "bma_gemm_nt 65 x 4096 x 22016 bf16 (input gradient of the fused gate/up product, 8-way split-K)"),
+    ("gemm_nt/qkv_dX_65x4096x12288", "gemm_nt", "gemm_nt_kernel<1, 6, 4, 4>/threads65536", "bma_gemm_nt 65 x 4096 x 12288 bf16 (input gradient of the fused q/k/v product, 8-way split-K)"),
     # library GEMMs (keys are matched by symbol prefix: the kernel name depends on the selection table)
     ("gemm/gate_up_17152x22016x4096", "gemm_gate_up_proj", "Cijk", "fused gate/up product of the C3 ragged candidate forward, 17152 x 22016 x 4096 bf16"),
     ("gemm/down_17152x4096x11008", "gemm_down_proj", "Cijk", "down_proj, 17152 x 4096 x 11008 bf16"),
