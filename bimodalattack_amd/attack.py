@@ -279,6 +279,8 @@ class BimodalAttack:
         change during an attack, so the whole forward+backward is captured into a hipGraph
         on the first call (after one eager run) and replayed afterwards; results are the
         eager ones (same kernels, same order)."""
+        if self._tp_active():
+            return self._gradient_tp(optim_ids, image)
         if image is not None and self._gp_enabled():
             try:
                 if self._gp is None:
@@ -303,6 +305,27 @@ class BimodalAttack:
 
     _GRAD_ORDER = ["before_img", "image", "before_suffix", "optim", "after", "target"]
 
+    def _tp_active(self) -> bool:
+        if not (self.opt.tp_gradient and self.shard.enabled):
+            return False
+        if self.__dict__.get("_tp_checked") is None:
+            self._tp_checked = bool(self.fused.tp_ok(self.shard.world))
+            if not self._tp_checked:
+                self._fallback("tp_gradient", RuntimeError("projection widths / head counts do not divide over the ranks, "
+                               "or the decoder layers' structure is not one the fused forward restates"),
+                               "tensor-parallel gradient pass not applicable; every rank runs the whole pass")
+        return self._tp_checked
+
+    def _gradient_tp(self, optim_ids: Tensor, image: Optional[Tensor] = None):
+        """The gradient pass cut over the ranks (EngineOptions.tp_gradient): every rank runs the replicated parts
+        (embeddings, norms, residual stream, vision tower, head, cross-entropy) and ITS rows / columns of the decoder
+        projections; the all-reduces inside leave identical token and pixel gradients on every rank."""
+        self.fused.tp = (self.shard.rank, self.shard.world, self.shard.group)
+        try:
+            return self._gradient_eager(optim_ids, image)
+        finally:
+            self.fused.tp = None
+
     def _gp_enabled(self) -> bool:
         """PGD + GCG with the image in FRONT of the suffix (LLaVA layout).  Joint mode: the prefix pass candidate
         scoring runs on the image a PGD step has just produced -- vision tower + prompt up to the suffix, batch 1 --
@@ -313,7 +336,7 @@ class BimodalAttack:
         pass of the next step back-propagates through the history that prefix pass kept.  Needs the gradient pass
         and the scoring call to be the same function of the same segments (:968, :981-991 against :1142,
         :1150-1163: true for the llava order and an unscaled embedding table)."""
-        if self._gp is False:
+        if self._gp is False or (self.opt.tp_gradient and self.shard.enabled):
             return False
         if self._gp_flag is None:
             cfg, hf, opt = self.config, self.hf, self.opt

@@ -139,6 +139,12 @@ class EngineOptions:
     # gradients through the transposed copies) on the hand-written weight-streaming kernel bma_gemm_nt instead of the
     # library (process-wide switch: ops.SKINNY_GEMM).
     skinny_gemm: bool = True
+    # Several GPUs: run the batch-1 gradient pass TENSOR-PARALLEL over the ranks instead of redundantly on each --
+    # q/k/v/gate/up cut by output rows (whole heads), o/down by input columns, two all-reduces per decoder layer and
+    # direction (540 KB each at LLaVA width) -- the one lever left on the serial quarter of an 8-GPU step.
+    # Correctness is tested (2 ranks, equal to the replicated pass); its speed has never been measured on real xGMI
+    # (this pool has one GPU per box), the pass runs eagerly (no hipGraph), so it is OFF by default.
+    tp_gradient: bool = False
     # joint_eval: the step's loss is the winner's row of the candidate batch (scored with the image, in the
     # re-score's own segment order) instead of a second, batch-1 forward of the same sequence (:605-612).
     joint_winner_from_batch: bool = True
@@ -226,6 +232,8 @@ class EngineOptions:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
+        if "BMA_TP_GRADIENT" in env:
+            opts.tp_gradient = env["BMA_TP_GRADIENT"] not in ("0", "false", "False")
         if "BMA_SKINNY_GEMM" in env:
             opts.skinny_gemm = env["BMA_SKINNY_GEMM"] not in ("0", "false", "False")
         if "BMA_FUSE_ADD_NORM" in env:

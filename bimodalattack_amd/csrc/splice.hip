@@ -181,7 +181,9 @@ extern "C" int bma_splice_rows(const bma_segment* segs_host, int n_segs, const v
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(n_rows)), block(256);
   uint4_t* o = static_cast<uint4_t*>(out);
-  BMA_PROF_BEGIN(BMA_K_SPLICE, st, 2.0 * static_cast<double>(n_rows) * D * es);   // every row read once, written once
+  // the row list is WRITTEN once; its sources -- at most n_opt*topk + n_opt table rows and the shared segments' rows,
+  // each read by many output rows -- stay in cache, so the write is the kernel's HBM traffic
+  BMA_PROF_BEGIN(BMA_K_SPLICE, st, static_cast<double>(n_rows) * D * es);
   switch (dtype) {
     case BMA_F32:
       hipLaunchKernelGGL((splice_rows_kernel<BMA_F32>), grid, block, 0, st, a, emb, V, ids, B, n_opt, S, cpr, emb_scale, slot, o);

@@ -142,6 +142,41 @@ def _decoder_layers(model, norm_info):
     return out
 
 
+class _TPCopy(torch.autograd.Function):
+    """Megatron's f: identity forward, all-reduce of the gradient backward (the input of column-parallel layers)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.contiguous().clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+class _TPReduce(torch.autograd.Function):
+    """Megatron's g: all-reduce forward (the partial outputs of a row-parallel layer), identity backward."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        import torch.distributed as dist
+        y = x.contiguous().clone()
+        dist.all_reduce(y, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+_TP_COLUMN = ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")
+_TP_ROW = ("o_proj", "down_proj")
+
+
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
                  fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True):
@@ -152,6 +187,11 @@ class FusedInference:
         self.layers: List[Tuple[torch.nn.Module, str, torch.nn.Module]] = []   # (decoder layer, kind, the norm that reads its output)
         self._norm_info = {}                         # id(norm module) -> (eps, gemma)
         self._stash = {}                             # id(norm module) -> (sum tensor, its norm): handed over by the layer in front
+        # tensor-parallel gradient pass (EngineOptions.tp_gradient): (rank, world, process group) while a pass runs with
+        # every decoder projection cut over the ranks -- q/k/v/gate/up by output rows (whole heads), o/down by input
+        # columns, two all-reduces per layer and direction; set before entering the context, None otherwise
+        self.tp = None
+        self._tp_roles = {}
         self.gemm_probe = None                       # measurement hook for products no nn.Linear module owns
         cache = _COPY_CACHES.get(model)
         if cache is None:
@@ -177,6 +217,11 @@ class FusedInference:
                     and m.q_proj.weight.dtype in (torch.bfloat16, torch.float16) \
                     and not hasattr(m, "q_norm"):      # per-head norms (Gemma-3) want dense projection outputs
                 self.qkv.append(m)
+            if hasattr(m, "q_proj") or hasattr(m, "gate_proj"):
+                for name in _TP_COLUMN + _TP_ROW:
+                    lin = getattr(m, name, None)
+                    if isinstance(lin, torch.nn.Linear) and hasattr(m, "layer_idx" if name in ("q_proj", "k_proj", "v_proj", "o_proj") else "down_proj"):
+                        self._tp_roles[id(lin)] = (lin, "column" if name in _TP_COLUMN else "row")
             if weight_copies and (hasattr(m, "q_proj") or hasattr(m, "gate_proj")):
                 # bias-free projections of the decoder layers (attention and MLP blocks)
                 for name in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"):
@@ -263,6 +308,37 @@ class FusedInference:
             return ops.FrozenLinearFn.apply(x, w, wt)
         return forward
 
+    def _tp_linear(self, m, kind):
+        """This rank's part of a decoder projection: `column` = its block of output rows (whole heads / its share of the
+        MLP width), input replicated; `row` = its block of input columns, partial outputs summed over the ranks."""
+        def forward(x):
+            rank, world, group = self.tp
+            w = m.weight
+            if kind == "column":
+                n = w.shape[0] // world
+                return torch.nn.functional.linear(x, w[rank * n:(rank + 1) * n], None if m.bias is None else m.bias[rank * n:(rank + 1) * n])
+            k = w.shape[1] // world
+            y = torch.nn.functional.linear(x, w[:, rank * k:(rank + 1) * k])
+            y = _TPReduce.apply(y, group)
+            return y if m.bias is None else y + m.bias
+        return forward
+
+    def tp_ok(self, world: int) -> bool:
+        """Can the gradient pass be cut `world` ways?  Known layer structure (the fused layer forward carries the f
+        operator), every projection width and head count divisible."""
+        if not (self.enabled and self.layers and self._tp_roles):
+            return False
+        for lin, kind in self._tp_roles.values():
+            if (lin.weight.shape[0] if kind == "column" else lin.weight.shape[1]) % world:
+                return False
+        for layer, _, _ in self.layers:
+            cfg = getattr(layer.self_attn, "config", None)
+            heads = getattr(cfg, "num_attention_heads", 0)
+            kv = getattr(cfg, "num_key_value_heads", heads) or heads
+            if heads % world or kv % world:
+                return False
+        return True
+
     def _qkv_forwards(self, attn):
         """q_proj / k_proj / v_proj of one attention block as ONE product against the concatenated
         weight (16-bit models): three N = 4096 GEMMs fill 3 x 4.4 of 15 tile rounds on 256 CUs, one
@@ -329,7 +405,7 @@ class FusedInference:
     def _gate_up_weight(self, m):
         """The chunk-interleaved [gate_proj; up_proj] weight of a 16-bit MLP (ops.interleave_gate_up), or None when
         the block does not qualify (or a capture is running and the copy does not exist yet)."""
-        if not self.fuse_gate_up:
+        if not self.fuse_gate_up or self.tp is not None:
             return None
         g, u = m.gate_proj, m.up_proj
         ok = self._gu_ok.get(id(m))
@@ -424,11 +500,16 @@ class FusedInference:
                 return type(layer).forward(layer, hidden_states, *args, **kwargs)
             residual = hidden_states
             h = layer.input_layernorm(hidden_states)
+            tp = self.tp
+            if tp is not None:
+                h = _TPCopy.apply(h, tp[2])          # replicated input of the column-parallel q/k/v
             h, _ = layer.self_attn(hidden_states=h, **kwargs)
             if gem:
                 residual, h = self._add_norm(residual, h, layer.pre_feedforward_layernorm, pre=layer.post_attention_layernorm)
             else:
                 residual, h = self._add_norm(residual, h, layer.post_attention_layernorm)
+            if tp is not None:
+                h = _TPCopy.apply(h, tp[2])          # ... and of gate/up
             h = layer.mlp(h)
             if next_norm is None:
                 return residual + (layer.post_feedforward_layernorm(h) if gem else h)
@@ -471,10 +552,14 @@ class FusedInference:
             m.forward = self._norm_forward(m, eps, gemma, type(m).forward.__get__(m))
         for m in self.mlps:
             m.forward = self._mlp_forward(m, type(m).forward.__get__(m))
-        for m in self.linears:
-            m.forward = self._linear_forward(m, type(m).forward.__get__(m))
-        for attn in self.qkv:                      # after the per-projection patches: these win for q/k/v
-            attn.q_proj.forward, attn.k_proj.forward, attn.v_proj.forward = self._qkv_forwards(attn)
+        if self.tp is not None:
+            for lin, kind in self._tp_roles.values():
+                lin.forward = self._tp_linear(lin, kind)
+        else:
+            for m in self.linears:
+                m.forward = self._linear_forward(m, type(m).forward.__get__(m))
+            for attn in self.qkv:                      # after the per-projection patches: these win for q/k/v
+                attn.q_proj.forward, attn.k_proj.forward, attn.v_proj.forward = self._qkv_forwards(attn)
         for layer, kind, nxt in self.layers:
             layer.forward = self._layer_forward(layer, kind, nxt)
         for mod in self.rope_modules:
@@ -497,6 +582,8 @@ class FusedInference:
                 m.__dict__.pop("forward", None)
         for layer, _, _ in self.layers:
             layer.__dict__.pop("forward", None)
+        for lin, _ in self._tp_roles.values():
+            lin.__dict__.pop("forward", None)
         self._stash.clear()
         for mod, fn in self._saved_rope.items():
             mod.apply_rotary_pos_emb = fn

@@ -48,7 +48,7 @@ def _ambiguous_tokens(grad_row, allowed, k, tol):
     return set(order[close].tolist()) | set(order[close + 1].tolist())
 
 
-def check_against_golden(golden_dir, name, m, res, trace, tmp):
+def check_against_golden(golden_dir, name, m, res, trace, tmp, png=True):
     """Step-by-step comparison with the reference's trajectory.  Two layers:
     (1) in situ, on the engine's OWN intermediate values: the kernels' outputs equal the
         oracle's, exactly -- always required;
@@ -120,8 +120,9 @@ def check_against_golden(golden_dir, name, m, res, trace, tmp):
     assert [len(getattr(res, k_)) for k_ in ("gradient_times", "sampling_times", "loss_times", "pgd_times",
                                              "total_times")] == m["n_timing"]
     assert res.model_outputs == [""] * m["steps"]
+    check_png = png
     png = os.path.join(golden_dir, f"g5_{name}_png0.npz")
-    if os.path.exists(png):
+    if check_png and os.path.exists(png):
         from PIL import Image
         got = np.array(Image.open(os.path.join(tmp, "0.png")))
         want = np.load(png)["png"]
@@ -456,6 +457,44 @@ def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
         for a, b in zip(cand_losses, [st["losses"][0] for st in trace1 if st["losses"]]):
             np.testing.assert_allclose(a, b, rtol=1e-5)
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2]          # ranks agree bit for bit
+
+
+def _tp_worker(rank, world, port, name, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+        m, res, trace, tmp = run_case(name, tp_gradient=True)
+        check_against_golden(golden_dir, name, m, res, trace, tmp, png=rank == 0)     # (only rank 0 writes the images)
+        out.put((rank, res.losses, res.strings))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["llava_joint", "llava_pgd_gcg", "gemma3_joint"])
+def test_sharded_engine_with_tensor_parallel_gradient_pass(golden_dir, name):
+    """EngineOptions.tp_gradient on two ranks (gloo, both on cuda:0): the batch-1 gradient pass is cut over the ranks --
+    each computes its heads / its share of the MLP width, two all-reduces per layer and direction -- while candidate
+    scoring is sharded as before; every rank reproduces the reference trajectory (token and pixel gradients to the
+    goldens' tolerance, ids, survivors, losses) and the ranks agree bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL cannot put two ranks on one)")

@@ -88,6 +88,15 @@ def cases():
         cos, sin = ang.cos().to(bf), ang.sin().to(bf)
         return lambda: ops.rope_(q, cos, sin)
 
+    def rope_qk(N, H, Hk, Dh):
+        # q and k of one attention block in one launch, as strided views of a fused q/k/v product's output
+        qkv = torch.randn((1, N, (H + 2 * Hk) * Dh), generator=g, device=DEV).to(bf)
+        q = qkv[..., :H * Dh].view(1, N, H, Dh).transpose(1, 2)
+        k = qkv[..., H * Dh:(H + Hk) * Dh].view(1, N, Hk, Dh).transpose(1, 2)
+        ang = torch.rand((1, N, Dh), generator=g, device=DEV)
+        cos, sin = ang.cos().to(bf), ang.sin().to(bf)
+        return lambda: ops.rope2(q, k, cos, sin, inplace=True)
+
     def merge(B, L, H, Dh):
         o1 = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf)
         o2 = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf)
@@ -232,6 +241,7 @@ def cases():
         "linf/gemma_3x896x896": ("linf", lambda: linf(3 * 896 * 896)),
         "sample_scatter/B512": ("sample_scatter", lambda: scatter(512)),
         # round 3: residual add + norm in one pass, the row list straight from the segments, the skinny weight-streaming product
+        "rope/c3r_qk_N17152_H32_Dh128": ("rope", lambda: rope_qk(17152, 32, 32, 128)),
         "add_rmsnorm/c3r_17152x4096": ("add_rmsnorm", lambda: add_rmsnorm(17152, 4096)),
         "add_rmsnorm/n8_2816x4096": ("add_rmsnorm", lambda: add_rmsnorm(2816, 4096)),
         "splice/c3r_rows_17152_D4096": ("splice", lambda: splice_rows(512, 19, 44, 20, 21, 4096)),
