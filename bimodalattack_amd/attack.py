@@ -559,8 +559,9 @@ class BimodalAttack:
         """(loss (m_out,) fp32, early-stop hit or None) of this rank's candidates through the ragged forward, or None
         when this draw does not fit the row count asked for (then the caller scores the padded block).  host_ids: this
         rank's DISTINCT candidates (host copy); inverse: which of them each candidate to report is (None: one each, in
-        order).  From the second step that meets a row count on, the whole forward -- row-list splice, model, target
-        cross-entropy -- is ONE hipGraph replay (``_ScoreGraph``); the host only plans and uploads the index maps."""
+        order).  From the second ragged forward of an attack on, the whole forward of a row count -- row-list splice,
+        model, target cross-entropy -- is ONE hipGraph replay (``_ScoreGraph``); the host only plans and uploads the
+        index maps."""
         hf, dev, cfg = self.hf, self.model.device, self.config
         from .prefix_attention import RaggedMaps, fused_ragged_route
         # the same predicate the attention function evaluates on the tensors: the library route needs the padded-block
@@ -579,26 +580,28 @@ class BimodalAttack:
         ids = np.concatenate([plan["cand"], host_parent.reshape(1, -1)])
         E = self.embedding_layer.weight
 
-        def forward(maps, blocks):
+        def forward(maps, blocks, segs_=segs, cache_=cache):
             # the row list straight from the segments and the table: the padded (blocks, L, D) block is never built
-            rows = ops.splice(segs, blocks, E, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
-            logits = hf.target_logits_ragged(rows, self.T, cache, maps)
+            rows = ops.splice(segs_, blocks, E, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
+            logits = hf.target_logits_ragged(rows, self.T, cache_, maps)
             loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
             return loss, hit
 
-        graphs_on = bool(self.opt.score_graphs > 0 and fused and hf.ragged_ok)      # (the first forward of an attack runs eagerly)
+        # (the first ragged forward of an attack runs eagerly; the prefix must be the recording kind, whose tensors the
+        # graph can keep and refresh)
+        graphs_on = bool(self.opt.score_graphs > 0 and fused and hf.ragged_ok and hasattr(cache, "k") and hasattr(cache, "v"))
         if graphs_on:
             cap_m = max(m_out, m_cap or 0)
             cap_b2 = max(host_ids.shape[0], cap_m) + 1
-            kptr = cache.k[0].data_ptr() if hasattr(cache, "k") else 0
-            key = (int(plan["N"]), cap_b2, cap_m, int(plan["n_opt"]), L, P, kptr, bool(cfg.early_stop))
+            shape_of = tuple((k_, None if t is None else tuple(t.shape)) for k_, t in segs)
+            key = (int(plan["N"]), cap_b2, cap_m, int(plan["n_opt"]), L, P, len(cache.k), shape_of, bool(cfg.early_stop))
             g = self._score_graphs.get(key)
             if g is None and self._score_graphs.get(("failed",)) is None:
                 seen = self._score_seen.get(key, 0) + 1
                 self._score_seen[key] = seen
                 if seen >= self.opt.score_graph_after:      # (1: capture at first sight -- a capture runs no kernel, the replay that follows does)
                     try:
-                        g = _ScoreGraph(self, key, plan, ids, forward, cap_b2, cap_m)
+                        g = _ScoreGraph(self, key, plan, ids, forward, cap_b2, cap_m, segs, cache)
                         while len(self._score_graphs) >= self.opt.score_graphs:
                             old = next(iter(self._score_graphs))
                             del self._score_graphs[old]
@@ -612,7 +615,7 @@ class BimodalAttack:
                         g = None
             if g is not None:
                 self._score_graphs[key] = self._score_graphs.pop(key)          # most recently used last
-                loss, hit = g(plan, ids, self._stage)
+                loss, hit = g(plan, ids, self._stage, segs, cache)
                 return loss[:m_out], (None if hit is None else hit[:m_out])
         maps = RaggedMaps(plan, dev, ids=ids, stage=self._stage)
         return forward(maps, mu + 1)
@@ -1301,27 +1304,44 @@ class _GradPrefix:
 class _ScoreGraph:
     """The ragged candidate forward of one row count -- row-list splice, the model on the row list, target cross-entropy
     -- as one hipGraph.  What changes from step to step is data, not shape: the index maps of the step's plan go into a
-    static device buffer of a fixed byte layout (``RaggedMaps`` with caps), the prefix keys/values and the prompt
-    segments are the attack's own long-lived tensors (the key holds the prefix's address: another prefix, another
-    capture), the losses come back in a static output."""
+    static device buffer of a fixed byte layout (``RaggedMaps`` with caps), the losses come back in a static output.
+    Every other tensor the captured kernels read -- the prompt segments, the prefix keys/values of every layer -- is
+    HELD by this object (so its memory cannot be handed to anybody else) and compared by address on every call: the
+    attack's own long-lived tensors and the outputs of the prefix graphs are the same storage step after step and cost
+    nothing; a caller that built them afresh (eager prefix pass, eager image features) gets them copied into the
+    captured ones."""
 
-    def __init__(self, attack: "BimodalAttack", key, plan, ids, forward, cap_b2: int, cap_m: int):
-        from .prefix_attention import RaggedMaps
+    def __init__(self, attack: "BimodalAttack", key, plan, ids, forward, cap_b2: int, cap_m: int, segs, cache):
+        from .prefix_attention import RaggedMaps, RecordingKV
         dev = attack.model.device
         probe = RaggedMaps(plan, dev, ids=ids, stage=attack._stage, b2_cap=cap_b2, m_cap=cap_m)
         self.buf = torch.empty(probe.nbytes, dtype=torch.uint8, device=dev)
         self.cap_b2, self.cap_m = cap_b2, cap_m
         maps = RaggedMaps(plan, dev, ids=ids, stage=attack._stage, b2_cap=cap_b2, m_cap=cap_m, out=self.buf)
         self.maps = maps                       # views into self.buf: what the captured kernels read
+        self.segs = list(segs)                 # (kind, tensor) as captured
+        self.cache = RecordingKV(len(cache.k))
+        self.cache.k, self.cache.v = list(cache.k), list(cache.v)
         if attack._score_pool is None:
             attack._score_pool = torch.cuda.graph_pool_handle()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, pool=attack._score_pool, capture_error_mode=_CAPTURE_MODE):
-            self.loss, self.hit = forward(maps, cap_b2)
+            self.loss, self.hit = forward(maps, cap_b2, self.segs, self.cache)
 
-    def __call__(self, plan, ids, stage):
+    @staticmethod
+    def _refresh(held: Tensor, new: Tensor) -> None:
+        if new is not held and (new.data_ptr() != held.data_ptr() or new.shape != held.shape or new.stride() != held.stride()):
+            held.copy_(new)
+
+    def __call__(self, plan, ids, stage, segs, cache):
         from .prefix_attention import RaggedMaps
+        with torch.no_grad():
+            for (_, held), (_, new) in zip(self.segs, segs):
+                if held is not None:
+                    self._refresh(held, new)
+            for held, new in zip(self.cache.k + self.cache.v, list(cache.k) + list(cache.v)):
+                self._refresh(held, new)
         RaggedMaps(plan, self.buf.device, ids=ids, stage=stage, b2_cap=self.cap_b2, m_cap=self.cap_m, out=self.buf)
         self.graph.replay()
         return self.loss, self.hit

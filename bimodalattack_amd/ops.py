@@ -633,12 +633,17 @@ def gemm_nt_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
 def gemm_nt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """linear(x, w) = x @ w^T through bma_gemm_nt (include/bma.h); x (..., K) contiguous, w (N, K) contiguous."""
     dev = _need_gpu(x, w)
+    if w.dim() != 2 or x.dim() < 1 or x.shape[-1] != w.shape[1] or x.dtype != w.dtype or x.dtype not in (torch.bfloat16, torch.float16) \
+            or not x.is_contiguous() or not w.is_contiguous() or w.shape[1] % 64:
+        raise ValueError("gemm_nt wants contiguous 16-bit x (..., K) and w (N, K) of one dtype with K a multiple of 64")
     K, N = w.shape[1], w.shape[0]
     M = x.numel() // K
     pair = gemm_workspace(dev)
     if pair is None:
         raise RuntimeError("bma_gemm_nt workspace requested inside a graph capture before it was allocated")
     ws, cnt = pair
+    if lib.bma_gemm_nt_ws_bytes(M, N, K) > ws.numel() or lib.bma_gemm_nt_tiles(M, N, K) > cnt.numel():
+        raise ValueError("product beyond the fixed split-K workspace")
     if GEMM_NT_HOOK is not None:
         GEMM_NT_HOOK(x, w)
     y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=dev)
