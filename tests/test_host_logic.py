@@ -332,3 +332,148 @@ def test_padded_heads_attention_is_the_same_attention():
     assert torch.allclose(o1, o0, atol=1e-6)
     for a, b in zip(g1, g0):
         assert torch.allclose(a, b, atol=1e-5)
+
+
+# ------------------------------------------------------------------ round 3 host logic
+def test_decoder_layer_structure_is_read_from_source():
+    """The fused layer forward (residual add + norm in one pass) is installed only on decoder layers whose forward is,
+    statement for statement, a structure it restates: llama / mistral / qwen2 share one, gemma3 has its four norms,
+    anything else -- another family, or a subclass that changed a line -- keeps HuggingFace's own code."""
+    from bimodalattack_amd import fused, synthetic as S
+    from transformers.models.gemma3.modeling_gemma3 import Gemma3DecoderLayer
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer
+    from transformers.models.mistral.modeling_mistral import MistralDecoderLayer
+    from transformers.models.opt.modeling_opt import OPTDecoderLayer
+    from transformers.models.qwen2.modeling_qwen2 import Qwen2DecoderLayer
+    kinds = {c.__name__: fused._layer_kind(c.__new__(c)) for c in
+             (LlamaDecoderLayer, MistralDecoderLayer, Qwen2DecoderLayer, Gemma3DecoderLayer, OPTDecoderLayer)}
+    assert kinds == {"LlamaDecoderLayer": "llama", "MistralDecoderLayer": "llama", "Qwen2DecoderLayer": "llama",
+                     "Gemma3DecoderLayer": "gemma", "OPTDecoderLayer": None}
+
+    class Scaled(LlamaDecoderLayer):                      # one changed statement: not the structure any more
+        def forward(self, hidden_states, **kwargs):
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+            hidden_states, _ = self.self_attn(hidden_states=hidden_states, **kwargs)
+            hidden_states = residual + 0.5 * hidden_states
+            residual = hidden_states
+            hidden_states = self.post_attention_layernorm(hidden_states)
+            hidden_states = self.mlp(hidden_states)
+            hidden_states = residual + hidden_states
+            return hidden_states
+
+    assert fused._layer_kind(Scaled.__new__(Scaled)) is None
+    for kind, want in (("llava", "llama"), ("gemma3", "gemma"), ("opt", None)):
+        model = S.tiny_case(kind)[0]
+        f = fused.FusedInference(model)
+        assert [k for _, k, _ in f.layers] == ([want] * 2 if want else [])
+        if want:
+            # every layer hands over to the NEXT layer's input norm, the last one to the stack's final norm
+            (l0, _, n0), (l1, _, n1) = f.layers
+            assert n0 is l1.input_layernorm and type(n1).__name__.endswith("RMSNorm") and n1 is not l1.input_layernorm
+            assert f.tp_ok(2) and not f.tp_ok(3)
+    # the context patches and restores on a CPU model too (the kernels step aside, the structure runs)
+    model = S.tiny_case("llava")[0]
+    f = fused.FusedInference(model)
+    x = torch.randn(2, 7, model.get_input_embeddings().weight.shape[1])
+    lm = model.model.language_model
+    want = lm(inputs_embeds=x, use_cache=False).last_hidden_state
+    with f:
+        got = lm(inputs_embeds=x, use_cache=False).last_hidden_state
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6) and not any("forward" in m.__dict__ for m in model.modules())
+
+
+def test_ragged_maps_fixed_layout_for_graph_replay():
+    """``RaggedMaps`` with caps: whatever the draw's number of distinct candidates, the packed index maps have ONE byte
+    layout (what lets a captured hipGraph read them from a static buffer): per-block arrays and ids padded with EMPTY
+    blocks, the target-row index padded by repeating its last candidate."""
+    from bimodalattack_amd.layout import ragged_plan
+    from bimodalattack_amd.prefix_attention import RaggedMaps
+    n_opt, L, T, P, n = 6, 15, 4, 11, 12
+    parent = np.arange(n_opt)
+    rng = np.random.default_rng(0)
+    layouts = []
+    for distinct in (12, 7, 3):
+        cand = np.tile(parent, (n, 1))
+        for i in range(n):
+            cand[i, rng.integers(0, n_opt)] = 10 + (i % distinct)
+        uniq, inv = np.unique(cand, axis=0, return_inverse=True)
+        plan = ragged_plan(uniq, parent, L, T, P, n_rows=None, dedup=False, padded_maps=False, inverse=np.asarray(inv).reshape(-1))
+        assert plan is not None and plan["m"] == uniq.shape[0]
+        ids = np.concatenate([plan["cand"], parent[None]])
+        out = torch.zeros(0, dtype=torch.uint8)
+        probe = RaggedMaps(plan, "cpu", ids=ids, b2_cap=n + 1, m_cap=n)
+        out = torch.empty(probe.nbytes, dtype=torch.uint8)
+        maps = RaggedMaps(plan, "cpu", ids=ids, b2_cap=n + 1, m_cap=n, out=out)
+        # everything but the two per-row arrays (flat, pos: N entries each) has the caps' size
+        layouts.append((probe.nbytes - plan["N"] * (4 + 8), tuple(maps.ids.shape), maps.cstart.shape[0], maps.keep.shape[0]))
+        assert maps.flat.shape[0] == plan["N"] and maps.pos.shape == (1, plan["N"])
+        m = plan["m"]
+        assert maps.B2 == n + 1 and maps.m_out == n and maps.m_real == n
+        assert maps.clen[:m + 1].tolist() == plan["clen"].tolist() and maps.clen[m + 1:].tolist() == [0] * (n - m)
+        assert maps.ids[:m + 1].tolist() == ids.tolist() and int(maps.ids[m + 1:].abs().sum()) == 0
+        assert maps.keep.tolist() == plan["keep"].tolist()              # (already one entry per input candidate)
+        assert maps.flat.data_ptr() >= out.data_ptr() and maps.flat.data_ptr() < out.data_ptr() + out.numel()
+        with pytest.raises(ValueError):
+            RaggedMaps(plan, "cpu", ids=ids, b2_cap=m, m_cap=n)          # fewer blocks than the draw has
+    assert len(set(layouts)) == 1
+    # a dealt share: fewer candidates than the cap -> the index repeats its last candidate
+    cand = np.tile(parent, (5, 1))
+    cand[np.arange(5), [0, 1, 2, 3, 4]] = 50 + np.arange(5)
+    plan = ragged_plan(cand, parent, L, T, P, n_rows=None, dedup=False, padded_maps=False)
+    maps = RaggedMaps(plan, "cpu", ids=np.concatenate([plan["cand"], parent[None]]), b2_cap=9, m_cap=8)
+    assert maps.m_out == 8 and maps.m_real == 5 and maps.keep.shape[0] == 8 * T
+    assert maps.keep[5 * T:].tolist() == plan["keep"][-T:].tolist() * 3
+
+
+def test_derived_weight_copies_are_versioned():
+    from bimodalattack_amd.fused import _CopyCache
+    c = _CopyCache()
+    w = torch.randn(4, 3)
+    wt = c.put(("wt", 1), w.t().contiguous(), (w,))
+    assert c.get(("wt", 1), (w,)) is wt and c.get(("wt", 2), (w,)) is None and len(c) == 1
+    w.add_(1.0)                                           # an in-place change bumps the version counter
+    assert c.get(("wt", 1), (w,)) is None and len(c) == 0
+    wt = c.put(("wt", 1), w.t().contiguous(), (w,))
+    assert c.get(("wt", 1), (w.clone(),)) is None         # another tensor (another address) is another source
+
+
+def test_gemm_nt_plan_and_routing_rule():
+    """Split-K planning of bma_gemm_nt through the C ABI (no launch): the workgroups of a product fill the CUs in whole
+    rounds, the workspace covers every partial tile, and ops.gemm_nt_ok routes only products the library must split."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    for M, N, K in ((65, 4096, 22016), (65, 4096, 12288), (44, 4096, 22016), (65, 22016, 4096), (96, 4096, 4096)):
+        tiles = lib.bma_gemm_nt_tiles(M, N, K)
+        assert tiles == -(-N // 128)
+        bm = 64 if M <= 64 else 96
+        ws = lib.bma_gemm_nt_ws_bytes(M, N, K)
+        assert ws % (tiles * bm * 128 * 4) == 0
+        S = ws // (tiles * bm * 128 * 4) if ws else 1
+        assert 1 <= S <= 16 and (tiles * S <= 256 or S == 1 or (tiles * S) % 256 < 256)
+        if N == 4096 and K >= 12288:
+            assert tiles * S == 256                         # 32 slabs x 8 splits: one full round
+    assert lib.bma_gemm_nt_ws_bytes(65, 4096, 100) == 0 and lib.bma_gemm_nt_tiles(0, 4096, 4096) == 0
+    assert lib.bma_gemm_nt(16, 4096, 16, 4096, 16, 4096, 8, 4096, 100, 1, None, 0, None, 0, None) == -5     # K % 64
+    assert lib.bma_gemm_nt(16, 4096, 16, 4096, 16, 4096, 8, 4096, 4096, 0, None, 0, None, 0, None) == -2    # fp32
+    assert lib.bma_gemm_nt(None, 4096, 16, 4096, 16, 4096, 0, 4096, 4096, 1, None, 0, None, 0, None) == 0   # no rows
+    assert ops.GEMM_NT_MIN_K_OVER_N == 3.0 and ops.GEMM_NT_MAX_ROWS == 96
+    x = torch.zeros(65, 4096, dtype=torch.bfloat16)
+    assert not ops.gemm_nt_ok(x, torch.zeros(4096, 4096, dtype=torch.bfloat16))          # (CPU tensors never qualify)
+
+
+def test_bench_gemm_roles_and_extra_workloads():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from types import SimpleNamespace as NS
+    tc = NS(hidden_size=4096, intermediate_size=11008, num_attention_heads=32, num_key_value_heads=32)
+    r = bench.gemm_roles(tc, 32064)
+    assert r[(22016, 4096)] == "gate_up_proj (fused)" and r[(4096, 22016)] == "gate_up_proj (fused) dX"
+    assert r[(12288, 4096)] == "qkv_proj (fused)" and r[(4096, 11008)] == "down_proj" and r[(11008, 4096)] == "down_proj dX"
+    assert r[(4096, 4096)] == "o_proj" and r[(32064, 4096)] == "lm_head / token scores"
+    g = NS(hidden_size=2560, intermediate_size=10240, num_attention_heads=8, num_key_value_heads=4, head_dim=256)
+    rg = bench.gemm_roles(g, 262208)
+    assert rg[(20480, 2560)] == "gate_up_proj (fused)" and rg[(2560, 2048)] == "o_proj" and rg[(1024, 2560)] == "k_proj / v_proj"
+    assert set(bench.WORKLOADS) >= {"gcg", "joint", "pgd", "pgd_gcg", "gemma_joint", "opt125m"}
+    assert bench.COPY_CEILING_GBS < bench.HBM_PEAK_GBS and bench.MFMA_PEAK_TFLOPS == 2500.0
