@@ -30,8 +30,10 @@
 // decomposition (every CU the same number of k-steps, partial tiles summed by the last arriver: the 2 x 48-98 KB of
 // partials per workgroup cost more than the balance gains, 0.65-0.94x), 3 or 5 LDS stages instead of 4 (+-1 %: the
 // pipeline is not latency-bound), W addressed as if pre-tiled per stage (contiguous 16 KiB per stage: +3-14 %), and the
-// same kernel at 599-643 rows (0.5-0.8x of the library: a 96 x 128 tile moves 28 KB per stage through a load path
-// that fills ~28 B/clk per CU, i.e. ~1000 cycles against 384 cycles of MFMA).
+// same kernel at 599-643 rows, with 96 x 128 tiles (0.5-0.8x of the library) and with two row tiles of 320 / 352 rows x
+// 192- or 128-row slabs in two 64-KB LDS stages (0.4-0.9x): one stage in flight per CU is ~21 GB/s at the 2.5-3 us a
+// fill takes under load, a third of what the MFMA work of such a tile needs -- the LDS cannot hold the bytes in flight
+// that would hide that latency, so a tall tile does not pay without operands that hit in the XCD's own L2.
 //
 // Algorithmic bytes per launch: (M*K + N*K + M*N) * es.
 

@@ -8,6 +8,7 @@ anything is launched.
 
 from __future__ import annotations
 
+import os as _os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -592,7 +593,6 @@ def prefix_attention(query: torch.Tensor, prefix_k: torch.Tensor, prefix_v: torc
 # ---------------------------------------------------------------------------
 # skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
 SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
-import os as _os
 GEMM_NT_MAX_ROWS = int(_os.environ.get("BMA_GEMM_NT_MAX_ROWS", "96"))   # one 64- or 96-row tile: the shapes the kernel is built and measured for
 GEMM_NT_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_NT_MIN_K_OVER_N", "3"))   # routed only where the library must split K
 _GEMM_WS_BYTES = 64 << 20
