@@ -163,6 +163,7 @@ class BimodalAttack:
         self._score_graphs: Dict[tuple, object] = {}    # ragged candidate forward per row-count grid point (LRU, insertion-ordered)
         self._score_pool = None                         # one memory pool for all of them (never replayed concurrently)
         self._score_seen: Dict[tuple, int] = {}
+        self._tp_checked: Optional[bool] = None         # tensor-parallel gradient pass applicable to this model / world size?
         self._gp = None                            # _GradPrefix: scoring prefix reused by the gradient pass (joint mode)
         self._gp_flag: Optional[bool] = None
         self._feat_graph = None                    # image -> image features (no autograd)
@@ -308,7 +309,7 @@ class BimodalAttack:
     def _tp_active(self) -> bool:
         if not (self.opt.tp_gradient and self.shard.enabled):
             return False
-        if self.__dict__.get("_tp_checked") is None:
+        if self._tp_checked is None:
             self._tp_checked = bool(self.fused.tp_ok(self.shard.world))
             if not self._tp_checked:
                 self._fallback("tp_gradient", RuntimeError("projection widths / head counts do not divide over the ranks, "

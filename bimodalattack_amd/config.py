@@ -100,10 +100,12 @@ class EngineOptions:
     # forward, then the prompt+image prefix through the LM with a recording cache).
     graph_prefix: bool = True
     # ... and for the ragged candidate forward itself (splice of the row list, the model, the target cross-entropy): one
-    # hipGraph per row-count grid point (two at BASELINE's width), the step's index maps uploaded into a static buffer.
-    # The eager forward costs the host ~9 ms of enqueue per step: hidden behind 165 ms of GPU work on one GPU, a third
-    # of the scoring phase on eight.  At most `score_graphs` captures are kept (0: off).
-    score_graphs: int = 4
+    # hipGraph per row-count grid point (three or four at BASELINE's width), the step's index maps uploaded into a
+    # static buffer; at most `score_graphs` captures are kept.  OFF by default (0): measured on one GPU and as rank 0 of
+    # an emulated eight it buys nothing -- the eager forward's ~9 ms of host enqueue hide behind the GPU work even at an
+    # eighth of the rows -- while every capture costs 7-55 ms of host time once (profiles/r3_ab_engine_options.txt,
+    # DESIGN.md 7).  For hosts where eight ranks do contend for cores.
+    score_graphs: int = 0
     score_graph_after: int = 1          # capture a row count when it has been met this many times
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
