@@ -117,7 +117,7 @@ def build_model(kind: str, device, dtype, layers: int, share: bool = False):
     if not share or key not in _MODELS:
         if kind == "gemma":
             log("building Gemma-3-4b-shaped model on the device")
-            model = S.gemma3_4b_shaped(dtype=dtype, device=device, seed=0)
+            model = S.gemma3_4b_shaped(dtype=dtype, device=device, seed=0, text_layers=34 if layers == 32 else layers)
         elif kind == "opt":
             model = S.opt_125m_shaped(50272, dtype=dtype, device=device, seed=0)
         else:
@@ -139,8 +139,16 @@ def build_plugins(workload: str, device, dtype, layers: int, share: bool = False
     if workload == "gemma_joint":
         # Gemma-3 layout 20|19|3|256|6|20: suffix in FRONT of the image
         tok = S.build_tokenizer(262144, 0, 0)
-        tok.chat_template = S.GEMMA_TEMPLATE
-        proc = S.Gemma3Processor(tok, S.GEMMA_TEMPLATE)
+        # the real Gemma tokenizer spends 3 tokens between the suffix and the image and 6 behind it; the word-level
+        # stand-in would spend 2 and 2, so filler words keep SURVEY.md 8's segment lengths (S = 324)
+        f1, _ = S.synthetic_prompt(tok, 1, 1, seed=3)
+        f4, _ = S.synthetic_prompt(tok, 4, 1, seed=4)
+        tpl = ("{{ bos_token }}<start_of_turn>user\n"
+               "{% for item in messages[0]['content'] %}"
+               "{% if item['type'] == 'text' %}{{ item['text'] }}{% elif item['type'] == 'image' %} " + f1 + " <start_of_image>{% endif %}"
+               "{% endfor %} <end_of_turn> " + f4 + " <start_of_turn>model\n")
+        tok.chat_template = tpl
+        proc = S.Gemma3Processor(tok, tpl)
         model = build_model("gemma", device, dtype, layers, share)
         goal, target = S.synthetic_prompt(tok, 18, 20, seed=0)        # <start_of_turn>user + 18 + BOS = 20
         image = S.synthetic_image(896, 896, seed=0, device=device)

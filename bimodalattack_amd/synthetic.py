@@ -298,10 +298,11 @@ def tiny_gemma3(vocab_rows: int, dtype=torch.float32, device="cpu", seed: int = 
     return _gemma3(vocab_rows, 32, 64, 2, 4, 2, 8, 32, 64, 2, 4, 56, 14, 4, 64, dtype, device, seed, attn, std)
 
 
-def gemma3_4b_shaped(dtype=torch.bfloat16, device="cuda", seed: int = 0, vocab_rows: int = 262208):
+def gemma3_4b_shaped(dtype=torch.bfloat16, device="cuda", seed: int = 0, vocab_rows: int = 262208,
+                     text_layers: int = 34):
     """Gemma-3-4b-it shape: 2560 / 34 layers / 8 heads (4 kv) x 256, FFN 10240,
     SigLIP-So400m 896 px tower (1152 / 27 layers), N_img = 256."""
-    return _gemma3(vocab_rows, 2560, 10240, 34, 8, 4, 256, 1152, 4304, 27, 16, 896, 14, 256, 1024,
+    return _gemma3(vocab_rows, 2560, 10240, text_layers, 8, 4, 256, 1152, 4304, 27, 16, 896, 14, 256, 1024,
                    dtype, device, seed, "sdpa")
 
 

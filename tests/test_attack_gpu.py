@@ -783,6 +783,123 @@ def test_scoring_forward_graph_equals_eager(workload):
     assert ga.score_stats["ragged_calls"] == 6 and ga.score_stats["padded_calls"] == 0
 
 
+def test_gemma3_4b_scoring_fp32_within_1e_4():
+    """The same bar at BASELINE configs[4]'s width: Gemma-3-4b-it shape (D = 2560, 8 query heads on 4 key/value heads x
+    256, FFN 10240, V = 262208, scaled embedding, q/k norms, sandwich norms, suffix in FRONT of the 256 image tokens:
+    S = 324), fp32, 3 decoder layers, 64 candidates: ragged rows, the padded block and padded chunks of 24 against the
+    reference's call shape, every loss within 1e-4 relative."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import segment_order
+
+    dev = torch.device(DEV)
+    n = 64
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("gemma_joint", dev, torch.float32, 3)
+    tc = model.config.text_config
+    assert (tc.hidden_size, tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim, tc.num_hidden_layers) == (2560, 8, 4, 256, 3)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=n, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=True,
+                              joint_eval=True, images_folder=tempfile.mkdtemp())
+    order = segment_order("pgd", "gemma3", single=True)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    n_opt = ids.shape[1]
+    cand = ids.repeat(n, 1)
+    pos = torch.randint(0, n_opt, (n,), generator=g, device=DEV)
+    cand[torch.arange(n, device=DEV), pos] = torch.randint(5, 262144, (n,), generator=g, device=DEV)
+    cand[7] = cand[3]
+    cand[11] = ids[0]
+    cand = cand.contiguous()
+    got = {}
+    for name, kw in (("ragged", {}), ("padded", dict(ragged_suffix=False)), ("chunks of 24", dict(ragged_suffix=False, chunk=24))):
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False,
+                                                                                strict=True, **kw))
+        atk._prepare_prompt(messages, target)
+        assert atk.hf.emb_scale != 1.0 and atk.embedding_layer.num_embeddings == 262208
+        with torch.no_grad():
+            feats = atk.hf.image_features(image)
+            got[name] = atk.score_candidates(cand, order, feats, parent=ids).float().cpu().numpy()
+        assert not atk.fallbacks, atk.fallbacks
+    with torch.no_grad():
+        want = _reference_call_shape_losses(model, atk, cand, order, feats, chunk=4)
+    assert sum((n_opt if nm == "optim" else (256 if nm == "image" else atk.seg[nm].shape[1])) for nm in order) == 324
+    for name, v in got.items():
+        rel = np.abs(v - want) / np.abs(want)
+        print(f"fp32 gemma3-4b {name}: max rel {rel.max():.2e} mean {rel.mean():.2e}; loss range [{want.min():.5f}, {want.max():.5f}]")
+        np.testing.assert_allclose(v, want, rtol=1e-4, atol=0)
+    assert got["ragged"][7] == got["ragged"][3]
+
+
+@pytest.mark.parametrize("workload", ["gcg", "joint"])
+def test_7b_gradient_fp32_matches_reference_call_shape(workload):
+    """The gradient pass at BASELINE width in fp32 (LLaVA-1.5-7B width, 4 decoder layers, the CLIP tower in joint mode)
+    against the reference's own formulation (:953-1028): a one-hot leaf times the embedding table, the llava segment
+    order, FULL (1,S,V) logits, torch cross-entropy over the shifted target slice, autograd to the one-hot and the
+    pixels.  The engine's pass (embedding leaf + E^T product, target rows only, HIP cross-entropy with its own backward,
+    fused norm / MLP / rotary backward halves, mask-free attention) must give the same token gradient (19 x 32064) and
+    pixel gradient to 1e-4 of their scale, the same loss to 1e-5, and -- what the attack consumes -- the same top-256
+    tokens per position wherever the reference's own gradient is not tied within that tolerance."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig, ops
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+    joint = workload == "joint"
+    model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, dev, torch.float32, 4)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=8, seed=1, verbosity="ERROR", pgd_attack=joint, gcg_attack=True,
+                              joint_eval=joint, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, graph_gradient=False, strict=True))
+    atk._prepare_prompt(messages, target)
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    img = image.detach().clone().requires_grad_() if joint else None
+    g_tok, g_img, loss = atk._gradient_eager(ids, img)
+    # the reference's formulation
+    E = atk.embedding_layer
+    V = E.num_embeddings
+    onehot = torch.nn.functional.one_hot(ids, num_classes=V).to(model.dtype).requires_grad_()
+    optim_embeds = onehot @ E.weight
+    img_r = image.detach().clone().requires_grad_() if joint else None
+    if joint:
+        feats = atk.hf.image_features(img_r)
+        parts = [atk.seg["before_img"], feats.to(model.dtype), atk.seg["before_suffix"], optim_embeds, atk.seg["after"], atk.seg["target"]]
+    else:
+        parts = [atk.seg["before"], optim_embeds, atk.seg["after"], atk.seg["target"]]
+    x = torch.cat(parts, dim=1)
+    logits = model(inputs_embeds=x, use_cache=False).logits
+    T = atk.T
+    shift = x.shape[1] - T
+    ref_loss = torch.nn.functional.cross_entropy(logits[0, shift - 1:-1, :], atk.target_ids[0])
+    grads = torch.autograd.grad(ref_loss, [onehot] + ([img_r] if joint else []))
+    assert x.shape[1] == (644 if joint else 66)
+    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=1e-5)
+    ref_tok = grads[0][0]
+    err = float((g_tok[0] - ref_tok).abs().max() / ref_tok.abs().max())
+    print(f"fp32 gradient {workload}: loss {float(loss):.6f}, token-gradient max err / scale {err:.2e}"
+          + (f", pixel-gradient {float((g_img - grads[1]).abs().max() / grads[1].abs().max()):.2e}" if joint else ""))
+    assert err < 1e-4
+    if joint:
+        assert float((g_img - grads[1]).abs().max() / grads[1].abs().max()) < 1e-4
+    # the selection the attack makes from it
+    mine = ops.mask_topk(g_tok[0].contiguous(), atk.mask_bits, 256).cpu().numpy()
+    theirs = ops.mask_topk(ref_tok.contiguous(), atk.mask_bits, 256).cpu().numpy()
+    tol = 4 * float((g_tok[0] - ref_tok).abs().max())
+    rt = ref_tok.cpu().numpy()
+    for p_ in range(mine.shape[0]):
+        if not np.array_equal(mine[p_], theirs[p_]):
+            diff = set(mine[p_].tolist()) ^ set(theirs[p_].tolist())
+            edge = np.sort(rt[p_][theirs[p_]])[-1]
+            # only tokens whose gradient sits within the tolerance of the 256th value, or near-tied neighbours in order
+            assert all(abs(rt[p_][t_] - edge) <= tol for t_ in diff), (p_, diff)
+            vals_m, vals_t = rt[p_][mine[p_]], rt[p_][theirs[p_]]
+            assert np.abs(np.sort(vals_m) - np.sort(vals_t)).max() <= tol
+
+
 def test_gemma3_4b_scoring_equals_reference_call_shape():
     """Gemma-3-4b-it shape, bf16 (BASELINE configs[4]): 34 layers, 256-wide heads, grouped K/V heads, V = 262208,
     suffix in FRONT of the image (:1150-1163), scaled embedding (:1142).  The engine's scoring path for the joint
