@@ -25,6 +25,11 @@
 //
 // Algorithmic bytes per launch: q + k + v read once, o written once = 4 * N * H * Dh * es
 // (prefix and parent rows are re-read from L2).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 #include "bma_common.h"
 #include "bma_profile.h"
 
@@ -44,6 +49,7 @@ struct Args {
   int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs, pk_rs, pk_hs, pv_rs, pv_hs;
   int B2, H, Hk, P, N, nz;
   float scale_log2e;
+  unsigned long long* stamps;   // diagnostic builds only (-DBMA_LONG_STAMPS): 12 clock stamps per wave
 };
 
 template <int DT>
@@ -296,8 +302,519 @@ void ragged_attn_kernel(const Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Long blocks (Gemma-3 joint scoring: padded candidates of 303 tokens, 256-wide heads, two query heads on one
+// key/value head).  The kernel above gives such a block one workgroup per 64 queries with one 16-query tile per wave
+// and ONE 32-key chunk in flight: 128 KB of LDS reads and a full memory latency per 32 keys x 64 queries, measured 0.27
+// of the HBM roofline / 0.09 of MFMA peak with the LDS pipe 30-40 % busy and everything else idle.  This one is built
+// like a flash-attention forward instead:
+//
+//   workgroup   4*REP waves = 128 queries of REP query heads that share one key/value head; a wave owns 32 queries
+//               (two 16-query tiles), so every K fragment (ds_read_b128) and V^T fragment (ds_read_b64_tr_b16) read
+//               from LDS feeds two MFMAs, and a key/value row fetched into LDS serves 128*REP queries, not 64
+//   staging     32 keys per stage, a ring of four stages filled by LDS-DMA (global_load_lds_dwordx4: no staging
+//               registers, no ds_write); three stages are in flight while one is multiplied; per stage one counted
+//               s_waitcnt vmcnt + one raw s_barrier
+//   LDS image   rows of 2*DH bytes without padding (the DMA writes 1 KiB = 64 lanes x 16 B contiguously); bank
+//               conflicts are avoided by permuting the 16-byte pieces inside each 256-byte half row ON THE SOURCE
+//               SIDE (the lane that fills LDS piece `pos` of key row `row` loads piece pos ^ f(row)) and applying the
+//               same XOR to the reads:  K image f = row & 15 (ds_read_b128 by 16 rows x 4 pieces: 16 distinct slots
+//               per 16-lane group), V image f = (row & 7) << 1 (transposing reads by 8 rows x 32 bytes per half wave)
+//   softmax     as in prefix_attention.hip: maximum on raw scores, the scale folded into the exponent's fma, row
+//               reductions by v_permlane16/32_swap, rescaling skipped (wave-uniform) when no maximum moved; only the
+//               stages that touch the diagonal or the end of the keys run the masked copy of the code
+//   epilogue    the ring is free after the last stage: every wave parks its 32 finished rows in its own 1/8 of it and
+//               stores whole rows, 16 bytes per lane
+//
+// The REP heads' waves take the 32-query pairs in opposite order (pair j and pair 3-j land on the same SIMD), so every
+// SIMD has the same number of causal stages to multiply.
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vmax1(float x, float y) {      // one v_max_f32, no canonicalising pre-ops
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+// all-reduce over the four 16-lane rows of a wave (a query's keys are spread over lanes l, l+16, l+32, l+48)
+__device__ __forceinline__ float rows_max(float x) {
+  u32x2 p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = vmax1(__uint_as_float(p.x), __uint_as_float(p.y));
+  u32x2 q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return vmax1(__uint_as_float(q.x), __uint_as_float(q.y));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  u32x2 p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = __uint_as_float(p.x) + __uint_as_float(p.y);
+  u32x2 q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(q.x) + __uint_as_float(q.y);
+}
+
+constexpr int kLongMin = 96;     // shortest max_len that takes this kernel
+constexpr int kRing = 4;         // stages of 32 keys in the LDS ring: two pairs
+
+// ds_read_b64_tr_b16 by hand (see the kernel's PV loop): the result is NOT tracked by the compiler's lgkmcnt
+// bookkeeping; wait_lgkm ties the registers to the wait so that nothing consuming them moves above it.
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x2 (&l)[4], u32x2 (&h)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
+               : "n"(N));
+}
+#ifndef BMA_LONG_SCHED
+#define BMA_LONG_SCHED 7
+#endif
+#define BMA_LONG_SB0 do { if (BMA_LONG_SCHED & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BMA_LONG_SB1 do { if (BMA_LONG_SCHED & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BMA_LONG_SB2 do { if (BMA_LONG_SCHED & 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int DT, int DH, int REP, int QT, int TW>
+__global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const Args a) {
+  constexpr int NW = TW * REP;              // waves
+  constexpr int QW = 16 * QT;               // queries per wave
+  constexpr int QB = TW * QW;               // queries per workgroup and head
+  constexpr int KS = DH / 32, NT = DH / 16;
+  constexpr int ROWB = 2 * DH;              // bytes of an LDS row
+  constexpr int IMGB = 32 * ROWB;           // one 32-key image
+  constexpr int STAGEB = 2 * IMGB;          // K image + V image
+  constexpr int LPR = DH / 8;               // lanes (16-byte pieces) per row
+  constexpr int RPI = 64 / LPR;             // rows per DMA instruction (1 KiB)
+  constexpr int NPI = 32 / RPI;             // DMA instructions per 32-key image
+  constexpr int IPW = (NPI + NW - 1) / NW;  // ... per wave (piece j = wave + it * NW, when j < NPI)
+  static_assert(NW * QW * ROWB <= kRing * STAGEB, "the epilogue parks a wave's rows in the ring");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * STAGEB];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  // workgroup -> (candidate i, key/value head hk, head group, stretch): sharers of the same key/value rows 8 linear
+  // ids apart, i.e. on one XCD and dispatched back to back (see ragged_attn_kernel)
+  const int rep = a.H / a.Hk;
+  const int hg = rep / REP;
+  const int S = hg * a.nz;
+  const int lin = blockIdx.x, tq = lin >> 3;
+  const int grp = (tq / S) * 8 + (lin & 7);
+  if (grp >= a.B2 * a.Hk) return;                         // uniform over the workgroup
+  const int sh = tq % S;
+  const int i = grp % a.B2, hk = grp / a.B2;
+  const int q0 = QB * (a.nz - 1 - sh / hg);           // longest stretch first
+  const int st = a.start[i], p0 = a.first[i], ln = a.len[i];
+  if (q0 >= ln) return;                                   // uniform over the workgroup
+#ifdef BMA_LONG_STAMPS
+  const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long ts_wait = 0, ts_qk = 0, ts_sm = 0, ts_pv = 0;
+#endif
+  const int hs = wave / TW;                               // which of the REP heads
+  const int pw = hs & 1 ? TW - 1 - wave % TW : wave % TW; // which 16*QT queries of the stretch
+  const int h = hk * rep + (sh % hg) * REP + hs;
+  const int qb = q0 + QW * pw;
+  const int P = a.P;
+  const int nkeys = P + p0 + ln;
+  const int qend = q0 + QB < ln ? q0 + QB : ln;
+  const int chunks = (P + p0 + qend + 31) >> 5;           // stages the workgroup walks
+  const bool wave_live = qb < ln;
+  const int last_key = P + p0 + (qb + QW - 1 < ln ? qb + QW - 1 : ln - 1);
+  const float NEG = -__builtin_inff();
+
+  uint4_t qf[QT][KS];                                     // Q tiles as B operands, loaded below
+
+  // ---- LDS-DMA: this lane's piece of every row it fetches ----------------------------------------------------------
+  const int lrow = lane / LPR, wp = lane % LPR;
+  const int half = wp >> 4, pos = wp & 15;
+  // Stages that lie entirely inside the candidate's own rows (all but the first one or two and possibly the last) take
+  // their addresses from per-lane pointers computed once: one 64-bit multiply-add per piece instead of the
+  // prefix / parent / own case analysis (31 vector instructions per K/V pair of pieces; the loop is VALU-bound).
+  const int own0 = P + p0;                                 // key index of the candidate's first own row
+  const unsigned char *kown[IPW], *vown[IPW];
+#pragma unroll
+  for (int it = 0; it < IPW; ++it) {
+    const int row = (wave + it * NW) * RPI + lrow;
+    const int64_t grow = static_cast<int64_t>(st) + row - own0;      // own row of key `row` (stage 0); may be negative
+    kown[it] = reinterpret_cast<const unsigned char*>(a.k) +
+               2 * (grow * a.k_rs + static_cast<int64_t>(hk) * a.k_hs + 128 * half + 8 * (pos ^ (row & 15)));
+    vown[it] = reinterpret_cast<const unsigned char*>(a.v) +
+               2 * (grow * a.v_rs + static_cast<int64_t>(hk) * a.v_hs + 128 * half + 8 * (pos ^ ((row & 7) << 1)));
+  }
+  const int64_t kstep = 64 * a.k_rs, vstep = 64 * a.v_rs;   // bytes per stage of 32 rows
+  auto issue = [&](int c, int slot) {
+    if (32 * c >= own0 && 32 * c + 32 <= nkeys) {            // wave-uniform
+#pragma unroll
+      for (int it = 0; it < IPW; ++it) {
+        if (NPI % NW && wave + it * NW >= NPI) break;       // wave-uniform
+        unsigned char* kd = lds + slot * STAGEB + (wave + it * NW) * RPI * ROWB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kown[it] + c * kstep),
+                                         (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vown[it] + c * vstep),
+                                         (__attribute__((address_space(3))) void*)(kd + IMGB), 16, 0, 0);
+      }
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < IPW; ++it) {
+      if (NPI % NW && wave + it * NW >= NPI) break;         // wave-uniform
+      const int row = (wave + it * NW) * RPI + lrow;         // key row inside the stage
+      int t = 32 * c + row;
+      t = t < nkeys ? t : nkeys - 1;                         // past the end: the last key again (masked; finite)
+      const uint16_t *kp, *vp;
+      if (t < P) {
+        kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs;
+        vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs;
+      } else {
+        const int tt = t - P;
+        const int64_t grow = tt < p0 ? tt : st + (tt - p0);  // the parent's row, or this candidate's own
+        kp = a.k + grow * a.k_rs + static_cast<int64_t>(hk) * a.k_hs;
+        vp = a.v + grow * a.v_rs + static_cast<int64_t>(hk) * a.v_hs;
+      }
+      kp += 128 * half + 8 * (pos ^ (row & 15));
+      vp += 128 * half + 8 * (pos ^ ((row & 7) << 1));
+      unsigned char* kd = lds + slot * STAGEB + (wave + it * NW) * RPI * ROWB;     // wave-uniform; the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
+                                       (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
+                                       (__attribute__((address_space(3))) void*)(kd + IMGB), 16, 0, 0);
+    }
+  };
+
+  f32x4 oacc[QT][NT];
+  float mrun[QT], lsum[QT];
+  int jq[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    mrun[t] = NEG;
+    lsum[t] = 0.0f;
+    jq[t] = p0 + qb + 16 * t + r;                          // this lane's query position behind the prefix
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+
+  // fragment offsets inside a stage (bytes)
+  const int q4 = r >> 2, p4 = r & 3;
+  const int vrow = 4 * g + q4;                             // key row of this lane's transposing reads (and + 16)
+  const int kbase = r * ROWB;
+  const int vbase = IMGB + vrow * ROWB + 8 * p4;
+  const int v7 = vrow & 7;
+
+  auto compute = [&](int c, const unsigned char* sb) {
+#ifdef BMA_LONG_STAMPS
+    const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- S^T = K Q^T for both query tiles -----------------------------------------------------------------------
+    f32x4 s[QT][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) s[t][kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4_t kf = *reinterpret_cast<const uint4_t*>(sb + kbase + 16 * kt * ROWB + 256 * (ks >> 2) +
+                                                             16 * ((4 * (ks & 3) + g) ^ r));
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s[t][kt] = mfma<DT>(kf, qf[t][ks], s[t][kt]);
+      }
+      BMA_LONG_SB0;
+    }
+#ifdef BMA_LONG_STAMPS
+    asm volatile("" ::"v"(s[0][0][0]), "v"(s[0][1][0]));       // the QK products are done
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- online softmax per tile ------------------------------------------------------------------------------------
+    uint4_t pf[QT];
+    float alpha[QT];
+    auto softmax = [&](auto masked) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        float e[2][4];
+        float cmax = NEG;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float v = s[t][kt][rr];
+            if (decltype(masked)::value) {
+              const int te = 32 * c + 16 * kt + 4 * g + rr;
+              const bool ok = te < nkeys && (te < P || te - P <= jq[t]);
+              v = ok ? v : NEG;
+            }
+            e[kt][rr] = v;
+            cmax = vmax1(cmax, v);
+          }
+        cmax = rows_max(cmax);
+        // key 0 (prefix, parent or the block's first token) is visible to every query and stage 0 comes first, so the
+        // running maximum is finite from the first stage on and NEG - NEG never happens
+        const float mnew = vmax1(mrun[t], cmax);
+        alpha[t] = __builtin_amdgcn_exp2f((mrun[t] - mnew) * a.scale_log2e);
+        const float mneg = -mnew * a.scale_log2e;
+        float rs = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            e[kt][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kt][rr], a.scale_log2e, mneg));
+            rs += e[kt][rr];
+          }
+        lsum[t] = lsum[t] * alpha[t] + rs;
+        mrun[t] = mnew;
+        pf[t].x = pack2<DT>(e[0][0], e[0][1]);
+        pf[t].y = pack2<DT>(e[0][2], e[0][3]);
+        pf[t].z = pack2<DT>(e[1][0], e[1][1]);
+        pf[t].w = pack2<DT>(e[1][2], e[1][3]);
+      }
+    };
+    if (32 * c + 32 > nkeys || 32 * c + 31 - P > p0 + qb) softmax(std::true_type{});
+    else softmax(std::false_type{});
+    bool moved = false;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) moved = moved || (alpha[t] != 1.0f);
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < NT; ++dt) {
+          oacc[t][dt][0] *= alpha[t]; oacc[t][dt][1] *= alpha[t]; oacc[t][dt][2] *= alpha[t]; oacc[t][dt][3] *= alpha[t];
+        }
+    }
+    // ---- O^T += V^T P^T: every V^T fragment feeds all the wave's tiles ------------------------------------------------
+    // The transposing reads are inline asm: issued through the builtin, the compiler puts an s_waitcnt vmcnt(0) in
+    // front of them (an LDS read it cannot tell apart from the LDS-DMA writes in flight), which drains the ring every
+    // stage.  So their completion is counted by hand too: groups of four 16-dim tiles, group n+1 in flight while group
+    // n is multiplied (lgkmcnt counts in order for LDS; anything else in flight only makes the wait conservative).
+#ifdef BMA_LONG_STAMPS
+    asm volatile("" ::"v"(pf[0].x), "v"(pf[0].w));
+    const unsigned long long tc2 = __builtin_amdgcn_s_memtime();
+#endif
+    BMA_LONG_SB1;
+    constexpr int NG = NT / 4;
+    const uint32_t va = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)sb)) + vbase;
+    u32x2 lo[2][4], hi[2][4];
+    auto read_group = [&](int gi, u32x2(&L)[4], u32x2(&H)[4]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int dt = 4 * gi + j;
+        const uint32_t ad = va + 32 * ((dt & 7) ^ v7);
+        if (dt >> 3) {
+          L[j] = tr_read<256>(ad);
+          H[j] = tr_read<256 + 16 * ROWB>(ad);
+        } else {
+          L[j] = tr_read<0>(ad);
+          H[j] = tr_read<16 * ROWB>(ad);
+        }
+      }
+    };
+    read_group(0, lo[0], hi[0]);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      if (gi + 1 < NG) {
+        read_group(gi + 1, lo[(gi + 1) & 1], hi[(gi + 1) & 1]);
+        wait_lgkm<8>(lo[gi & 1], hi[gi & 1]);
+      } else {
+        wait_lgkm<0>(lo[gi & 1], hi[gi & 1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint4_t vf;
+        vf.x = lo[gi & 1][j].x; vf.y = lo[gi & 1][j].y; vf.z = hi[gi & 1][j].x; vf.w = hi[gi & 1][j].y;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) oacc[t][4 * gi + j] = mfma<DT>(vf, pf[t], oacc[t][4 * gi + j]);
+      }
+      BMA_LONG_SB2;
+    }
+#ifdef BMA_LONG_STAMPS
+    asm volatile("" ::"v"(oacc[0][NT - 1][0]));
+    const unsigned long long tc3 = __builtin_amdgcn_s_memtime();
+    ts_qk += tc1 - tc0; ts_sm += tc2 - tc1; ts_pv += tc3 - tc2;
+#endif
+  };
+
+  // ---- the ring: two PAIRS of 32-key stages; one pair in flight while the other is multiplied -----------------------
+  // One barrier per 64 keys: with one per 32 the waves of a workgroup (different causal masks, different SIMD partners)
+  // lost a quarter of every stage waiting for the slowest of the eight.
+  issue(0, 0);
+  if (chunks > 1) issue(1, 1);
+  // Q tiles as B operands: lane (query r, dims 8g.. of k-step ks).  Loaded behind the first stages and waited for HERE,
+  // where the compiler can see it: its own wait-count bookkeeping does not know the counted waits of the loop (inline
+  // asm), and a register load still pending at the loop header in its books costs an s_waitcnt vmcnt(0) -- the whole
+  // ring drained -- in front of every stage.
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    int qi = qb + 16 * t + r;
+    qi = qi < ln ? qi : ln - 1;
+    const uint16_t* qp = a.q + static_cast<int64_t>(st + qi) * a.q_rs + static_cast<int64_t>(h) * a.q_hs + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[t][ks] = *reinterpret_cast<const uint4_t*>(qp + 32 * ks);
+  }
+
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      asm volatile("" ::"v"(qf[t][ks].x), "v"(qf[t][ks].y), "v"(qf[t][ks].z), "v"(qf[t][ks].w));
+  int sb = 0;                                              // first slot of the pair being multiplied
+#ifdef BMA_LONG_STAMPS
+  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+  // The stages this wave multiplies come first, in loops of their own: with the causal skip as a branch inside one
+  // loop the accumulators are merged values of that branch and the compiler keeps two copies of them, moving all 64
+  // registers twice per stage.  The last loop only keeps the ring and the barriers going for the other waves.
+  const int mine = wave_live ? (last_key >> 5) + 1 : 0;    // stages 0 .. mine-1 are multiplied by this wave (<= chunks)
+  auto advance = [&](int c) {                              // c = first stage of the pair about to be multiplied
+#ifdef BMA_LONG_STAMPS
+    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                         // everybody's pieces of the pair landed; the other pair is free
+#ifdef BMA_LONG_STAMPS
+    ts_wait += __builtin_amdgcn_s_memtime() - tw0;
+#endif
+    if (c + 2 < chunks) issue(c + 2, sb ^ 2);
+    if (c + 3 < chunks) issue(c + 3, (sb ^ 2) + 1);
+  };
+  int c = 0;
+  for (; c < mine; ++c) {                                  // one call site of the stage code: fewer live registers
+    if (!(c & 1)) {
+      if (c) sb ^= 2;
+      advance(c);
+    }
+    compute(c, lds + (sb + (c & 1)) * STAGEB);
+  }
+  for (c = (c + 1) & ~1; c < chunks; c += 2) {
+    if (c) sb ^= 2;                                         // (a wave without live queries starts here, at pair 0)
+    advance(c);
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------------
+  const int64_t o_rs = static_cast<int64_t>(a.H) * DH;
+#ifdef BMA_LONG_STAMPS
+  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+  __syncthreads();                                        // every wave is done reading the ring
+  unsigned char* park = lds + wave * QW * ROWB;            // this wave's rows
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const float l = rows_sum(lsum[t]);
+    const int qi = qb + 16 * t + r;
+    const int64_t row = st + (qi < ln ? qi : ln - 1);
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    float w1 = 0.0f;
+    const uint16_t* o1p = nullptr;
+    if (a.o1) {
+      // natural-log LSE of this part; weight of the prefix partial = 1 / (1 + exp(lse2 - lse1))
+      const float lse2 = l > 0.0f ? (mrun[t] * a.scale_log2e + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : NEG;
+      const float l1 = a.lse1[static_cast<int64_t>(h) * a.N + row];
+      w1 = 1.0f / (1.0f + expf(lse2 - l1));
+      o1p = a.o1 + row * o_rs + static_cast<int64_t>(h) * DH + 4 * g;
+    }
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      float o[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) o[rr] = oacc[t][dt][rr] * inv;
+      if (o1p) {
+        const bma::uint2_t pw2 = *reinterpret_cast<const bma::uint2_t*>(o1p + 16 * dt);
+        const float p1[4] = {bma::unpack16<DT>(pw2.x, 0), bma::unpack16<DT>(pw2.x, 1), bma::unpack16<DT>(pw2.y, 0),
+                             bma::unpack16<DT>(pw2.y, 1)};
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) o[rr] = o[rr] + w1 * (p1[rr] - o[rr]);
+      }
+      bma::uint2_t ow;
+      ow.x = pack2<DT>(o[0], o[1]);
+      ow.y = pack2<DT>(o[2], o[3]);
+      // dims 16dt + 4g .. +3 of row 16t + r: 16-byte piece 2*(dt & 7) + (g >> 1) of half dt >> 3, pieces XORed with r
+      *reinterpret_cast<bma::uint2_t*>(park + (16 * t + r) * ROWB + 256 * (dt >> 3) +
+                                       16 * ((2 * (dt & 7) + (g >> 1)) ^ r) + 8 * (g & 1)) = ow;
+    }
+  }
+  // the wave reads back what the wave wrote: LDS operations of one wave complete in order, no barrier
+#pragma unroll
+  for (int ps = 0; ps < QW / RPI; ++ps) {
+    const int rl = ps * RPI + lrow;
+    const int qrow = qb + rl;
+    if (qrow < ln) {
+      const uint4_t val = *reinterpret_cast<const uint4_t*>(park + rl * ROWB + 256 * half + 16 * (pos ^ (rl & 15)));
+      *reinterpret_cast<uint4_t*>(a.out + (st + qrow) * o_rs + static_cast<int64_t>(h) * DH + 128 * half + 8 * pos) = val;
+    }
+  }
+#ifdef BMA_LONG_STAMPS
+  if (a.stamps && lane == 0) {
+    const unsigned long long ts3 = __builtin_amdgcn_s_memtime();   // stores issued, not waited for
+    unsigned long long* o = a.stamps + (static_cast<int64_t>(blockIdx.x) * NW + wave) * 12;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts_wait; o[5] = chunks;
+    o[6] = tr0; o[7] = __builtin_amdgcn_s_memrealtime(); o[8] = ts_qk; o[9] = ts_sm; o[10] = ts_pv; o[11] = mine;
+  }
+#endif
+}
+
+// 0 = never, 1 = when the blocks are long enough (default)
+int long_blocks_mode() {
+  static const int mode = [] {
+    const char* e = getenv("BMA_RAGGED_LONG");
+    return e && *e ? atoi(e) : 1;
+  }();
+  return mode;
+}
+
+template <int DT, int DH, int REP, int QT, int TW>
+int launch_long_cfg(Args b, int max_len, hipStream_t st) {
+  constexpr int QB = 16 * QT * TW;
+  b.nz = (max_len + QB - 1) / QB;
+  const int rep = b.H / b.Hk;
+  const int64_t groups = static_cast<int64_t>(b.B2) * b.Hk, sharers = static_cast<int64_t>(rep / REP) * b.nz;
+  const int64_t blocks = (groups + 7) / 8 * sharers * 8;
+  if (blocks > 0x7fffffffLL) return BMA_ELIMIT;
+  const dim3 grid(static_cast<unsigned>(blocks));
+#ifdef BMA_LONG_STAMPS
+  // diagnostic build: BMA_RAGGED_STAMPS=<file> gets 12 x u64 per wave of every launch (overwritten per launch)
+  const char* dump = getenv("BMA_RAGGED_STAMPS");
+  if (dump && *dump) {
+    (void)hipMalloc(reinterpret_cast<void**>(&b.stamps), blocks * TW * REP * 96);
+    (void)hipMemsetAsync(b.stamps, 0, blocks * TW * REP * 96, st);
+  }
+#endif
+  hipLaunchKernelGGL((ragged_attn_long_kernel<DT, DH, REP, QT, TW>), grid, dim3(64 * TW * REP), 0, st, b);
+#ifdef BMA_LONG_STAMPS
+  if (b.stamps) {
+    std::vector<unsigned long long> host(blocks * TW * REP * 12);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(host.data(), b.stamps, blocks * TW * REP * 96, hipMemcpyDeviceToHost);
+    (void)hipFree(b.stamps);
+    if (FILE* f = fopen(dump, "wb")) {
+      fwrite(host.data(), 8, host.size(), f);
+      fclose(f);
+    }
+  }
+#endif
+  return BMA_OK;
+}
+
+template <int DT, int DH>
+int launch_long(const Args& a, int max_len, hipStream_t st) {
+  // 256-wide heads: one 16-query tile per wave (two would need 192 registers of accumulators and Q fragments alone,
+  // and two waves per SIMD have 256 each); 128-wide heads: two tiles per wave.  Four tile-waves per head: with six
+  // (12 waves, three per SIMD, 168 registers) a stage took 5.5k cycles instead of 3.3k -- the SIMDs' issue slots, not
+  // latency, bound the stage -- and Gemma-3 blocks ran 348 us instead of 255.
+  constexpr int QT = DH == 256 ? 1 : 2;
+  const int rep = a.H / a.Hk;
+  if (rep % 2 == 0) {
+    return launch_long_cfg<DT, DH, 2, QT, 4>(a, max_len, st);
+  }
+  return launch_long_cfg<DT, DH, 1, QT, 4>(a, max_len, st);
+}
+
 template <int DT, int DH>
 int launch_dh(const Args& a, int max_len, hipStream_t st) {
+  if constexpr (DH == 128 || DH == 256) {
+    // blocks of at least 96 tokens fill three quarters of a 128-query workgroup: the long-block kernel
+    if (max_len >= kLongMin && a.scale_log2e > 0.0f && long_blocks_mode() != 0) return launch_long<DT, DH>(a, max_len, st);
+  }
   const int qt = max_len >= 64 ? 4 : (max_len + 15) / 16;
   Args b = a;
   b.nz = (max_len + 16 * qt - 1) / (16 * qt);
@@ -354,6 +871,7 @@ extern "C" int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   a.pk_rs = pk_rs; a.pk_hs = pk_hs; a.pv_rs = pv_rs; a.pv_hs = pv_hs;
   a.B2 = B2; a.H = H; a.Hk = Hk; a.P = P; a.N = static_cast<int>(N);
   a.scale_log2e = scale * 1.4426950408889634f;
+  a.stamps = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int es = 2;
   BMA_PROF_BEGIN(BMA_K_RAGGED_ATTN, st, (2.0 * H + 2.0 * Hk) * static_cast<double>(N) * Dh * es);

@@ -345,6 +345,12 @@ def _ragged_attention_reference(q, k, v, pk, pv, plan, P, scale):
     (4, 6, 100, 10, 21, 4, 4, 128, False),    # 121 keys x 128: past the resident-LDS budget, streamed, two stretches
     (5, 6, 70, 10, 5, 4, 2, 64, False),       # two stretches with every chunk resident in LDS
     (2, 3, 303, 5, 0, 2, 1, 256, True),       # long blocks + merged prefix partial
+    # the long-block kernel (max_len >= 96 at 128 / 256-wide heads): head pairs per workgroup or single heads, two
+    # 128-query stretches, four query heads on one key/value head, odd head counts, a last stretch of 2 queries
+    (3, 4, 130, 10, 33, 8, 2, 128, False),
+    (2, 3, 200, 7, 40, 3, 3, 256, False),
+    (3, 5, 97, 9, 1, 6, 2, 128, False),
+    (3, 4, 80, 10, 7, 4, 2, 256, False),      # 256-wide blocks below 96 tokens: the short kernel's two stretches
 ])
 def test_ragged_attention_kernel_vs_fp32_loops(dtype, m, n_opt, L, T, P, H, Hk, Dh, merge):
     from bimodalattack_amd import ops

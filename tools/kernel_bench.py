@@ -13,6 +13,7 @@ V=262208 D=2560.
 from __future__ import annotations
 
 import argparse
+import re
 import json
 import os
 import sys
@@ -306,7 +307,15 @@ def main():
         gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] else 0.0
         results[name] = dict(symbol=p["symbol"], launches=p["launches"], avg_us=us, algorithmic_MB=mb,
                              achieved_GBps=gbs, frac_of_8TBps=gbs / 8000.0)
-        print(f"{name:40s} {us:9.1f} us  {mb:9.2f} MB  {gbs:8.0f} GB/s  {100 * gbs / 8000.0:5.1f}% of 8 TB/s", flush=True)
+        extra = ""
+        m = re.match(r"ragged_attn/\w+?_B(\d+)_L(\d+)_P(\d+)_H(\d+)(?:_Hk\d+)?_Dh(\d+)$", name)
+        if m:                                 # padded blocks: causal flops = 4 * Dh * H * B * (L*P + L*(L+1)/2)
+            B, L, P, H, Dh = (int(v) for v in m.groups())
+            gf = 4.0 * Dh * H * B * (L * P + L * (L + 1) / 2) / 1e9
+            tf = gf / 1e3 / (us * 1e-6)
+            results[name].update(algorithmic_GFLOP=gf, achieved_TFLOPs=tf, frac_of_2500TFLOPs=tf / 2500.0)
+            extra = f"  {gf:6.1f} GFLOP (causal) {tf:6.0f} TFLOP/s"
+        print(f"{name:40s} {us:9.1f} us  {mb:9.2f} MB  {gbs:8.0f} GB/s  {100 * gbs / 8000.0:5.1f}% of 8 TB/s{extra}", flush=True)
         del fn
         torch.cuda.empty_cache()
     if args.json:
