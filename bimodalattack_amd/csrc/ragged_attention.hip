@@ -304,30 +304,38 @@ void ragged_attn_kernel(const Args a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Long blocks (Gemma-3 joint scoring: padded candidates of 303 tokens, 256-wide heads, two query heads on one
-// key/value head).  The kernel above gives such a block one workgroup per 64 queries with one 16-query tile per wave
-// and ONE 32-key chunk in flight: 128 KB of LDS reads and a full memory latency per 32 keys x 64 queries, measured 0.27
-// of the HBM roofline / 0.09 of MFMA peak with the LDS pipe 30-40 % busy and everything else idle.  This one is built
-// like a flash-attention forward instead:
+// key/value head).  The kernel above gives such a block one workgroup per 64 queries of ONE head, one 32-key chunk in
+// flight through staging registers, two barriers per chunk: 246 us per launch on the Gemma-3 blocks (rocprofv3), 0.27
+// of the HBM roofline, 0.09 of MFMA peak, with the waves waiting and every pipe idle.  This one is built like a
+// flash-attention forward instead -- 203 us on the same input:
 //
-//   workgroup   4*REP waves = 128 queries of REP query heads that share one key/value head; a wave owns 32 queries
-//               (two 16-query tiles), so every K fragment (ds_read_b128) and V^T fragment (ds_read_b64_tr_b16) read
-//               from LDS feeds two MFMAs, and a key/value row fetched into LDS serves 128*REP queries, not 64
-//   staging     32 keys per stage, a ring of four stages filled by LDS-DMA (global_load_lds_dwordx4: no staging
-//               registers, no ds_write); three stages are in flight while one is multiplied; per stage one counted
-//               s_waitcnt vmcnt + one raw s_barrier
+//   workgroup   persistent, one per CU: 4*REP waves walk a list of items = 64 queries of REP query heads that share one
+//               key/value head (a wave owns one 16-query tile); a key/value row fetched into LDS serves 64*REP rows.
+//               The end of an item -- last stages, normalisation, stores -- overlaps the start of the next, whose first
+//               keys/values and Q rows are requested while the current item's last pair is multiplied
+//   staging     32 keys per stage, a ring of two PAIRS of stages filled by LDS-DMA (global_load_lds_dwordx4: no
+//               staging registers, no ds_write); one pair is in flight while the other is multiplied; per pair one
+//               s_waitcnt vmcnt(0) + one raw s_barrier.  The DMA instructions are issued from inside the stage code
+//               (behind the QK products), not together behind the barrier
 //   LDS image   rows of 2*DH bytes without padding (the DMA writes 1 KiB = 64 lanes x 16 B contiguously); bank
 //               conflicts are avoided by permuting the 16-byte pieces inside each 256-byte half row ON THE SOURCE
 //               SIDE (the lane that fills LDS piece `pos` of key row `row` loads piece pos ^ f(row)) and applying the
 //               same XOR to the reads:  K image f = row & 15 (ds_read_b128 by 16 rows x 4 pieces: 16 distinct slots
 //               per 16-lane group), V image f = (row & 7) << 1 (transposing reads by 8 rows x 32 bytes per half wave)
+//   LDS reads   inline asm with hand-counted s_waitcnt lgkmcnt: the compiler cannot tell an LDS read from the DMA
+//               writes in flight and drains the ring (vmcnt(0)) in front of every read it schedules itself
 //   softmax     as in prefix_attention.hip: maximum on raw scores, the scale folded into the exponent's fma, row
 //               reductions by v_permlane16/32_swap, rescaling skipped (wave-uniform) when no maximum moved; only the
 //               stages that touch the diagonal or the end of the keys run the masked copy of the code
-//   epilogue    the ring is free after the last stage: every wave parks its 32 finished rows in its own 1/8 of it and
-//               stores whole rows, 16 bytes per lane
+//   epilogue    the pair of the ring multiplied last is free: every wave parks its 16 finished rows in its own 1/8
+//               of it and stores whole rows, 16 bytes per lane
 //
-// The REP heads' waves take the 32-query pairs in opposite order (pair j and pair 3-j land on the same SIMD), so every
-// SIMD has the same number of causal stages to multiply.
+// The REP heads' waves take the 16-query tiles in opposite order (tile j and tile 3-j land on the same SIMD), so in
+// every pair of stages each SIMD has the same number of causal stages to multiply.
+// Where the time goes (tools/stamps_report.py on a -DBMA_LONG_STAMPS build; PMC: tools/pmc_kernel.py): the two waves of
+// a SIMD issue 18k VALU + 11k SALU + 2.4k MFMA + 4k LDS instructions each per launch, which fills the SIMD's issue
+// slots (400k cycles per wave, 443k per launch): the kernel is instruction-issue bound, not latency bound -- a third
+// wave per SIMD (12 waves, 168 registers) made every stage 1.7x longer.
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -365,6 +373,23 @@ __device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
   return v;
 }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ u32x4 row_read(uint32_t lds_addr) {   // ds_read_b128, completion counted by hand likewise
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+template <int N, int KS>
+__device__ __forceinline__ void wait_rows(u32x4 (&f)[KS]) {
+  static_assert(KS == 4 || KS == 8, "one wait ties 4 or 8 fragments");
+  if constexpr (KS == 8)
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+                 : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+}
 template <int N>
 __device__ __forceinline__ void wait_lgkm(u32x2 (&l)[4], u32x2 (&h)[4]) {
   asm volatile("s_waitcnt lgkmcnt(%8)"
@@ -377,6 +402,10 @@ __device__ __forceinline__ void wait_lgkm(u32x2 (&l)[4], u32x2 (&h)[4]) {
 #define BMA_LONG_SB0 do { if (BMA_LONG_SCHED & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define BMA_LONG_SB1 do { if (BMA_LONG_SCHED & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define BMA_LONG_SB2 do { if (BMA_LONG_SCHED & 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+struct LongItem {       // one (candidate, key/value head, head group, stretch): wave-uniform
+  int i, hk, hsel, q0, st, p0, ln, nkeys, chunks;
+};
 
 template <int DT, int DH, int REP, int QT, int TW>
 __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const Args a) {
@@ -391,93 +420,133 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   constexpr int RPI = 64 / LPR;             // rows per DMA instruction (1 KiB)
   constexpr int NPI = 32 / RPI;             // DMA instructions per 32-key image
   constexpr int IPW = (NPI + NW - 1) / NW;  // ... per wave (piece j = wave + it * NW, when j < NPI)
-  static_assert(NW * QW * ROWB <= kRing * STAGEB, "the epilogue parks a wave's rows in the ring");
+  static_assert(NW * QW * ROWB <= 2 * STAGEB, "the epilogue parks a wave's rows in ONE pair of the ring");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * STAGEB];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
-  // workgroup -> (candidate i, key/value head hk, head group, stretch): sharers of the same key/value rows 8 linear
-  // ids apart, i.e. on one XCD and dispatched back to back (see ragged_attn_kernel)
   const int rep = a.H / a.Hk;
   const int hg = rep / REP;
-  const int S = hg * a.nz;
-  const int lin = blockIdx.x, tq = lin >> 3;
-  const int grp = (tq / S) * 8 + (lin & 7);
-  if (grp >= a.B2 * a.Hk) return;                         // uniform over the workgroup
-  const int sh = tq % S;
-  const int i = grp % a.B2, hk = grp / a.B2;
-  const int q0 = QB * (a.nz - 1 - sh / hg);           // longest stretch first
-  const int st = a.start[i], p0 = a.first[i], ln = a.len[i];
-  if (q0 >= ln) return;                                   // uniform over the workgroup
+  const int S = hg * a.nz;                                 // workgroup items that share one (candidate, key/value head)
+  const int P = a.P;
+  const float NEG = -__builtin_inff();
+  // ---- the items of this workgroup -------------------------------------------------------------------------------
+  // The kernel is persistent: one workgroup per CU (the ring is 128 KB) walks a list of items, and the end of one item
+  // -- its last stages, the normalisation, the stores -- overlaps the start of the next, whose first key/value pair
+  // and Q rows are requested while the last pair of the current item is multiplied.  With one workgroup per item the
+  // 5-7k cycles in front of the first product (64 KB of Q + 64 KB of K/V at the CU's fill rate), the 5k behind the last
+  // and the hand-over between two workgroups (the second cannot start before the first has freed the LDS) were a
+  // third of a workgroup's 36k cycles, with nothing else resident on the CU to hide them.
+  // Workgroup b runs on XCD b & 7 (round-robin dispatch).  The sets of sharers -- the S items on one key/value head
+  // of one candidate -- go round the XCDs; inside an XCD its list of items, set after set, goes round the XCD's
+  // workgroups: the S items of a set run on S workgroups of ONE XCD at about the same time, so the rows one of them
+  // pulls from HBM are in that L2 for the others.
+  const int xcd = blockIdx.x & 7, wgx = gridDim.x >> 3;
+  const int groups = a.B2 * a.Hk;
+  const int n_items = groups > xcd ? ((groups - xcd + 7) >> 3) * S : 0;
+  auto decode = [&](int j, LongItem& it) -> int {          // the first item with live queries at j, j + wgx, ...; n_items if none
+    for (; j < n_items; j += wgx) {
+      const int sh = j % S, grp = xcd + 8 * (j / S);
+      const int i = grp % a.B2;
+      const int ln = a.len[i];
+      const int q0 = QB * (a.nz - 1 - sh / hg);              // longest stretch of a set first
+      if (q0 < ln) {
+        it.i = i; it.hk = grp / a.B2; it.hsel = sh % hg; it.q0 = q0; it.st = a.start[i]; it.p0 = a.first[i]; it.ln = ln;
+        it.nkeys = P + it.p0 + ln;
+        it.chunks = (P + it.p0 + (q0 + QB < ln ? q0 + QB : ln) + 31) >> 5;     // stages the workgroup walks
+        return j;
+      }
+    }
+    return n_items;
+  };
+  LongItem cur, nxt;
+  int j = decode(static_cast<int>(blockIdx.x >> 3), cur);
+  if (j >= n_items) return;                               // uniform over the workgroup
 #ifdef BMA_LONG_STAMPS
   const unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long ts_wait = 0, ts_qk = 0, ts_sm = 0, ts_pv = 0;
+  unsigned long long ts_wait = 0, ts_qk = 0, ts_sm = 0, ts_pv = 0, ts_epi = 0, n_it = 0, n_mine = 0, n_walk = 0;
 #endif
+  // (s_setprio 1 on the second head's waves -- the younger ones on their SIMDs, which reached every barrier last -- only
+  // swapped who waits: the SIMDs' issue slots are full, 413k cycles per wave against 397k.)
   const int hs = wave / TW;                               // which of the REP heads
   const int pw = hs & 1 ? TW - 1 - wave % TW : wave % TW; // which 16*QT queries of the stretch
-  const int h = hk * rep + (sh % hg) * REP + hs;
-  const int qb = q0 + QW * pw;
-  const int P = a.P;
-  const int nkeys = P + p0 + ln;
-  const int qend = q0 + QB < ln ? q0 + QB : ln;
-  const int chunks = (P + p0 + qend + 31) >> 5;           // stages the workgroup walks
-  const bool wave_live = qb < ln;
-  const int last_key = P + p0 + (qb + QW - 1 < ln ? qb + QW - 1 : ln - 1);
-  const float NEG = -__builtin_inff();
 
-  uint4_t qf[QT][KS];                                     // Q tiles as B operands, loaded below
+  uint4_t qf[QT][KS];                                     // Q tiles as B operands: lane (query r, dims 8g.. of k-step ks)
+  auto load_q = [&](const LongItem& it) {
+    const int h = it.hk * rep + it.hsel * REP + hs;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      int qi = it.q0 + QW * pw + 16 * t + r;
+      qi = qi < it.ln ? qi : it.ln - 1;
+      const uint16_t* qp = a.q + static_cast<int64_t>(it.st + qi) * a.q_rs + static_cast<int64_t>(h) * a.q_hs + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) qf[t][ks] = *reinterpret_cast<const uint4_t*>(qp + 32 * ks);
+    }
+  };
 
   // ---- LDS-DMA: this lane's piece of every row it fetches ----------------------------------------------------------
   const int lrow = lane / LPR, wp = lane % LPR;
   const int half = wp >> 4, pos = wp & 15;
   // Stages that lie entirely inside the candidate's own rows (all but the first one or two and possibly the last) take
-  // their addresses from per-lane pointers computed once: one 64-bit multiply-add per piece instead of the
+  // their addresses from per-lane pointers computed once per item: one 64-bit multiply-add per piece instead of the
   // prefix / parent / own case analysis (31 vector instructions per K/V pair of pieces; the loop is VALU-bound).
-  const int own0 = P + p0;                                 // key index of the candidate's first own row
-  const unsigned char *kown[IPW], *vown[IPW];
+  // (when a wave's pieces are a multiple of 16 rows apart they all have the same swizzle: one offset register per
+  // image, the piece's distance is a scalar)
+  constexpr bool SAME = (NW * RPI) % 16 == 0;
+  constexpr int NL = SAME ? 1 : IPW;
+  uint32_t klane[NL], vlane[NL];                            // this lane's byte offset inside a stage of own rows
 #pragma unroll
-  for (int it = 0; it < IPW; ++it) {
-    const int row = (wave + it * NW) * RPI + lrow;
-    const int64_t grow = static_cast<int64_t>(st) + row - own0;      // own row of key `row` (stage 0); may be negative
-    kown[it] = reinterpret_cast<const unsigned char*>(a.k) +
-               2 * (grow * a.k_rs + static_cast<int64_t>(hk) * a.k_hs + 128 * half + 8 * (pos ^ (row & 15)));
-    vown[it] = reinterpret_cast<const unsigned char*>(a.v) +
-               2 * (grow * a.v_rs + static_cast<int64_t>(hk) * a.v_hs + 128 * half + 8 * (pos ^ ((row & 7) << 1)));
+  for (int q = 0; q < NL; ++q) {
+    const int row = (wave + q * NW) * RPI + lrow;
+    klane[q] = 2 * (row * static_cast<uint32_t>(a.k_rs) + 128 * half + 8 * (pos ^ (row & 15)));
+    vlane[q] = 2 * (row * static_cast<uint32_t>(a.v_rs) + 128 * half + 8 * (pos ^ ((row & 7) << 1)));
   }
+  // own row of key 0 of an item (wave-uniform; may lie in front of the tensor)
+  auto own_k = [&](const LongItem& it) {
+    return reinterpret_cast<const unsigned char*>(a.k) +
+           2 * ((static_cast<int64_t>(it.st) - (P + it.p0)) * a.k_rs + static_cast<int64_t>(it.hk) * a.k_hs);
+  };
+  auto own_v = [&](const LongItem& it) {
+    return reinterpret_cast<const unsigned char*>(a.v) +
+           2 * ((static_cast<int64_t>(it.st) - (P + it.p0)) * a.v_rs + static_cast<int64_t>(it.hk) * a.v_hs);
+  };
   const int64_t kstep = 64 * a.k_rs, vstep = 64 * a.v_rs;   // bytes per stage of 32 rows
-  auto issue = [&](int c, int slot) {
-    if (32 * c >= own0 && 32 * c + 32 <= nkeys) {            // wave-uniform
+  auto issue = [&](const LongItem& it, int c, int slot) {
+    if (32 * c >= P + it.p0 && 32 * c + 32 <= it.nkeys) {                    // wave-uniform
+      const unsigned char *kown = own_k(it), *vown = own_v(it);
 #pragma unroll
-      for (int it = 0; it < IPW; ++it) {
-        if (NPI % NW && wave + it * NW >= NPI) break;       // wave-uniform
-        unsigned char* kd = lds + slot * STAGEB + (wave + it * NW) * RPI * ROWB;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kown[it] + c * kstep),
+      for (int q = 0; q < IPW; ++q) {
+        if (NPI % NW && wave + q * NW >= NPI) break;         // wave-uniform
+        unsigned char* kd = lds + slot * STAGEB + (wave + q * NW) * RPI * ROWB;
+        const unsigned char* kq = kown + c * kstep + (SAME ? 2 * q * NW * RPI * a.k_rs : 0);     // wave-uniform
+        const unsigned char* vq = vown + c * vstep + (SAME ? 2 * q * NW * RPI * a.v_rs : 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kq + klane[SAME ? 0 : q]),
                                          (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vown[it] + c * vstep),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vq + vlane[SAME ? 0 : q]),
                                          (__attribute__((address_space(3))) void*)(kd + IMGB), 16, 0, 0);
       }
       return;
     }
 #pragma unroll
-    for (int it = 0; it < IPW; ++it) {
-      if (NPI % NW && wave + it * NW >= NPI) break;         // wave-uniform
-      const int row = (wave + it * NW) * RPI + lrow;         // key row inside the stage
+    for (int q = 0; q < IPW; ++q) {
+      if (NPI % NW && wave + q * NW >= NPI) break;           // wave-uniform
+      const int row = (wave + q * NW) * RPI + lrow;          // key row inside the stage
       int t = 32 * c + row;
-      t = t < nkeys ? t : nkeys - 1;                         // past the end: the last key again (masked; finite)
+      t = t < it.nkeys ? t : it.nkeys - 1;                   // past the end: the last key again (masked; finite)
       const uint16_t *kp, *vp;
       if (t < P) {
-        kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(hk) * a.pk_hs;
-        vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(hk) * a.pv_hs;
+        kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(it.hk) * a.pk_hs;
+        vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(it.hk) * a.pv_hs;
       } else {
         const int tt = t - P;
-        const int64_t grow = tt < p0 ? tt : st + (tt - p0);  // the parent's row, or this candidate's own
-        kp = a.k + grow * a.k_rs + static_cast<int64_t>(hk) * a.k_hs;
-        vp = a.v + grow * a.v_rs + static_cast<int64_t>(hk) * a.v_hs;
+        const int64_t grow = tt < it.p0 ? tt : it.st + (tt - it.p0);   // the parent's row, or this candidate's own
+        kp = a.k + grow * a.k_rs + static_cast<int64_t>(it.hk) * a.k_hs;
+        vp = a.v + grow * a.v_rs + static_cast<int64_t>(it.hk) * a.v_hs;
       }
       kp += 128 * half + 8 * (pos ^ (row & 15));
       vp += 128 * half + 8 * (pos ^ ((row & 7) << 1));
-      unsigned char* kd = lds + slot * STAGEB + (wave + it * NW) * RPI * ROWB;     // wave-uniform; the DMA adds lane*16
+      unsigned char* kd = lds + slot * STAGEB + (wave + q * NW) * RPI * ROWB;      // wave-uniform; the DMA adds lane*16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
                                        (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp,
@@ -488,14 +557,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   f32x4 oacc[QT][NT];
   float mrun[QT], lsum[QT];
   int jq[QT];
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    mrun[t] = NEG;
-    lsum[t] = 0.0f;
-    jq[t] = p0 + qb + 16 * t + r;                          // this lane's query position behind the prefix
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  }
+  int qb = 0;                                              // first query of this wave in the current item
 
   // fragment offsets inside a stage (bytes)
   const int q4 = r >> 2, p4 = r & 3;
@@ -504,26 +566,54 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   const int vbase = IMGB + vrow * ROWB + 8 * p4;
   const int v7 = vrow & 7;
 
+  // The pair after the one being multiplied -- the item's next two stages, or the NEXT item's first two -- is planned
+  // at the pair's barrier and requested from INSIDE the stage code, one stage per stage multiplied, behind the QK
+  // products: eight waves issuing their 8 DMA instructions together right behind the barrier queued on the CU's one
+  // address path for ~2k cycles per pair (stamps: more time than the products).  Whatever a wave has not requested
+  // when it reaches the next barrier (it skipped a stage, or multiplies none) it requests there.
+  int pf_kind = 0, pf_c0 = 0, pf_n = 0, pf_done = 0, pf_slot = 0;   // wave-uniform: 0 nothing / 1 current item / 2 next item
+  auto pf_issue = [&](int k) {
+    if (k < pf_n && !(pf_done & (1 << k))) {
+      pf_done |= 1 << k;
+      if (pf_kind == 1) issue(cur, pf_c0 + k, pf_slot + k);
+      else issue(nxt, pf_c0 + k, pf_slot + k);
+    }
+  };
+
   auto compute = [&](int c, const unsigned char* sb) {
-#ifdef BMA_LONG_STAMPS
+#if defined(BMA_LONG_STAMPS) && BMA_LONG_STAMPS >= 2
     const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
 #endif
     // ---- S^T = K Q^T for both query tiles -----------------------------------------------------------------------
+    // The K fragments are read by hand as well: all of a stage's rows are requested at once (the compiler kept five
+    // reads in flight and waited for lgkmcnt(0) six times per stage), the second half lands while the first is multiplied.
     f32x4 s[QT][2];
+    u32x4 kf[2][KS];
+    const uint32_t ka = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)sb)) + kbase;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint32_t ad = ka + 16 * ((4 * (ks & 3) + g) ^ r);
+        if (kt == 0) kf[kt][ks] = ks >> 2 ? row_read<256>(ad) : row_read<0>(ad);
+        else kf[kt][ks] = ks >> 2 ? row_read<16 * ROWB + 256>(ad) : row_read<16 * ROWB>(ad);
+      }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      if (kt == 0) wait_rows<KS, KS>(kf[0]);
+      else wait_rows<0, KS>(kf[1]);
 #pragma unroll
       for (int t = 0; t < QT; ++t) s[t][kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const uint4_t kf = *reinterpret_cast<const uint4_t*>(sb + kbase + 16 * kt * ROWB + 256 * (ks >> 2) +
-                                                             16 * ((4 * (ks & 3) + g) ^ r));
+        const uint4_t kfr = __builtin_bit_cast(uint4_t, kf[kt][ks]);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) s[t][kt] = mfma<DT>(kf, qf[t][ks], s[t][kt]);
+        for (int t = 0; t < QT; ++t) s[t][kt] = mfma<DT>(kfr, qf[t][ks], s[t][kt]);
       }
       BMA_LONG_SB0;
     }
-#ifdef BMA_LONG_STAMPS
+    pf_issue(c & 1);
+#if defined(BMA_LONG_STAMPS) && BMA_LONG_STAMPS >= 2
     asm volatile("" ::"v"(s[0][0][0]), "v"(s[0][1][0]));       // the QK products are done
     const unsigned long long tc1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -542,7 +632,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
             float v = s[t][kt][rr];
             if (decltype(masked)::value) {
               const int te = 32 * c + 16 * kt + 4 * g + rr;
-              const bool ok = te < nkeys && (te < P || te - P <= jq[t]);
+              const bool ok = te < cur.nkeys && (te < P || te - P <= jq[t]);
               v = ok ? v : NEG;
             }
             e[kt][rr] = v;
@@ -570,7 +660,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
         pf[t].w = pack2<DT>(e[1][2], e[1][3]);
       }
     };
-    if (32 * c + 32 > nkeys || 32 * c + 31 - P > p0 + qb) softmax(std::true_type{});
+    if (32 * c + 32 > cur.nkeys || 32 * c + 31 - P > cur.p0 + qb) softmax(std::true_type{});
     else softmax(std::false_type{});
     bool moved = false;
 #pragma unroll
@@ -588,7 +678,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
     // front of them (an LDS read it cannot tell apart from the LDS-DMA writes in flight), which drains the ring every
     // stage.  So their completion is counted by hand too: groups of four 16-dim tiles, group n+1 in flight while group
     // n is multiplied (lgkmcnt counts in order for LDS; anything else in flight only makes the wait conservative).
-#ifdef BMA_LONG_STAMPS
+#if defined(BMA_LONG_STAMPS) && BMA_LONG_STAMPS >= 2
     asm volatile("" ::"v"(pf[0].x), "v"(pf[0].w));
     const unsigned long long tc2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -628,7 +718,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
       }
       BMA_LONG_SB2;
     }
-#ifdef BMA_LONG_STAMPS
+#if defined(BMA_LONG_STAMPS) && BMA_LONG_STAMPS >= 2
     asm volatile("" ::"v"(oacc[0][NT - 1][0]));
     const unsigned long long tc3 = __builtin_amdgcn_s_memtime();
     ts_qk += tc1 - tc0; ts_sm += tc2 - tc1; ts_pv += tc3 - tc2;
@@ -638,117 +728,170 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   // ---- the ring: two PAIRS of 32-key stages; one pair in flight while the other is multiplied -----------------------
   // One barrier per 64 keys: with one per 32 the waves of a workgroup (different causal masks, different SIMD partners)
   // lost a quarter of every stage waiting for the slowest of the eight.
-  issue(0, 0);
-  if (chunks > 1) issue(1, 1);
-  // Q tiles as B operands: lane (query r, dims 8g.. of k-step ks).  Loaded behind the first stages and waited for HERE,
-  // where the compiler can see it: its own wait-count bookkeeping does not know the counted waits of the loop (inline
-  // asm), and a register load still pending at the loop header in its books costs an s_waitcnt vmcnt(0) -- the whole
-  // ring drained -- in front of every stage.
-#pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    int qi = qb + 16 * t + r;
-    qi = qi < ln ? qi : ln - 1;
-    const uint16_t* qp = a.q + static_cast<int64_t>(st + qi) * a.q_rs + static_cast<int64_t>(h) * a.q_hs + 8 * g;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[t][ks] = *reinterpret_cast<const uint4_t*>(qp + 32 * ks);
-  }
-
-#pragma unroll
-  for (int t = 0; t < QT; ++t)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      asm volatile("" ::"v"(qf[t][ks].x), "v"(qf[t][ks].y), "v"(qf[t][ks].z), "v"(qf[t][ks].w));
   int sb = 0;                                              // first slot of the pair being multiplied
+  issue(cur, 0, 0);
+  if (cur.chunks > 1) issue(cur, 1, 1);
+  load_q(cur);
+  const int64_t o_rs = static_cast<int64_t>(a.H) * DH;
+  for (;;) {
+    const int jn = decode(j + wgx, nxt);
+    const bool has_next = jn < n_items;
+    const int h = cur.hk * rep + cur.hsel * REP + hs;
+    qb = cur.q0 + QW * pw;
+    const bool wave_live = qb < cur.ln;
+    const int last_key = P + cur.p0 + (qb + QW - 1 < cur.ln ? qb + QW - 1 : cur.ln - 1);
+    const int mine = wave_live ? (last_key >> 5) + 1 : 0;  // stages 0 .. mine-1 are multiplied by this wave (<= chunks)
+    const int chunks = cur.chunks;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      mrun[t] = NEG;
+      lsum[t] = 0.0f;
+      jq[t] = cur.p0 + qb + 16 * t + r;                      // this lane's query position behind the prefix
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    auto plan = [&](int c) {                                // c = first stage of the pair about to be multiplied
+      pf_done = 0;
+      pf_slot = sb ^ 2;
+      if (c + 2 < chunks) {
+        pf_kind = 1; pf_c0 = c + 2; pf_n = c + 3 < chunks ? 2 : 1;
+      } else if (has_next) {
+        pf_kind = 2; pf_c0 = 0; pf_n = nxt.chunks > 1 ? 2 : 1;
+      } else {
+        pf_kind = 0; pf_n = 0;
+      }
+    };
+    auto advance = [&](int c) {
+      pf_issue(0);
+      pf_issue(1);
 #ifdef BMA_LONG_STAMPS
-  const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
-  // The stages this wave multiplies come first, in loops of their own: with the causal skip as a branch inside one
-  // loop the accumulators are merged values of that branch and the compiler keeps two copies of them, moving all 64
-  // registers twice per stage.  The last loop only keeps the ring and the barriers going for the other waves.
-  const int mine = wave_live ? (last_key >> 5) + 1 : 0;    // stages 0 .. mine-1 are multiplied by this wave (<= chunks)
-  auto advance = [&](int c) {                              // c = first stage of the pair about to be multiplied
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();                       // everybody's pieces of the pair landed; the other pair is free
 #ifdef BMA_LONG_STAMPS
-    const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+      ts_wait += __builtin_amdgcn_s_memtime() - tw0;
 #endif
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();                         // everybody's pieces of the pair landed; the other pair is free
+      plan(c);
+    };
+    // ---- start of the item: its first pair and its Q rows were requested a pair ago (or in front of the loop) ---------
+    // The Q rows are waited for HERE, where the compiler can see it: its own wait-count bookkeeping does not know the
+    // waits of the loop (inline asm), and a register load still pending at a loop header in its books costs an
+    // s_waitcnt vmcnt(0) -- the ring drained -- in front of every stage.  At this point nothing else is in flight.
+    {
 #ifdef BMA_LONG_STAMPS
-    ts_wait += __builtin_amdgcn_s_memtime() - tw0;
+      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (c + 2 < chunks) issue(c + 2, sb ^ 2);
-    if (c + 3 < chunks) issue(c + 3, (sb ^ 2) + 1);
-  };
-  int c = 0;
-  for (; c < mine; ++c) {                                  // one call site of the stage code: fewer live registers
-    if (!(c & 1)) {
-      if (c) sb ^= 2;
+      wait_vm<0>();
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          asm volatile("" ::"v"(qf[t][ks].x), "v"(qf[t][ks].y), "v"(qf[t][ks].z), "v"(qf[t][ks].w));
+      __builtin_amdgcn_s_barrier();
+#ifdef BMA_LONG_STAMPS
+      ts_wait += __builtin_amdgcn_s_memtime() - tw0;
+#endif
+      plan(0);
+    }
+    // The stages this wave multiplies come first, in a loop of their own: with the causal skip as a branch inside one
+    // loop the accumulators are merged values of that branch and the compiler keeps two copies of them, moving all 64
+    // registers twice per stage.  The second loop only keeps the ring and the barriers going for the other waves.
+    int c = 0;
+    for (; c < mine; ++c) {                                // one call site of the stage code: fewer live registers
+      if (c && !(c & 1)) {
+        sb ^= 2;
+        advance(c);
+      }
+      compute(c, lds + (sb + (c & 1)) * STAGEB);
+    }
+    c = (c + 1) & ~1;
+    for (c = c < 2 ? 2 : c; c < chunks; c += 2) {
+      sb ^= 2;
       advance(c);
     }
-    compute(c, lds + (sb + (c & 1)) * STAGEB);
-  }
-  for (c = (c + 1) & ~1; c < chunks; c += 2) {
-    if (c) sb ^= 2;                                         // (a wave without live queries starts here, at pair 0)
-    advance(c);
-  }
+    pf_issue(0);                                           // (what of the next item's first pair is not requested yet)
+    pf_issue(1);
+    if (has_next) load_q(nxt);                             // the Q fragments are dead: the next item's, behind its first pair
 
-  // ---- epilogue -------------------------------------------------------------------------------------------------------
-  const int64_t o_rs = static_cast<int64_t>(a.H) * DH;
+    // ---- epilogue of the item -----------------------------------------------------------------------------------------
 #ifdef BMA_LONG_STAMPS
-  const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+    const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
-  __syncthreads();                                        // every wave is done reading the ring
-  unsigned char* park = lds + wave * QW * ROWB;            // this wave's rows
+    // (a raw barrier: __syncthreads() is a fence and would drain the next item's DMA and Q loads, which are in flight)
+    __builtin_amdgcn_s_barrier();                         // every wave is done reading the pair the rows are parked in
+    unsigned char* park = lds + sb * STAGEB + wave * QW * ROWB;   // this wave's rows
 #pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    const float l = rows_sum(lsum[t]);
-    const int qi = qb + 16 * t + r;
-    const int64_t row = st + (qi < ln ? qi : ln - 1);
-    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-    float w1 = 0.0f;
-    const uint16_t* o1p = nullptr;
-    if (a.o1) {
-      // natural-log LSE of this part; weight of the prefix partial = 1 / (1 + exp(lse2 - lse1))
-      const float lse2 = l > 0.0f ? (mrun[t] * a.scale_log2e + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : NEG;
-      const float l1 = a.lse1[static_cast<int64_t>(h) * a.N + row];
-      w1 = 1.0f / (1.0f + expf(lse2 - l1));
-      o1p = a.o1 + row * o_rs + static_cast<int64_t>(h) * DH + 4 * g;
-    }
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) {
-      float o[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) o[rr] = oacc[t][dt][rr] * inv;
-      if (o1p) {
-        const bma::uint2_t pw2 = *reinterpret_cast<const bma::uint2_t*>(o1p + 16 * dt);
-        const float p1[4] = {bma::unpack16<DT>(pw2.x, 0), bma::unpack16<DT>(pw2.x, 1), bma::unpack16<DT>(pw2.y, 0),
-                             bma::unpack16<DT>(pw2.y, 1)};
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) o[rr] = o[rr] + w1 * (p1[rr] - o[rr]);
+    for (int t = 0; t < QT; ++t) {
+      const float l = rows_sum(lsum[t]);
+      const int qi = qb + 16 * t + r;
+      const int64_t row = cur.st + (qi < cur.ln ? qi : cur.ln - 1);
+      const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+      float w1 = 0.0f;
+      const uint16_t* o1p = nullptr;
+      if (a.o1) {
+        // natural-log LSE of this part; weight of the prefix partial = 1 / (1 + exp(lse2 - lse1))
+        const float lse2 = l > 0.0f ? (mrun[t] * a.scale_log2e + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : NEG;
+        const float l1 = a.lse1[static_cast<int64_t>(h) * a.N + row];
+        w1 = 1.0f / (1.0f + expf(lse2 - l1));
+        o1p = a.o1 + row * o_rs + static_cast<int64_t>(h) * DH + 4 * g;
       }
-      bma::uint2_t ow;
-      ow.x = pack2<DT>(o[0], o[1]);
-      ow.y = pack2<DT>(o[2], o[3]);
-      // dims 16dt + 4g .. +3 of row 16t + r: 16-byte piece 2*(dt & 7) + (g >> 1) of half dt >> 3, pieces XORed with r
-      *reinterpret_cast<bma::uint2_t*>(park + (16 * t + r) * ROWB + 256 * (dt >> 3) +
-                                       16 * ((2 * (dt & 7) + (g >> 1)) ^ r) + 8 * (g & 1)) = ow;
-    }
-  }
-  // the wave reads back what the wave wrote: LDS operations of one wave complete in order, no barrier
 #pragma unroll
-  for (int ps = 0; ps < QW / RPI; ++ps) {
-    const int rl = ps * RPI + lrow;
-    const int qrow = qb + rl;
-    if (qrow < ln) {
-      const uint4_t val = *reinterpret_cast<const uint4_t*>(park + rl * ROWB + 256 * half + 16 * (pos ^ (rl & 15)));
-      *reinterpret_cast<uint4_t*>(a.out + (st + qrow) * o_rs + static_cast<int64_t>(h) * DH + 128 * half + 8 * pos) = val;
+      for (int dt = 0; dt < NT; ++dt) {
+        float o[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) o[rr] = oacc[t][dt][rr] * inv;
+        if (o1p) {
+          const bma::uint2_t pw2 = *reinterpret_cast<const bma::uint2_t*>(o1p + 16 * dt);
+          const float p1[4] = {bma::unpack16<DT>(pw2.x, 0), bma::unpack16<DT>(pw2.x, 1), bma::unpack16<DT>(pw2.y, 0),
+                               bma::unpack16<DT>(pw2.y, 1)};
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) o[rr] = o[rr] + w1 * (p1[rr] - o[rr]);
+        }
+        bma::uint2_t ow;
+        ow.x = pack2<DT>(o[0], o[1]);
+        ow.y = pack2<DT>(o[2], o[3]);
+        // dims 16dt + 4g .. +3 of row 16t + r: 16-byte piece 2*(dt & 7) + (g >> 1) of half dt >> 3, pieces XORed with r
+        *reinterpret_cast<bma::uint2_t*>(park + (16 * t + r) * ROWB + 256 * (dt >> 3) +
+                                         16 * ((2 * (dt & 7) + (g >> 1)) ^ r) + 8 * (g & 1)) = ow;
+      }
     }
+    // the wave reads back what the wave wrote: LDS operations of one wave complete in order, no barrier
+    // (read by hand like the fragments: a plain LDS load here waits, in the compiler's books, for the DMA in flight)
+    {
+      constexpr int NPS = QW / RPI;
+      static_assert(NPS == 4 || NPS == 8, "wait_rows ties 4 or 8 reads");
+      u32x4 rows[NPS];
+      const uint32_t pa = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)park));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the parking stores above
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int rl = ps * RPI + lrow;
+        rows[ps] = row_read<0>(pa + rl * ROWB + 256 * half + 16 * (pos ^ (rl & 15)));
+      }
+      wait_rows<0, NPS>(rows);
+#pragma unroll
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int qrow = qb + ps * RPI + lrow;
+        if (qrow < cur.ln)
+          *reinterpret_cast<uint4_t*>(a.out + (cur.st + qrow) * o_rs + static_cast<int64_t>(h) * DH + 128 * half + 8 * pos) =
+              __builtin_bit_cast(uint4_t, rows[ps]);
+      }
+    }
+#ifdef BMA_LONG_STAMPS
+    ts_epi += __builtin_amdgcn_s_memtime() - te0;
+    n_it += 1; n_mine += mine; n_walk += chunks;
+#endif
+    if (!has_next) break;
+    cur = nxt;
+    j = jn;
+    sb ^= 2;                                               // the next item's first pair went to the other half of the ring
   }
 #ifdef BMA_LONG_STAMPS
   if (a.stamps && lane == 0) {
-    const unsigned long long ts3 = __builtin_amdgcn_s_memtime();   // stores issued, not waited for
     unsigned long long* o = a.stamps + (static_cast<int64_t>(blockIdx.x) * NW + wave) * 12;
-    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts_wait; o[5] = chunks;
-    o[6] = tr0; o[7] = __builtin_amdgcn_s_memrealtime(); o[8] = ts_qk; o[9] = ts_sm; o[10] = ts_pv; o[11] = mine;
+    o[0] = ts0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = ts_wait; o[3] = ts_qk; o[4] = ts_sm; o[5] = ts_pv;
+    o[6] = tr0; o[7] = __builtin_amdgcn_s_memrealtime(); o[8] = ts_epi; o[9] = n_it; o[10] = n_mine; o[11] = n_walk;
   }
 #endif
 }
@@ -768,8 +911,14 @@ int launch_long_cfg(Args b, int max_len, hipStream_t st) {
   b.nz = (max_len + QB - 1) / QB;
   const int rep = b.H / b.Hk;
   const int64_t groups = static_cast<int64_t>(b.B2) * b.Hk, sharers = static_cast<int64_t>(rep / REP) * b.nz;
-  const int64_t blocks = (groups + 7) / 8 * sharers * 8;
-  if (blocks > 0x7fffffffLL) return BMA_ELIMIT;
+  if ((groups + 7) / 8 * sharers > 0x7fffffffLL) return BMA_ELIMIT;    // items per XCD list fit an int
+  // persistent: one workgroup per CU (the LDS ring admits no second), a multiple of 8 so that every XCD has as many
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return (n + 7) / 8 * 8;
+  }();
+  const int64_t blocks = cus;
   const dim3 grid(static_cast<unsigned>(blocks));
 #ifdef BMA_LONG_STAMPS
   // diagnostic build: BMA_RAGGED_STAMPS=<file> gets 12 x u64 per wave of every launch (overwritten per launch)
@@ -801,7 +950,7 @@ int launch_long(const Args& a, int max_len, hipStream_t st) {
   // and two waves per SIMD have 256 each); 128-wide heads: two tiles per wave.  Four tile-waves per head: with six
   // (12 waves, three per SIMD, 168 registers) a stage took 5.5k cycles instead of 3.3k -- the SIMDs' issue slots, not
   // latency, bound the stage -- and Gemma-3 blocks ran 348 us instead of 255.
-  constexpr int QT = DH == 256 ? 1 : 2;
+  constexpr int QT = 1;
   const int rep = a.H / a.Hk;
   if (rep % 2 == 0) {
     return launch_long_cfg<DT, DH, 2, QT, 4>(a, max_len, st);
