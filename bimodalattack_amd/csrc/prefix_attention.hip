@@ -13,6 +13,10 @@
 //   S^T = K Q^T v_mfma_f32_16x16x32: A = 16 keys x 32 dims from an LDS key row, B = Q fragment (registers,
 //               loaded once); a query is a lane column, its running max / sum live in the lane
 //   O^T += V^T P^T  the S^T accumulator, exponentiated and packed, IS the B operand
+//   LDS reads   left to the compiler's schedule (two fragment reads ahead of every pair of MFMAs): issued in groups
+//               with hand-counted waits as in the long-block kernel (bma_lds.h: all K fragments of a chunk at once,
+//               V^T in groups of four tiles) the launch took 303 us instead of 255 -- with two workgroups per CU
+//               and no DMA in flight the fine interleave is the better one
 //   staging     32 keys per chunk, two LDS image pairs: chunk c+1 travels L2 -> registers while chunk c is
 //               multiplied and is stored to the other pair afterwards; one barrier per chunk
 //   placement   blocks b and b+8 share an XCD (round-robin dispatch): block b works on head 4*(b%8) + (b/8)%4

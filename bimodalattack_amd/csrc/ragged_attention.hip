@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "bma_common.h"
+#include "bma_lds.h"
 #include "bma_profile.h"
 
 namespace {
@@ -341,7 +342,12 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+using bma::u32x2;
+using bma::u32x4;
+using bma::tr_read;
+using bma::row_read;
+using bma::wait_rows;
+using bma::wait_lgkm;
 
 __device__ __forceinline__ float vmax1(float x, float y) {      // one v_max_f32, no canonicalising pre-ops
   float r;
@@ -365,37 +371,6 @@ __device__ __forceinline__ float rows_sum(float x) {
 constexpr int kLongMin = 96;     // shortest max_len that takes this kernel
 constexpr int kRing = 4;         // stages of 32 keys in the LDS ring: two pairs
 
-// ds_read_b64_tr_b16 by hand (see the kernel's PV loop): the result is NOT tracked by the compiler's lgkmcnt
-// bookkeeping; wait_lgkm ties the registers to the wait so that nothing consuming them moves above it.
-template <int OFF>
-__device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {
-  u32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
-  return v;
-}
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int OFF>
-__device__ __forceinline__ u32x4 row_read(uint32_t lds_addr) {   // ds_read_b128, completion counted by hand likewise
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
-  return v;
-}
-template <int N, int KS>
-__device__ __forceinline__ void wait_rows(u32x4 (&f)[KS]) {
-  static_assert(KS == 4 || KS == 8, "one wait ties 4 or 8 fragments");
-  if constexpr (KS == 8)
-    asm volatile("s_waitcnt lgkmcnt(%8)"
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
-                 : "n"(N));
-  else
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm(u32x2 (&l)[4], u32x2 (&h)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%8)"
-               : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
-               : "n"(N));
-}
 #ifndef BMA_LONG_SCHED
 #define BMA_LONG_SCHED 7
 #endif
@@ -589,7 +564,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
     // reads in flight and waited for lgkmcnt(0) six times per stage), the second half lands while the first is multiplied.
     f32x4 s[QT][2];
     u32x4 kf[2][KS];
-    const uint32_t ka = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)sb)) + kbase;
+    const uint32_t ka = bma::lds_addr(sb) + kbase;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -684,7 +659,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
 #endif
     BMA_LONG_SB1;
     constexpr int NG = NT / 4;
-    const uint32_t va = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)sb)) + vbase;
+    const uint32_t va = bma::lds_addr(sb) + vbase;
     u32x2 lo[2][4], hi[2][4];
     auto read_group = [&](int gi, u32x2(&L)[4], u32x2(&H)[4]) {
 #pragma unroll
@@ -862,7 +837,7 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
       constexpr int NPS = QW / RPI;
       static_assert(NPS == 4 || NPS == 8, "wait_rows ties 4 or 8 reads");
       u32x4 rows[NPS];
-      const uint32_t pa = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) unsigned char*)park));
+      const uint32_t pa = bma::lds_addr(park);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the parking stores above
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
