@@ -487,15 +487,15 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
            2 * ((static_cast<int64_t>(it.st) - (P + it.p0)) * a.v_rs + static_cast<int64_t>(it.hk) * a.v_hs);
   };
   const int64_t kstep = 64 * a.k_rs, vstep = 64 * a.v_rs;   // bytes per stage of 32 rows
-  auto issue = [&](const LongItem& it, int c, int slot) {
+  // kc / vc: the item's own row of key 32c (wave-uniform; kept as running pointers by the caller)
+  auto issue = [&](const LongItem& it, int c, int slot, const unsigned char* kc, const unsigned char* vc) {
     if (32 * c >= P + it.p0 && 32 * c + 32 <= it.nkeys) {                    // wave-uniform
-      const unsigned char *kown = own_k(it), *vown = own_v(it);
 #pragma unroll
       for (int q = 0; q < IPW; ++q) {
         if (NPI % NW && wave + q * NW >= NPI) break;         // wave-uniform
         unsigned char* kd = lds + slot * STAGEB + (wave + q * NW) * RPI * ROWB;
-        const unsigned char* kq = kown + c * kstep + (SAME ? 2 * q * NW * RPI * a.k_rs : 0);     // wave-uniform
-        const unsigned char* vq = vown + c * vstep + (SAME ? 2 * q * NW * RPI * a.v_rs : 0);
+        const unsigned char* kq = kc + (SAME ? 2 * q * NW * RPI * a.k_rs : 0);     // wave-uniform
+        const unsigned char* vq = vc + (SAME ? 2 * q * NW * RPI * a.v_rs : 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kq + klane[SAME ? 0 : q]),
                                          (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vq + vlane[SAME ? 0 : q]),
@@ -503,24 +503,27 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
       }
       return;
     }
+    // a stage with prefix keys, the parent's rows or the end of the block in it: per-lane row lookup, written with
+    // selects (as branches the three cases cost two exec-mask regions per piece)
+    const unsigned char* pkb = reinterpret_cast<const unsigned char*>(a.pk) + 2 * static_cast<int64_t>(it.hk) * a.pk_hs;
+    const unsigned char* pvb = reinterpret_cast<const unsigned char*>(a.pv) + 2 * static_cast<int64_t>(it.hk) * a.pv_hs;
+    const unsigned char* kb = reinterpret_cast<const unsigned char*>(a.k) + 2 * static_cast<int64_t>(it.hk) * a.k_hs;
+    const unsigned char* vb = reinterpret_cast<const unsigned char*>(a.v) + 2 * static_cast<int64_t>(it.hk) * a.v_hs;
+    const uint32_t pk_rb = 2 * static_cast<uint32_t>(a.pk_rs), pv_rb = 2 * static_cast<uint32_t>(a.pv_rs);
+    const uint32_t k_rb = 2 * static_cast<uint32_t>(a.k_rs), v_rb = 2 * static_cast<uint32_t>(a.v_rs);
 #pragma unroll
     for (int q = 0; q < IPW; ++q) {
       if (NPI % NW && wave + q * NW >= NPI) break;           // wave-uniform
       const int row = (wave + q * NW) * RPI + lrow;          // key row inside the stage
       int t = 32 * c + row;
       t = t < it.nkeys ? t : it.nkeys - 1;                   // past the end: the last key again (masked; finite)
-      const uint16_t *kp, *vp;
-      if (t < P) {
-        kp = a.pk + static_cast<int64_t>(t) * a.pk_rs + static_cast<int64_t>(it.hk) * a.pk_hs;
-        vp = a.pv + static_cast<int64_t>(t) * a.pv_rs + static_cast<int64_t>(it.hk) * a.pv_hs;
-      } else {
-        const int tt = t - P;
-        const int64_t grow = tt < it.p0 ? tt : it.st + (tt - it.p0);   // the parent's row, or this candidate's own
-        kp = a.k + grow * a.k_rs + static_cast<int64_t>(it.hk) * a.k_hs;
-        vp = a.v + grow * a.v_rs + static_cast<int64_t>(it.hk) * a.v_hs;
-      }
-      kp += 128 * half + 8 * (pos ^ (row & 15));
-      vp += 128 * half + 8 * (pos ^ ((row & 7) << 1));
+      const bool inpre = t < P;
+      const int tt = t - P;
+      const uint32_t grow = inpre ? t : (tt < it.p0 ? tt : it.st + (tt - it.p0));   // prefix row / the parent's row / own row
+      const unsigned char* kp = (inpre ? pkb : kb) + static_cast<uint64_t>(grow) * (inpre ? pk_rb : k_rb) +
+                                2 * (128 * half + 8 * (pos ^ (row & 15)));
+      const unsigned char* vp = (inpre ? pvb : vb) + static_cast<uint64_t>(grow) * (inpre ? pv_rb : v_rb) +
+                                2 * (128 * half + 8 * (pos ^ ((row & 7) << 1)));
       unsigned char* kd = lds + slot * STAGEB + (wave + q * NW) * RPI * ROWB;      // wave-uniform; the DMA adds lane*16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp,
                                        (__attribute__((address_space(3))) void*)kd, 16, 0, 0);
@@ -547,11 +550,13 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   // address path for ~2k cycles per pair (stamps: more time than the products).  Whatever a wave has not requested
   // when it reaches the next barrier (it skipped a stage, or multiplies none) it requests there.
   int pf_kind = 0, pf_c0 = 0, pf_n = 0, pf_done = 0, pf_slot = 0;   // wave-uniform: 0 nothing / 1 current item / 2 next item
+  const unsigned char *pf_k = nullptr, *pf_v = nullptr;     // own row of key 32 * pf_c0 of the planned item
+  const unsigned char *kfetch = nullptr, *vfetch = nullptr; // ... of the current item's next stage to plan (running)
   auto pf_issue = [&](int k) {
     if (k < pf_n && !(pf_done & (1 << k))) {
       pf_done |= 1 << k;
-      if (pf_kind == 1) issue(cur, pf_c0 + k, pf_slot + k);
-      else issue(nxt, pf_c0 + k, pf_slot + k);
+      if (pf_kind == 1) issue(cur, pf_c0 + k, pf_slot + k, pf_k + k * kstep, pf_v + k * vstep);
+      else issue(nxt, pf_c0 + k, pf_slot + k, pf_k + k * kstep, pf_v + k * vstep);
     }
   };
 
@@ -704,8 +709,8 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   // One barrier per 64 keys: with one per 32 the waves of a workgroup (different causal masks, different SIMD partners)
   // lost a quarter of every stage waiting for the slowest of the eight.
   int sb = 0;                                              // first slot of the pair being multiplied
-  issue(cur, 0, 0);
-  if (cur.chunks > 1) issue(cur, 1, 1);
+  issue(cur, 0, 0, own_k(cur), own_v(cur));
+  if (cur.chunks > 1) issue(cur, 1, 1, own_k(cur) + kstep, own_v(cur) + vstep);
   load_q(cur);
   const int64_t o_rs = static_cast<int64_t>(a.H) * DH;
   for (;;) {
@@ -717,6 +722,8 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
     const int last_key = P + cur.p0 + (qb + QW - 1 < cur.ln ? qb + QW - 1 : cur.ln - 1);
     const int mine = wave_live ? (last_key >> 5) + 1 : 0;  // stages 0 .. mine-1 are multiplied by this wave (<= chunks)
     const int chunks = cur.chunks;
+    kfetch = own_k(cur) + 2 * kstep;
+    vfetch = own_v(cur) + 2 * vstep;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       mrun[t] = NEG;
@@ -730,8 +737,11 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
       pf_slot = sb ^ 2;
       if (c + 2 < chunks) {
         pf_kind = 1; pf_c0 = c + 2; pf_n = c + 3 < chunks ? 2 : 1;
+        pf_k = kfetch; pf_v = vfetch;
+        kfetch += 2 * kstep; vfetch += 2 * vstep;
       } else if (has_next) {
         pf_kind = 2; pf_c0 = 0; pf_n = nxt.chunks > 1 ? 2 : 1;
+        pf_k = own_k(nxt); pf_v = own_v(nxt);
       } else {
         pf_kind = 0; pf_n = 0;
       }
@@ -937,7 +947,10 @@ template <int DT, int DH>
 int launch_dh(const Args& a, int max_len, hipStream_t st) {
   if constexpr (DH == 128 || DH == 256) {
     // blocks of at least 96 tokens fill three quarters of a 128-query workgroup: the long-block kernel
-    if (max_len >= kLongMin && a.scale_log2e > 0.0f && long_blocks_mode() != 0) return launch_long<DT, DH>(a, max_len, st);
+    // (its row lookups multiply a row index by a 32-bit row stride in bytes)
+    const bool strides32 = a.k_rs < (1 << 30) && a.v_rs < (1 << 30) && a.pk_rs < (1 << 30) && a.pv_rs < (1 << 30) &&
+                           a.k_rs >= 0 && a.v_rs >= 0 && a.pk_rs >= 0 && a.pv_rs >= 0;
+    if (max_len >= kLongMin && a.scale_log2e > 0.0f && strides32 && long_blocks_mode() != 0) return launch_long<DT, DH>(a, max_len, st);
   }
   const int qt = max_len >= 64 ? 4 : (max_len + 15) / 16;
   Args b = a;
