@@ -549,6 +549,8 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
   // products: eight waves issuing their 8 DMA instructions together right behind the barrier queued on the CU's one
   // address path for ~2k cycles per pair (stamps: more time than the products).  Whatever a wave has not requested
   // when it reaches the next barrier (it skipped a stage, or multiplies none) it requests there.
+  // (Splitting a stage's four DMA instructions between the K reads' latency and the end of the QK products: 244 us
+  // against 231; with the level-2 stamps the DMA block costs ~550 cycles per stage where it stands.)
   int pf_kind = 0, pf_c0 = 0, pf_n = 0, pf_done = 0, pf_slot = 0;   // wave-uniform: 0 nothing / 1 current item / 2 next item
   const unsigned char *pf_k = nullptr, *pf_v = nullptr;     // own row of key 32 * pf_c0 of the planned item
   const unsigned char *kfetch = nullptr, *vfetch = nullptr; // ... of the current item's next stage to plan (running)
