@@ -259,7 +259,12 @@ int bma_prefix_attention(const void* q, int64_t q_row_stride, int64_t q_head_str
  *   q/k/v: row-list tensors addressed as base + row*rs + head*hs (elements; multiples of 8);
  *   pk/pv likewise with P rows; H query heads, Hk key/value heads (H % Hk == 0), Dh in {32,64,128,256}.
  *   out: [N][H][Dh] contiguous.  If o1/lse1 are given (o1 [N][H][Dh], lse1 [H][N] fp32: a prefix
- *   partial computed elsewhere, then pass P = 0) the result is merged with it as bma_attn_merge does. */
+ *   partial computed elsewhere, then pass P = 0) the result is merged with it as bma_attn_merge does.
+ *   Two kernels behind the one entry: blocks of max_len >= 96 tokens at Dh 128 / 256 (Gemma-3's padded candidates)
+ *   take a persistent flash-attention-style kernel -- one workgroup per CU, LDS-DMA ring, two query heads of a
+ *   key/value head per workgroup; shorter blocks and the other head widths one workgroup per (candidate, head,
+ *   64 queries).  Same arithmetic (32-key online-softmax steps, fp32 accumulation, one rounding), not bit-identical.
+ *   BMA_RAGGED_LONG=0 in the environment keeps every shape on the second. */
 int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
                          const void* v, int64_t v_rs, int64_t v_hs, const void* pk, int64_t pk_rs, int64_t pk_hs,
                          const void* pv, int64_t pv_rs, int64_t pv_hs, int P, const int* start, const int* first,
