@@ -846,23 +846,27 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
     // the wave reads back what the wave wrote: LDS operations of one wave complete in order, no barrier
     // (read by hand like the fragments: a plain LDS load here waits, in the compiler's books, for the DMA in flight)
     {
-      constexpr int NPS = QW / RPI;
-      static_assert(NPS == 4 || NPS == 8, "wait_rows ties 4 or 8 reads");
-      u32x4 rows[NPS];
+      constexpr int NPS = QW / RPI;                          // row groups of this wave
+      constexpr int NB = NPS >= 8 ? 8 : 4;                   // ... read back NB at a time
+      static_assert(NPS % NB == 0, "row groups do not divide into batches");
       const uint32_t pa = bma::lds_addr(park);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the parking stores above
 #pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) {
-        const int rl = ps * RPI + lrow;
-        rows[ps] = row_read<0>(pa + rl * ROWB + 256 * half + 16 * (pos ^ (rl & 15)));
-      }
-      wait_rows<0, NPS>(rows);
+      for (int pb = 0; pb < NPS; pb += NB) {
+        u32x4 rows[NB];
 #pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) {
-        const int qrow = qb + ps * RPI + lrow;
-        if (qrow < cur.ln)
-          *reinterpret_cast<uint4_t*>(a.out + (cur.st + qrow) * o_rs + static_cast<int64_t>(h) * DH + 128 * half + 8 * pos) =
-              __builtin_bit_cast(uint4_t, rows[ps]);
+        for (int ps = 0; ps < NB; ++ps) {
+          const int rl = (pb + ps) * RPI + lrow;
+          rows[ps] = row_read<0>(pa + rl * ROWB + 256 * half + 16 * (pos ^ (rl & 15)));
+        }
+        wait_rows<0, NB>(rows);
+#pragma unroll
+        for (int ps = 0; ps < NB; ++ps) {
+          const int qrow = qb + (pb + ps) * RPI + lrow;
+          if (qrow < cur.ln)
+            *reinterpret_cast<uint4_t*>(a.out + (cur.st + qrow) * o_rs + static_cast<int64_t>(h) * DH + 128 * half + 8 * pos) =
+                __builtin_bit_cast(uint4_t, rows[ps]);
+        }
       }
     }
 #ifdef BMA_LONG_STAMPS
@@ -937,6 +941,10 @@ int launch_long(const Args& a, int max_len, hipStream_t st) {
   // and two waves per SIMD have 256 each); 128-wide heads: two tiles per wave.  Four tile-waves per head: with six
   // (12 waves, three per SIMD, 168 registers) a stage took 5.5k cycles instead of 3.3k -- the SIMDs' issue slots, not
   // latency, bound the stage -- and Gemma-3 blocks ran 348 us instead of 255.
+  // The opposite corner -- ONE wave per SIMD with two tiles each (4 waves: 64 queries of two heads, or 128 of one; the
+  // structure of the guide's fastest forward) -- compiles to 498 registers without scratch and runs 1288 / 1744 us:
+  // past 256 the compiler parks vector registers in accumulator registers and copies them back around every use.
+  // That design needs its register allocation done by hand.
   constexpr int QT = 1;
   const int rep = a.H / a.Hk;
   if (rep % 2 == 0) {
