@@ -15,6 +15,7 @@ extern "C" const char* bma_strerror(int code) {
     case BMA_EALIGN: return "pointer or stride not aligned";
     case BMA_ELAUNCH: return "kernel launch failed";
     case BMA_ELIMIT: return "size beyond kernel limit";
+    case BMA_ECOLL: return "collective library missing or failed";
     default: return "unknown error";
   }
 }

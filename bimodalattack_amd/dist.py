@@ -13,11 +13,12 @@ image then overwrite everybody's in ONE packed broadcast per step (``sync_state`
 cannot drift apart through last-bit differences in redundantly computed gradients.  With the
 loss all-gather that makes two collectives per step (early_stop adds a third, two floats).
 
-The C ABI has no collective entry point: SURVEY.md 8b sketched ``bma_allgather_f32(local,
-n_local, out, rank, world, comm)``, but the communicator belongs to the host framework --
-torch.distributed owns the RCCL communicator, its stream ordering and its error handling, and a
-second communicator inside libbma_hip.so would need its own bootstrap (unique-id exchange) for a
-<= 2 KiB payload.  The boundary for the exchange is therefore this module.
+The C ABI's collective, ``bma_allgather_f32(local, n_local, out, rank, world, comm, stream)``, takes
+the HOST's ``ncclComm_t`` and calls ``ncclAllGather`` of the RCCL instance already in the process: it is for hosts that
+created their communicator themselves (C, C++, Go).  This module does not go through it: torch.distributed owns the
+RCCL communicator of a PyTorch job, its stream ordering and its error handling, and does not hand the handle out; a
+second communicator inside libbma_hip.so would need its own bootstrap (unique-id exchange) for a <= 2 KiB payload.
+The boundary for the exchange under PyTorch is therefore this module.
 """
 
 from __future__ import annotations

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 102 /* 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 103 /* 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -40,7 +40,8 @@ enum {
   BMA_EDTYPE = -2,   /* unsupported dtype code */
   BMA_EALIGN = -3,   /* pointer / stride not aligned as the kernel requires */
   BMA_ELAUNCH = -4,  /* hipLaunchKernel reported an error */
-  BMA_ELIMIT = -5    /* size beyond what the kernel was built for */
+  BMA_ELIMIT = -5,   /* size beyond what the kernel was built for */
+  BMA_ECOLL = -6     /* bma_allgather_f32: no RCCL in the process, or RCCL reported an error */
 };
 
 int bma_version(void);
@@ -226,6 +227,15 @@ int bma_attn_merge_rows(const void* o1, const void* o2, const float* lse1, const
                         void* stream);
 int bma_gather_rows(const void* src, const int* idx, int64_t n_out, int64_t n_src, int64_t row_bytes,
                     void* out, void* stream);
+
+/* bma_allgather_f32 (the reference, bimodal_attack.py:1282-1299, scores every candidate on one GPU): the
+ *   collective of the sharded chunk loop -- every rank's n_local fp32 values (its candidates' losses, padded with
+ *   +inf to the common count) gathered into out[world][n_local] on every rank, in rank order, on `stream`.
+ *   `comm` is the host's ncclComm_t (RCCL), created by the host with ncclCommInitRank; this library calls
+ *   ncclAllGather of the RCCL instance already loaded into the process (it does not link one).  comm == NULL is
+ *   accepted for world == 1 only (out = local).  local may be out + rank*n_local (in place).  BMA_ECOLL when no RCCL
+ *   can be found or RCCL reports an error.  Device pointers, 4-byte aligned. */
+int bma_allgather_f32(const float* local, int64_t n_local, float* out, int rank, int world, void* comm, void* stream);
 
 /* bma_gemm_nt: y[M][N] = x[M][K] . w[N][K]^T for the SKINNY products of the batch-1 gradient pass (a1, :953-1028: every
  *   linear layer of the language model applied to a handful of rows): bf16 / f16 operands with K contiguous, fp32

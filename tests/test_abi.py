@@ -54,6 +54,12 @@ def test_argument_validation_launches_nothing():
     assert lib.bma_splice(segs, 1, None, 0, None, 0, 0, 8, 1, 1.0, None, None) == 0
     bad = (BmaSegment * 1)(BmaSegment(16, 4, 7))
     assert lib.bma_splice(bad, 1, None, 0, None, 2, 0, 8, 1, 1.0, 16, None) == -1
+    # the collective: validation only -- no communicator, no device
+    assert lib.bma_allgather_f32(None, -1, None, 0, 1, None, None) == -1
+    assert lib.bma_allgather_f32(None, 0, None, 1, 2, None, None) == 0                 # nothing to gather
+    assert lib.bma_allgather_f32(16, 4, 16, 2, 2, None, None) == -1                    # rank outside the world
+    assert lib.bma_allgather_f32(16, 4, 16, 0, 2, None, None) == -1                    # a world of two needs a communicator
+    assert lib.bma_allgather_f32(18, 4, 16, 0, 1, None, None) == -3                    # misaligned
     # round 3 entry points
     assert lib.bma_splice_rows(segs, 1, None, 0, None, 2, 0, 8, 1, 1.0, 16, 0, None, None) == 0        # no rows: nothing to do
     assert lib.bma_splice_rows(segs, 1, None, 0, None, 2, 0, 8, 1, 1.0, None, 5, 16, None) == -1       # no slot map

@@ -439,3 +439,48 @@ def test_gemm_nt_under_autograd_and_in_a_graph(monkeypatch):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ops.gemm_nt(xs, w)) and torch.equal(out2, ops.gemm_nt(out, wt))
+
+
+@pytest.mark.gpu
+def test_allgather_f32_world_of_one_through_rccl():
+    """bma_allgather_f32 against a one-rank RCCL communicator made with the RCCL instance torch loaded (the entry point
+    must find THAT instance, not link its own), in place and out of place, and without a communicator."""
+    import ctypes
+    import torch
+    from bimodalattack_amd import native
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    x = torch.randn(1000, device=dev)
+    out = torch.full((1000,), float("nan"), device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    assert native.lib.bma_allgather_f32(x.data_ptr(), 1000, out.data_ptr(), 0, 1, None, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, x)
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so"):
+        try:
+            rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", name))
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL next to torch")
+    class UniqueId(ctypes.Structure):                              # ncclUniqueId: 128 opaque bytes, passed BY VALUE
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        out.fill_(float("nan"))
+        assert native.lib.bma_allgather_f32(x.data_ptr(), 1000, out.data_ptr(), 0, 1, comm, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out, x)
+        y = x.clone()                                                # in place: local = out + rank * n_local
+        assert native.lib.bma_allgather_f32(y.data_ptr(), 1000, y.data_ptr(), 0, 1, comm, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y, x)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
