@@ -896,6 +896,17 @@ int long_blocks_mode() {
   return mode;
 }
 
+// shortest max_len that takes the long-block kernel (BMA_RAGGED_LONG_MIN overrides, for experiments: with 16 every
+// ragged test passes through it, and the LLaVA row list / padded blocks take 335 / 261 us instead of 156 / 167 -- items
+// of three stages are all start and end)
+int long_min() {
+  static const int v = [] {
+    const char* e = getenv("BMA_RAGGED_LONG_MIN");
+    return e && *e ? atoi(e) : kLongMin;
+  }();
+  return v;
+}
+
 template <int DT, int DH, int REP, int QT, int TW>
 int launch_long_cfg(Args b, int max_len, hipStream_t st) {
   constexpr int QB = 16 * QT * TW;
@@ -960,7 +971,7 @@ int launch_dh(const Args& a, int max_len, hipStream_t st) {
     // (its row lookups multiply a row index by a 32-bit row stride in bytes)
     const bool strides32 = a.k_rs < (1 << 30) && a.v_rs < (1 << 30) && a.pk_rs < (1 << 30) && a.pv_rs < (1 << 30) &&
                            a.k_rs >= 0 && a.v_rs >= 0 && a.pk_rs >= 0 && a.pv_rs >= 0;
-    if (max_len >= kLongMin && a.scale_log2e > 0.0f && strides32 && long_blocks_mode() != 0) return launch_long<DT, DH>(a, max_len, st);
+    if (max_len >= long_min() && a.scale_log2e > 0.0f && strides32 && long_blocks_mode() != 0) return launch_long<DT, DH>(a, max_len, st);
   }
   const int qt = max_len >= 64 ? 4 : (max_len + 15) / 16;
   Args b = a;
