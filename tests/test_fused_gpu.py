@@ -657,3 +657,46 @@ def test_gradient_pass_fused_equals_eager_gradient():
 
     ge, gf = grad(False), grad(True)
     assert float((ge - gf).abs().max()) <= 1e-4 * float(ge.abs().max())
+
+
+def test_block_attention_at_gemma_size_properties():
+    """The long-block attention kernel at BASELINE configs[4]'s full size (164 padded candidates of 303 tokens behind a
+    20-key prefix, 8 query heads on 4 key/value heads, 256 wide) through size-independent properties: causality bit for
+    bit, linearity in the values, and three whole blocks against fp32 attention over the concatenated sequence."""
+    from bimodalattack_amd import ops
+    B, L, P, H, Hk, Dh = 164, 303, 20, 8, 4, 256
+    dt = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(7)
+    q = torch.randn((1, B * L, H, Dh), generator=g, device=DEV).to(dt).transpose(1, 2)
+    k, v, v2 = (torch.randn((1, B * L, Hk, Dh), generator=g, device=DEV).to(dt).transpose(1, 2) for _ in range(3))
+    pk, pv = (torch.randn((1, P, Hk, Dh), generator=g, device=DEV).to(dt).transpose(1, 2) for _ in range(2))
+    cs = torch.arange(B, dtype=torch.int32, device=DEV) * L
+    cf = torch.zeros(B, dtype=torch.int32, device=DEV)
+    cl = torch.full((B,), L, dtype=torch.int32, device=DEV)
+    scale = Dh ** -0.5
+    run = lambda kk, vv, pvv=pv: ops.ragged_attention(q, kk, vv, pk, pvv, cs, cf, cl, L, scale).view(B, L, H, Dh)
+    out = run(k, v)
+    assert torch.isfinite(out.float()).all()
+    # causality: keys and values behind position j do not touch the queries up to j -- not in the last bit
+    j = 200
+    k2, vv2 = k.clone(), v.clone()
+    k2.view(1, Hk, B, L, Dh)[:, :, :, j + 1:] = torch.randn((1, Hk, B, L - j - 1, Dh), generator=g, device=DEV).to(dt) * 3
+    vv2.view(1, Hk, B, L, Dh)[:, :, :, j + 1:] = torch.randn((1, Hk, B, L - j - 1, Dh), generator=g, device=DEV).to(dt) * 3
+    out2 = run(k2, vv2)
+    assert torch.equal(out[:, :j + 1], out2[:, :j + 1]) and not torch.equal(out[:, j + 1:], out2[:, j + 1:])
+    # linearity in the values (the weights depend on q and k only): attn(v) + attn(v2) = attn(v + v2) up to bf16 rounding
+    pv2 = torch.randn((1, P, Hk, Dh), generator=g, device=DEV).to(dt).transpose(1, 2)
+    lhs = run(k, v).float() + run(k, v2, pv2).float()
+    rhs = run(k, (v.float() + v2.float()).to(dt), (pv.float() + pv2.float()).to(dt)).float()
+    assert float((lhs - rhs).abs().max()) < 6e-2 and float((lhs - rhs).abs().mean()) < 4e-3
+    # three whole blocks against fp32 attention over [prefix | block]
+    rep = H // Hk
+    for b in (0, 77, B - 1):
+        qb = q[0, :, b * L:(b + 1) * L].float()                                        # (H,L,Dh)
+        kb = torch.cat([pk[0], k[0, :, b * L:(b + 1) * L]], dim=1).float().repeat_interleave(rep, dim=0)
+        vb = torch.cat([pv[0], v[0, :, b * L:(b + 1) * L]], dim=1).float().repeat_interleave(rep, dim=0)
+        mask = torch.ones((L, P + L), dtype=torch.bool, device=DEV)
+        mask[:, P:] = torch.tril(torch.ones((L, L), dtype=torch.bool, device=DEV))
+        s_ = (qb @ kb.transpose(-1, -2)) * scale
+        want = (torch.softmax(s_.masked_fill(~mask, float("-inf")), -1) @ vb).transpose(0, 1)    # (L,H,Dh)
+        assert float((out[b].float() - want).abs().max()) < 2e-2
