@@ -700,3 +700,77 @@ def test_block_attention_at_gemma_size_properties():
         s_ = (qb @ kb.transpose(-1, -2)) * scale
         want = (torch.softmax(s_.masked_fill(~mask, float("-inf")), -1) @ vb).transpose(0, 1)    # (L,H,Dh)
         assert float((out[b].float() - want).abs().max()) < 2e-2
+
+
+def test_prefix_attention_at_joint_size_properties():
+    """bma_prefix_attention at BASELINE configs[3]'s full size (17152 scoring rows against the 599 shared prefix keys,
+    32 heads of 128): a row's result does not depend on which other rows are in the launch (bit for bit), linearity
+    in the values, the LSE does not depend on the values, and 256 rows against fp32 attention."""
+    from bimodalattack_amd import ops
+    N, P, H, Dh = 17152, 599, 32, 128
+    dt = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q = torch.randn((1, N, H, Dh), generator=g, device=DEV).to(dt).transpose(1, 2)
+    pk, pv, pv2 = (torch.randn((1, P, H, Dh), generator=g, device=DEV).to(dt).transpose(1, 2) for _ in range(3))
+    scale = Dh ** -0.5
+    o, lse = ops.prefix_attention(q, pk, pv, scale)
+    assert o.shape == (N, H, Dh) and torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    lo, hi = 3001, 4500                                                        # off the 128-row workgroup grid
+    o_s, lse_s = ops.prefix_attention(q[:, :, lo:hi], pk, pv, scale)
+    assert torch.equal(o_s, o[lo:hi]) and torch.equal(lse_s, lse[:, lo:hi])
+    o2, lse2 = ops.prefix_attention(q, pk, pv2, scale)
+    o12, lse12 = ops.prefix_attention(q, pk, (pv.float() + pv2.float()).to(dt), scale)
+    assert torch.equal(lse, lse2) and torch.equal(lse, lse12)
+    d = (o.float() + o2.float() - o12.float()).abs()
+    assert float(d.max()) < 3e-2 and float(d.mean()) < 2e-3
+    rows = torch.randperm(N, generator=torch.Generator().manual_seed(3))[:256].to(DEV)
+    s_ = (q[0, :, rows].float() @ pk[0].float().transpose(-1, -2)) * scale                      # (H,256,P)
+    want = (torch.softmax(s_, -1) @ pv[0].float()).transpose(0, 1)
+    assert float((o[rows].float() - want).abs().max()) < 2e-2
+    np.testing.assert_allclose(lse[:, rows].cpu().numpy(), torch.logsumexp(s_, -1).cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_ragged_attention_at_c3_size_properties():
+    """bma_ragged_attention on the ragged row list of BASELINE configs[2] at full size (512 sampled candidates of a
+    19-token suffix, 44-token blocks behind 21 shared prefix keys, 32 heads of 128): linearity in the values, changes
+    to one candidate's own rows touch that candidate only (bit for bit), and five candidates against fp32 loops."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.layout import ragged_plan
+    m, n_opt, L, T, P, H, Dh = 512, 19, 44, 20, 21, 32, 128
+    dt = torch.bfloat16
+    rng = np.random.default_rng(0)
+    parent = rng.integers(0, 32000, n_opt)
+    cand = np.tile(parent, (m, 1))
+    cand[np.arange(m), rng.integers(0, n_opt, m)] = rng.integers(0, 256, m) + 40000
+    plan = ragged_plan(cand, parent, L, T, P)
+    N = plan["N"]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q, k, v, v2 = (torch.randn((N, H, Dh), generator=g, device=DEV).to(dt) for _ in range(4))
+    pk, pv, pv2 = (torch.randn((P, H, Dh), generator=g, device=DEV).to(dt) for _ in range(3))
+    as4 = lambda t: t.unsqueeze(0).transpose(1, 2)
+    cs, cf, cl = (torch.from_numpy(plan[n]).to(DEV) for n in ("cstart", "cfirst", "clen"))
+    scale = Dh ** -0.5
+    run = lambda kk, vv, pvv: ops.ragged_attention(as4(q), as4(kk), as4(vv), as4(pk), as4(pvv), cs, cf, cl, L, scale)
+    out = run(k, v, pv)
+    assert out.shape == (N, H, Dh) and torch.isfinite(out.float()).all()
+    lhs = out.float() + run(k, v2, pv2).float()
+    rhs = run(k, (v.float() + v2.float()).to(dt), (pv.float() + pv2.float()).to(dt)).float()
+    assert float((lhs - rhs).abs().max()) < 6e-2 and float((lhs - rhs).abs().mean()) < 4e-3
+    # one candidate's own rows (not the parent's: those are everybody's keys) changed: only its outputs move
+    starts, lens = plan["cstart"].tolist(), plan["clen"].tolist()
+    victim = next(i for i in range(len(starts) - 1, -1, -1) if starts[i] >= int(plan["cfirst"].max()))   # its rows are nobody's parent rows
+    a0, a1 = starts[victim], starts[victim] + lens[victim]
+    k2, vv2 = k.clone(), v.clone()
+    k2[a0:a1] = torch.randn((a1 - a0, H, Dh), generator=g, device=DEV).to(dt)
+    vv2[a0:a1] = torch.randn((a1 - a0, H, Dh), generator=g, device=DEV).to(dt)
+    out2 = run(k2, vv2, pv)
+    keep = torch.ones(N, dtype=torch.bool, device=DEV)
+    keep[a0:a1] = False
+    assert torch.equal(out[keep], out2[keep]) and not torch.equal(out[a0:a1], out2[a0:a1])
+    pick = [0, 1, len(starts) // 2, len(starts) - 2, len(starts) - 1]
+    sub = dict(cstart=plan["cstart"][pick], cfirst=plan["cfirst"][pick], clen=plan["clen"][pick])
+    ref = _ragged_attention_reference(q.float().cpu(), k.float().cpu(), v.float().cpu(), pk.float().cpu(), pv.float().cpu(),
+                                      sub, P, scale)
+    for i in pick:
+        a, b = starts[i], starts[i] + lens[i]
+        assert float((out[a:b].float().cpu() - ref[a:b]).abs().max()) < 2e-2
