@@ -492,7 +492,10 @@ def test_add_rmsnorm_is_the_add_followed_by_the_norm(dtype, gemma):
     through the separate Functions, bit for bit as well (the fused backward rounds where the accumulation would)."""
     from bimodalattack_amd import ops
     g = torch.Generator(device=DEV).manual_seed(31)
-    for rows, D in ((65, 4096), (1000, 2560), (3, 128), (17, 8192 if dtype != torch.float32 else 4096)):
+    sizes = ((65, 4096), (1000, 2560), (3, 128), (17, 8192 if dtype != torch.float32 else 4096))
+    if dtype == torch.bfloat16:
+        sizes += ((17152, 4096),)                       # the C3 candidate forward's row list at full size
+    for rows, D in sizes:
         res = (torch.randn((1, rows, D), generator=g, device=DEV) * 3).to(dtype)
         h = (torch.randn((1, rows, D), generator=g, device=DEV) * 2).to(dtype)
         w = (torch.randn(D, generator=g, device=DEV) * 0.3 + (0.0 if gemma else 1.0)).to(dtype)
