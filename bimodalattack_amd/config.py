@@ -137,6 +137,9 @@ class EngineOptions:
     # every residual add of a decoder layer fused into the RMSNorm that follows it (also across the layer boundary) and
     # q/k rotary as one launch: see fused.py (_layer_forward); known llama- / gemma3-style layer structures only.
     fuse_add_norm: bool = True
+    # Gemma-3's per-head q_norm / k_norm inside the rotary launch of the no-grad scoring forward (bma_qknorm_rope2): one
+    # pass over q and k instead of two
+    fuse_qk_rope: bool = True
     # batch-1 gradient pass: products with at most 96 rows (16-bit, bias-free decoder projections and their input
     # gradients through the transposed copies) on the hand-written weight-streaming kernel bma_gemm_nt instead of the
     # library (process-wide switch: ops.SKINNY_GEMM).
@@ -240,6 +243,8 @@ class EngineOptions:
             opts.skinny_gemm = env["BMA_SKINNY_GEMM"] not in ("0", "false", "False")
         if "BMA_FUSE_ADD_NORM" in env:
             opts.fuse_add_norm = env["BMA_FUSE_ADD_NORM"] not in ("0", "false", "False")
+        if "BMA_FUSE_QK_ROPE" in env:
+            opts.fuse_qk_rope = env["BMA_FUSE_QK_ROPE"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:
             opts.backward_weight_copies = env["BMA_BACKWARD_WEIGHT_COPIES"] not in ("0", "false", "False")
         if "BMA_SHARED_PREFIX_ATTENTION" in env:

@@ -308,11 +308,16 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
 // instruction loads/stores 1 KiB of contiguous memory when heads are adjacent (a projection
 // output), and the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
 // Requires cph = Dh*es/16 to be a power of two <= 64 (Dh = 64..512 for 16-bit dtypes).
-template <int DT>
+// NORM: the per-head RMSNorm of Gemma-3's q_norm / k_norm (weight `nw` [Dh], `neps`, `ngemma` = the (1 + w) form) is
+// applied to the head vector first, with rmsnorm_short_kernel's arithmetic -- the lane's eight squares, then the xor
+// shuffles over the head's lanes, the normalised value rounded to the model dtype -- so the result is, bit for bit, that
+// kernel followed by the rotation, in one pass over q and k instead of two.
+template <int DT, bool NORM = false>
 __device__ __forceinline__ void rope_row(const void* q, int64_t sb, int64_t sh, int64_t sl, void* dst,
                                          int64_t db, int64_t dh, int64_t dl, int B, int H, int L, int Dh,
                                          const void* __restrict__ cosp, const void* __restrict__ sinp,
-                                         int cos_batch, int cph_log2, float sin_sign) {
+                                         int cos_batch, int cph_log2, float sin_sign,
+                                         const void* __restrict__ nw = nullptr, float neps = 0.0f, int ngemma = 0) {
   constexpr int NE = Chunk<DT>::NE;
   constexpr int ES = bma::elem_bytes<DT>::value;
   const int cph = 1 << cph_log2;               // chunks per head vector
@@ -332,7 +337,23 @@ __device__ __forceinline__ void rope_row(const void* q, int64_t sb, int64_t sh, 
     const uint4_t* px = reinterpret_cast<const uint4_t*>(qrow + static_cast<int64_t>(h) * sh * ES) + c;
     uint4_t* pd = reinterpret_cast<uint4_t*>(drow + static_cast<int64_t>(h) * dh * ES) + c;
     const uint4_t cw = crow[c], sw = srow[c];
-    const uint4_t xw = *px;
+    uint4_t xw = *px;
+    if (NORM) {
+      float v[NE], wf[NE], o[NE];
+      Chunk<DT>::unpack(xw, v);
+      float ss = 0.0f;
+#pragma unroll
+      for (int j = 0; j < NE; ++j) ss += v[j] * v[j];
+      for (int o_ = half; o_ > 0; o_ >>= 1) ss += __shfl_xor(ss, o_, BMA_WAVE);
+      const float rstd = 1.0f / sqrtf(ss / static_cast<float>(Dh) + neps);
+      Chunk<DT>::unpack(reinterpret_cast<const uint4_t*>(nw)[c], wf);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        if (ngemma) o[j] = v[j] * rstd * (1.0f + wf[j]);
+        else o[j] = wf[j] * rnd<DT>(v[j] * rstd);
+      }
+      xw = Chunk<DT>::pack(o);
+    }
     uint4_t pw;                                 // the partner half's chunk
     pw.x = __shfl_xor(xw.x, half, BMA_WAVE);
     pw.y = __shfl_xor(xw.y, half, BMA_WAVE);
@@ -374,6 +395,16 @@ __global__ __launch_bounds__(256) void rope2_kernel(RopeTensor tq, RopeTensor tk
                                                     int cos_batch, int cph_log2, float sin_sign) {
   const RopeTensor& t = blockIdx.y ? tk : tq;
   rope_row<DT>(t.src, t.sb, t.sh, t.sl, t.dst, t.db, t.dh, t.dl, B, t.H, L, Dh, cosp, sinp, cos_batch, cph_log2, sin_sign);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void qknorm_rope2_kernel(RopeTensor tq, RopeTensor tk, int B, int L, int Dh,
+                                                           const void* __restrict__ cosp, const void* __restrict__ sinp,
+                                                           int cos_batch, int cph_log2, const void* __restrict__ wq,
+                                                           const void* __restrict__ wk, float eps, int gemma) {
+  const RopeTensor& t = blockIdx.y ? tk : tq;
+  rope_row<DT, true>(t.src, t.sb, t.sh, t.sl, t.dst, t.db, t.dh, t.dl, B, t.H, L, Dh, cosp, sinp, cos_batch, cph_log2, 1.0f,
+                     blockIdx.y ? wk : wq, eps, gemma);
 }
 
 template <int DT>
@@ -621,6 +652,47 @@ extern "C" int bma_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, v
   else if (dtype == BMA_BF16) BMA_ROPE2_GO(BMA_BF16);
   else BMA_ROPE2_GO(BMA_F16);
 #undef BMA_ROPE2_GO
+  BMA_PROF_END(BMA_K_ROPE, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+extern "C" int bma_qknorm_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, void* qd, int64_t qd_b, int64_t qd_h,
+                                int64_t qd_l, int Hq, const void* k, int64_t k_b, int64_t k_h, int64_t k_l, void* kd,
+                                int64_t kd_b, int64_t kd_h, int64_t kd_l, int Hk, int B, int L, int Dh, const void* wq,
+                                const void* wk, float eps, int gemma, const void* cos, const void* sin, int cos_batch,
+                                int dtype, void* stream) {
+  if (B < 0 || Hq <= 0 || Hk <= 0 || L < 0 || Dh <= 0 || (cos_batch != 1 && cos_batch != B)) return BMA_EINVAL;
+  if (B == 0 || L == 0) return BMA_OK;
+  if (!q || !qd || !k || !kd || !cos || !sin || !wq || !wk) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  const int ne = 16 / es;
+  if (Dh % (2 * ne)) return BMA_EALIGN;
+  const int cph_host = Dh / ne;
+  if (cph_host > 64 || (cph_host & (cph_host - 1))) return BMA_ELIMIT;   // a head's chunks: one aligned group of lanes
+  const int64_t strides[12] = {q_b, q_h, q_l, qd_b, qd_h, qd_l, k_b, k_h, k_l, kd_b, kd_h, kd_l};
+  for (int i = 0; i < 12; ++i)
+    if ((strides[i] * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(qd) | reinterpret_cast<uintptr_t>(k) |
+       reinterpret_cast<uintptr_t>(kd) | reinterpret_cast<uintptr_t>(cos) | reinterpret_cast<uintptr_t>(sin) |
+       reinterpret_cast<uintptr_t>(wq) | reinterpret_cast<uintptr_t>(wk)) % 16)
+    return BMA_EALIGN;
+  int cph_log2 = 0;
+  while ((1 << cph_log2) < cph_host) ++cph_log2;
+  const int64_t rows = static_cast<int64_t>(B) * L;
+  if (rows > 0x7fffffffLL) return BMA_ELIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(rows), 2), block(256);
+  const RopeTensor tq{q, qd, q_b, q_h, q_l, qd_b, qd_h, qd_l, Hq};
+  const RopeTensor tk{k, kd, k_b, k_h, k_l, kd_b, kd_h, kd_l, Hk};
+  BMA_PROF_BEGIN(BMA_K_ROPE, st, 2.0 * static_cast<double>(B) * (Hq + Hk) * L * Dh * es);
+#define BMA_QKR_GO(DT_) \
+  hipLaunchKernelGGL((qknorm_rope2_kernel<DT_>), grid, block, 0, st, tq, tk, B, L, Dh, cos, sin, cos_batch, cph_log2, wq, wk, eps, gemma)
+  if (dtype == BMA_F32) BMA_QKR_GO(BMA_F32);
+  else if (dtype == BMA_BF16) BMA_QKR_GO(BMA_BF16);
+  else BMA_QKR_GO(BMA_F16);
+#undef BMA_QKR_GO
   BMA_PROF_END(BMA_K_ROPE, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;

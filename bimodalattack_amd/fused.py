@@ -173,14 +173,37 @@ class _TPReduce(torch.autograd.Function):
         return g, None
 
 
+_NORM_ROPE_LINES = ("query_states = self.q_norm(query_states)", "key_states = self.k_norm(key_states)",
+                    "query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)")
+
+
+def _norms_then_rope(attn) -> bool:
+    """Does the attention block's forward apply q_norm, k_norm and the rotary embedding back to back, in that order,
+    with nothing in between (read from its source)?  Only then may the two norms be deferred into the rotary launch."""
+    import inspect
+    try:
+        lines = [ln.strip() for ln in inspect.getsource(type(attn).forward).splitlines() if ln.strip()]
+    except (OSError, TypeError):
+        return False
+    try:
+        i = lines.index(_NORM_ROPE_LINES[0])
+    except ValueError:
+        return False
+    rest = [ln for ln in lines[i:i + 6] if not ln.startswith("#") and ln != "cos, sin = position_embeddings"]
+    return tuple(rest[:3]) == _NORM_ROPE_LINES
+
+
 _TP_COLUMN = ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")
 _TP_ROW = ("o_proj", "down_proj")
 
 
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
-                 fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True):
+                 fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True, fuse_qk_rope: bool = True):
         self.enabled = enabled
+        self.fuse_qk_rope = fuse_qk_rope
+        self._rope_norms = {}                        # id(q_norm / k_norm module) of attention blocks whose forward rotates right behind them
+        self._pending = {}                           # id(tensor) -> (tensor, weight, eps, gemma): a head norm deferred into the rotary launch
         self.weight_copies = weight_copies
         self.fuse_gate_up = fuse_gate_up
         self.fuse_add_norm = fuse_add_norm
@@ -217,6 +240,9 @@ class FusedInference:
                     and m.q_proj.weight.dtype in (torch.bfloat16, torch.float16) \
                     and not hasattr(m, "q_norm"):      # per-head norms (Gemma-3) want dense projection outputs
                 self.qkv.append(m)
+            if fuse_qk_rope and hasattr(m, "q_norm") and hasattr(m, "k_norm") and _norms_then_rope(m):
+                self._rope_norms[id(m.q_norm)] = m.q_norm
+                self._rope_norms[id(m.k_norm)] = m.k_norm
             if hasattr(m, "q_proj") or hasattr(m, "gate_proj"):
                 for name in _TP_COLUMN + _TP_ROW:
                     lin = getattr(m, name, None)
@@ -281,6 +307,12 @@ class FusedInference:
                     or m.weight.dtype != x.dtype:
                 return orig(x)
             if x.dim() == 4 and not x.is_contiguous() and x.transpose(1, 2).is_contiguous():
+                if id(m) in self._rope_norms and not self._tracking(x) and ops.qknorm_rope_ok(x):
+                    # Gemma-3's q_norm / k_norm in the no-grad scoring forward: the rotation is the very next thing the
+                    # attention block does with this tensor (checked from its source), so the norm rides in the rotary
+                    # launch (bma_qknorm_rope2) -- x goes back as it is, with a note for apply_rotary_pos_emb
+                    self._pending[id(x)] = (x, m.weight, eps, gemma)
+                    return x
                 # per-head q/k norm on a (B,H,L,Dh) VIEW of the projection's (B,L,H,Dh) output: rows
                 # are rows in either order, so normalise in place of layout instead of copying
                 return forward(x.transpose(1, 2)).transpose(1, 2)
@@ -504,6 +536,9 @@ class FusedInference:
             if tp is not None:
                 h = _TPCopy.apply(h, tp[2])          # replicated input of the column-parallel q/k/v
             h, _ = layer.self_attn(hidden_states=h, **kwargs)
+            if self._pending:
+                self._pending.clear()
+                raise RuntimeError("bimodalattack_amd.fused: a deferred q/k norm was not picked up by the rotary embedding")
             if gem:
                 residual, h = self._add_norm(residual, h, layer.pre_feedforward_layernorm, pre=layer.post_attention_layernorm)
             else:
@@ -520,6 +555,19 @@ class FusedInference:
 
     def _rope(self, orig):
         def apply_rotary_pos_emb(q, k, cos, sin, *args, unsqueeze_dim=1, **kw):
+            pq, pk = self._pending.pop(id(q), None), self._pending.pop(id(k), None)
+            if pq is not None or pk is not None:
+                fused_ok = (pq is not None and pk is not None and pq[0] is q and pk[0] is k and pq[2:] == pk[2:]
+                            and not args and not kw and unsqueeze_dim == 1 and cos.dim() == 3 and cos.dtype == q.dtype
+                            and cos.shape[-1] == q.shape[-1] and q.shape[0] == k.shape[0] and q.shape[2:] == k.shape[2:]
+                            and not (cos.requires_grad or sin.requires_grad))
+                if fused_ok:
+                    return ops.qknorm_rope2(q, k, pq[1], pk[1], pq[2], pq[3], cos, sin, inplace=True)
+                # not the shapes the fused launch takes after all: the deferred norms now, then the usual route
+                if pq is not None:
+                    q = ops.rmsnorm(q.transpose(1, 2), pq[1], pq[2], pq[3]).transpose(1, 2)
+                if pk is not None:
+                    k = ops.rmsnorm(k.transpose(1, 2), pk[1], pk[2], pk[3]).transpose(1, 2)
             ok = (self._usable(q) and not args and not kw and unsqueeze_dim == 1 and q.dim() == 4 and k.dim() == 4
                   and cos.dim() == 3 and cos.dtype == q.dtype and k.dtype == q.dtype and q.stride(3) == 1
                   and k.stride(3) == 1 and cos.shape[-1] == q.shape[-1]
@@ -588,4 +636,8 @@ class FusedInference:
         for mod, fn in self._saved_rope.items():
             mod.apply_rotary_pos_emb = fn
         self._saved_rope.clear()
+        if self._pending:                          # (not when an exception is already on its way out)
+            self._pending.clear()
+            if exc[0] is None:
+                raise RuntimeError("bimodalattack_amd.fused: a deferred q/k norm was not picked up by the rotary embedding")
         return False

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 103
+ABI_VERSION = 104
 
 
 class BmaSegment(Structure):
@@ -63,6 +63,9 @@ PROTOTYPES = {
     "bma_rope2": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
                           c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
                           c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "bma_qknorm_rope2": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                 c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                 c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "bma_rmsnorm": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bma_swiglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bma_gated_act": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),

@@ -440,6 +440,44 @@ def rope2(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor
     return qo, ko
 
 
+def qknorm_rope_ok(x: torch.Tensor) -> bool:
+    """Can bma_qknorm_rope2 take this (B,H,L,Dh) view?  A head's 16-byte chunks must be one aligned group of at most 64
+    lanes (Dh * es / 16 a power of two), every stride a multiple of 16 bytes."""
+    es = x.element_size()
+    c = x.shape[-1] * es // 16
+    return (x.is_cuda and x.dim() == 4 and x.stride(3) == 1 and (x.shape[-1] * es) % 32 == 0 and 0 < c <= 64 and (c & (c - 1)) == 0
+            and all((st * es) % 16 == 0 for st in x.stride()[:3]) and x.data_ptr() % 16 == 0)
+
+
+def qknorm_rope2(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: float, gemma: bool,
+                 cos: torch.Tensor, sin: torch.Tensor, inplace: bool = False):
+    """Per-head RMSNorm of q (B,H,L,Dh) and k (B,Hk,L,Dh) -- weights wq / wk (Dh,) -- and their rotary embedding in ONE
+    launch (bma_qknorm_rope2): bit for bit `rmsnorm` on the head rows followed by `rope2`.  No autograd form."""
+    dev = _need_gpu(q, k, cos, sin, wq, wk)
+    if q.dim() != 4 or k.dim() != 4 or q.stride(3) != 1 or k.stride(3) != 1 or cos.shape != sin.shape or cos.dim() != 3:
+        raise ValueError("q/k must be (B,heads,L,Dh) with a contiguous last dim; cos/sin (1|B,L,Dh)")
+    B, H, L, Dh = q.shape
+    Hk = k.shape[1]
+    if k.shape != (B, Hk, L, Dh) or k.dtype != q.dtype or cos.shape[1] != L or cos.shape[2] != Dh \
+            or cos.shape[0] not in (1, B) or cos.dtype != q.dtype:
+        raise ValueError("k / cos / sin do not match q")
+    for w in (wq, wk):
+        if w.shape != (Dh,) or w.dtype != q.dtype or not w.is_contiguous():
+            raise ValueError("norm weights must be contiguous (Dh,) tensors of the q/k dtype")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    if inplace:
+        qo, ko = q, k
+    else:
+        qo = torch.empty((B, L, H, Dh), dtype=q.dtype, device=dev).transpose(1, 2)
+        ko = torch.empty((B, L, Hk, Dh), dtype=q.dtype, device=dev).transpose(1, 2)
+    check("bma_qknorm_rope2", lib.bma_qknorm_rope2(
+        q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), qo.data_ptr(), qo.stride(0), qo.stride(1), qo.stride(2), H,
+        k.data_ptr(), k.stride(0), k.stride(1), k.stride(2), ko.data_ptr(), ko.stride(0), ko.stride(1), ko.stride(2), Hk,
+        B, L, Dh, wq.data_ptr(), wk.data_ptr(), float(eps), 1 if gemma else 0, cos.data_ptr(), sin.data_ptr(), cos.shape[0],
+        _dt(q), _stream(dev)))
+    return qo, ko
+
+
 class RoPE2Fn(torch.autograd.Function):
     """q and k rotated by one launch; the backward is the inverse rotation of (dq, dk), one launch again."""
 

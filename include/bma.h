@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 103 /* 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 104 /* 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -197,6 +197,16 @@ int bma_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, void* qd, in
               int64_t qd_l, int Hq, const void* k, int64_t k_b, int64_t k_h, int64_t k_l, void* kd,
               int64_t kd_b, int64_t kd_h, int64_t kd_l, int Hk, int B, int L, int Dh, const void* cos,
               const void* sin, int cos_batch, float sin_sign, int dtype, void* stream);
+
+/* bma_qknorm_rope2: bma_rope2 with the per-head RMSNorm of q and k in front of the rotation (Gemma-3's q_norm / k_norm:
+ *   weights wq / wk [Dh] of `dtype`, `eps`, `gemma` != 0 for the (1 + w) form) in the same pass: bit for bit bma_rmsnorm
+ *   on the head rows followed by bma_rope2, one read and one write of q and k instead of two.  Forward rotation only
+ *   (the no-grad scoring forward); same layout rules as bma_rope2, Dh * es / 16 a power of two <= 64. */
+int bma_qknorm_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, void* qd, int64_t qd_b, int64_t qd_h,
+                     int64_t qd_l, int Hq, const void* k, int64_t k_b, int64_t k_h, int64_t k_l, void* kd,
+                     int64_t kd_b, int64_t kd_h, int64_t kd_l, int Hk, int B, int L, int Dh, const void* wq,
+                     const void* wk, float eps, int gemma, const void* cos, const void* sin, int cos_batch,
+                     int dtype, void* stream);
 /* Backward halves, used by the gradient pass (autograd at batch 1; weights are constants, so no
  * weight gradients): bma_rmsnorm_bwd: dx from x, weight, dy (D*es <= 16 KiB);
  * bma_swiglu_bwd: dgate, dup from gate, up, dy.  RoPE's backward is bma_rope_inplace with -sin. */

@@ -777,3 +777,60 @@ def test_ragged_attention_at_c3_size_properties():
     for i in pick:
         a, b = starts[i], starts[i] + lens[i]
         assert float((out[a:b].float().cpu() - ref[a:b]).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_qknorm_rope2_is_the_norm_followed_by_rope2(dtype):
+    """bma_qknorm_rope2 against the two launches it replaces -- the per-head RMSNorm of q and k (bma_rmsnorm on the head
+    rows), then bma_rope2 -- BIT for bit: Gemma-3's (1 + w) form and the plain one, grouped heads, the transposed views
+    of separate projections, in place and out of place."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(17)
+    for B, L, H, Hk, Dh in ((3, 303, 8, 4, 256), (1, 65, 4, 4, 128), (2, 7, 6, 2, 64)):
+        q = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2)
+        k = torch.randn((B, L, Hk, Dh), generator=g, device=DEV).to(dtype).transpose(1, 2)
+        wq, wk = ((torch.randn(Dh, generator=g, device=DEV) * 0.3).to(dtype) for _ in range(2))
+        ang = torch.randn((1, L, Dh // 2), generator=g, device=DEV)
+        cos, sin = torch.cat([ang.cos()] * 2, -1).to(dtype), torch.cat([ang.sin()] * 2, -1).to(dtype)
+        assert ops.qknorm_rope_ok(q) and ops.qknorm_rope_ok(k)
+        for gemma in (True, False):
+            qn = ops.rmsnorm(q.transpose(1, 2), wq, 1e-6, gemma).transpose(1, 2)
+            kn = ops.rmsnorm(k.transpose(1, 2), wk, 1e-6, gemma).transpose(1, 2)
+            want_q, want_k = ops.rope2(qn, kn, cos, sin)
+            got_q, got_k = ops.qknorm_rope2(q, k, wq, wk, 1e-6, gemma, cos, sin)
+            assert torch.equal(got_q, want_q) and torch.equal(got_k, want_k)
+            q2, k2 = q.clone(memory_format=torch.preserve_format), k.clone(memory_format=torch.preserve_format)
+            r = ops.qknorm_rope2(q2, k2, wq, wk, 1e-6, gemma, cos, sin, inplace=True)
+            assert r[0] is q2 and torch.equal(q2, want_q) and torch.equal(k2, want_k)
+
+
+def test_fused_context_defers_gemma_head_norms_into_the_rotation():
+    """A small Gemma-3 text model under the fused context with and without `fuse_qk_rope`: the same logits bit for bit
+    (the deferred q_norm / k_norm ride in bma_qknorm_rope2), nothing left pending, and with autograd the norms run on
+    their own as before."""
+    from transformers import Gemma3TextConfig
+    from transformers.models.gemma3.modeling_gemma3 import Gemma3ForCausalLM
+    from bimodalattack_amd.fused import FusedInference
+    torch.manual_seed(0)
+    cfg = Gemma3TextConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                           num_key_value_heads=2, head_dim=64, sliding_window=512, max_position_embeddings=512)
+    model = Gemma3ForCausalLM(cfg).to(DEV, torch.bfloat16).eval()
+    ids = torch.randint(0, 512, (3, 40), device=DEV)
+    on, off = FusedInference(model, fuse_qk_rope=True), FusedInference(model, fuse_qk_rope=False)
+    assert len(on._rope_norms) == 4 and not off._rope_norms
+    with torch.no_grad():
+        with on:
+            a = model(input_ids=ids).logits
+            assert not on._pending
+        with off:
+            b = model(input_ids=ids).logits
+    assert torch.equal(a, b)
+    emb = model.get_input_embeddings()(ids).detach().requires_grad_()
+    with on:
+        ya = model(inputs_embeds=emb).logits
+    (ga,) = torch.autograd.grad(ya.float().sum(), emb)
+    emb2 = emb.detach().clone().requires_grad_()
+    with off:
+        yb = model(inputs_embeds=emb2).logits
+    (gb,) = torch.autograd.grad(yb.float().sum(), emb2)
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)

@@ -98,6 +98,15 @@ def cases():
         cos, sin = ang.cos().to(bf), ang.sin().to(bf)
         return lambda: ops.rope2(q, k, cos, sin, inplace=True)
 
+    def qknorm_rope(B, L, H, Hk, Dh):
+        # Gemma-3 scoring: the per-head q/k norms inside the rotary launch, on the separate projections' outputs
+        q = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2)
+        k = torch.randn((B, L, Hk, Dh), generator=g, device=DEV).to(bf).transpose(1, 2)
+        wq, wk = (torch.randn(Dh, generator=g, device=DEV).to(bf) for _ in range(2))
+        ang = torch.rand((1, L, Dh), generator=g, device=DEV)
+        cos, sin = ang.cos().to(bf), ang.sin().to(bf)
+        return lambda: ops.qknorm_rope2(q, k, wq, wk, 1e-6, True, cos, sin, inplace=True)
+
     def merge(B, L, H, Dh):
         o1 = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf)
         o2 = torch.randn((B, L, H, Dh), generator=g, device=DEV).to(bf)
@@ -243,6 +252,7 @@ def cases():
         "sample_scatter/B512": ("sample_scatter", lambda: scatter(512)),
         # round 3: residual add + norm in one pass, the row list straight from the segments, the skinny weight-streaming product
         "rope/c3r_qk_N17152_H32_Dh128": ("rope", lambda: rope_qk(17152, 32, 32, 128)),
+        "rope/gemma_qknorm_B160_L303_H8_Hk4_Dh256": ("rope", lambda: qknorm_rope(160, 303, 8, 4, 256)),
         "add_rmsnorm/c3r_17152x4096": ("add_rmsnorm", lambda: add_rmsnorm(17152, 4096)),
         "add_rmsnorm/n8_2816x4096": ("add_rmsnorm", lambda: add_rmsnorm(2816, 4096)),
         "splice/c3r_rows_17152_D4096": ("splice", lambda: splice_rows(512, 19, 44, 20, 21, 4096)),

@@ -84,6 +84,7 @@ CASES = [
     ("rope/c3_B512_L44_H32_Dh128", "rope", "rope_kernel<1>/threads5767168", "B=512 L=44 H=32 Dh=128 bf16"),
     ("attn_merge/c4_B512_L45_H32_Dh128", "attn_merge", "attn_merge_kernel<1>/threads5898240", "B=512 L=45 H=32 Dh=128 bf16 (C4)"),
     ("rope/c3r_qk_N17152_H32_Dh128", "rope", "rope2_kernel<1>/threads4390912", "q and k of 17152 rows in one launch, H=32+32 Dh=128 bf16, strided views of the fused q/k/v output"),
+    ("rope/gemma_qknorm_B160_L303_H8_Hk4_Dh256", "rope", "qknorm_rope2_kernel<1>/threads12410880", "Gemma-3 chunk of 160 candidates x 303 tokens: per-head q/k norm + rotary of 8 + 4 heads x 256 in one launch"),
     ("add_rmsnorm/c3r_17152x4096", "add_rmsnorm", "add_rmsnorm_kernel<1, 2, false, false>/threads4390912", "17152 x 4096 bf16: residual add + RMSNorm in one pass (C3 ragged candidate forward)"),
     ("splice/c3r_rows_17152_D4096", "splice", "splice_rows_kernel<1>/threads4390912", "C3 ragged row list: 17152 rows of 8 KiB straight from the segments and the table"),
     ("gemm_nt/gate_up_dX_65x4096x22016", "gemm_nt", "gemm_nt_kernel<1, 6, 4, 4>/threads65536", "bma_gemm_nt 65 x 4096 x 22016 bf16 (input gradient of the fused gate/up product, 8-way split-K)"),
