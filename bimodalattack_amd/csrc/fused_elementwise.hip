@@ -308,6 +308,29 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
 // instruction loads/stores 1 KiB of contiguous memory when heads are adjacent (a projection
 // output), and the update is safely in place.  cos/sin: [cb][L][Dh], cb = 1 or B.
 // Requires cph = Dh*es/16 to be a power of two <= 64 (Dh = 64..512 for 16-bit dtypes).
+// Sum over the aligned group of `cph` lanes (a power of two <= 64) that hold one head: the xor butterfly of
+// rmsnorm_short_kernel -- partners cph/2, ..., 2, 1 lanes away, in that order, so the sum is the same fp32 number -- but
+// without the LDS crossbar: the 32- and 16-lane exchanges are gfx950's row swaps, and below 16 a ROTATION by 8, 4, 2, 1
+// inside the 16-lane row (one DPP add each) meets the same partner value, because after the step before it the partial
+// sums repeat with that period.  Five ds_bpermute round trips in a kernel with one 16-byte load per lane were most of a
+// workgroup's life.
+__device__ __forceinline__ float head_sum(float ss, int cph) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  if (cph >= 64) {
+    const u32x2_t p = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+    ss = __uint_as_float(p.x) + __uint_as_float(p.y);
+  }
+  if (cph >= 32) {
+    const u32x2_t p = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+    ss = __uint_as_float(p.x) + __uint_as_float(p.y);
+  }
+  if (cph >= 16) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x128, 0xf, 0xf, false));   // row_ror:8
+  if (cph >= 8) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x124, 0xf, 0xf, false));    // row_ror:4
+  if (cph >= 4) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x122, 0xf, 0xf, false));    // row_ror:2
+  if (cph >= 2) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x121, 0xf, 0xf, false));    // row_ror:1
+  return ss;
+}
+
 // NORM: the per-head RMSNorm of Gemma-3's q_norm / k_norm (weight `nw` [Dh], `neps`, `ngemma` = the (1 + w) form) is
 // applied to the head vector first, with rmsnorm_short_kernel's arithmetic -- the lane's eight squares, then the xor
 // shuffles over the head's lanes, the normalised value rounded to the model dtype -- so the result is, bit for bit, that
@@ -344,7 +367,7 @@ __device__ __forceinline__ void rope_row(const void* q, int64_t sb, int64_t sh, 
       float ss = 0.0f;
 #pragma unroll
       for (int j = 0; j < NE; ++j) ss += v[j] * v[j];
-      for (int o_ = half; o_ > 0; o_ >>= 1) ss += __shfl_xor(ss, o_, BMA_WAVE);
+      ss = head_sum(ss, cph);
       const float rstd = 1.0f / sqrtf(ss / static_cast<float>(Dh) + neps);
       Chunk<DT>::unpack(reinterpret_cast<const uint4_t*>(nw)[c], wf);
 #pragma unroll
