@@ -312,10 +312,14 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
 // rmsnorm_short_kernel -- partners cph/2, ..., 2, 1 lanes away, in that order, so the sum is the same fp32 number -- but
 // without the LDS crossbar: the 32- and 16-lane exchanges are gfx950's row swaps, and below 16 a ROTATION by 8, 4, 2, 1
 // inside the 16-lane row (one DPP add each) meets the same partner value, because after the step before it the partial
-// sums repeat with that period.  Five ds_bpermute round trips in a kernel with one 16-byte load per lane were most of a
+// sums repeat with that period (heads of at least 16 lanes; narrower ones keep the shuffles).  Five ds_bpermute round trips in a kernel with one 16-byte load per lane were most of a
 // workgroup's life.
 __device__ __forceinline__ float head_sum(float ss, int cph) {
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  if (cph < 16) {                               // (a head narrower than a 16-lane row: the rotations would reach into its neighbour)
+    for (int o = cph >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, BMA_WAVE);
+    return ss;
+  }
   if (cph >= 64) {
     const u32x2_t p = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
     ss = __uint_as_float(p.x) + __uint_as_float(p.y);
@@ -324,10 +328,10 @@ __device__ __forceinline__ float head_sum(float ss, int cph) {
     const u32x2_t p = __builtin_amdgcn_permlane16_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
     ss = __uint_as_float(p.x) + __uint_as_float(p.y);
   }
-  if (cph >= 16) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x128, 0xf, 0xf, false));   // row_ror:8
-  if (cph >= 8) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x124, 0xf, 0xf, false));    // row_ror:4
-  if (cph >= 4) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x122, 0xf, 0xf, false));    // row_ror:2
-  if (cph >= 2) ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x121, 0xf, 0xf, false));    // row_ror:1
+  ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x128, 0xf, 0xf, false));   // row_ror:8
+  ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x124, 0xf, 0xf, false));   // row_ror:4
+  ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x122, 0xf, 0xf, false));   // row_ror:2
+  ss += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ss), 0x121, 0xf, 0xf, false));   // row_ror:1
   return ss;
 }
 
