@@ -131,6 +131,9 @@ class EngineOptions:
     # vision towers whose head width is not a multiple of 32 (SigLIP: 72): zero-pad q/k/v to a width the library's
     # attention kernels are built for (prefix_attention.padded_heads_attention); same attention, faster kernels
     pad_vision_heads: bool = True
+    # CLIP's QuickGELU (x * sigmoid(1.702 x): three launches forward, five backward on a launch-bound tower) as one
+    # launch each way, bit-identical (bma_quick_gelu)
+    fuse_quick_gelu: bool = True
     # gate_proj / up_proj of a gated MLP as one GEMM against their chunk-interleaved weights (16-bit models; one
     # more copy of those two matrices, two in the gradient pass): see fused.py.
     fuse_gate_up: bool = True
@@ -235,6 +238,8 @@ class EngineOptions:
             opts.threaded_filter = env["BMA_THREADED_FILTER"] not in ("0", "false", "False")
         if "BMA_PAD_VISION_HEADS" in env:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
+        if "BMA_FUSE_QUICK_GELU" in env:
+            opts.fuse_quick_gelu = env["BMA_FUSE_QUICK_GELU"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
         if "BMA_TP_GRADIENT" in env:

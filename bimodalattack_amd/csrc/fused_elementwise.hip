@@ -300,6 +300,72 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4_t* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------- QuickGELU (CLIP's MLP)
+// y = x * sigmoid(1.702 x) as HuggingFace's QuickGELUActivation evaluates it on a 16-bit tensor -- three aten kernels,
+// each rounding to the tensor dtype: t = rnd(1.702 x), s = rnd(sigmoid(t)), y = rnd(x s) -- and the five kernels of its
+// autograd backward -- dy s, dy x, sigmoid_backward, the scalar product, the accumulation -- in one launch each, with
+// the roundings where aten has them (bit-identical; tests/test_fused_gpu.py).
+#define BMA_SIGMOID(x) (1.0f / (1.0f + expf(-(x))))   // accurate exp + IEEE division, as aten's sigmoid kernel
+template <int DT, bool BWD>
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const uint4_t* __restrict__ x, const uint4_t* __restrict__ dy,
+                                                         int64_t n_chunks, uint4_t* __restrict__ out) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * (kSwiChunks * 256) + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < kSwiChunks; ++j) {
+    const int64_t i = base + j * 256;
+    if (i >= n_chunks) continue;
+    float xf[NE], gf[NE], o[NE];
+    Chunk<DT>::unpack(x[i], xf);
+    if (BWD) Chunk<DT>::unpack(dy[i], gf);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const float t = rnd<DT>(1.702f * xf[e]);
+      const float sg = rnd<DT>(BMA_SIGMOID(t));
+      if (!BWD) {
+        o[e] = xf[e] * sg;
+      } else {
+        const float g1 = rnd<DT>(gf[e] * sg);                 // d/dx through the product's first factor
+        const float gs = rnd<DT>(gf[e] * xf[e]);              // gradient arriving at the sigmoid
+        // aten's sigmoid_backward, `a * (scalar_t(1) - b) * b`, is written on the TENSOR type: every operator rounds
+        const float gt = rnd<DT>(rnd<DT>(gs * rnd<DT>(1.0f - sg)) * sg);
+        const float g2 = rnd<DT>(gt * 1.702f);
+        o[e] = g1 + g2;
+      }
+    }
+    out[i] = Chunk<DT>::pack(o);
+  }
+}
+
+static int quick_gelu_launch(const void* x, const void* dy, bool bwd, int64_t n, int dtype, void* out, void* stream) {
+  if (n < 0) return BMA_EINVAL;
+  if (n == 0) return BMA_OK;
+  if (!x || (bwd && !dy) || !out) return BMA_EINVAL;
+  if (dtype != BMA_F32 && dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((n * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(out)) % 16) return BMA_EALIGN;
+  const int64_t chunks = n * es / 16;
+  const int64_t blocks = (chunks + kSwiChunks * 256 - 1) / (kSwiChunks * 256);
+  if (blocks > 0x7fffffffLL) return BMA_ELIMIT;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+  const uint4_t* xp = static_cast<const uint4_t*>(x);
+  const uint4_t* gp = static_cast<const uint4_t*>(dy);
+  uint4_t* yp = static_cast<uint4_t*>(out);
+#define BMA_QG_GO(DT_)                                                                                     \
+  do {                                                                                                     \
+    if (bwd) hipLaunchKernelGGL((quick_gelu_kernel<DT_, true>), grid, block, 0, st, xp, gp, chunks, yp);    \
+    else hipLaunchKernelGGL((quick_gelu_kernel<DT_, false>), grid, block, 0, st, xp, gp, chunks, yp);       \
+  } while (0)
+  if (dtype == BMA_F32) BMA_QG_GO(BMA_F32);
+  else if (dtype == BMA_BF16) BMA_QG_GO(BMA_BF16);
+  else BMA_QG_GO(BMA_F16);
+#undef BMA_QG_GO
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
 // ---------------------------------------------------------------------------- rope
 // q is addressed through strides (elements): element (b,h,l,d) at q + b*sb + h*sh + l*sl + d.
 // One lane owns ONE 16-byte chunk of a head vector; the chunk of the other half of the head
@@ -599,6 +665,14 @@ extern "C" int bma_gated_act(const void* gate, const void* up, int64_t n, int dt
 
 extern "C" int bma_gated_act_il(const void* gate_up, int64_t n, int dtype, int act, void* out, void* stream) {
   return gated_act_launch(gate_up, nullptr, true, n, dtype, act, out, stream);
+}
+
+extern "C" int bma_quick_gelu(const void* x, int64_t n, int dtype, void* out, void* stream) {
+  return quick_gelu_launch(x, nullptr, false, n, dtype, out, stream);
+}
+
+extern "C" int bma_quick_gelu_bwd(const void* x, const void* dy, int64_t n, int dtype, void* dx, void* stream) {
+  return quick_gelu_launch(x, dy, true, n, dtype, dx, stream);
 }
 
 extern "C" int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream) {

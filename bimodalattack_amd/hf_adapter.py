@@ -103,6 +103,8 @@ class HFAdapter:
         self.ragged_ok: Optional[bool] = None
         self.pad_vision_heads = True            # EngineOptions.pad_vision_heads, set by the attack object
         self._vision_cfgs = None
+        self.fuse_quick_gelu = True             # EngineOptions.fuse_quick_gelu: CLIP's MLP activation as one launch each way
+        self._quick_gelus = None
 
     # ------------------------------------------------------------ vision
     def vision_configs(self) -> list:
@@ -114,6 +116,46 @@ class HFAdapter:
             self._vision_cfgs = pa.vision_configs(self.model) if ok else []
         return self._vision_cfgs if self.pad_vision_heads else []
 
+    def quick_gelu_modules(self) -> list:
+        """The model's QuickGELUActivation modules (CLIP's MLPs) whose forward is, to the letter, the expression
+        bma_quick_gelu restates; [] on the CPU or with the option off."""
+        if self._quick_gelus is None:
+            import inspect
+            found = []
+            if self.device.type == "cuda":
+                for m in self.model.modules():
+                    if type(m).__name__ != "QuickGELUActivation":
+                        continue
+                    try:
+                        src = inspect.getsource(type(m).forward)
+                    except (OSError, TypeError):
+                        continue
+                    if "return input * torch.sigmoid(1.702 * input)" in src:
+                        found.append(m)
+            self._quick_gelus = found
+        return self._quick_gelus if self.fuse_quick_gelu else []
+
+    @contextlib.contextmanager
+    def _fused_activations(self):
+        """For one tower forward: QuickGELU as ONE launch (three aten kernels, and five more in their autograd backward,
+        on a launch-bound 577-token tower; bit-identical)."""
+        from . import ops
+        mods = self.quick_gelu_modules()
+
+        def forward(x):
+            if not ops.quick_gelu_ok(x):
+                return x * torch.sigmoid(1.702 * x)
+            if torch.is_grad_enabled() and x.requires_grad:
+                return ops.QuickGELUFn.apply(x)
+            return ops.quick_gelu(x)
+        try:
+            for m in mods:
+                m.forward = forward
+            yield
+        finally:
+            for m in mods:
+                m.__dict__.pop("forward", None)
+
     def image_features(self, image: torch.Tensor) -> torch.Tensor:
         px = self.normalize(image)
         cfgs = self.vision_configs()
@@ -122,7 +164,7 @@ class HFAdapter:
             ctx = pa.causal_b1(cfgs, pa.NAME_VIS)
         else:
             ctx = contextlib.nullcontext()
-        with ctx:
+        with ctx, self._fused_activations():
             if self.is_gemma_processor:
                 out = self.model.get_image_features(pixel_values=px)
             else:

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 104
+ABI_VERSION = 105
 
 
 class BmaSegment(Structure):
@@ -42,6 +42,8 @@ class BmaError(RuntimeError):
 PROTOTYPES = {
     "bma_version": (c_int, []),
     "bma_strerror": (c_char_p, [c_int]),
+    "bma_quick_gelu": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "bma_quick_gelu_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "bma_allgather_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "bma_linf_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
     "bma_ce_target_ws_bytes": (c_size_t, [c_int, c_int]),

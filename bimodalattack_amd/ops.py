@@ -440,6 +440,42 @@ def rope2(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor
     return qo, ko
 
 
+def quick_gelu_ok(x: torch.Tensor) -> bool:
+    # (not fp16: aten's half-precision sigmoid on this stack is up to 7 units in the last place off the correctly
+    # rounded value -- x = -2.93 gives 0.0067968 for 0.0067713 -- and the kernel does not imitate that; such tensors keep
+    # the eager chain)
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.is_contiguous()
+            and (x.numel() * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(1.702 x) in one launch, bit-identical to HuggingFace's QuickGELUActivation on the same tensor."""
+    dev = _need_gpu(x)
+    if not x.is_contiguous():
+        raise ValueError("quick_gelu needs a contiguous tensor")
+    out = torch.empty_like(x)
+    check("bma_quick_gelu", lib.bma_quick_gelu(x.data_ptr(), x.numel(), _dt(x), out.data_ptr(), _stream(dev)))
+    return out
+
+
+class QuickGELUFn(torch.autograd.Function):
+    """QuickGELU with its whole autograd backward in one launch (the sigmoid is recomputed from the input)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return quick_gelu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check("bma_quick_gelu_bwd", lib.bma_quick_gelu_bwd(x.data_ptr(), dy.data_ptr(), x.numel(), _dt(x), dx.data_ptr(),
+                                                             _stream(x.device)))
+        return dx
+
+
 def qknorm_rope_ok(x: torch.Tensor) -> bool:
     """Can bma_qknorm_rope2 take this (B,H,L,Dh) view?  A head's 16-byte chunks must be one aligned group of at most 64
     lanes (Dh * es / 16 a power of two), every stride a multiple of 16 bytes."""

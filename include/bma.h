@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 104 /* 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 105 /* 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -197,6 +197,15 @@ int bma_rope2(const void* q, int64_t q_b, int64_t q_h, int64_t q_l, void* qd, in
               int64_t qd_l, int Hq, const void* k, int64_t k_b, int64_t k_h, int64_t k_l, void* kd,
               int64_t kd_b, int64_t kd_h, int64_t kd_l, int Hk, int B, int L, int Dh, const void* cos,
               const void* sin, int cos_batch, float sin_sign, int dtype, void* stream);
+
+/* bma_quick_gelu / bma_quick_gelu_bwd: CLIP's MLP activation, y = x * sigmoid(1.702 x), on n contiguous elements as
+ *   HuggingFace's QuickGELUActivation evaluates it -- three aten kernels forward, five in its autograd backward, each
+ *   rounding to `dtype` -- in ONE launch each with the roundings where aten has them (bit-identical).  The backward
+ *   recomputes the sigmoid from x: dx = dy*s + 1.702 * (dy*x) * (1 - s) * s.  (bf16 and fp32 are bit-identical to
+ *   aten; fp16 is computed the same way, but aten's own fp16 sigmoid is not correctly rounded, so the host keeps fp16 eager.)  n * element size a multiple of 16,
+ *   16-byte aligned pointers; out may alias x (forward) or dy (backward). */
+int bma_quick_gelu(const void* x, int64_t n, int dtype, void* out, void* stream);
+int bma_quick_gelu_bwd(const void* x, const void* dy, int64_t n, int dtype, void* dx, void* stream);
 
 /* bma_qknorm_rope2: bma_rope2 with the per-head RMSNorm of q and k in front of the rotation (Gemma-3's q_norm / k_norm:
  *   weights wq / wk [Dh] of `dtype`, `eps`, `gemma` != 0 for the (1 + w) form) in the same pass: bit for bit bma_rmsnorm

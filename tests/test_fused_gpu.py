@@ -834,3 +834,34 @@ def test_fused_context_defers_gemma_head_norms_into_the_rotation():
         yb = model(inputs_embeds=emb2).logits
     (gb,) = torch.autograd.grad(yb.float().sum(), emb2)
     assert torch.equal(ya, yb) and torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_quick_gelu_is_the_eager_chain_bit_for_bit(dtype):
+    """bma_quick_gelu and its backward against HuggingFace's QuickGELUActivation under autograd -- three aten kernels
+    forward, five backward, each rounding to the dtype -- BIT for bit, at CLIP's MLP size and with extreme inputs."""
+    from transformers.activations import QuickGELUActivation
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(21)
+    act = QuickGELUActivation()
+    for shape, scale in (((1, 577, 4096), 3.0), ((3, 8), 1.0), ((2, 577, 4096), 40.0)):
+        x = (torch.randn(shape, generator=g, device=DEV) * scale).to(dtype)
+        if x.numel() >= 8:
+            x.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e4, -1e4, 88.0, -88.0, 1e-30, -3.0], device=DEV).to(dtype)
+        dy = torch.randn(shape, generator=g, device=DEV).to(dtype)
+        xa = x.clone().requires_grad_()
+        ya = act(xa)
+        (ga,) = torch.autograd.grad(ya, xa, dy)
+        xb = x.clone().requires_grad_()
+        yb = ops.QuickGELUFn.apply(xb)
+        (gb,) = torch.autograd.grad(yb, xb, dy)
+        same = lambda a, b: torch.equal(a.view(torch.int32 if dtype == torch.float32 else torch.int16),
+                                        b.view(torch.int32 if dtype == torch.float32 else torch.int16))
+        if dtype == torch.float32:
+            # fp32: aten rounds nothing in between, but its compiler may contract differently: a few ulp
+            np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), rtol=2e-6, atol=1e-30)
+            np.testing.assert_allclose(gb.cpu().numpy(), ga.cpu().numpy(), rtol=4e-6, atol=1e-30)
+        else:
+            assert same(yb.detach(), ya.detach()) and same(gb, ga)
+        assert torch.equal(ops.quick_gelu(x), yb.detach())
+    assert not ops.quick_gelu_ok(torch.zeros(8, device=DEV, dtype=torch.float16))      # fp16 keeps the eager chain
