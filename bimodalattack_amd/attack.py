@@ -149,6 +149,7 @@ class BimodalAttack:
         self.hf = HFAdapter(model, processor, normalize)
         self.hf.pad_vision_heads = bool(self.opt.pad_vision_heads)
         self.hf.fuse_quick_gelu = bool(self.opt.fuse_quick_gelu)
+        self.hf.fuse_tower_qkv = bool(self.opt.fuse_tower_qkv)
         self.embedding_layer = self.hf.embedding
         self.not_allowed_ids = None if config.allow_non_ascii else get_nonascii_toks(tokenizer, device=model.device)
         self.mask_bits = ops.build_mask_bits(self.not_allowed_ids, self.embedding_layer.num_embeddings, model.device)

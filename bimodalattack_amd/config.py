@@ -134,6 +134,8 @@ class EngineOptions:
     # CLIP's QuickGELU (x * sigmoid(1.702 x): three launches forward, five backward on a launch-bound tower) as one
     # launch each way, bit-identical (bma_quick_gelu)
     fuse_quick_gelu: bool = True
+    # the vision tower's q/k/v projections (with their biases) as one product, forward and input-gradient
+    fuse_tower_qkv: bool = True
     # gate_proj / up_proj of a gated MLP as one GEMM against their chunk-interleaved weights (16-bit models; one
     # more copy of those two matrices, two in the gradient pass): see fused.py.
     fuse_gate_up: bool = True
@@ -240,6 +242,8 @@ class EngineOptions:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_QUICK_GELU" in env:
             opts.fuse_quick_gelu = env["BMA_FUSE_QUICK_GELU"] not in ("0", "false", "False")
+        if "BMA_FUSE_TOWER_QKV" in env:
+            opts.fuse_tower_qkv = env["BMA_FUSE_TOWER_QKV"] not in ("0", "false", "False")
         if "BMA_FUSE_GATE_UP" in env:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
         if "BMA_TP_GRADIENT" in env:

@@ -105,6 +105,8 @@ class HFAdapter:
         self._vision_cfgs = None
         self.fuse_quick_gelu = True             # EngineOptions.fuse_quick_gelu: CLIP's MLP activation as one launch each way
         self._quick_gelus = None
+        self.fuse_tower_qkv = True              # EngineOptions.fuse_tower_qkv: the tower's q/k/v projections as one product
+        self._tower_attn = None
 
     # ------------------------------------------------------------ vision
     def vision_configs(self) -> list:
@@ -135,6 +137,83 @@ class HFAdapter:
             self._quick_gelus = found
         return self._quick_gelus if self.fuse_quick_gelu else []
 
+    def tower_attention_modules(self) -> list:
+        """The vision tower's attention blocks (CLIP / SigLIP modelling files) whose q_proj / k_proj / v_proj are plain
+        16-bit Linear layers over one input, applied in that order (read from the block's source): their three products
+        run as one (`_tower_qkv_forwards`).  [] on the CPU or with the option off."""
+        if self._tower_attn is None:
+            found = []
+            if self.device.type == "cuda":
+                for m in self.model.modules():
+                    if type(m).__module__.rsplit(".", 1)[-1] not in ("modeling_clip", "modeling_siglip") or \
+                            not type(m).__name__.endswith("Attention"):
+                        continue
+                    lins = [getattr(m, n, None) for n in ("q_proj", "k_proj", "v_proj")]
+                    if not all(type(l) is torch.nn.Linear for l in lins) or len({l.in_features for l in lins}) != 1 or \
+                            lins[0].weight.dtype not in (torch.bfloat16, torch.float16) or \
+                            len({l.bias is None for l in lins}) != 1:
+                        continue
+                    try:
+                        src = inspect.getsource(type(m).forward)
+                    except (OSError, TypeError):
+                        continue
+                    iq, ik, iv = (src.find(f"self.{n}(hidden_states)") for n in ("q_proj", "k_proj", "v_proj"))
+                    if 0 <= iq < ik < iv:
+                        found.append(m)
+            self._tower_attn = found
+        return self._tower_attn if self.fuse_tower_qkv else []
+
+    def _tower_qkv_forwards(self, attn):
+        """q_proj, k_proj and v_proj of one tower attention block as ONE product against the concatenated weight (and
+        bias): on a 577-token tower three 11 us launches forward and three input-gradient products plus two accumulation
+        adds backward become one product each way and one concatenation.  As fused.py does for the language model: the
+        first of the three calls does the product, the other two hand out their column slices (same input tensor,
+        checked by identity)."""
+        from .fused import _COPY_CACHES, _CopyCache
+        mods = (attn.q_proj, attn.k_proj, attn.v_proj)
+        origs = [type(m).forward.__get__(m) for m in mods]
+        sizes = [m.out_features for m in mods]
+        cache = _COPY_CACHES.get(self.model)
+        if cache is None:
+            cache = _COPY_CACHES[self.model] = _CopyCache()
+        srcs = tuple(m.weight for m in mods) + tuple(m.bias for m in mods if m.bias is not None)
+        slot = {}
+
+        def fused():
+            hit = cache.get(("tower_wqkv", id(attn)), srcs)
+            if hit is None:
+                if torch.cuda.is_current_stream_capturing():
+                    return None
+                with torch.no_grad():
+                    w = torch.cat([m.weight.detach() for m in mods], dim=0).contiguous()
+                    b = None if mods[0].bias is None else torch.cat([m.bias.detach() for m in mods]).contiguous()
+                hit = cache.put(("tower_wqkv", id(attn)), (w, b), srcs)
+            return hit
+
+        def first(x):
+            slot.clear()
+            if not (x.is_cuda and x.dtype == mods[0].weight.dtype and x.dim() >= 2):
+                return origs[0](x)
+            wb = fused()
+            if wb is None:
+                return origs[0](x)
+            parts = torch.split(torch.nn.functional.linear(x, wb[0], wb[1]), sizes, dim=-1)
+            slot["x"], slot["y"] = x, parts
+            return parts[0]
+
+        def later(i):
+            def forward(x):
+                y = slot.get("y")
+                if y is None or slot.get("x") is not x:
+                    return origs[i](x)
+                out = y[i]
+                if i == 2:
+                    slot.clear()
+                return out
+            return forward
+
+        return first, later(1), later(2)
+
     @contextlib.contextmanager
     def _fused_activations(self):
         """For one tower forward: QuickGELU as ONE launch (three aten kernels, and five more in their autograd backward,
@@ -148,13 +227,19 @@ class HFAdapter:
             if torch.is_grad_enabled() and x.requires_grad:
                 return ops.QuickGELUFn.apply(x)
             return ops.quick_gelu(x)
+        attns = self.tower_attention_modules()
         try:
             for m in mods:
                 m.forward = forward
+            for a in attns:
+                a.q_proj.forward, a.k_proj.forward, a.v_proj.forward = self._tower_qkv_forwards(a)
             yield
         finally:
             for m in mods:
                 m.__dict__.pop("forward", None)
+            for a in attns:
+                for lin in (a.q_proj, a.k_proj, a.v_proj):
+                    lin.__dict__.pop("forward", None)
 
     def image_features(self, image: torch.Tensor) -> torch.Tensor:
         px = self.normalize(image)

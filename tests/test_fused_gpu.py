@@ -865,3 +865,45 @@ def test_quick_gelu_is_the_eager_chain_bit_for_bit(dtype):
             assert same(yb.detach(), ya.detach()) and same(gb, ga)
         assert torch.equal(ops.quick_gelu(x), yb.detach())
     assert not ops.quick_gelu_ok(torch.zeros(8, device=DEV, dtype=torch.float16))      # fp16 keeps the eager chain
+
+
+def test_tower_qkv_as_one_product_matches_the_three():
+    """A small CLIP vision tower in bf16 with its q/k/v projections (weights and biases) run as ONE product and its
+    QuickGELU as one launch (hf_adapter._fused_activations) against the untouched modules: features and pixel gradient
+    within bf16 noise (another GEMM shape sums in another order), the patches gone afterwards, and a weight changed in
+    place is noticed."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from bimodalattack_amd.hf_adapter import HFAdapter
+    torch.manual_seed(0)
+    cfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+                           image_size=112, patch_size=14, hidden_act="quick_gelu")
+    tower = CLIPVisionModel(cfg).to(DEV, torch.bfloat16).eval()
+
+    class Shell:                                   # the three things the two helpers ask of the adapter
+        pass
+    sh = Shell()
+    sh.model, sh.device = tower, torch.device(DEV)
+    sh.fuse_quick_gelu = sh.fuse_tower_qkv = True
+    sh._quick_gelus = sh._tower_attn = None
+    for name in ("quick_gelu_modules", "tower_attention_modules", "_tower_qkv_forwards", "_fused_activations"):
+        setattr(sh, name, getattr(HFAdapter, name).__get__(sh))
+    assert len(sh.tower_attention_modules()) == 3 and len(sh.quick_gelu_modules()) == 3
+
+    def run(fused):
+        px = torch.randn((1, 3, 112, 112), generator=torch.Generator(device=DEV).manual_seed(1), device=DEV).to(torch.bfloat16).requires_grad_()
+        ctx = sh._fused_activations() if fused else contextlib.nullcontext()
+        with ctx:
+            out = tower(pixel_values=px).last_hidden_state
+        (g,) = torch.autograd.grad(out.float().pow(2).sum(), px)
+        return out.detach().float(), g.float()
+    import contextlib
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    attn0 = next(m for m in tower.modules() if hasattr(m, "q_proj"))
+    assert "forward" not in attn0.q_proj.__dict__
+    assert float((o0 - o1).abs().max()) <= 3e-2 * float(o0.abs().max()) and float((g0 - g1).abs().max()) <= 5e-2 * float(g0.abs().max())
+    with torch.no_grad():
+        attn0.k_proj.weight.mul_(0.5)
+    o2, _ = run(False)
+    o3, _ = run(True)
+    assert float((o2 - o3).abs().max()) <= 3e-2 * float(o2.abs().max()) and float((o2 - o0).abs().max()) > 1e-3
