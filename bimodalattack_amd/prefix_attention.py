@@ -492,6 +492,7 @@ def tail_grad_attention(module, query, key, value, attention_mask=None, dropout:
 
 NAME_VIS = "bma_padded_heads"
 PAD_HEADS_MIN_TOKENS = int(os.environ.get("BMA_PAD_HEADS_MIN_TOKENS", "1024"))
+TOWER_EFFICIENT_FIRST = os.environ.get("BMA_TOWER_EFFICIENT_FIRST", "1") not in ("0", "false", "False")
 
 
 def padded_width(head_dim: int, grad: bool) -> int:
@@ -516,6 +517,13 @@ def padded_heads_attention(module, query, key, value, attention_mask=None, dropo
     W = padded_width(Dh, grad) if S >= PAD_HEADS_MIN_TOKENS else Dh
     causal = bool(is_causal) and attention_mask is None and S > 1
     if W == Dh:
+        if TOWER_EFFICIENT_FIRST and grad and attention_mask is None and query.dtype in (torch.bfloat16, torch.float16):
+            # CLIP's 577 tokens x 16 heads of 64 with autograd: the efficient backend's forward + backward pair measures
+            # 89 us against 101 us for the flash pair (MI355X)
+            from torch.nn.attention import SDPBackend, sdpa_kernel
+            with sdpa_kernel([SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH], set_priority=True):
+                out = F.scaled_dot_product_attention(query, key, value, dropout_p=dropout, is_causal=causal, scale=scale)
+            return out.transpose(1, 2).contiguous(), None
         out = F.scaled_dot_product_attention(query, key, value, attn_mask=attention_mask, dropout_p=dropout,
                                              is_causal=causal, scale=scale)
         return out.transpose(1, 2).contiguous(), None
@@ -539,8 +547,9 @@ def vision_configs(model) -> list:
             continue
         if getattr(m, "is_causal", False) or hasattr(m, "layer_idx"):
             return []
-        if padded_width(int(m.head_dim), True) != int(m.head_dim):
-            cfgs[id(m.config)] = m.config
+        if padded_width(int(m.head_dim), True) != int(m.head_dim) or \
+                (TOWER_EFFICIENT_FIRST and m.q_proj.weight.dtype in (torch.bfloat16, torch.float16)):
+            cfgs[id(m.config)] = m.config          # (16-bit towers of any head width: the backend order under autograd)
     return list(cfgs.values())
 
 
