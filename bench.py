@@ -542,7 +542,10 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
                   pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
                   eps=64 / 255, alpha=4 / 255)
     timed_end = warmup + steps
-    total = timed_end + n_prof
+    # The engine pipelines across the step boundary (gradient_ahead: step i+1's gradient pass is queued during step i;
+    # fuse_pgd_only likewise), so the timed region [hook(warmup), hook(timed_end)) holds K gradient passes and K scoring
+    # passes only if a step follows it: at least one untimed step runs behind the region.
+    total = timed_end + max(n_prof, 1)
     width_of = None
     if wl.get("gemma"):
         # BASELINE configs[4]: dynamic_search 512 -> 128 over 600 steps (reference :919-923).  K timed steps sample

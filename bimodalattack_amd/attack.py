@@ -102,6 +102,23 @@ class AttackBuffer:
         logger.info("buffer:" + "".join(f"\nloss: {l} | string: {t}" for l, t in zip(self._loss, shown)))
 
 
+class _Span:
+    """GPU time between two points of the current stream, read later: a phase timer that does not stop the host."""
+
+    def __init__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def stop(self) -> "_Span":
+        self.b.record()
+        return self
+
+    def seconds(self) -> float:
+        self.b.synchronize()
+        return self.a.elapsed_time(self.b) * 1e-3
+
+
 class _PngWriter:
     """images_folder/{i}.png every step (reference :744, :1312-1317) with the same
     truncating *255 -> uint8 quantisation, done on the device; the 8-bit pixels are
@@ -172,6 +189,8 @@ class BimodalAttack:
         self._prefix_graphs: Dict[tuple, object] = {}   # image features -> prefix keys/values
         self._match: Optional[Tensor] = None
         self.opt_b1_min = int(os.environ.get("BMA_B1_MIN_TOKENS", "2"))
+        self._t_read = 0.0                         # host clock at the last packed read-back (gradient_ahead's phase books)
+        self._rb: Optional[Tensor] = None          # pinned block of the step's packed read-back (_read_later)
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
@@ -550,6 +569,22 @@ class BimodalAttack:
             self._prefix_graphs[key] = g
             self.graphs_captured.append("prefix:" + "|".join(key))
         return g(feats)
+
+    def _read_later(self, packed: Tensor):
+        """Device vector -> host list without stopping the stream: the copy lands in a pinned block, an event marks
+        it, and the returned callable waits for THAT event only -- work queued behind it keeps the GPU busy."""
+        n = packed.numel()
+        if self._rb is None or self._rb.numel() < n or self._rb.dtype != packed.dtype:
+            self._rb = torch.empty(max(n, 64), dtype=packed.dtype).pin_memory()
+        dst = self._rb[:n]
+        dst.copy_(packed, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def read() -> list:
+            done.synchronize()
+            return dst.tolist()
+        return read
 
     def _upload(self, host: np.ndarray) -> Tensor:
         """Host array -> device without holding the host: through a pinned block of torch's caching host allocator
@@ -957,8 +992,11 @@ class BimodalAttack:
                         note(g)
                     return g, dt
 
-                if pending is not None:        # PGD-only: computed while scoring the previous step
-                    (g_tok, g_img, _), grad_time = pending
+                span = None
+                if pending is not None:
+                    # PGD-only: computed while scoring the previous step.  gradient_ahead: queued behind the previous
+                    # step's scoring forward and possibly still running; `span` holds its stream events
+                    (g_tok, g_img, _), grad_time, span = pending
                     note((g_tok, g_img))
                     pending = None
                 else:
@@ -986,11 +1024,21 @@ class BimodalAttack:
 
                 # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
-                t0 = self._sync()
-                sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok,
-                                                           image if (cfg.pgd_attack and not image_synced) else None)
+                flying = None
+                if span is not None and not cfg.pgd_attack:
+                    # the gradient pass was queued ahead and may still be running: the sampling kernels go in behind it
+                    # and the host carries on to the scoring call -- the first thing to wait for the stream is the copy
+                    # of the sampled ids its plan needs.  Both phases are timed by stream events, read after the step.
+                    s2 = _Span()
+                    sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, None)
+                    flying = (span, s2.stop())
+                else:
+                    t0 = self._sync()
+                    sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok,
+                                                               image if (cfg.pgd_attack and not image_synced) else None)
+                    if cfg.gcg_attack:
+                        samp_time = self._sync() - t0
                 if cfg.gcg_attack:
-                    samp_time = self._sync() - t0
                     if st is not None:
                         st["sampled"] = self._last["sampled"].cpu().numpy()
                         st["topk_idx"] = self._last["topk_idx"].cpu().numpy()
@@ -998,11 +1046,12 @@ class BimodalAttack:
                         st["rank"] = self._last["rank"].cpu().numpy()
 
                 # ---- phase D: scoring -----------------------------------------------------
-                t0 = self._sync()
+                t0 = time.perf_counter() if flying is not None else self._sync()
                 with torch.no_grad():
-                    def survivors(loss_all: Tensor):
+                    def survivors(loss_all: Tensor, defer_hit: bool = False):
                         """Apply the retokenisation filter, computed on the host while the GPU
-                        scored, to the losses: the reference's filtered vector, in order."""
+                        scored, to the losses: the reference's filtered vector, in order.  `defer_hit`: the
+                        early-stop verdict is handed back as a device tensor instead of being read here."""
                         keep = job.result()
                         if len(keep) == loss_all.shape[0]:
                             idx = None
@@ -1010,22 +1059,25 @@ class BimodalAttack:
                         else:
                             idx = self._upload(np.asarray(keep, dtype=np.int64))
                             out = loss_all[idx], sampled_all[idx]
+                        hit = None
                         if cfg.early_stop and self._match is not None:
                             hit = self._match if idx is None else self._match[idx]
-                            if bool(hit.any().item()):
+                            if not defer_hit and bool(hit.any().item()):
                                 self.stop_flag = True
                         if st is not None:
                             if cfg.filter_ids:
                                 st["filtered"] = out[1].cpu().numpy()
                             st["losses"].append(out[0].float().cpu().numpy())
-                        return out
+                        return (*out, hit) if defer_hit else out
 
                     prefetch_s = 0.0
+                    t_read = None           # when the host had this step's outcome (gradient_ahead: the stream is still busy then)
+                    ids_host = None
                     parent = optim_ids if cfg.gcg_attack else None      # what the candidates were sampled from
                     if fuse_pgd and i + 1 < cfg.num_steps:
                         # the forward of the NEXT gradient pass scores the image just updated
                         with torch.enable_grad():
-                            pending = grad_pass(record=False)
+                            pending = (*grad_pass(record=False), None)
                         prefetch_s = pending[1]
                         full = pending[0][2].reshape(1)
                         if self.opt.loss_in_model_dtype:
@@ -1068,6 +1120,38 @@ class BimodalAttack:
                         current_loss = full.item()
                         if st is not None:
                             st["losses"].append(full.float().cpu().numpy())
+                    elif self.opt.gradient_ahead:
+                        # GCG-only, the outcome stays on the device: argmin -> winner -> next gradient pass, with ONE
+                        # packed read-back (index, loss, early-stop verdict, the winner's ids) for the host's books
+                        loss, sampled, hit = survivors(self.score_candidates(
+                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent), defer_hit=True)
+                        at = loss.argmin().reshape(1)
+                        winner = sampled.index_select(0, at)
+                        f64 = torch.float64
+                        read = self._read_later(torch.cat([
+                            at.to(f64), loss.index_select(0, at).to(f64),
+                            (hit.any().reshape(1) if hit is not None else at.new_zeros(1)).to(f64),
+                            winner.reshape(-1).to(f64)]))
+                        if i + 1 < cfg.num_steps:
+                            # behind the scoring forward on the stream, in front of the host's read: whatever the
+                            # host does from here to the next sampling launch, the GPU is not waiting for it
+                            sp = _Span()
+                            with torch.enable_grad():
+                                g_next = self.compute_gradient(winner, None)
+                            pending = (g_next, None, sp.stop())
+                        host = read()
+                        t_read = time.perf_counter()
+                        if flying is not None:
+                            # the phases tile the step: what is left of the period between two read-backs after the
+                            # gradient pass and the sampling kernels is the scoring phase (host planning included)
+                            grad_time, samp_time = flying[0].seconds(), flying[1].seconds()
+                            t_grad.append(grad_time)
+                            t0 = min(t_read, self._t_read + grad_time + samp_time)
+                        self._t_read = t_read
+                        best_idx, current_loss = int(host[0]), float(host[1])
+                        if host[2] != 0.0:
+                            self.stop_flag = True
+                        ids_host = [int(v) for v in host[3:]]
                     else:
                         loss, sampled = survivors(self.score_candidates(
                             sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent))
@@ -1077,13 +1161,14 @@ class BimodalAttack:
                     n = sampled.shape[0]
                     optim_ids = winner                      # greedy: accepted even when worse (:613, :638)
                     losses.append(current_loss)
-                    strings.append(tok.batch_decode(optim_ids)[0])
+                    strings.append(tok.batch_decode(optim_ids if ids_host is None else [ids_host])[0])
                     if buffer.size == 0 or current_loss < buffer.get_highest_loss():
                         buffer.add(current_loss, optim_ids)
                     self.n_scored.append(n)
                     if st is not None:
                         st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
-                loss_time = max(self._sync() - t0 - prefetch_s, 0.0)   # a prefetched gradient pass is booked as gradient time
+                # a prefetched gradient pass is booked as gradient time
+                loss_time = max((self._sync() if t_read is None else t_read) - t0 - prefetch_s, 0.0)
                 if cfg.gcg_attack:
                     # the reference books the filter under "sampling"; here it ran beside the forward, so what it
                     # cost this section is the time result() was blocked on it
@@ -1099,7 +1184,7 @@ class BimodalAttack:
                     outputs.append(self._debug_generate(sampled, image if cfg.pgd_attack else None, n))
                 else:
                     outputs.append("")
-                suffixes.append(tok.batch_decode(optim_ids)[0])
+                suffixes.append(strings[-1])           # the reference decodes the same ids a second time (:782)
                 buffer.log_buffer(tok)
                 if self.stop_flag:
                     logger.info("Early stopping due to finding a perfect match.")

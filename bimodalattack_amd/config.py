@@ -178,6 +178,13 @@ class EngineOptions:
     # i+1's gradient pass (same ids, same image).  Run it once: one forward+backward per step
     # instead of two forwards and a backward.  Same numbers, same lists in the result.
     fuse_pgd_only: bool = True
+    # GCG (with or without the joint PGD step): the NEXT step's gradient pass needs nothing from the host -- its
+    # input is the winner, a device-side argmin of the losses -- so it is queued right behind the scoring forward,
+    # before the host reads this step's outcome.  The host's work at the step boundary (one packed read-back,
+    # decoding, the buffer, logging) and the launch of the gradient graph then happen while the GPU is busy instead
+    # of in front of an idle one.  Same kernels on the same inputs in the same stream order; the phase times of the
+    # result come from stream events instead of host clocks around synchronisations.
+    gradient_ahead: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
     # Padded scoring (no ragged rows: Gemma-3's layout, fp32 models) runs chunks whose candidate count is a
@@ -264,6 +271,8 @@ class EngineOptions:
             opts.gemm_tuning = env["BMA_GEMM_TUNING"]
         if "BMA_FUSE_PGD_ONLY" in env:
             opts.fuse_pgd_only = env["BMA_FUSE_PGD_ONLY"] not in ("0", "false", "False")
+        if "BMA_GRADIENT_AHEAD" in env:
+            opts.gradient_ahead = env["BMA_GRADIENT_AHEAD"] not in ("0", "false", "False")
         if "BMA_CHUNK_QUANTUM" in env:
             opts.chunk_quantum = max(1, int(env["BMA_CHUNK_QUANTUM"]))
         if "BMA_CHUNK" in env:
