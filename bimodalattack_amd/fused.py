@@ -228,6 +228,8 @@ class FusedInference:
         self._saved_rope = {}
         self._gu_ok = {}
         self.depth = 0
+        self._patches = None                       # (module, replacement forward) pairs, made at the first __enter__
+        self._linear_patches = None
         if not enabled:
             return
         files = set()
@@ -598,21 +600,26 @@ class FusedInference:
             return self
         # (instance attributes written straight into __dict__: nn.Module.__setattr__ checks every value against its
         # parameter / buffer / submodule tables, ~2 us a time over ~450 modules, in front of an idle GPU)
-        for m, eps, gemma in self.norms:
-            m.__dict__["forward"] = self._norm_forward(m, eps, gemma, type(m).forward.__get__(m))
-        for m in self.mlps:
-            m.__dict__["forward"] = self._mlp_forward(m, type(m).forward.__get__(m))
+        # the replacement forwards of norms, MLPs, plain projections and layers keep no tensors between calls (their
+        # state lives on this object and is cleared on the way out), so they are made once; the fused q/k/v triples
+        # hold the product they share and are made afresh
+        if self._patches is None:
+            self._patches = (
+                [(m, self._norm_forward(m, eps, gemma, type(m).forward.__get__(m))) for m, eps, gemma in self.norms]
+                + [(m, self._mlp_forward(m, type(m).forward.__get__(m))) for m in self.mlps]
+                + [(layer, self._layer_forward(layer, kind, nxt)) for layer, kind, nxt in self.layers])
+            self._linear_patches = [(m, self._linear_forward(m, type(m).forward.__get__(m))) for m in self.linears]
+        for m, fn in self._patches:
+            m.__dict__["forward"] = fn
         if self.tp is not None:
             for lin, kind in self._tp_roles.values():
                 lin.__dict__["forward"] = self._tp_linear(lin, kind)
         else:
-            for m in self.linears:
-                m.__dict__["forward"] = self._linear_forward(m, type(m).forward.__get__(m))
+            for m, fn in self._linear_patches:
+                m.__dict__["forward"] = fn
             for attn in self.qkv:                      # after the per-projection patches: these win for q/k/v
                 fq, fk, fv = self._qkv_forwards(attn)
                 attn.q_proj.__dict__["forward"], attn.k_proj.__dict__["forward"], attn.v_proj.__dict__["forward"] = fq, fk, fv
-        for layer, kind, nxt in self.layers:
-            layer.__dict__["forward"] = self._layer_forward(layer, kind, nxt)
         for mod in self.rope_modules:
             self._saved_rope[mod] = mod.apply_rotary_pos_emb
             mod.apply_rotary_pos_emb = self._rope(mod.apply_rotary_pos_emb)
