@@ -190,6 +190,8 @@ class BimodalAttack:
         self._match: Optional[Tensor] = None
         self.opt_b1_min = int(os.environ.get("BMA_B1_MIN_TOKENS", "2"))
         self._t_read = 0.0                         # host clock at the last packed read-back (gradient_ahead's phase books)
+        self._parent_host: Optional[List[int]] = None   # the current suffix ids as the host last read them (early_plan)
+        self._early: Optional[dict] = None         # draws of the next sampling step made ahead of its gradient pass (_draw_ahead)
         self._rb: Optional[Tensor] = None          # pinned block of the step's packed read-back (_read_later)
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
@@ -435,6 +437,39 @@ class BimodalAttack:
         return out.requires_grad_()
 
     # ------------------------------------------------------------ sampling
+    def _width(self, step: int) -> int:
+        cfg = self.config
+        if self.opt.width_override is not None:
+            return int(self.opt.width_override(step))
+        return dynamic_width(step, cfg.search_width, cfg.num_steps, cfg.min_search_width, cfg.dynamic_search)
+
+    def _draw_ahead(self, step: int, n_opt: int) -> None:
+        """early_plan: the random part of step `step`'s sampling (:150-160) one phase early -- positions and top-k
+        ranks do not depend on the gradient -- with a copy on its way to the host, in FRONT of the gradient pass the
+        caller queues next.  Several GPUs: rank 0's draws overwrite everybody's, as its candidates will."""
+        rnd, rank = self._draw(self._width(step), n_opt)
+        pos = ops.rand_positions(rnd, self.config.n_replace)
+        self.shard.sync_state(pos, rank)
+        both = torch.stack([pos, rank])
+        host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+        host.copy_(both, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._early = dict(step=step, pos=pos, rank=rank, host=host, event=done)
+
+    @staticmethod
+    def _virtual_ids(early: dict, parent: List[int]):
+        """Host stand-ins for the candidates sampled from `parent` with these draws: the parent with -1 - rank at each
+        drawn position.  Two stand-ins are equal exactly when the draws are, and then the candidates are; a stand-in
+        differs from the parent first at its smallest drawn position, and the candidate no earlier (it may not differ
+        at all -- a top-k token can be the one already there -- which costs rows, not correctness)."""
+        early["event"].synchronize()
+        pos, rank = early["host"][0].numpy(), early["host"][1].numpy()
+        par = np.asarray(parent, dtype=np.int64)
+        fake = np.repeat(par[None, :], pos.shape[0], axis=0)
+        np.put_along_axis(fake, pos, -1 - rank, axis=1)
+        return fake, par
+
     def candidate_sampling(self, step: int, optim_ids: Tensor, g_tok: Optional[Tensor], image: Optional[Tensor] = None):
         """mask -> top-k -> random position/rank -> scatter (:130-163).  Returns every sampled
         candidate and a FilterJob: the retokenisation filter (:166-186) runs on the host while
@@ -442,17 +477,18 @@ class BimodalAttack:
         candidates -- and its PGD image, when there is one -- overwrite every rank's here, in one
         broadcast (the shapes are a function of the step number, so nothing else is exchanged)."""
         cfg = self.config
-        width = dynamic_width(step, cfg.search_width, cfg.num_steps, cfg.min_search_width, cfg.dynamic_search)
-        if self.opt.width_override is not None:
-            width = int(self.opt.width_override(step))
         if not cfg.gcg_attack:
             if image is not None:
                 self.shard.sync_state(image)
             return optim_ids, FilterJob(optim_ids, self.tokenizer, False)
         ids = optim_ids[0].contiguous()
-        rnd, rank = self._draw(width, ids.numel())
+        early, self._early = self._early, None
+        if early is not None and early["step"] == step:       # drawn one phase early (_draw_ahead): same generator, same order
+            pos, rank = early["pos"], early["rank"]
+        else:
+            rnd, rank = self._draw(self._width(step), ids.numel())
+            pos = ops.rand_positions(rnd, cfg.n_replace)
         topk_idx = ops.mask_topk(g_tok[0], self.mask_bits, cfg.topk)
-        pos = ops.rand_positions(rnd, cfg.n_replace)
         sampled = ops.sample_scatter(ids, topk_idx, pos, rank)
         self.shard.sync_state(*([sampled] if image is None else [sampled, image]))
         self._last = dict(topk_idx=topk_idx, pos=pos, rank=rank, sampled=sampled)
@@ -471,12 +507,14 @@ class BimodalAttack:
         return out
 
     def score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
-                         allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
+                         allow_prefix: bool = True, parent: Optional[Tensor] = None, virtual=None) -> Tensor:
         """Per-candidate mean target CE (:1278-1310) of this rank's slice of `sampled`,
         all-gathered to the full vector.  `order` ends in "target".  `parent` (1,n_opt): the ids
-        the candidates were sampled from, when the caller knows them (enables ragged scoring)."""
+        the candidates were sampled from, when the caller knows them (enables ragged scoring).
+        `virtual`: (stand-in ids (n,n_opt), parent ids) on the host (``_virtual_ids``) -- the ragged plan is made
+        from them and `sampled` is not waited for."""
         with self.fused:
-            return self._score_candidates(sampled, order, feats, allow_prefix, parent)
+            return self._score_candidates(sampled, order, feats, allow_prefix, parent, virtual)
 
     def scoring_features(self, image: Tensor) -> Tensor:
         """Image features for scoring (no autograd): the vision tower at batch 1 is launch-bound,
@@ -593,7 +631,8 @@ class BimodalAttack:
         return torch.from_numpy(np.ascontiguousarray(host)).pin_memory().to(self.model.device, non_blocking=True)
 
     def _ragged_score(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
-                      n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None, m_cap: Optional[int] = None):
+                      n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None, m_cap: Optional[int] = None,
+                      real=None):
         """(loss (m_out,) fp32, early-stop hit or None) of this rank's candidates through the ragged forward, or None
         when this draw does not fit the row count asked for (then the caller scores the padded block).  host_ids: this
         rank's DISTINCT candidates (host copy); inverse: which of them each candidate to report is (None: one each, in
@@ -627,6 +666,13 @@ class BimodalAttack:
 
         # (the first ragged forward of an attack runs eagerly; the prefix must be the recording kind, whose tensors the
         # graph can keep and refresh)
+        if real is not None:
+            # host_ids are stand-ins (``_virtual_ids``): the maps go up without ids, the forward reads the device's
+            maps = RaggedMaps(plan, dev, ids=None, stage=self._stage)
+            maps.ids = torch.cat([real[0], real[1]], dim=0)
+            if maps.ids.shape != (mu + 1, int(plan["n_opt"])):
+                raise RuntimeError("ragged scoring: gathered ids do not match the plan")
+            return forward(maps, mu + 1)
         graphs_on = bool(self.opt.score_graphs > 0 and fused and hf.ragged_ok and hasattr(cache, "k") and hasattr(cache, "v"))
         if graphs_on:
             cap_m = max(m_out, m_cap or 0)
@@ -666,7 +712,7 @@ class BimodalAttack:
         return ragged_rows(need, cap)
 
     def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
-                          allow_prefix: bool = True, parent: Optional[Tensor] = None) -> Tensor:
+                          allow_prefix: bool = True, parent: Optional[Tensor] = None, virtual=None) -> Tensor:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         dealt = None           # (order over distinct candidates, device index candidate -> gathered slot, distinct count, first positions) when dealing
@@ -678,12 +724,18 @@ class BimodalAttack:
                        and self.opt.target_rows_only and self.opt.shared_prefix_attention and hf.shared_prefix_configs())
         want_ragged = bool(plan_ok and hf.ragged_ok is not False and hf.shared_ok is not False)
         host_mine = host_par = inv_mine = None
-        if plan_ok:
+        pick = None            # virtual ids: which rows of `sampled` the distinct candidates of `host_mine` are
+        if plan_ok and virtual is not None:
+            # planned while the gradient pass ran, from the draws alone: nothing here waits for the stream
+            host_all, host_par = virtual
+            uniq, inv, first_at = unique_rows(host_all, return_first=True)
+        elif plan_ok:
             # ONE device-to-host copy (ids + parent) and ONE exact dedup per step feed both the partition over
             # ranks and the ragged plan
             both_h = torch.cat([sampled, parent.reshape(1, -1).to(sampled.device)], dim=0).cpu().numpy()
             host_all, host_par = both_h[:n], both_h[n]
             uniq, inv = unique_rows(host_all)
+            first_at = None
         if plan_ok and (self.shard.enabled or emulate) and n > world:
             # Ragged scoring on several GPUs: every rank sees the same ids, so each can drop the
             # duplicates, sort the distinct candidates by first replaced position and take every
@@ -695,7 +747,11 @@ class BimodalAttack:
             by_cost = np.argsort(first, kind="stable")
             take = by_cost[0::world] if emulate else self.shard.deal(by_cost)
             host_mine = np.ascontiguousarray(uniq[take])
-            mine = self._upload(host_mine)
+            if first_at is None:
+                mine = self._upload(host_mine)
+            else:
+                pick = np.ascontiguousarray(first_at[take])
+                mine = sampled.index_select(0, self._upload(pick))
             # where each of the n candidates' loss will sit in the gathered buffer: uploaded NOW, while the stream
             # is idle -- behind the forward the same pageable copy would hold the host until the GPU had finished,
             # and the retokenisation filter would run after the forward instead of beside it (dist.dealt_index)
@@ -711,9 +767,11 @@ class BimodalAttack:
             mine = sampled[lo:hi].contiguous()
             if plan_ok:
                 if (lo, hi) == (0, n):
-                    host_mine, inv_mine = uniq, inv
-                else:
+                    host_mine, inv_mine, pick = uniq, inv, first_at
+                elif first_at is None:
                     host_mine, inv_mine = unique_rows(host_all[lo:hi])
+                else:
+                    host_mine, inv_mine, pick = unique_rows(host_all[lo:hi], return_first=True)
         m = mine.shape[0]
         E = self.embedding_layer.weight
         feats = None if feats is None else feats.to(E.dtype)
@@ -759,7 +817,13 @@ class BimodalAttack:
                             # a few rows after dealing): one set of GEMM shapes per step on all ranks
                             n_rows = self._dealt_rows(dealt, world, L, mine.shape[1])
                             m_cap = -(-n // world)      # most candidates a rank can be dealt: the captured forward's fixed size
-                        scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, m_cap)
+                        real = None
+                        if pick is not None:
+                            # the stand-ins planned it; the forward embeds the real ids, gathered on the device
+                            # (dealt: `mine` IS that gather; else the first appearances within this rank's slice)
+                            real = (mine if dealt is not None else mine.index_select(0, self._upload(pick)),
+                                    parent.reshape(1, -1).to(sampled.device))
+                        scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, m_cap, real)
                         hf.ragged_ok = True
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):
@@ -955,6 +1019,7 @@ class BimodalAttack:
             hook = self.opt.step_hook
             n_done = 0
             pending = None
+            self._early, self._parent_host = None, None      # nothing of an earlier run (an early stop leaves unused draws)
             # PGD-only: nothing is sampled, so the loss of the updated image can come out of the
             # next step's gradient pass (fuse_pgd_only); early_stop needs the argmax test of a
             # scoring call, so it keeps the plain loop
@@ -1025,13 +1090,17 @@ class BimodalAttack:
                 # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
                 samp_time = 0.0
                 flying = None
+                virtual = None          # early_plan: host stand-ins of this step's candidates, known before they exist
                 if span is not None and not cfg.pgd_attack:
                     # the gradient pass was queued ahead and may still be running: the sampling kernels go in behind it
                     # and the host carries on to the scoring call -- the first thing to wait for the stream is the copy
                     # of the sampled ids its plan needs.  The phases are timed by stream events, read after the step.
                     s2 = _Span()
+                    early = self._early if (self._early is not None and self._early["step"] == i) else None
                     sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, None)
                     flying = (span, s2.stop())
+                    if early is not None and self._parent_host is not None:
+                        virtual = self._virtual_ids(early, self._parent_host)
                 else:
                     t0 = self._sync()
                     sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok,
@@ -1085,6 +1154,8 @@ class BimodalAttack:
                             winner.reshape(-1).to(f64)]))
                         queued = None
                         if i + 1 < cfg.num_steps:
+                            if self.opt.early_plan and self.opt.score_graphs == 0 and cfg.gcg_attack:
+                                self._draw_ahead(i + 1, winner.shape[1])
                             sp = _Span()
                             with torch.enable_grad():
                                 g_next = self.compute_gradient(winner, img)
@@ -1147,7 +1218,8 @@ class BimodalAttack:
                             st["losses"].append(full.float().cpu().numpy())
                     elif ahead_ok:
                         loss, sampled, hit = survivors(self.score_candidates(
-                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent), defer_hit=True)
+                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent,
+                            virtual=virtual), defer_hit=True)
                         winner, host, t_read, pending = settle(loss, sampled, hit, None)
                     else:
                         loss, sampled = survivors(self.score_candidates(
@@ -1160,6 +1232,7 @@ class BimodalAttack:
                         if host[2] != 0.0:
                             self.stop_flag = True
                         ids_host = [int(v) for v in host[3:]]
+                        self._parent_host = ids_host
                         if flying is not None:
                             # the phases tile the step: what is left of the period between two read-backs after the
                             # gradient pass and the sampling kernels is the scoring phase (host planning included)

@@ -185,6 +185,13 @@ class EngineOptions:
     # of in front of an idle one.  Same kernels on the same inputs in the same stream order; the phase times of the
     # result come from stream events instead of host clocks around synchronisations.
     gradient_ahead: bool = True
+    # ... and with the gradient pass queued ahead, the ragged plan of the NEXT scoring forward is made while that pass
+    # runs: the random draws of a sampling step (positions, top-k ranks) do not depend on the gradient, so they are
+    # made -- in the same order of the same generator -- before the pass is queued, copied to the host behind it, and
+    # the host plans on "virtual" ids (the parent with a placeholder per drawn (position, rank)) that coincide exactly
+    # where the real candidates must; the real ids never visit the host before the forward (the retokenisation filter
+    # still gets its copy, beside the forward), they are gathered on the device.  Off with score_graphs.
+    early_plan: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
     # Padded scoring (no ragged rows: Gemma-3's layout, fp32 models) runs chunks whose candidate count is a
@@ -273,6 +280,8 @@ class EngineOptions:
             opts.fuse_pgd_only = env["BMA_FUSE_PGD_ONLY"] not in ("0", "false", "False")
         if "BMA_GRADIENT_AHEAD" in env:
             opts.gradient_ahead = env["BMA_GRADIENT_AHEAD"] not in ("0", "false", "False")
+        if "BMA_EARLY_PLAN" in env:
+            opts.early_plan = env["BMA_EARLY_PLAN"] not in ("0", "false", "False")
         if "BMA_CHUNK_QUANTUM" in env:
             opts.chunk_quantum = max(1, int(env["BMA_CHUNK_QUANTUM"]))
         if "BMA_CHUNK" in env:

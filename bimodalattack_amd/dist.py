@@ -11,7 +11,8 @@ slices are padded to `per` slots with +inf, which can never win the argmin.
 Every rank runs gradient -> PGD -> sampling redundantly; rank 0's sampled ids and PGD
 image then overwrite everybody's in ONE packed broadcast per step (``sync_state``), so ranks
 cannot drift apart through last-bit differences in redundantly computed gradients.  With the
-loss all-gather that makes two collectives per step (early_stop adds a third, two floats).
+loss all-gather that makes two collectives per step (early_stop adds a two-float one; GCG-only steps with
+early_plan one more, rank 0's random draws -- 8 KB, queued in front of the gradient pass).
 
 The C ABI's collective, ``bma_allgather_f32(local, n_local, out, rank, world, comm, stream)``, takes
 the HOST's ``ncclComm_t`` and calls ``ncclAllGather`` of the RCCL instance already in the process: it is for hosts that

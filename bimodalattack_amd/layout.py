@@ -111,17 +111,19 @@ def ragged_rows(needed: int, cap: int) -> int:
 _HASH_MUL = None
 
 
-def unique_rows(rows):
+def unique_rows(rows, return_first: bool = False):
     """(distinct rows in order of first appearance, inverse map) of an integer matrix -- what
     ``np.unique(axis=0)`` yields up to the order, ~10x faster at 512 x 19: rows are grouped by a 64-bit
     multiplicative hash and the grouping is then VERIFIED element by element (an unequal pair in one group
-    sends the call to np.unique), so the result is exact whatever the hash does."""
+    sends the call to np.unique), so the result is exact whatever the hash does.  `return_first`: also the index
+    of each distinct row's first appearance in `rows` (uniq == rows[first])."""
     import numpy as np
     global _HASH_MUL
     rows = np.ascontiguousarray(rows)
     n, w = rows.shape
     if n <= 1:
-        return rows.copy(), np.zeros(n, dtype=np.int64)
+        out = rows.copy(), np.zeros(n, dtype=np.int64)
+        return (*out, np.arange(n, dtype=np.int64)) if return_first else out
     if _HASH_MUL is None or _HASH_MUL.shape[0] < w:
         _HASH_MUL = (np.random.RandomState(0x5eed).randint(1, 2 ** 62, size=max(w, 64), dtype=np.int64).astype(np.uint64) << np.uint64(1)) | np.uint64(1)
     with np.errstate(over="ignore"):
@@ -132,10 +134,13 @@ def unique_rows(rows):
     rank = np.empty_like(order)
     rank[order] = np.arange(order.shape[0])
     inv = rank[np.asarray(inv).reshape(-1)]
-    uniq = rows[first_idx[order]]
+    first = first_idx[order]
+    uniq = rows[first]
     if not np.array_equal(uniq[inv], rows):                  # a hash collision: the exact, slower way
-        uniq, inv = np.unique(rows, axis=0, return_inverse=True)
+        uniq, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
         inv = np.asarray(inv).reshape(-1)
+    if return_first:
+        return uniq, inv.astype(np.int64), np.asarray(first, dtype=np.int64)
     return uniq, inv.astype(np.int64)
 
 

@@ -151,6 +151,8 @@ def test_trajectory_matches_reference(golden_dir, name):
                                     dict(fuse_add_norm=False),
                                     # the host reads each step's outcome before the next gradient pass is launched
                                     dict(gradient_ahead=False),
+                                    # ... or launches it ahead but plans the ragged forward from the sampled ids
+                                    dict(early_plan=False),
                                     # everything eager and unfused
                                     dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
                                          fused_elementwise=False, gemm_tuning="off")])
@@ -167,6 +169,7 @@ def test_restructurings_do_not_change_results(golden_dir, name, engine):
                                     dict(joint_winner_from_batch=False),
                                     dict(fuse_pgd_only=False),
                                     dict(gradient_ahead=False),
+                                    dict(early_plan=False),
                                     dict(grad_prefix_reuse=False),
                                     dict(ragged_suffix=False, chunk=7)])
 def test_early_stop_and_gemma_orders_under_restructurings(golden_dir, name, engine):
@@ -182,21 +185,25 @@ def test_early_stop_and_gemma_orders_under_restructurings(golden_dir, name, engi
 @pytest.mark.parametrize("name", ["opt_gcg", "llava_gcg_early"])
 def test_gradient_queued_ahead_gives_the_same_run(name):
     """GCG-only without a trace (nothing but the packed read-back stops the host): the run whose next gradient pass
-    is queued behind the scoring forward returns what the run that reads every step's outcome first returns --
+    is queued behind the scoring forward -- with the ragged plan made from the random draws while that pass runs, or
+    from the sampled ids afterwards -- returns what the run that reads every step's outcome first returns --
     losses, strings, the step an early stop ends it at, one timing entry per phase and step."""
     from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
     m = META["cases"][name]
     out = []
-    for ahead in (True, False):
+    for ahead, early in ((True, True), (True, False), (False, False)):
         model, tok, proc, image = S.tiny_case(m["kind"], device=DEV)
         cfg = BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=m["optim_str_init"],
                                   images_folder=tempfile.mkdtemp(prefix="bma_gpu_"), **m["config"])
         out.append(run(model, tok, proc, m["goal"], m["goal"], m["target"], image, cfg,
                        normalize=S.Normalize(S.CLIP_MEAN, S.CLIP_STD), rng_device="cpu", strict=True,
-                       gradient_ahead=ahead))
-    a, b = out
-    assert a.losses == b.losses and a.strings == b.strings and a.adversarial_suffixes == b.adversarial_suffixes
-    assert a.best_loss == b.best_loss and a.best_string == b.best_string
+                       gradient_ahead=ahead, early_plan=early))
+    a = out[0]
+    for b in out[1:]:
+        # (the ragged plan made from the draws may compute a few rows more than the one made from the ids -- a
+        # candidate that happens to equal its parent -- which moves no loss: rows are independent)
+        assert a.losses == b.losses and a.strings == b.strings and a.adversarial_suffixes == b.adversarial_suffixes
+        assert a.best_loss == b.best_loss and a.best_string == b.best_string
     assert len(a.losses) == m["steps"]
     for r in out:
         assert len(r.gradient_times) == len(r.losses) and len(r.loss_times) == len(r.losses)
@@ -553,7 +560,7 @@ def test_sharded_engine_two_ranks_rccl(golden_dir, name):
 def test_bench_self_launch_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` as the driver calls it (no launcher): the script starts its two ranks itself
     (rehearsed with gloo on the one GPU of this box; the driver's node runs RCCL), prints ONE JSON line with
-    n_gpus = 2, candidates sharded, two data-path collectives per step."""
+    n_gpus = 2, candidates sharded, two data-path collectives per step plus the early draws' broadcast."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -568,8 +575,9 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "candidates/2" and d["scaling"] == "strong"
-    # one loss gather for the initial suffix, then two collectives per step (ids broadcast + loss gather), 4 steps
-    assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) and not d["engine"]["fallbacks"]
+    # one loss gather for the initial suffix, then two collectives per step (ids broadcast + loss gather), 4 steps;
+    # from the second step on the draws made ahead of the gradient pass are broadcast as well (early_plan: 8 KB)
+    assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) + 3 and not d["engine"]["fallbacks"]
     assert d["roofline"]["bound"] in ("mfma", "hbm") and d["value"] > 0
 
 

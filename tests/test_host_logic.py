@@ -477,3 +477,38 @@ def test_bench_gemm_roles_and_extra_workloads():
     assert rg[(20480, 2560)] == "gate_up_proj (fused)" and rg[(2560, 2048)] == "o_proj" and rg[(1024, 2560)] == "k_proj / v_proj"
     assert set(bench.WORKLOADS) >= {"gcg", "joint", "pgd", "pgd_gcg", "gemma_joint", "opt125m"}
     assert bench.COPY_CEILING_GBS < bench.HBM_PEAK_GBS and bench.MFMA_PEAK_TFLOPS == 2500.0
+
+
+def test_virtual_ids_plan_what_the_real_candidates_need():
+    """early_plan (attack.py `_virtual_ids`): the host plans the ragged forward from the random draws alone, on
+    stand-ins for ids it has not seen.  For every draw: equal stand-ins mean equal candidates (so the dedup never
+    merges two different ones), a stand-in's first difference from the parent is no later than the candidate's (so
+    every row a candidate needs is computed), and `unique_rows(return_first)` names a row of the batch that IS the
+    distinct candidate."""
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.layout import ragged_plan, unique_rows
+
+    class Done:
+        def synchronize(self):
+            pass
+
+    rng = np.random.RandomState(7)
+    for n_opt, n_replace, topk, width in [(20, 1, 8, 512), (12, 2, 4, 256), (5, 1, 2, 64), (9, 3, 3, 128)]:
+        parent = rng.randint(0, 50, size=n_opt)
+        table = np.stack([rng.permutation(50)[:topk] for _ in range(n_opt)])         # top-k ids per position: distinct
+        table[:, 0] = parent                          # rank 0 proposes the token already there: candidate == parent
+        pos = np.stack([rng.permutation(n_opt)[:n_replace] for _ in range(width)])
+        rank = rng.randint(0, topk, size=(width, n_replace))
+        real = np.repeat(parent[None], width, 0)
+        np.put_along_axis(real, pos, table[pos, rank], axis=1)
+        early = dict(event=Done(), host=torch.from_numpy(np.stack([pos, rank])))
+        fake, par = BimodalAttack._virtual_ids(early, parent.tolist())
+        assert (par == parent).all() and fake.shape == real.shape
+        uniq, inv, first = unique_rows(fake, return_first=True)
+        assert (real[first][inv] == real).all()                      # merged stand-ins <=> identical candidates
+        d_fake, d_real = fake != parent, real != parent
+        p_fake = np.where(d_fake.any(1), d_fake.argmax(1), n_opt - 1)
+        p_real = np.where(d_real.any(1), d_real.argmax(1), n_opt - 1)
+        assert (p_fake <= p_real).all() and (p_fake == pos.min(1)).all()
+        plan = ragged_plan(uniq, par, L=n_opt + 6, T=3, P=11, dedup=False, padded_maps=False, inverse=inv)
+        assert plan is not None and (plan["cand"] == uniq).all() and (plan["p"] <= p_real[first]).all()
