@@ -1070,11 +1070,17 @@ class BimodalAttack:
                 # ---- phase B: PGD update; phase C: second gradient pass -------------------
                 pgd_time = 0.0
                 image_synced = False
+                pgd_span = None
                 if cfg.pgd_attack:
-                    t0 = self._sync()
-                    image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
-                    pgd_time = self._sync() - t0
-                    t_pgd.append(pgd_time)
+                    if span is not None:           # gradient_ahead: timed on the stream, read after the step
+                        pgd_span = _Span()
+                        image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
+                        pgd_span.stop()
+                    else:
+                        t0 = self._sync()
+                        image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
+                        pgd_time = self._sync() - t0
+                        t_pgd.append(pgd_time)
                     if st is not None:
                         st["image_after_pgd"] = image.detach().cpu().numpy()
                     if cfg.gcg_attack and not cfg.joint_eval:
@@ -1091,14 +1097,17 @@ class BimodalAttack:
                 samp_time = 0.0
                 flying = None
                 virtual = None          # early_plan: host stand-ins of this step's candidates, known before they exist
-                if span is not None and not cfg.pgd_attack:
+                if span is not None:
                     # the gradient pass was queued ahead and may still be running: the sampling kernels go in behind it
                     # and the host carries on to the scoring call -- the first thing to wait for the stream is the copy
-                    # of the sampled ids its plan needs.  The phases are timed by stream events, read after the step.
-                    s2 = _Span()
+                    # of the sampled ids its plan needs (none at all with early_plan).  The gradient pass is timed by stream
+                    # events, read after the step.
                     early = self._early if (self._early is not None and self._early["step"] == i) else None
-                    sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, None)
-                    flying = (span, s2.stop())
+                    t_s = time.perf_counter()
+                    sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, image if cfg.pgd_attack else None)
+                    # (the sampling kernels' own ~0.3 ms of GPU time are booked with the scoring phase: event pairs
+                    # around them, recorded while the gradient graph was still running, read 3-18 ms too long)
+                    flying = (span, time.perf_counter() - t_s, pgd_span)
                     if early is not None and self._parent_host is not None:
                         virtual = self._virtual_ids(early, self._parent_host)
                 else:
@@ -1163,8 +1172,6 @@ class BimodalAttack:
                         host = read()
                         return winner, host, time.perf_counter(), queued
 
-                    # (GCG-only steps.  The joint step was tried the same way -- winner and image both live on the device
-                    # -- and measured no faster: 237.5 against 237.9 ms on one box, so it keeps the plain order)
                     ahead_ok = bool(self.opt.gradient_ahead and not (self.opt.tp_gradient and self.shard.enabled))
                     prefetch_s = 0.0
                     t_read = None           # when the host had this step's outcome (gradient_ahead: the stream is still busy then)
@@ -1182,6 +1189,18 @@ class BimodalAttack:
                         best_idx, sampled, winner = 0, sampled_all, sampled_all[0:1].contiguous()
                         if st is not None:
                             st["losses"].append(full.float().cpu().numpy())
+                    elif (cfg.pgd_attack and cfg.gcg_attack and cfg.joint_eval and ahead_ok and self.opt.joint_winner_from_batch
+                          and segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt)):
+                        # joint mode with the winner's loss taken from the batch (see below): nothing but the outcome's
+                        # read-back needs the host, and the next gradient pass -- the tail rows against the prefix this
+                        # scoring call records -- needs the winner and the image, both on the device
+                        feats = self.scoring_features(image)
+                        loss, sampled, hit = survivors(self.score_candidates(
+                            sampled_all, segment_order("pgd", mt, single=True), feats, parent=parent, virtual=virtual),
+                            defer_hit=True)
+                        winner, host, t_read, pending = settle(loss, sampled, hit, image)
+                        if st is not None:
+                            st["losses"].append(np.asarray([host[1]], dtype=np.float32))
                     elif cfg.pgd_attack:
                         feats = self.scoring_features(image)
                         if cfg.joint_eval:
@@ -1235,10 +1254,14 @@ class BimodalAttack:
                         self._parent_host = ids_host
                         if flying is not None:
                             # the phases tile the step: what is left of the period between two read-backs after the
-                            # gradient pass and the sampling kernels is the scoring phase (host planning included)
-                            grad_time, samp_time = flying[0].seconds(), flying[1].seconds()
+                            # gradient pass, the PGD update and the sampling kernels is the scoring phase (host
+                            # planning included)
+                            grad_time, samp_time = flying[0].seconds(), flying[1]
                             t_grad.append(grad_time)
-                            t0 = min(t_read, self._t_read + grad_time + samp_time)
+                            if flying[2] is not None:
+                                pgd_time = flying[2].seconds()
+                                t_pgd.append(pgd_time)
+                            t0 = min(t_read, self._t_read + grad_time + pgd_time + samp_time)
                         self._t_read = t_read
                     n = sampled.shape[0]
                     optim_ids = winner                      # greedy: accepted even when worse (:613, :638)

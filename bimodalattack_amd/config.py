@@ -178,7 +178,7 @@ class EngineOptions:
     # i+1's gradient pass (same ids, same image).  Run it once: one forward+backward per step
     # instead of two forwards and a backward.  Same numbers, same lists in the result.
     fuse_pgd_only: bool = True
-    # GCG (with or without the joint PGD step): the NEXT step's gradient pass needs nothing from the host -- its
+    # GCG-only steps and joint steps whose winner's loss comes from the batch: the NEXT step's gradient pass needs nothing from the host -- its
     # input is the winner, a device-side argmin of the losses -- so it is queued right behind the scoring forward,
     # before the host reads this step's outcome.  The host's work at the step boundary (one packed read-back,
     # decoding, the buffer, logging) and the launch of the gradient graph then happen while the GPU is busy instead
