@@ -102,6 +102,35 @@ class AttackBuffer:
         logger.info("buffer:" + "".join(f"\nloss: {l} | string: {t}" for l, t in zip(self._loss, shown)))
 
 
+class _PinnedRing:
+    """Pinned staging blocks the engine keeps for its small host-to-device uploads.  Each slot remembers the event
+    behind its last copy and is reused once that has passed -- with eight slots and a few uploads per step, always.
+    (Blocks from PyTorch's pinned allocator come back only when the stream has reached the point where they were
+    dropped; with the next gradient pass always queued ahead that is late, and every miss is a new pinned allocation,
+    which stops the host until the stream has drained.)"""
+
+    def __init__(self, slots: int = 8):
+        self.blocks: List[Optional[Tensor]] = [None] * slots
+        self.events: List[Optional[torch.cuda.Event]] = [None] * slots
+        self.at = 0
+
+    def upload(self, host: np.ndarray, device) -> Tensor:
+        arr = np.ascontiguousarray(host)
+        if arr.nbytes == 0:
+            return torch.from_numpy(arr).to(device)
+        i, self.at = self.at, (self.at + 1) % len(self.blocks)
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        blk = self.blocks[i]
+        if blk is None or blk.numel() < arr.nbytes:
+            blk = self.blocks[i] = torch.empty(max(arr.nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        blk.numpy()[:arr.nbytes] = arr.reshape(-1).view(np.uint8)
+        dev = blk[:arr.nbytes].to(device, non_blocking=True)
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record()
+        return dev.view(torch.from_numpy(arr[:0].reshape(-1)).dtype).view(arr.shape)
+
+
 class _Span:
     """GPU time between two points of the current stream, read later: a phase timer that does not stop the host."""
 
@@ -191,6 +220,9 @@ class BimodalAttack:
         self.opt_b1_min = int(os.environ.get("BMA_B1_MIN_TOKENS", "2"))
         self._t_read = 0.0                         # host clock at the last packed read-back (gradient_ahead's phase books)
         self._parent_host: Optional[List[int]] = None   # the current suffix ids as the host last read them (early_plan)
+        self._pins = _PinnedRing()                 # staging blocks of the small uploads (_upload)
+        self._filter_pin: Optional[Tensor] = None  # the retokenisation filter's host copy of the sampled ids
+        self._early_pin: Optional[Tensor] = None   # the host copy of the draws made ahead
         self._early: Optional[dict] = None         # draws of the next sampling step made ahead of its gradient pass (_draw_ahead)
         self._rb: Optional[Tensor] = None          # pinned block of the step's packed read-back (_read_later)
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
@@ -451,7 +483,9 @@ class BimodalAttack:
         pos = ops.rand_positions(rnd, self.config.n_replace)
         self.shard.sync_state(pos, rank)
         both = torch.stack([pos, rank])
-        host = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+        if self._early_pin is None or self._early_pin.numel() < both.numel():
+            self._early_pin = torch.empty(max(both.numel(), 4096), dtype=both.dtype, pin_memory=True)
+        host = self._early_pin[:both.numel()].view(both.shape)
         host.copy_(both, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
@@ -492,7 +526,11 @@ class BimodalAttack:
         sampled = ops.sample_scatter(ids, topk_idx, pos, rank)
         self.shard.sync_state(*([sampled] if image is None else [sampled, image]))
         self._last = dict(topk_idx=topk_idx, pos=pos, rank=rank, sampled=sampled)
-        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids, threaded=self.opt.threaded_filter)
+        if cfg.filter_ids and (self._filter_pin is None or self._filter_pin.numel() < sampled.numel()):
+            self._filter_pin = torch.empty(max(sampled.numel(), cfg.search_width * sampled.shape[1]), dtype=sampled.dtype,
+                                           pin_memory=True)
+        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids, threaded=self.opt.threaded_filter,
+                                  pinned=self._filter_pin)
 
     # ------------------------------------------------------------ scoring
     def _segments(self, order, feats):
@@ -625,10 +663,9 @@ class BimodalAttack:
         return read
 
     def _upload(self, host: np.ndarray) -> Tensor:
-        """Host array -> device without holding the host: through a pinned block of torch's caching host allocator
-        (which keeps the block from being reused until the copy has run) and a non-blocking copy.  A `.to(device)`
-        from pageable memory waits for the stream on ROCm."""
-        return torch.from_numpy(np.ascontiguousarray(host)).pin_memory().to(self.model.device, non_blocking=True)
+        """Host array -> device without holding the host: through a pinned block of the engine's own ring
+        (``_PinnedRing``) and a non-blocking copy.  A `.to(device)` from pageable memory waits for the stream on ROCm."""
+        return self._pins.upload(host, self.model.device)
 
     def _ragged_score(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
                       n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None, m_cap: Optional[int] = None,
@@ -1190,7 +1227,12 @@ class BimodalAttack:
                         if st is not None:
                             st["losses"].append(full.float().cpu().numpy())
                     elif (cfg.pgd_attack and cfg.gcg_attack and cfg.joint_eval and ahead_ok and self.opt.joint_winner_from_batch
-                          and segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt)):
+                          and segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt)
+                          and segment_order("pgd", mt, single=True) == self._GRAD_ORDER):
+                        # (image-in-front layouts only.  Gemma-3's joint step, suffix in front, was measured 10 % SLOWER
+                        # this way -- 491.8 -> 539.8 ms, same kernels and launch counts, the library GEMMs of its padded
+                        # scoring chunks each 10-16 % longer with the whole forward queued far ahead -- and keeps the
+                        # plain order)
                         # joint mode with the winner's loss taken from the batch (see below): nothing but the outcome's
                         # read-back needs the host, and the next gradient pass -- the tail rows against the prefix this
                         # scoring call records -- needs the winner and the image, both on the device
@@ -1277,8 +1319,11 @@ class BimodalAttack:
                 if cfg.gcg_attack:
                     # the reference books the filter under "sampling"; here it ran beside the forward, so what it
                     # cost this section is the time result() was blocked on it
-                    samp_time += job.waited
-                    loss_time = max(loss_time - job.waited, 0.0)
+                    # (gradient_ahead: result() is reached while the stream is still on its way to the ids' copy --
+                    # that wait is the gradient pass's, already booked; the round trip's own duration counts)
+                    filt = job.seconds if flying is not None else job.waited
+                    samp_time += filt
+                    loss_time = max(loss_time - filt, 0.0)
                     t_samp.append(samp_time)
                 t_loss.append(loss_time)
                 logger.info(f"[Iteration {i}] Current loss: {current_loss:.4f} | Best loss: {buffer.get_lowest_loss():.4f} | ")

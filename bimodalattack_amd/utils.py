@@ -78,7 +78,8 @@ class FilterJob:
     the same candidates win as if they had been filtered first.  ``seconds`` is the round
     trip's own duration, ``waited`` what the caller actually spent blocked in ``result()``."""
 
-    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool, threaded: bool = False):
+    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool, threaded: bool = False,
+                 pinned: Optional[torch.Tensor] = None):
         self.n = ids.shape[0]
         self.tokenizer = tokenizer
         self.enabled = enabled
@@ -88,7 +89,13 @@ class FilterJob:
         self._error: Optional[BaseException] = None
         self._thread = None
         if enabled:
-            self.host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
+            # `pinned`: a block the caller keeps between steps.  A fresh pinned allocation per step is recycled by
+            # PyTorch's host allocator only once the stream has passed the point where the previous one was dropped;
+            # with work always queued ahead that is late, and a NEW pinned allocation stops the host behind the stream
+            if pinned is not None and pinned.dtype == ids.dtype and pinned.numel() >= ids.numel():
+                self.host = pinned[:ids.numel()].view(ids.shape)
+            else:
+                self.host = torch.empty(ids.shape, dtype=ids.dtype, pin_memory=True)
             self.host.copy_(ids, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(ids.device))
