@@ -15,9 +15,13 @@ per step is fixed, so scaling is "strong".  The K timed steps carry no instrumen
 per-kernel HIP-event brackets behind `roofline`, `gemms` and `kernels` run in
 --profile-steps extra steps AFTER the timed region.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  `value` is whole-step
-candidate forwards per second (all ranks, wall clock, max over ranks); the per-phase
-rate the reference's tables quote (search_width / loss-phase seconds) is given beside it.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"), at most LINE_LIMIT (6000) characters of strict JSON:
+the contract's fields, `roofline`, `forward_roofline`, `cpu_baseline`, `finite` and one short entry per extra
+workload (`build_line`).  Everything else -- per-GEMM tables, per-kernel figures, engine state, the notes that say
+how each number was taken -- goes to the detail file (--detail, default gpurun_out/bench_detail.json).  `value` is
+whole-step candidate forwards per second (all ranks, wall clock, max over ranks); the per-phase rate the reference's
+tables quote (search_width / loss-phase seconds) is given beside it.  A workload whose timed steps hold a non-finite
+loss is marked `"finite": false`; when it is the headline workload the process exits with status 3 after printing.
 
 The line's `value` / `config` are the --workload run (default: BASELINE configs[2], GCG-only).  On one GPU the
 other single-GPU BASELINE configurations -- joint (configs[3]) and PGD-only (configs[1]) on the SAME LLaVA model,
@@ -34,6 +38,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import tempfile
@@ -469,6 +474,102 @@ def gemm_roles(tc, vocab_rows: int) -> dict:
     return r
 
 
+LINE_LIMIT = 6000          # the driver keeps the last 8000 characters of stdout: the ONE line must fit with room to spare
+
+
+def _strict(o):
+    """JSON without NaN / Infinity (not JSON: strict parsers refuse the whole line): non-finite floats become null."""
+    if isinstance(o, float):
+        return o if math.isfinite(o) else None
+    if isinstance(o, dict):
+        return {str(k): _strict(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_strict(v) for v in o]
+    return o
+
+
+def _sig(o, digits: int = 5):
+    """Floats to `digits` significant figures (the line is a summary; the detail file keeps every bit)."""
+    if isinstance(o, float):
+        return float(f"{o:.{digits}g}") if math.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: _sig(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_sig(v, digits) for v in o]
+    return o
+
+
+def _short_roofline(r, keys=("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                             "avg_launch_us", "launches")):
+    if not r:
+        return None
+    d = {k: r[k] for k in keys if k in r}
+    if isinstance(d.get("kernel"), str):
+        d["kernel"] = d["kernel"][:120]
+    if isinstance(d.get("traffic_source"), str):
+        d["traffic_source"] = d["traffic_source"].split(" (")[0][:80] + " (committed rocprofv3 --pmc pass)"
+    return d
+
+
+def build_line(out: dict, detail_file=None) -> dict:
+    """The ONE stdout line from a full result: the contract's fields, `roofline` / `forward_roofline` / `cpu_baseline`,
+    one short entry per extra workload -- no prose, no tables (those live in the detail file).  Stays under LINE_LIMIT
+    characters: optional blocks are dropped, least important first, if it would not."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+    line = {k: out.get(k) for k in head}
+    line["finite"] = bool(out.get("finite", False))
+    line["final_loss"] = out.get("final_loss")
+    for k in ("attack_steps_per_sec", "scoring_phase_candidate_forwards_per_sec", "phase_s_per_step", "projected_value"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    line["roofline"] = _short_roofline(out.get("roofline"))
+    line["forward_roofline"] = _short_roofline(out.get("forward_roofline"), ("bound", "achieved", "peak", "unit", "frac"))
+    gp = out.get("gradient_pass") or {}
+    if "replayed_pass_ms" in gp:
+        line["gradient_pass"] = {k: gp.get(k) for k in ("replayed_pass_ms", "passes_per_step", "gemm_ms_per_pass",
+                                                          "gemms_frac_of_8TBps", "gemms_frac_of_mfma_peak")}
+    if out.get("kernels"):
+        line["kernels"] = {n: {"avg_us": k.get("avg_us"), "frac_of_8TBps": k.get("frac_of_8TBps_hbm", k.get("frac_of_8TBps"))}
+                           for n, k in out["kernels"].items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        cb = dict(cb)
+        if isinstance(cb.get("sample"), str):
+            cb["sample"] = cb["sample"][:200]
+        line["cpu_baseline"] = cb
+    else:
+        line["cpu_baseline"] = None
+    if out.get("workloads"):
+        ws = {}
+        for name, w in out["workloads"].items():
+            if "error" in w:
+                ws[name] = {"error": str(w["error"])[:160], "finite": False}
+                continue
+            r = w.get("roofline") or {}
+            ws[name] = {"ms_per_step": w.get("ms_per_step"), "value": w.get("value"), "unit": w.get("unit"),
+                        "steps": w.get("steps"), "final_loss": w.get("final_loss"), "finite": bool(w.get("finite", False)),
+                        "roofline": {"kernel": str(r.get("kernel"))[:100], "frac": r.get("frac"), "bound": r.get("bound")},
+                        "forward_frac": (w.get("forward_roofline") or {}).get("frac"),
+                        "gradient_pass_ms": (w.get("gradient_pass") or {}).get("replayed_pass_ms")}
+        line["workloads"] = ws
+    if out.get("rccl"):
+        rc = out["rccl"]
+        line["rccl"] = {k: rc.get(k) for k in ("backend", "world", "rccl_version", "collectives_per_step",
+                                               "allgather_bytes_per_step", "state_broadcast_bytes_per_step")}
+        line["rccl"]["devices"] = len(rc.get("device_names") or [])
+    eng = out.get("engine") or {}
+    line["engine"] = {"fallbacks": eng.get("fallbacks"), "graphs": len(eng.get("graphs_captured") or []),
+                      "tuned_gemms": eng.get("tuned_gemms"), "collectives": eng.get("collectives")}
+    line["detail_file"] = detail_file
+    line = _strict(_sig(line))
+    for drop in ("kernels", "engine", "gradient_pass", "phase_s_per_step", "rccl", "workloads"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
 def self_launch(args) -> None:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as CHILD processes
     (python -m torch.distributed.run, rendezvous on 127.0.0.1) before this process has touched the GPU, pass
@@ -495,7 +596,7 @@ def committed_profile(name: str):
     """A committed measurement file under profiles/ (the newest round that has one), parsed; (None, None) when absent."""
     if name not in _PMC:
         hit = (None, None)
-        for tag in ("r3", "r2"):
+        for tag in ("r4", "r3", "r2"):
             path = os.path.join(REPO, "profiles", f"{tag}_{name}")
             try:
                 with open(path) as f:
@@ -794,6 +895,10 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
         "profiled_steps_after_timed_region": n_prof,
         "engine": attack.engine_state(),
         "final_loss": res.losses[timed_end - 1],
+        # every loss of the timed steps, checked: a step loop that went non-finite was not the workload (and trivial
+        # operands flatter the GEMMs)
+        "finite": bool(all(math.isfinite(float(v)) for v in res.losses[warmup:timed_end])),
+        "losses_timed": [float(v) for v in res.losses[warmup:timed_end]],
         "gradient_pass_ms_each": [round(1e3 * t, 2) for t in res.gradient_times[:timed_end * grad_per_step]],
     }
     if emulate:
@@ -849,6 +954,8 @@ def main() -> None:
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-prefix-reuse", action="store_true")
+    ap.add_argument("--detail", default=None, help="where the full result goes (default gpurun_out/bench_detail.json); "
+                                                   "the stdout line is the short summary of it")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 8 if args.workload == "opt125m" else 5
@@ -902,7 +1009,7 @@ def main() -> None:
         out["workloads"] = {}
         short = ("ms_per_step", "value", "unit", "steps", "warmup", "attack_steps_per_sec",
                  "scoring_phase_candidate_forwards_per_sec", "phase_s_per_step", "roofline", "forward_roofline",
-                 "gradient_pass", "engine", "config", "final_loss")
+                 "gradient_pass", "engine", "config", "final_loss", "finite", "losses_timed")
         for w in extra:
             if w not in WORKLOADS or w == args.workload:
                 continue
@@ -931,7 +1038,20 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        detail = args.detail or os.path.join(REPO, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
+            with open(detail, "w") as fh:
+                json.dump(_strict(out), fh, indent=1)
+            log(f"full detail (per-GEMM tables, kernels, engine state, notes) written to {detail}")
+        except OSError as e:
+            log(f"detail file not written: {e}")
+            detail = None
+        line = build_line(out, None if detail is None else os.path.relpath(detail, REPO))
+        print(json.dumps(line, allow_nan=False), flush=True)
+        if not line["finite"]:
+            log("NON-FINITE loss inside the timed steps of the headline workload: the number above is not a measurement")
+            sys.exit(3)
 
 
 if __name__ == "__main__":

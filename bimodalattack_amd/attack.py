@@ -43,7 +43,7 @@ from torch import Tensor
 from . import ops
 from .config import BimodalAttackConfig, BimodalAttackResult, EngineOptions
 from .dist import CandidateSharder
-from .fused import FusedInference
+from .fused import DeferredNormMissed, FusedInference
 from . import gemm_tuning
 from .hf_adapter import HFAdapter
 from .layout import ragged_plan, ragged_rows, dynamic_width, segment_order, split_at_suffix, unique_rows
@@ -232,6 +232,7 @@ class BimodalAttack:
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
                                     self.opt.fuse_gate_up, self.opt.fuse_add_norm, self.opt.fuse_qk_rope)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
+        logger.info(f"Fused forward admitted: {self.fused.admitted}")
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
         if model.dtype in (torch.float32, torch.float64):
@@ -258,7 +259,7 @@ class BimodalAttack:
         hf = self.hf
         return dict(tuned_gemms=self.tuned_gemms, prefix_ok=hf.prefix_ok, shared_ok=hf.shared_ok, ragged_ok=hf.ragged_ok,
                     graphs_captured=list(self.graphs_captured), fallbacks=dict(self.fallbacks),
-                    fused_elementwise=bool(self.fused.enabled), chunk_cap=self._chunk_cap,
+                    fused_elementwise=bool(self.fused.enabled), fusions=dict(self.fused.admitted), chunk_cap=self._chunk_cap,
                     collectives=self.shard.n_collectives if self.shard.enabled else 0)
 
     # ------------------------------------------------------------------ setup
@@ -328,6 +329,17 @@ class BimodalAttack:
             rnd = torch.rand((width, n_opt), device=dev)
             rank = torch.randint(0, cfg.topk, (width, cfg.n_replace, 1), device=dev).squeeze(2)
         return rnd.contiguous(), rank.contiguous()
+
+    def _rng_state(self, restore=None):
+        """The state of the generator ``_draw`` takes from (read, or put back)."""
+        on_cpu = self.opt.rng_device == "cpu"
+        if restore is None:
+            return torch.get_rng_state() if on_cpu else torch.cuda.get_rng_state(self.model.device)
+        if on_cpu:
+            torch.set_rng_state(restore)
+        else:
+            torch.cuda.set_rng_state(restore, self.model.device)
+        return None
 
     # ------------------------------------------------------------ gradient pass
     def compute_gradient(self, optim_ids: Tensor, image: Optional[Tensor] = None, tokens_only: bool = False):
@@ -551,8 +563,14 @@ class BimodalAttack:
         the candidates were sampled from, when the caller knows them (enables ragged scoring).
         `virtual`: (stand-in ids (n,n_opt), parent ids) on the host (``_virtual_ids``) -- the ragged plan is made
         from them and `sampled` is not waited for."""
-        with self.fused:
-            return self._score_candidates(sampled, order, feats, allow_prefix, parent, virtual)
+        try:
+            with self.fused:
+                return self._score_candidates(sampled, order, feats, allow_prefix, parent, virtual)
+        except DeferredNormMissed as e:
+            # (fused.py has switched the deferral off: the same call again runs the head norms as their own launches)
+            self._fallback("fuse_qk_rope", e, "q/k norm inside the rotary launch not applicable to this model's attention blocks")
+            with self.fused:
+                return self._score_candidates(sampled, order, feats, allow_prefix, parent, virtual)
 
     def scoring_features(self, image: Tensor) -> Tensor:
         """Image features for scoring (no autograd): the vision tower at batch 1 is launch-bound,
@@ -931,6 +949,13 @@ class BimodalAttack:
             full, self._match = self.shard.gather2(losses, match, n)
         if self.opt.loss_in_model_dtype:
             full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
+        if self.opt.score_log is not None:
+            # debugging aid (tools/nan_bisect.py): which route scored this call and whether every loss is finite -- kept
+            # as device scalars, read by the owner of the list after the run, so that nothing here stops the host
+            self.opt.score_log.append(dict(n=n, m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared),
+                                           use_prefix=bool(use_prefix), rows=self.score_stats["rows"],
+                                           bad=(~torch.isfinite(full.float())).sum(),
+                                           first_bad=(~torch.isfinite(full.float())).to(torch.int32).argmax()))
         return full
 
     def rescore_winner(self, winner: Tensor, order: List[str], feats: Tensor) -> Tensor:
@@ -1199,14 +1224,24 @@ class BimodalAttack:
                             (hit.any().reshape(1) if hit is not None else at.new_zeros(1)).to(f64),
                             winner.reshape(-1).to(f64)]))
                         queued = None
+                        rng_before = None
                         if i + 1 < cfg.num_steps:
-                            if self.opt.early_plan and self.opt.score_graphs == 0 and cfg.gcg_attack:
+                            # the draws of step i+1 come out of the global generator HERE, ahead of whatever else step i
+                            # still takes from it in the reference's order -- debug_output's generate() under a sampling
+                            # generation_config (:745-777) -- so that mode keeps the plain order; and a step that turns
+                            # out to stop the run (early_stop) gives its draws back, as if they had never been made
+                            if self.opt.early_plan and self.opt.score_graphs == 0 and cfg.gcg_attack and not cfg.debug_output:
+                                if cfg.early_stop:
+                                    rng_before = self._rng_state()
                                 self._draw_ahead(i + 1, winner.shape[1])
                             sp = _Span()
                             with torch.enable_grad():
                                 g_next = self.compute_gradient(winner, img)
                             queued = (g_next, None, sp.stop())
                         host = read()
+                        if rng_before is not None and host[2] != 0.0:
+                            self._rng_state(rng_before)
+                            self._early = None
                         return winner, host, time.perf_counter(), queued
 
                     ahead_ok = bool(self.opt.gradient_ahead and not (self.opt.tp_gradient and self.shard.enabled))

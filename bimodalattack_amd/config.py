@@ -210,6 +210,9 @@ class EngineOptions:
     save_images: bool = True
     # Record per-step internals (sampled ids, N after filter, best_idx, ...).
     trace: Optional[list] = None
+    # Debugging aid: a list that receives one dict per scoring call (route taken, sizes, count of non-finite losses as a
+    # device scalar); see tools/nan_bisect.py.
+    score_log: Optional[list] = None
     # torch.distributed process group used to shard candidate scoring; None =
     # the default group when initialised, else single process.
     group: object = None

@@ -4,7 +4,7 @@
 //
 // The communicator is the HOST's (an ncclComm_t of the RCCL instance the host process already uses): this library
 // must call into that same instance, so it does not link RCCL -- it looks `ncclAllGather` up in the RCCL already
-// loaded into the process (dlopen with RTLD_NOLOAD), and only loads one itself when there is none.  The Python host
+// loaded into the process (dlopen with RTLD_NOLOAD) and never loads one itself (see resolve()).  The Python host
 // of this repo does not come through here (torch.distributed owns its communicator and does not hand it out:
 // bimodalattack_amd/dist.py); a C, C++ or Go host that created its communicator with ncclCommInitRank does.
 #include <dlfcn.h>
@@ -20,19 +20,23 @@ namespace {
 typedef int (*all_gather_fn)(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, void* stream);
 constexpr int kNcclFloat32 = 7;
 
+// Only an RCCL that is ALREADY in the process will do: the communicator belongs to the instance that made it, and a second
+// instance loaded here (another soname, another copy) would be handed a pointer it never created -- undefined behaviour,
+// not an error code.  So: the loaded library by its usual sonames (RTLD_NOLOAD), else whatever the process exports under
+// the symbol's name (a host that links RCCL statically); else no collective (BMA_ECOLL).  A miss is not remembered: the
+// host may load RCCL later.
 all_gather_fn resolve() {
-  static std::once_flag once;
+  static std::mutex mu;
   static all_gather_fn fn = nullptr;
-  std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "libnccl.so.2"};
-    void* h = nullptr;
-    for (const char* n : names)
-      if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;         // the instance the host already has
-    if (!h)
-      for (const char* n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (h) fn = reinterpret_cast<all_gather_fn>(dlsym(h, "ncclAllGather"));
-  });
+  std::lock_guard<std::mutex> lock(mu);
+  if (fn) return fn;
+  const char* names[] = {"librccl.so.1", "librccl.so", "libnccl.so.2"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  void* sym = h ? dlsym(h, "ncclAllGather") : nullptr;
+  if (!sym) sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+  fn = reinterpret_cast<all_gather_fn>(sym);
   return fn;
 }
 

@@ -193,6 +193,12 @@ def _norms_then_rope(attn) -> bool:
     return tuple(rest[:3]) == _NORM_ROPE_LINES
 
 
+class DeferredNormMissed(RuntimeError):
+    """A q/k norm deferred into the rotary launch was not picked up (the attention block did something else with the
+    tensor first).  By the time this is raised the deferral is switched off for good on this object: the caller runs
+    the forward again and gets the unfused norms."""
+
+
 _TP_COLUMN = ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")
 _TP_ROW = ("o_proj", "down_proj")
 
@@ -203,6 +209,7 @@ class FusedInference:
         self.enabled = enabled
         self.fuse_qk_rope = fuse_qk_rope
         self._rope_norms = {}                        # id(q_norm / k_norm module) of attention blocks whose forward rotates right behind them
+        self.admitted = {}
         self._pending = {}                           # id(tensor) -> (tensor, weight, eps, gemma): a head norm deferred into the rotary launch
         self.weight_copies = weight_copies
         self.fuse_gate_up = fuse_gate_up
@@ -233,6 +240,7 @@ class FusedInference:
         if not enabled:
             return
         files = set()
+        norm_rope_blocks = []
         for m in model.modules():
             cls = type(m).__name__
             w = getattr(m, "weight", None)
@@ -243,8 +251,7 @@ class FusedInference:
                     and not hasattr(m, "q_norm"):      # per-head norms (Gemma-3) want dense projection outputs
                 self.qkv.append(m)
             if fuse_qk_rope and hasattr(m, "q_norm") and hasattr(m, "k_norm") and _norms_then_rope(m):
-                self._rope_norms[id(m.q_norm)] = m.q_norm
-                self._rope_norms[id(m.k_norm)] = m.k_norm
+                norm_rope_blocks.append(m)
             if hasattr(m, "q_proj") or hasattr(m, "gate_proj"):
                 for name in _TP_COLUMN + _TP_ROW:
                     lin = getattr(m, name, None)
@@ -271,6 +278,20 @@ class FusedInference:
             mod = sys.modules.get(f)
             if mod is not None and f.rsplit(".", 1)[-1] in _ROPE_FILES and hasattr(mod, "apply_rotary_pos_emb"):
                 self.rope_modules.append(mod)
+        # a head norm may only be deferred into the rotary launch of a block whose modelling file's apply_rotary_pos_emb
+        # IS patched here: anywhere else nobody would pick the un-normalised tensor up
+        for m in norm_rope_blocks:
+            if sys.modules.get(type(m).__module__) in self.rope_modules:
+                self._rope_norms[id(m.q_norm)] = m.q_norm
+                self._rope_norms[id(m.k_norm)] = m.k_norm
+        kinds = sorted({k for _, k, _ in self.layers})
+        # what was admitted (the source-text checks above turn a fusion off silently on a transformers upgrade or a
+        # .pyc-only install: the engine logs this and bench.py prints it with the engine state)
+        self.admitted = dict(rmsnorms=len(self.norms), gated_mlps=len(self.mlps), fused_qkv_blocks=len(self.qkv),
+                             transposed_copy_projections=len(self.linears), add_norm_layers=len(self.layers),
+                             layer_kinds=kinds, rotary_files=[m.__name__.rsplit(".", 1)[-1] for m in self.rope_modules],
+                             qk_norm_in_rotary_blocks=len(self._rope_norms) // 2,
+                             qk_norm_blocks_not_admitted=len(norm_rope_blocks) - len(self._rope_norms) // 2)
 
     @staticmethod
     def _act_code(act_fn):
@@ -539,8 +560,7 @@ class FusedInference:
                 h = _TPCopy.apply(h, tp[2])          # replicated input of the column-parallel q/k/v
             h, _ = layer.self_attn(hidden_states=h, **kwargs)
             if self._pending:
-                self._pending.clear()
-                raise RuntimeError("bimodalattack_amd.fused: a deferred q/k norm was not picked up by the rotary embedding")
+                self._missed()
             if gem:
                 residual, h = self._add_norm(residual, h, layer.pre_feedforward_layernorm, pre=layer.post_attention_layernorm)
             else:
@@ -554,6 +574,16 @@ class FusedInference:
             self._stash[id(next_norm)] = (out, normed)
             return out
         return forward
+
+    def _missed(self):
+        """A deferred head norm nobody picked up: the result of this forward is wrong, so it must not be used -- but
+        only this once: the deferral is off from here on and the same call goes through unfused."""
+        self._pending.clear()
+        n = len(self._rope_norms) // 2
+        self._rope_norms.clear()
+        self.admitted["qk_norm_in_rotary_blocks"] = 0
+        raise DeferredNormMissed(f"bimodalattack_amd.fused: a deferred q/k norm was not picked up by the rotary embedding "
+                                 f"({n} blocks had been admitted; the deferral is now off for this model)")
 
     def _rope(self, orig):
         def apply_rotary_pos_emb(q, k, cos, sin, *args, unsqueeze_dim=1, **kw):
@@ -647,7 +677,7 @@ class FusedInference:
             mod.apply_rotary_pos_emb = fn
         self._saved_rope.clear()
         if self._pending:                          # (not when an exception is already on its way out)
-            self._pending.clear()
             if exc[0] is None:
-                raise RuntimeError("bimodalattack_amd.fused: a deferred q/k norm was not picked up by the rotary embedding")
+                self._missed()
+            self._pending.clear()
         return False

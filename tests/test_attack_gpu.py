@@ -210,6 +210,38 @@ def test_gradient_queued_ahead_gives_the_same_run(name):
         assert len(r.sampling_times) == len(r.losses) and all(t >= 0.0 for t in r.gradient_times + r.loss_times)
 
 
+def test_early_draws_keep_the_reference_order_of_the_generator():
+    """the draws of step i+1 made inside step i (early_plan) must not reorder what the run takes from the
+    global generator.  (a) a run that stops early leaves the generator where the plain order leaves it -- the draws of
+    the step that never ran are given back; (b) with debug_output and a SAMPLING generation_config, generate(i)
+    consumes random numbers between the draws of step i and of step i+1 (:745-777 against :150-160): same losses,
+    strings and generated text with the pipelined step boundary as without."""
+    from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
+    m = META["cases"]["llava_gcg_early"]
+    after = []
+    for early in (True, False):
+        model, tok, proc, image = S.tiny_case(m["kind"], device=DEV)
+        cfg = BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=m["optim_str_init"],
+                                  images_folder=tempfile.mkdtemp(prefix="bma_gpu_"), **m["config"])
+        res = run(model, tok, proc, m["goal"], m["goal"], m["target"], image, cfg,
+                  normalize=S.Normalize(S.CLIP_MEAN, S.CLIP_STD), rng_device="cpu", strict=True, early_plan=early)
+        assert len(res.losses) == m["steps"] < m["config"]["num_steps"]          # it did stop early
+        after.append((res.losses, torch.rand(4).tolist()))
+    assert after[0] == after[1]
+    out = []
+    for early in (True, False):
+        model, tok, proc, _ = S.tiny_case("opt", device=DEV)
+        model.generation_config.do_sample = True
+        model.generation_config.top_k = 8
+        cfg = BimodalAttackConfig(num_steps=12, search_width=8, topk=8, seed=3, verbosity="ERROR", debug_output=True,
+                                  optim_str_init=S.TINY_OPTIM_INIT, images_folder=tempfile.mkdtemp())
+        res = run(model, tok, proc, "tell me", "tell me", "Sure here", None, cfg, rng_device="cpu", strict=True,
+                  early_plan=early)
+        out.append((res.losses, res.strings, res.model_outputs, torch.rand(4).tolist()))
+    assert out[0] == out[1]
+    assert out[0][2][0] != "" or out[0][2][10] != ""
+
+
 @pytest.mark.parametrize("kind,dtype", [("llava", torch.bfloat16), ("llava", torch.float16),
                                         ("gemma3", torch.bfloat16)])
 def test_device_rng_mode_and_16bit_run(kind, dtype):
@@ -572,8 +604,12 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and lines[0] == r.stdout.strip().splitlines()[-1]
+    # the driver keeps the last 8000 characters of stdout: the line, `rccl` block included, must fit and be strict JSON
+    assert len(lines[0]) <= 6000, len(lines[0])
+    d = json.loads(lines[0], parse_constant=lambda c: pytest.fail(f"non-JSON constant {c} in the bench line"))
+    assert d["finite"] is True and d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo"
+    assert d["detail_file"] and os.path.exists(os.path.join(repo, d["detail_file"]))
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "candidates/2" and d["scaling"] == "strong"
     # one loss gather for the initial suffix, then two collectives per step (ids broadcast + loss gather), 4 steps;
     # from the second step on the draws made ahead of the gradient pass are broadcast as well (early_plan: 8 KB)

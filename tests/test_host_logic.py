@@ -479,6 +479,68 @@ def test_bench_gemm_roles_and_extra_workloads():
     assert bench.COPY_CEILING_GBS < bench.HBM_PEAK_GBS and bench.MFMA_PEAK_TFLOPS == 2500.0
 
 
+def test_qk_norm_is_deferred_only_where_the_rotary_function_is_patched(monkeypatch):
+    """a head norm may be deferred into the rotary launch only in blocks whose modelling file's
+    apply_rotary_pos_emb the fused context patches -- elsewhere nobody picks the un-normalised tensor up.  The
+    admission is recorded (`admitted`), and a missed pick-up switches the deferral off instead of failing every call."""
+    from bimodalattack_amd import fused, synthetic as S
+    model, _, _, _ = S.tiny_case("gemma3")
+    f = fused.FusedInference(model)
+    assert f.admitted["qk_norm_in_rotary_blocks"] == 2 and f.admitted["qk_norm_blocks_not_admitted"] == 0
+    assert f.admitted["rotary_files"] == ["modeling_gemma3"] and f.admitted["layer_kinds"] == ["gemma"]
+    with pytest.raises(fused.DeferredNormMissed):
+        f._pending[1] = (None, None, 0.0, True)
+        f._missed()
+    assert not f._rope_norms and not f._pending and f.admitted["qk_norm_in_rotary_blocks"] == 0
+    monkeypatch.setattr(fused, "_ROPE_FILES", ("modeling_llama",))
+    g = fused.FusedInference(model)
+    assert not g._rope_norms and g.admitted["qk_norm_blocks_not_admitted"] == 2 and g.admitted["rotary_files"] == []
+
+
+def test_bench_line_fits_the_drivers_window_and_is_strict_json():
+    """The driver keeps the last 8000 characters of bench.py's stdout and parses the last line (round 3's 44 KB line
+    did not parse).  build_line() turns a full result -- here round 3's own, NaN loss of the Gemma workload included,
+    then the same blown up with prose and workloads -- into one line under LINE_LIMIT that strict JSON parsers take,
+    carrying the contract's fields, `roofline`, `cpu_baseline` and a `finite` verdict per workload."""
+    import json
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    full = json.load(open(os.path.join(repo, "profiles", "r3_bench_driver.json")))
+    full["finite"] = True
+    full["workloads"]["joint"]["finite"] = True
+    full["workloads"]["gemma_joint"]["final_loss"] = float("nan")
+    full["workloads"]["gemma_joint"]["finite"] = False
+    full["rccl"] = dict(backend="nccl", world=8, rccl_version="2.26.6", device_names=["rank %d: AMD Instinct MI355X" % i for i in range(8)],
+                        collectives_per_step=2.0, allgather_bytes_per_step=2048, allgather_bytes_per_rank=256,
+                        state_broadcast_bytes_per_step=77824, what="x" * 500)
+    for blow in (0, 1):
+        if blow:
+            full["roofline"]["note"] = "prose " * 2000
+            full["roofline"]["kernel"] = "K" * 900
+            full["cpu_baseline"]["sample"] = "s" * 5000
+            for i in range(40):
+                full["workloads"][f"extra{i}"] = dict(full["workloads"]["joint"])
+        line = bench.build_line(full, "gpurun_out/bench_detail.json")
+        text = json.dumps(line, allow_nan=False)                 # raises on NaN / Infinity
+        assert len(text) <= bench.LINE_LIMIT < 8000, len(text)
+        back = json.loads(text, parse_constant=lambda c: pytest.fail(f"non-JSON constant {c}"))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "finite", "detail_file"):
+            assert k in back, k
+        assert back["finite"] is True and back["value"] == pytest.approx(full["value"], rel=1e-4)
+        assert set(back["roofline"]) >= {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"}
+        assert back["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+        assert set(back["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+        assert "model" not in back["config"] and "workload" in back["config"]
+        if not blow:
+            g = back["workloads"]["gemma_joint"]
+            assert g["finite"] is False and g["final_loss"] is None and back["workloads"]["joint"]["finite"] is True
+            assert back["rccl"]["world"] == 8 and back["rccl"]["devices"] == 8 and "what" not in back["rccl"]
+    assert bench._strict({"a": [float("inf"), 1.0, {"b": float("nan")}]}) == {"a": [None, 1.0, {"b": None}]}
+
+
 def test_virtual_ids_plan_what_the_real_candidates_need():
     """early_plan (attack.py `_virtual_ids`): the host plans the ragged forward from the random draws alone, on
     stand-ins for ids it has not seen.  For every draw: equal stand-ins mean equal candidates (so the dedup never

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Where does a non-finite value first appear in a full-size attack run?  (the Gemma-3-4b joint
+workload ended with a NaN loss while the oracle on the same model stays finite.)
+
+    python tools/nan_bisect.py [--workload gemma_joint] [--steps 3] [--width 64] [--variants default,nopad,...]
+
+Runs the workload's engine on bench.py's plugins with the step trace on, once per option variant, and prints for
+every step whether the token gradient, the pixel gradient, the image after PGD, the candidate losses and the step
+loss are finite (and their extremes).  One JSON document goes to --out."""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+VARIANTS = {
+    "default": {},
+    "nopad": dict(pad_vision_heads=False),
+    "nographs": dict(graph_gradient=False, graph_prefix=False, graph_rescore=False),
+    "notowerqkv": dict(fuse_tower_qkv=False),
+    "noaddnorm": dict(fuse_add_norm=False),
+    "noqkrope": dict(fuse_qk_rope=False),
+    "nofused": dict(fused_elementwise=False),
+    "noskinny": dict(skinny_gemm=False),
+    "nogateup": dict(fuse_gate_up=False, fuse_qkv=False),
+    "nobwdcopies": dict(backward_weight_copies=False),
+    "nomaskless": dict(maskless_b1_attention=False),
+    "plain": dict(pad_vision_heads=False, graph_gradient=False, graph_prefix=False, graph_rescore=False, fuse_tower_qkv=False,
+                  fuse_add_norm=False, fuse_qk_rope=False, fused_elementwise=False, skinny_gemm=False, fuse_gate_up=False,
+                  fuse_qkv=False, backward_weight_copies=False, maskless_b1_attention=False, shared_prefix_attention=False,
+                  ragged_suffix=False, gradient_ahead=False, early_plan=False, gemm_tuning="off"),
+}
+
+
+def stats(a) -> dict:
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64)
+    fin = np.isfinite(a)
+    return dict(finite=bool(fin.all()), n_bad=int((~fin).sum()), n=int(a.size),
+                absmax=float(np.abs(a[fin]).max()) if fin.any() else None)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="gemma_joint")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--variants", default="default")
+    ap.add_argument("--no-trace", action="store_true", help="no step trace (its device-to-host copies synchronise every phase)")
+    ap.add_argument("--bench-schedule", action="store_true", help="bench.py's widths: 2 steps at the full width, then the "
+                    "600-step schedule sampled evenly over steps-4 steps, then 2 at its middle")
+    ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "nan_bisect.json"))
+    args = ap.parse_args()
+
+    import torch
+    import bench
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack, logger
+    from bimodalattack_amd.config import EngineOptions
+
+    logger.setLevel("ERROR")
+    dev = torch.device("cuda", 0)
+    wl = bench.WORKLOADS[args.workload]
+    model, tok, proc, messages, goal, target, image0, norm = bench.build_plugins(args.workload, dev, torch.bfloat16, args.layers, share=True)
+    report = {}
+    for name in args.variants.split(","):
+        kw = dict(VARIANTS[name])
+        trace = None if args.no_trace else []
+        score_log = []
+        kw["score_log"] = score_log
+        if args.bench_schedule:
+            from bimodalattack_amd.layout import dynamic_width
+            K = max(1, args.steps - 4)
+
+            def width_of(i, K=K):
+                v = 0 if i < 2 else (int(round((i - 2 + 0.5) * 600 / K)) if i < 2 + K else 300)
+                return dynamic_width(min(v, 599), args.width, 600, min(128, args.width), True)
+            kw["width_override"] = width_of
+        cfg = BimodalAttackConfig(num_steps=args.steps, search_width=args.width, topk=256, seed=1, verbosity="ERROR",
+                                  pgd_attack=wl["pgd_attack"], gcg_attack=wl["gcg_attack"], joint_eval=wl["joint_eval"],
+                                  eps=64 / 255, alpha=4 / 255, images_folder=tempfile.mkdtemp(prefix="bma_nan_"),
+                                  dynamic_search=bool(wl.get("gemma")), min_search_width=min(128, args.width))
+        image = None if image0 is None else image0.detach().clone()
+        attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, trace=trace, **kw))
+        try:
+            res = attack.run(messages, goal, target, image)
+            err = None
+        except Exception as e:        # report and carry on with the next variant
+            res, err = None, f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+        rows = []
+        for i, st in enumerate(trace or []):
+            row = dict(step=i, n_grad=st.get("n_grad"))
+            for k in ("grad_tok", "grad_img", "losses"):
+                row[k] = [stats(a) for a in st.get(k, [])]
+            if "image_after_pgd" in st:
+                row["image_after_pgd"] = stats(st["image_after_pgd"])
+            row["current_loss"] = st.get("current_loss")
+            rows.append(row)
+        calls = [{k: (int(v.item()) if hasattr(v, "item") else v) for k, v in c.items()} for c in score_log]
+        kw.pop("score_log", None)
+        kw.pop("width_override", None)
+        for c in calls:
+            print(f"   score call: n={c['n']} m={c['m']} L={c['L']} P={c['P']} chunk={c['chunk']} ragged={c['ragged']} shared={c['shared']} "
+                  f"rows={c['rows']} bad={c['bad']} first_bad={c['first_bad']}", flush=True)
+        rep = dict(options=kw, error=err, score_calls=calls, init_losses=[float(v) for v in attack.init_losses.tolist()] if hasattr(attack, "init_losses") else None,
+                   losses=None if res is None else res.losses, steps=rows, engine=attack.engine_state())
+        report[name] = rep
+        print(f"== {name}: init {rep['init_losses']} losses {rep['losses']} error {err}", flush=True)
+        for r in rows:
+            def f(lst):
+                return "/".join(("ok" if s["finite"] else f"BAD{s['n_bad']}") + (f"({s['absmax']:.3g})" if s["absmax"] is not None else "") for s in lst) or "-"
+            print(f"   step {r['step']}: g_tok {f(r['grad_tok'])}  g_img {f(r['grad_img'])}  image "
+                  f"{f([r['image_after_pgd']]) if 'image_after_pgd' in r else '-'}  cand {f(r['losses'])}  loss {r['current_loss']}", flush=True)
+        del attack
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as fh:
+        json.dump(report, fh, indent=1, default=str)
+
+
+if __name__ == "__main__":
+    main()
