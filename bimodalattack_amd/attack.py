@@ -424,7 +424,7 @@ class BimodalAttack:
         if cfg.gcg_attack:
             emb.requires_grad_()
         if cfg.pgd_attack:
-            feats = self.hf.image_features(image)
+            feats = self.image_features(image)
             parts = [self.seg["before_img"], feats.to(emb.dtype), self.seg["before_suffix"], emb, self.seg["after"],
                      self.seg["target"]]
         else:
@@ -572,6 +572,16 @@ class BimodalAttack:
             with self.fused:
                 return self._score_candidates(sampled, order, feats, allow_prefix, parent, virtual)
 
+    def image_features(self, image: Tensor) -> Tensor:
+        """``model.get_image_features`` on the normalised image (reference :526-536, :877-884, :970-979), inside the fused
+        context: the projector's RMSNorm (Gemma-3's ``mm_soft_emb_norm``, on a transposed view of the pooled patches)
+        then runs ``bma_rmsnorm`` instead of ATen's strided-mean reduction.  That reduction is a multi-block one with
+        a scratch buffer and semaphores, and replayed from a hipGraph on this stack it returned NaN rows for some images
+        (rows 64-255 of 256, the eager call on the same input finite: tools/nan_bisect.py --probe-feats; rounds 2 and
+        3 shipped a Gemma-3 workload with NaN losses because of it)."""
+        with self.fused:
+            return self.hf.image_features(image)
+
     def scoring_features(self, image: Tensor) -> Tensor:
         """Image features for scoring (no autograd): the vision tower at batch 1 is launch-bound,
         so it is replayed from a hipGraph after the first call."""
@@ -583,16 +593,16 @@ class BimodalAttack:
                 self._gp = False
                 torch.cuda.synchronize(self.model.device)
         if not self.opt.graph_prefix or self._feat_graph is False:
-            return self.hf.image_features(image)
+            return self.image_features(image)
         if self._feat_graph is None:
             try:
-                self._feat_graph = _ReplayGraph(self.model.device, self.hf.image_features, image)
+                self._feat_graph = _ReplayGraph(self.model.device, self.image_features, image)
                 self.graphs_captured.append("image_features")
             except Exception as e:
                 self._fallback("graph_features", e, "image features not captured into a graph; running eager")
                 self._feat_graph = False
                 torch.cuda.synchronize(self.model.device)
-                return self.hf.image_features(image)
+                return self.image_features(image)
         return self._feat_graph(image)
 
     def _wants_shared(self, P: int, total_len: int = 0) -> bool:
@@ -923,6 +933,9 @@ class BimodalAttack:
                     loss, hit = scored
                 else:
                     loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
+                if self.opt.score_log is not None and logits is not None:
+                    self.opt.score_log.append(dict(chunk_at=s, b=b, logits_bad=(~torch.isfinite(logits.float())).sum(),
+                                                   x_bad=None if x is None else (~torch.isfinite(x.float())).sum()))
                 losses[s:s + b] = loss[:b]       # (the padding's losses are dropped)
                 if match is not None:
                     match[s:s + b] = hit[:b].to(torch.float32)
@@ -952,7 +965,16 @@ class BimodalAttack:
         if self.opt.score_log is not None:
             # debugging aid (tools/nan_bisect.py): which route scored this call and whether every loss is finite -- kept
             # as device scalars, read by the owner of the list after the run, so that nothing here stops the host
-            self.opt.score_log.append(dict(n=n, m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared),
+            extra = {}
+            if feats is not None:
+                extra["feats_bad"] = (~torch.isfinite(feats.float())).sum()
+            extra["ids_min"], extra["ids_max"] = sampled.min(), sampled.max()
+            if cache is not None and hasattr(cache, "k"):
+                extra["prefix_bad"] = sum((~torch.isfinite(t.float())).sum() for t in list(cache.k) + list(cache.v))
+            for k_, t in segs:
+                if t is not None and k_ == "shared":
+                    extra["segs_bad"] = extra.get("segs_bad", 0) + (~torch.isfinite(t.float())).sum()
+            self.opt.score_log.append(dict(n=n, m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared), **extra,
                                            use_prefix=bool(use_prefix), rows=self.score_stats["rows"],
                                            bad=(~torch.isfinite(full.float())).sum(),
                                            first_bad=(~torch.isfinite(full.float())).to(torch.int32).argmax()))
@@ -1010,7 +1032,7 @@ class BimodalAttack:
         mt = self.hf.model_type
         with torch.no_grad():
             if cfg.pgd_attack:
-                feats = self.hf.image_features(image)
+                feats = self.image_features(image)
                 losses = self.score_candidates(ids[:n], segment_order("gcg_pgd", mt, single=True), feats)
             else:
                 losses = self.score_candidates(ids[:n], segment_order("gcg", mt, no_joint_eval=True), None)
@@ -1394,7 +1416,7 @@ class BimodalAttack:
         mt, E = self.hf.model_type, self.embedding_layer.weight
         with torch.no_grad():
             if image is not None:
-                feats = self.hf.image_features(image).to(E.dtype)
+                feats = self.image_features(image).to(E.dtype)
                 order = segment_order("gcg_pgd", mt, no_target=True)
             else:
                 feats, order = None, segment_order("gcg", mt, no_target=True)
@@ -1448,7 +1470,7 @@ class _GradPrefix:
     def _prefix_fn(self):
         a = self.a
         with torch.enable_grad():
-            feats = a.hf.image_features(self.image)
+            feats = a.image_features(self.image)
             x = torch.cat([a.seg["before_img"], feats.to(a.model.dtype), a.seg["before_suffix"]], dim=1)
             with a.fused, a._b1_attention(x.shape[1]):
                 rec = a.hf.build_prefix_recording(x)

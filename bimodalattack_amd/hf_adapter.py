@@ -107,6 +107,7 @@ class HFAdapter:
         self._quick_gelus = None
         self.fuse_tower_qkv = True              # EngineOptions.fuse_tower_qkv: the tower's q/k/v projections as one product
         self._tower_attn = None
+        self._proj_norms = None
 
     # ------------------------------------------------------------ vision
     def vision_configs(self) -> list:
@@ -136,6 +137,14 @@ class HFAdapter:
                         found.append(m)
             self._quick_gelus = found
         return self._quick_gelus if self.fuse_quick_gelu else []
+
+    def projector_norms(self) -> list:
+        """RMSNorm modules of the multimodal projector (Gemma-3's ``mm_soft_emb_norm``)."""
+        if self._proj_norms is None:
+            proj = getattr(self.model, "multi_modal_projector", None) or getattr(getattr(self.model, "model", None),
+                                                                                  "multi_modal_projector", None)
+            self._proj_norms = [] if proj is None else [m for m in proj.modules() if type(m).__name__.endswith("RMSNorm")]
+        return self._proj_norms
 
     def tower_attention_modules(self) -> list:
         """The vision tower's attention blocks (CLIP / SigLIP modelling files) whose q_proj / k_proj / v_proj are plain
@@ -228,11 +237,18 @@ class HFAdapter:
                 return ops.QuickGELUFn.apply(x)
             return ops.quick_gelu(x)
         attns = self.tower_attention_modules()
+        # the projector's norms (Gemma-3: mm_soft_emb_norm) are handed a TRANSPOSED view of the pooled patches; ATen's
+        # mean over that strided dim is a multi-block reduction (scratch buffer + semaphores) which, replayed from a
+        # hipGraph on this stack, returned NaN rows (attack.image_features).  A contiguous input keeps it a one-block-
+        # per-row reduction.  (Only where the engine's fused context has not already replaced the norm's forward.)
+        proj_norms = [m for m in self.projector_norms() if "forward" not in m.__dict__]
         try:
             for m in mods:
                 m.forward = forward
             for a in attns:
                 a.q_proj.forward, a.k_proj.forward, a.v_proj.forward = self._tower_qkv_forwards(a)
+            for m in proj_norms:
+                m.__dict__["forward"] = (lambda x, _f=type(m).forward.__get__(m): _f(x.contiguous()))
             yield
         finally:
             for m in mods:
@@ -240,6 +256,8 @@ class HFAdapter:
             for a in attns:
                 for lin in (a.q_proj, a.k_proj, a.v_proj):
                     lin.__dict__.pop("forward", None)
+            for m in proj_norms:
+                m.__dict__.pop("forward", None)
 
     def image_features(self, image: torch.Tensor) -> torch.Tensor:
         px = self.normalize(image)

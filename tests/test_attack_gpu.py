@@ -971,6 +971,133 @@ def test_7b_gradient_fp32_matches_reference_call_shape(workload):
             assert np.abs(np.sort(vals_m) - np.sort(vals_t)).max() <= tol
 
 
+def _reference_gradient(model, atk, ids, image):
+    """The reference's gradient pass (:953-1028) as it calls the model: one-hot @ E.weight (the UNSCALED table, whatever
+    the model family), the llava segment order, full (1,S,V) logits, torch's mean cross-entropy on the target slice."""
+    E = atk.embedding_layer
+    dt = E.weight.dtype
+    onehot = torch.nn.functional.one_hot(ids, num_classes=E.num_embeddings).to(dt).requires_grad_()
+    optim_embeds = onehot @ E.weight
+    img = image.detach().clone().requires_grad_()
+    feats = atk.hf.image_features(img)
+    parts = [atk.seg["before_img"].to(dt), feats.to(dt), atk.seg["before_suffix"].to(dt), optim_embeds, atk.seg["after"].to(dt),
+             atk.seg["target"].to(dt)]
+    x = torch.cat(parts, dim=1)
+    logits = model(inputs_embeds=x, use_cache=False).logits
+    shift = x.shape[1] - atk.T
+    loss = torch.nn.functional.cross_entropy(logits[0, shift - 1:-1, :], atk.target_ids[0])
+    g_tok, g_img = torch.autograd.grad(loss, [onehot, img])
+    return g_tok[0].detach(), g_img.detach(), float(loss.detach())
+
+
+def test_gemma3_4b_gradient_matches_reference_call_shape():
+    """VERDICT r3 item 2(a).  Gemma-3-4b-it width (D = 2560, 256-wide heads, grouped K/V, V = 262208, SigLIP tower of
+    4096 patches with 72-wide heads pooled to 256 image tokens).  (1) fp32, 4 text layers: the engine's gradient pass
+    (target rows only, fused norms / gates / rotary, padded vision heads, transposed weight copies, its own
+    cross-entropy) against the reference's call shape -- llava segment order, unscaled table (:968, :981-991) --
+    token and pixel gradients within 1e-4 of the gradient's scale.  (2) the full-depth bf16 model: both gradients
+    finite, and as close to the fp32 model's as the reference's own bf16 pass is (x1.5 + 2e-3, relative L2)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+
+    def engine(dtype, layers, **opts):
+        model, tok, proc, messages, goal, target, image, norm = build_plugins("gemma_joint", dev, dtype, layers)
+        cfg = BimodalAttackConfig(num_steps=1, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=True,
+                                  joint_eval=True, images_folder=tempfile.mkdtemp())
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True, **opts))
+        atk._prepare_prompt(messages, target)
+        ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+        return model, atk, ids, image
+
+    # ---- (1) fp32, 4 layers ----------------------------------------------------------------------------------
+    model, atk, ids, image = engine(torch.float32, 4, graph_gradient=False)
+    assert atk.hf.model_type == "gemma3" and atk.hf.emb_scale != 1.0
+    g_tok, g_img, loss = atk._gradient_eager(ids, image.detach().clone().requires_grad_())
+    r_tok, r_img, r_loss = _reference_gradient(model, atk, ids, image)
+    np.testing.assert_allclose(float(loss), r_loss, rtol=1e-5)
+    e_tok = float((g_tok[0] - r_tok).abs().max() / r_tok.abs().max())
+    e_img = float((g_img - r_img).abs().max() / r_img.abs().max())
+    print(f"gemma3-4b fp32 gradient (4 layers): loss {float(loss):.6f}, token-gradient max err / scale {e_tok:.2e}, pixel-gradient {e_img:.2e}")
+    assert e_tok < 1e-4 and e_img < 1e-4
+    del model, atk
+    torch.cuda.empty_cache()
+
+    # ---- (2) bf16, full depth: the replayed pass the attack runs ------------------------------------------------
+    model, atk, ids, image = engine(torch.bfloat16, 34)
+    img = image.detach().clone().requires_grad_()
+    with torch.enable_grad():
+        first = [t.clone() for t in atk.compute_gradient(ids, img)]          # eager warm-up + capture + first replay
+        again = atk.compute_gradient(ids, img)                                # a replay
+    assert "gradient" in atk.graphs_captured and not atk.fallbacks
+    for a, b in zip(first, again):
+        # (the library's attention backward accumulates with atomics: two replays agree to rounding, not bit for bit)
+        assert bool(torch.isfinite(a.float()).all()) and bool(torch.isfinite(b.float()).all())
+        assert float((a.float() - b.float()).norm() / b.float().norm()) < 2e-2
+    g_tok, g_img = first[0][0].float(), first[1].float()
+    b_tok, b_img, b_loss = _reference_gradient(model, atk, ids, image)         # the reference's own bf16 computation
+    segs16 = atk.seg
+    model.float()
+    atk.embedding_layer.embed_scale.fill_(atk.hf.emb_scale)                    # (keeps the bf16-rounded sqrt(D))
+    atk.seg = {k_: v_.float() for k_, v_ in segs16.items()}
+    f_tok, f_img, f_loss = _reference_gradient(model, atk, ids, image)
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())              # noqa: E731
+    noise_tok, noise_img = rel(b_tok, f_tok), rel(b_img, f_img)
+    err_tok, err_img = rel(g_tok, f_tok), rel(g_img, f_img)
+    print(f"gemma3-4b bf16 gradient (34 layers): loss engine {float(first[2]):.4f} reference-bf16 {b_loss:.4f} fp32 {f_loss:.4f}; "
+          f"token gradient rel-L2 vs fp32: engine {err_tok:.3e}, reference-bf16 {noise_tok:.3e}; pixel gradient: engine "
+          f"{err_img:.3e}, reference-bf16 {noise_img:.3e}")
+    assert abs(float(first[2]) - f_loss) <= 1.5 * abs(b_loss - f_loss) + 2e-2 * abs(f_loss)
+    assert err_tok <= 1.5 * noise_tok + 2e-3 and err_img <= 1.5 * noise_img + 2e-3
+
+
+@pytest.mark.parametrize("width", [64, 512])
+def test_gemma3_4b_joint_steps_finite(width):
+    """VERDICT r3 item 2(b).  bench.py's Gemma-3-4b joint workload (BASELINE configs[4]: dynamic search width, suffix in
+    front of the image, hipGraphs on), a few steps with NO step trace -- the configuration rounds 2 and 3 shipped with
+    NaN losses: the image features replayed from a hipGraph held NaN rows at every step whose width was not 512 or 256
+    (ATen's strided mean inside the projector's RMSNorm; ``BimodalAttack.image_features``).  Every loss finite and in
+    the range the CPU oracle reports for this model (14.4 at the start, slowly falling), the image inside [0, 1] and
+    within eps of the original, features of the final image finite and equal to the eager call's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import dynamic_width
+
+    dev = torch.device(DEV)
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("gemma_joint", dev, torch.bfloat16, 34)
+    steps = 3 if width == 64 else 6
+    # the widths of a 600-step run sampled evenly (bench.py): 460, 358, ... -- none of them 512 or 256 until late
+    sched = (lambda i: dynamic_width(min(int(round((i + 0.5) * 600 / steps)), 599), width, 600, min(128, width), True)) \
+        if width == 512 else None
+    eps = 64 / 255
+    cfg = BimodalAttackConfig(num_steps=steps, search_width=width, topk=256, seed=1, verbosity="ERROR", pgd_attack=True,
+                              gcg_attack=True, joint_eval=True, eps=eps, alpha=4 / 255, dynamic_search=True,
+                              min_search_width=min(128, width) if width == 512 else 16, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True, width_override=sched))
+    x0 = image.detach().clone()
+    res = atk.run(messages, goal, target, image.detach().clone())
+    assert len(res.losses) == steps and all(np.isfinite(res.losses)), res.losses
+    assert all(12.0 < l < 15.5 for l in res.losses), res.losses
+    assert {"gradient", "image_features"} <= set(atk.graphs_captured) and not atk.fallbacks
+    final = atk.final_image.detach()
+    assert bool(torch.isfinite(final).all()) and float(final.min()) >= 0.0 and float(final.max()) <= 1.0
+    assert float((final - x0).abs().max()) <= eps + 1e-6
+    with torch.no_grad():
+        replayed = atk.scoring_features(final).clone()
+        eager = atk.image_features(final)
+    assert bool(torch.isfinite(replayed.float()).all()) and torch.equal(replayed, eager)
+    assert len(set(atk.n_scored)) > 1                      # the width did change from step to step
+
+
 def test_gemma3_4b_scoring_equals_reference_call_shape():
     """Gemma-3-4b-it shape, bf16 (BASELINE configs[4]): 34 layers, 256-wide heads, grouped K/V heads, V = 262208,
     suffix in FRONT of the image (:1150-1163), scaled embedding (:1142).  The engine's scoring path for the joint

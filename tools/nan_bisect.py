@@ -25,6 +25,10 @@ VARIANTS = {
     "nopad": dict(pad_vision_heads=False),
     "nographs": dict(graph_gradient=False, graph_prefix=False, graph_rescore=False),
     "notowerqkv": dict(fuse_tower_qkv=False),
+    "nofeatgraph": dict(graph_prefix=False),
+    "nogradgraph": dict(graph_gradient=False),
+    "norescoregraph": dict(graph_rescore=False),
+    "cpurng": dict(rng_device="cpu"),
     "noaddnorm": dict(fuse_add_norm=False),
     "noqkrope": dict(fuse_qk_rope=False),
     "nofused": dict(fused_elementwise=False),
@@ -57,6 +61,8 @@ def main() -> None:
     ap.add_argument("--no-trace", action="store_true", help="no step trace (its device-to-host copies synchronise every phase)")
     ap.add_argument("--bench-schedule", action="store_true", help="bench.py's widths: 2 steps at the full width, then the "
                     "600-step schedule sampled evenly over steps-4 steps, then 2 at its middle")
+    ap.add_argument("--probe-feats", action="store_true", help="check the image features right after they are made; when "
+                    "non-finite: the graph's input, a second replay, the eager function on the same image")
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "nan_bisect.json"))
     args = ap.parse_args()
 
@@ -90,6 +96,59 @@ def main() -> None:
                                   dynamic_search=bool(wl.get("gemma")), min_search_width=min(128, args.width))
         image = None if image0 is None else image0.detach().clone()
         attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, trace=trace, **kw))
+        if args.probe_feats:
+            orig = attack.scoring_features
+            rec, arm = [], {"v": False}
+            if not getattr(model, "_bma_probe_hooks", False):
+                model._bma_probe_hooks = True
+                model._bma_probe = (rec, arm)
+
+                def hook(nm):
+                    def h(mod, a, out):
+                        r, on = model._bma_probe
+                        if on["v"] and torch.cuda.is_current_stream_capturing():
+                            t = out[0] if isinstance(out, tuple) else out
+                            if torch.is_tensor(t):
+                                r.append((nm, t))
+                    return h
+                for nm, mod in model.named_modules():
+                    if ("vision_tower" in nm or "multi_modal_projector" in nm) and len(list(mod.children())) == 0:
+                        mod.register_forward_hook(hook(nm))
+            model._bma_probe = (rec, arm)
+
+            def probed(img, orig=orig, attack=attack, rec=rec, arm=arm):
+                arm["v"] = True
+                f = orig(img)
+                arm["v"] = False
+                bad = ~torch.isfinite(f.float())
+                nb = int(bad.sum())
+                g = attack._feat_graph
+                msg = f"   features: bad={nb} of {f.numel()} shape={tuple(f.shape)} graph={'yes' if g not in (None, False) else 'no'} img_bad={int((~torch.isfinite(img)).sum())}"
+                if nb:
+                    rows = bad[0].any(1).nonzero().flatten()
+                    cols = bad[0].any(0).nonzero().flatten()
+                    msg += f" rows[{int(rows.min())}..{int(rows.max())}]x{rows.numel()} cols[{int(cols.min())}..{int(cols.max())}]x{cols.numel()}"
+                    if g not in (None, False):
+                        msg += f" graph_input_bad={int((~torch.isfinite(g.inputs[0])).sum())} input_eq_img={bool(torch.equal(g.inputs[0], img.detach()))}"
+                        g.graph.replay()
+                        torch.cuda.synchronize()
+                        msg += f" replay_again_bad={int((~torch.isfinite(g.out.float())).sum())}"
+                    shown = 0
+                    for nm, t in rec:
+                        b = ~torch.isfinite(t.float())
+                        if bool(b.any()):
+                            r2 = b.reshape(-1, b.shape[-1]).any(1).nonzero().flatten()
+                            msg += f"\n      bad module output: {nm} {tuple(t.shape)} bad={int(b.sum())} rows {int(r2.min())}..{int(r2.max())} x{r2.numel()}"
+                            shown += 1
+                            if shown >= 4:
+                                break
+                    msg += f"\n      recorded {len(rec)} outputs"
+                    with torch.no_grad():
+                        e = attack.hf.image_features(img.detach())
+                    msg += f" eager_bad={int((~torch.isfinite(e.float())).sum())}"
+                print(msg, flush=True)
+                return f
+            attack.scoring_features = probed
         try:
             res = attack.run(messages, goal, target, image)
             err = None
@@ -109,8 +168,7 @@ def main() -> None:
         kw.pop("score_log", None)
         kw.pop("width_override", None)
         for c in calls:
-            print(f"   score call: n={c['n']} m={c['m']} L={c['L']} P={c['P']} chunk={c['chunk']} ragged={c['ragged']} shared={c['shared']} "
-                  f"rows={c['rows']} bad={c['bad']} first_bad={c['first_bad']}", flush=True)
+            print("   " + " ".join(f"{k}={v}" for k, v in c.items()), flush=True)
         rep = dict(options=kw, error=err, score_calls=calls, init_losses=[float(v) for v in attack.init_losses.tolist()] if hasattr(attack, "init_losses") else None,
                    losses=None if res is None else res.losses, steps=rows, engine=attack.engine_state())
         report[name] = rep
