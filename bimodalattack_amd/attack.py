@@ -212,6 +212,7 @@ class BimodalAttack:
         self._score_pool = None                         # one memory pool for all of them (never replayed concurrently)
         self._score_seen: Dict[tuple, int] = {}
         self._tp_checked: Optional[bool] = None         # tensor-parallel gradient pass applicable to this model / world size?
+        self._tp_graph = None                           # its hipGraph (None: not tried; False: eager for good)
         self._gp = None                            # _GradPrefix: scoring prefix reused by the gradient pass (joint mode)
         self._gp_flag: Optional[bool] = None
         self._feat_graph = None                    # image -> image features (no autograd)
@@ -348,7 +349,22 @@ class BimodalAttack:
         on the first call (after one eager run) and replayed afterwards; results are the
         eager ones (same kernels, same order)."""
         if self._tp_active():
-            return self._gradient_tp(optim_ids, image)
+            # the pass cut over the ranks, its all-reduces included, is one hipGraph too (RCCL collectives are capturable:
+            # the process group's stream fork/join lands in the graph); eager if this stack refuses the capture
+            if self._tp_graph is None and self.shard.backend() != "nccl":
+                self._tp_graph = False         # (a gloo rehearsal: its collectives run on the host and cannot be captured)
+            if not self.opt.graph_gradient or self._tp_graph is False:
+                return self._gradient_tp(optim_ids, image)
+            if self._tp_graph is None:
+                try:
+                    self._tp_graph = _GradientGraph(self, optim_ids, image, fn=self._gradient_tp)
+                    self.graphs_captured.append("gradient_tp")
+                except Exception as e:
+                    self._fallback("graph_gradient_tp", e, "tensor-parallel gradient pass not captured into a graph; running eager")
+                    self._tp_graph = False
+                    torch.cuda.synchronize(self.model.device)
+                    return self._gradient_tp(optim_ids, image)
+            return self._tp_graph(optim_ids, image)
         if image is not None and self._gp_enabled():
             try:
                 if self._gp is None:
@@ -1647,19 +1663,20 @@ class _GradientGraph:
     overwritten before each replay; outputs are static too and stay valid until the next
     replay (the loop consumes them at once)."""
 
-    def __init__(self, attack: "BimodalAttack", optim_ids: Tensor, image: Optional[Tensor]):
+    def __init__(self, attack: "BimodalAttack", optim_ids: Tensor, image: Optional[Tensor], fn=None):
         dev = attack.model.device
+        fn = fn or attack._gradient_eager
         self.ids = optim_ids.detach().clone()
         self.image = None if image is None else image.detach().clone().requires_grad_()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):          # lazy initialisations must not land in the capture
-            attack._gradient_eager(self.ids, self.image)
+            fn(self.ids, self.image)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
-            self.out = attack._gradient_eager(self.ids, self.image)
+            self.out = fn(self.ids, self.image)
 
     def __call__(self, optim_ids: Tensor, image: Optional[Tensor]):
         with torch.no_grad():

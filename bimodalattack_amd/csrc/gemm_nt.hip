@@ -47,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kBN = 128;          // W rows per workgroup
+constexpr int kNW = 4;            // waves per workgroup
 constexpr int kBK = 64;           // k per stage
 constexpr int kRowB = kBK * 2;    // bytes per LDS row (16-bit types only)
 
@@ -59,6 +59,8 @@ struct GemmArgs {
   int* cnt;
   int64_t ldx, ldw, ldy;   // elements
   int M, N, K, S, m_tiles;
+  int R;                   // rows of w per slab (<= 64 * NTW, a multiple of 4)
+  int xcd;                 // 1: workgroup ids remapped so that the splits of a tile share an XCD (grid a multiple of 8)
 };
 
 template <int DT>
@@ -73,52 +75,72 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int MT, int NW, int ST>
-__global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
+// MT row tiles of x (64 or 96 rows), NTW 16-row tiles of w per wave (slabs of up to 128 or 192 rows), ST ring stages,
+// NTL: the weight stream with the non-temporal policy (read once; x, which every workgroup re-reads, keeps the default)
+template <int DT, int MT, int NTW, int ST, bool NTL>
+__global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
   constexpr int BM = 16 * MT;
-  constexpr int NTW = (kBN / 16) / NW;              // n-tiles per wave
-  constexpr int PIECES = (BM + kBN) / 8;            // 1 KiB pieces per stage
-  constexpr int PW = PIECES / NW;                   // ... issued by each wave
-  constexpr int STAGE = (BM + kBN) * kRowB;
-  static_assert((kBN / 16) % NW == 0 && PIECES % NW == 0, "tile does not divide over the waves");
+  constexpr int BN = 16 * NTW * kNW;
+  constexpr int PXW = BM / 8 / kNW;                 // 1 KiB pieces of x issued by each wave per stage
+  constexpr int PWW = BN / 8 / kNW;                 // ... of w
+  constexpr int PW = PXW + PWW;
+  constexpr int STAGE = (BM + BN) * kRowB;
+  static_assert(BM % (8 * kNW) == 0, "x tile does not divide over the waves");
   static_assert(PW * (ST - 2) <= 63, "vmcnt is six bits");
+  static_assert(ST * STAGE <= 160 * 1024, "ring beyond the LDS");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[ST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
+  if (a.xcd) bid = (bid & 7) * (static_cast<int>(gridDim.x) >> 3) + (bid >> 3);   // blocks b, b+8, ... share an XCD: one tile's splits
   const int split = bid % a.S;
   const int tile = bid / a.S;
   const int m0 = (tile % a.m_tiles) * BM;
-  const int n0 = (tile / a.m_tiles) * kBN;
+  const int n0 = (tile / a.m_tiles) * a.R;
   const int T = a.K / kBK;
   const int t0 = static_cast<int>(static_cast<int64_t>(T) * split / a.S);
   const int t1 = static_cast<int>(static_cast<int64_t>(T) * (split + 1) / a.S);
+  int rows_here = a.N - n0;                                     // w rows this slab really has
+  rows_here = rows_here < a.R ? rows_here : a.R;
 
-  // ---- per-wave DMA pieces: piece p covers tile rows 8p .. 8p+7 (x rows first, then W rows) -------------------
+  // ---- per-wave DMA pieces: a piece is 8 tile rows x 128 B; x rows first in the stage image, then w rows ------------
+  // (Every piece of the image is fetched every stage, padding rows as re-reads of a real one.  Fetching only the pieces
+  // that carry real rows -- 9 of x for 65 rows, 11 of w for an 86-row slab, dealt round-robin so that a wave issues C or
+  // C-1 per stage, the loop instantiated per C -- was built and measured in round 4: no faster at equal slab height
+  // (46.0 against 42.3 us on the gate/up shape) and slower wherever K is split, so the step time is not set by the
+  // piece count.)
   const int prow = lane >> 3;                                  // row inside the piece == (tile row & 7)
   const int pchunk = (lane & 7) ^ prow;                        // source chunk that lands at LDS position lane & 7
-  const char* src[PW];
+  const char* srcx[PXW];
+  const char* srcw[PWW];
 #pragma unroll
-  for (int i = 0; i < PW; ++i) {
-    const int p = wave * PW + i;
-    const int r = p * 8 + prow;
-    if (r < BM) {
-      int m = m0 + r;
-      m = m < a.M ? m : a.M - 1;                               // rows past M repeat the last one (never stored)
-      src[i] = a.x + (static_cast<int64_t>(m) * a.ldx) * 2 + pchunk * 16;
-    } else {
-      int n = n0 + (r - BM);
-      n = n < a.N ? n : a.N - 1;
-      src[i] = a.w + (static_cast<int64_t>(n) * a.ldw) * 2 + pchunk * 16;
-    }
+  for (int i = 0; i < PXW; ++i) {
+    int m = m0 + (wave * PXW + i) * 8 + prow;
+    m = m < a.M ? m : a.M - 1;                                 // rows past M repeat the last one (never stored)
+    srcx[i] = a.x + (static_cast<int64_t>(m) * a.ldx) * 2 + pchunk * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < PWW; ++i) {
+    int r = (wave * PWW + i) * 8 + prow;
+    r = r < rows_here ? r : rows_here - 1;                      // rows past the slab repeat its last one: cache hits, never stored
+    srcw[i] = a.w + (static_cast<int64_t>(n0 + r) * a.ldw) * 2 + pchunk * 16;
   }
   auto issue = [&](int t, int slot) {
+    unsigned char* base = lds + slot * STAGE;
 #pragma unroll
-    for (int i = 0; i < PW; ++i) {
-      unsigned char* dst = lds + slot * STAGE + (wave * PW + i) * 1024;     // wave-uniform; the DMA adds lane*16
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + static_cast<int64_t>(t) * kRowB),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    for (int i = 0; i < PXW; ++i)                               // wave-uniform destination; the DMA adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcx[i] + static_cast<int64_t>(t) * kRowB),
+                                       (__attribute__((address_space(3))) void*)(base + (wave * PXW + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PWW; ++i) {
+      unsigned char* dst = base + BM * kRowB + (wave * PWW + i) * 1024;
+      if (NTL)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcw[i] + static_cast<int64_t>(t) * kRowB),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 2);
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcw[i] + static_cast<int64_t>(t) * kRowB),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
 
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
   // ---- split-K: publish the partial, the last arriver of a tile sums them in split order ---------------------------
   if (a.S > 1) {
     f32x4* wsv = reinterpret_cast<f32x4*>(a.ws);
-    const int64_t per = static_cast<int64_t>(NW) * NTW * MT * 64;         // float4 per (tile, split)
+    const int64_t per = static_cast<int64_t>(kNW) * NTW * MT * 64;        // float4 per (tile, split)
     f32x4* mine = wsv + (static_cast<int64_t>(tile) * a.S + split) * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane;
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
@@ -196,7 +218,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
     __syncthreads();
     if (*flag == 0) return;
     // every partial -- this workgroup's own too -- is read back in split order: all loads of a split are independent
-    // (a per-element "own registers or load" select would serialise them behind one wait each)
+    // (a per-element "own registers or load" select would serialise them behind one wait each; issuing the loads of
+    // four splits together before adding, measured in round 4, was no faster)
     const f32x4* base = wsv + static_cast<int64_t>(tile) * a.S * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane;
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
@@ -218,21 +241,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
   // ---- epilogue: a lane holds y[m][n .. n+3] for each of its tiles -------------------------------------------------
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
-    const int n = n0 + (wave * NTW + j) * 16 + fg * 4;
+    const int rs = (wave * NTW + j) * 16 + fg * 4;             // row inside the slab
+    const int n = n0 + rs;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int row = m0 + m * 16 + frow;
-      if (row < a.M && n < a.N) {
+      if (row < a.M && rs < rows_here) {
         char* dst = a.y + (static_cast<int64_t>(row) * a.ldy + n) * 2;
         const f32x4 v = acc[j][m];
-        if (n + 3 < a.N) {
+        if (rs + 3 < rows_here) {
           bma::uint2_t o;
           o.x = bma::pack16<DT>(v.x, v.y);
           o.y = bma::pack16<DT>(v.z, v.w);
           *reinterpret_cast<bma::uint2_t*>(dst) = o;
-        } else {                                                 // N not a multiple of 4: element by element
+        } else {                                                 // the slab (or N) ends inside these four: element by element
           const float e[4] = {v.x, v.y, v.z, v.w};
-          for (int r = 0; r < 4 && n + r < a.N; ++r)
+          for (int r = 0; r < 4 && rs + r < rows_here; ++r)
             reinterpret_cast<uint16_t*>(dst)[r] = static_cast<uint16_t>(bma::pack16<DT>(e[r], 0.0f) & 0xffffu);
         }
       }
@@ -241,42 +265,88 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_kernel(GemmArgs a) {
 }
 
 constexpr int kMaxSplit = 16;
-
-// Split count: fill the 256 CUs in whole rounds.  cost = rounds x k-steps per workgroup (+ a little per split for the
-// partial traffic and the reducer's serial reads).
-int choose_split(int tiles, int T, int cus) {
-  int best = 1;
-  double best_cost = 1e30;
-  for (int s = 1; s <= kMaxSplit && s <= T; ++s) {
-    const int wgs = tiles * s;
-    const int rounds = (wgs + cus - 1) / cus;
-    const double steps = static_cast<double>((T + s - 1) / s);
-    const double cost = rounds * (steps + 6.0) + (s > 1 ? 1.5 * s : 0.0);     // 6: pipeline fill + epilogue, in k-steps
-    if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
-  }
-  return best;
-}
+constexpr int kCUs = 256;
 
 struct Plan {
-  int mt, m_tiles, slabs, S;
+  int mt, m_tiles, ntw, R, slabs, S, xcd, ntl;
 };
+
+// tuning override (bma_gemm_nt_set_plan): 0 = the planner's choice
+int g_ntw = 0, g_R = 0, g_S = 0, g_flags = -1;
+
+// What one decomposition costs, in units of one stage of a 96 + 128-row image: the workgroups run in rounds of 256 (one
+// per CU, the ring fills the LDS); a round lasts (k-steps + pipeline fill) stages, a stage costs in proportion to the
+// rows of its image, and a split of K costs the partial-sum round trip
+// plus the reducer's tail -- a lot: calibrated on the round-4 sweep (profiles/r4_gemm_sweep.txt), where two splits of
+// 172-row slabs on all 256 CUs (52 us) lost to one pass over 128-row slabs on 172 of them (42 us) for N = 22016, while
+// N = 4096 wants its eight splits.
+double plan_cost(int bm, int bn, int R, int wgs, int T, int S) {
+  const int rounds = (wgs + kCUs - 1) / kCUs;
+  const double steps = static_cast<double>((T + S - 1) / S);
+  (void)R;
+  const double rows = bm + bn;                                 // the whole image is fetched every stage, padding rows too
+  return rounds * (steps + 6.0) * rows / 224.0 + (S > 1 ? 25.0 + 1.0 * S : 0.0);
+}
 
 bool make_plan(int M, int N, int K, Plan& p) {
   if (M <= 0 || N <= 0 || K <= 0 || K % kBK) return false;
   p.mt = M <= 64 ? 4 : 6;                      // 64- or 96-row tiles
   const int bm = 16 * p.mt;
   p.m_tiles = (M + bm - 1) / bm;
-  p.slabs = (N + kBN - 1) / kBN;
-  p.S = choose_split(p.slabs * p.m_tiles, K / kBK, 256);
+  const int T = K / kBK;
+  double best = 1e300;
+  p.ntw = 2; p.R = 128; p.S = 1;
+  for (int ntw = 2; ntw <= 3; ++ntw) {
+    if (g_ntw && ntw != g_ntw) continue;
+    const int bn = 64 * ntw;
+    // candidate slab heights: the full tile, and every height that makes slabs x splits x row tiles a whole number of
+    // rounds (172 rows x 2 splits for N = 22016, 192 x 4 for N = 12288, 172 x 4 for N = 11008, 128 x 8 for N = 4096)
+    for (int S = 1; S <= kMaxSplit && S <= T; ++S) {
+      if (g_S && S != g_S) continue;
+      for (int rounds = 1; rounds <= 3; ++rounds) {
+        const int want = rounds * kCUs / (S * p.m_tiles);       // slabs that fill `rounds` rounds exactly
+        for (int pass = 0; pass < 2; ++pass) {
+          // (a slab shorter than the tile only to spread ONE pass over more CUs does not pay -- 251 slabs of 88 rows
+          // measured slower than 172 of 128: the padding rows are fetched all the same -- so balanced heights only
+          // where K is split anyway)
+          int R = pass == 0 ? bn : ((want > 0 && S > 1) ? ((N + want - 1) / want + 3) / 4 * 4 : 0);
+          if (g_R) R = g_R;
+          if (R < 16 || R > bn) continue;
+          const int slabs = (N + R - 1) / R;
+          const double c = plan_cost(bm, bn, R, slabs * p.m_tiles * S, T, S);
+          if (c < best - 1e-9) { best = c; p.ntw = ntw; p.R = R; p.S = S; }
+        }
+      }
+    }
+  }
+  if (best >= 1e299) return false;
+  p.slabs = (N + p.R - 1) / p.R;
+  const int grid = p.slabs * p.m_tiles * p.S;
+  const int flags = g_flags >= 0 ? g_flags : 3;
+  p.xcd = (flags & 1) && p.S > 1 && grid % 8 == 0;
+  p.ntl = (flags & 2) ? 1 : 0;
   return true;
 }
 
 }  // namespace
 
+extern "C" void bma_gemm_nt_set_plan(int ntw, int rows_per_slab, int splits, int flags) {
+  g_ntw = ntw; g_R = rows_per_slab; g_S = splits; g_flags = flags;
+}
+
+extern "C" int bma_gemm_nt_plan(int M, int N, int K, int* out8) {
+  Plan p;
+  if (!make_plan(M, N, K, p)) return BMA_EINVAL;
+  if (out8) {
+    out8[0] = p.mt; out8[1] = p.m_tiles; out8[2] = p.ntw; out8[3] = p.R; out8[4] = p.slabs; out8[5] = p.S; out8[6] = p.xcd; out8[7] = p.ntl;
+  }
+  return BMA_OK;
+}
+
 extern "C" size_t bma_gemm_nt_ws_bytes(int M, int N, int K) {
   Plan p;
   if (!make_plan(M, N, K, p) || p.S == 1) return 0;
-  return static_cast<size_t>(p.slabs) * p.m_tiles * p.S * (16 * p.mt) * kBN * sizeof(float);
+  return static_cast<size_t>(p.slabs) * p.m_tiles * p.S * (16 * p.mt) * (64 * p.ntw) * sizeof(float);
 }
 
 extern "C" int bma_gemm_nt_tiles(int M, int N, int K) {
@@ -309,18 +379,26 @@ extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ld
   a.ws = static_cast<float*>(ws);
   a.cnt = counters;
   a.ldx = ldx; a.ldw = ldw; a.ldy = ldy;
-  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles;
+  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles; a.R = p.R; a.xcd = p.xcd;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(tiles * p.S)), block(256);
   BMA_PROF_BEGIN(BMA_K_GEMM_NT, st, 2.0 * (static_cast<double>(M) * K + static_cast<double>(N) * K + static_cast<double>(M) * N));
-#define BMA_GEMM_GO(DT_)                                                                      \
-  do {                                                                                        \
-    if (p.mt == 4) hipLaunchKernelGGL((gemm_nt_kernel<DT_, 4, 4, 4>), grid, block, 0, st, a);  \
-    else hipLaunchKernelGGL((gemm_nt_kernel<DT_, 6, 4, 4>), grid, block, 0, st, a);            \
+#define BMA_GEMM_GO3(DT_, MT_, NTW_)                                                                    \
+  do {                                                                                                  \
+    if (p.ntl) hipLaunchKernelGGL((gemm_nt_kernel<DT_, MT_, NTW_, 4, true>), grid, block, 0, st, a);    \
+    else hipLaunchKernelGGL((gemm_nt_kernel<DT_, MT_, NTW_, 4, false>), grid, block, 0, st, a);         \
+  } while (0)
+#define BMA_GEMM_GO(DT_)                                     \
+  do {                                                       \
+    if (p.mt == 4 && p.ntw == 2) BMA_GEMM_GO3(DT_, 4, 2);    \
+    else if (p.mt == 4) BMA_GEMM_GO3(DT_, 4, 3);             \
+    else if (p.ntw == 2) BMA_GEMM_GO3(DT_, 6, 2);            \
+    else BMA_GEMM_GO3(DT_, 6, 3);                            \
   } while (0)
   if (dtype == BMA_BF16) BMA_GEMM_GO(BMA_BF16);
   else BMA_GEMM_GO(BMA_F16);
 #undef BMA_GEMM_GO
+#undef BMA_GEMM_GO3
   BMA_PROF_END(BMA_K_GEMM_NT, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;

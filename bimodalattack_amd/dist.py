@@ -42,6 +42,12 @@ class CandidateSharder:
         self.enabled = self.enabled and self.world > 1
         self.n_collectives = 0          # data-path collectives issued (tests and bench.py read it)
 
+    def backend(self) -> Optional[str]:
+        """"nccl" (= RCCL), "gloo", ... of the group the candidates are sharded over; None without a process group."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        return dist.get_backend(self.group)
+
     # -- partition ---------------------------------------------------------
     def per_rank(self, n: int) -> int:
         return -(-n // self.world)

@@ -23,12 +23,19 @@ import torch
 
 
 def features_tensor(out) -> torch.Tensor:
-    """``get_image_features`` returned a (1,N,D) tensor in transformers 4.50 (reference
-    pins 4.50.2) and returns an output object in 5.x whose ``pooler_output`` is a
-    tensor (Gemma-3) or a per-image list of (N,D) (LLaVA)."""
+    """What ``get_image_features`` hands back, as the (B,N,D) tensor the reference indexes (:528-536, :877-884, :972-979):
+    transformers 4.50.2 (the reference's pin, requirements.txt:4) returns that tensor itself; 4.5x LLaVA releases a
+    per-image list / tuple of (N,D) tensors; 5.x an output object whose ``pooler_output`` is the tensor (Gemma-3) or
+    such a per-image list (LLaVA) -- and, called with ``return_dict=False``, that object's tuple
+    ``(last_hidden_state, pooler_output, ...)``."""
     if torch.is_tensor(out):
         return out
     p = getattr(out, "pooler_output", None)
+    if p is None and isinstance(out, (list, tuple)) and len(out) > 0:
+        if all(torch.is_tensor(t) and t.dim() == 2 for t in out):
+            p = out                                  # one (N,D) block per image
+        elif len(out) >= 2 and (torch.is_tensor(out[1]) or isinstance(out[1], (list, tuple))):
+            p = out[1]                               # the output object as a tuple: pooler_output comes second
     if p is None:
         raise TypeError(f"cannot find image features in {type(out).__name__}")
     return p if torch.is_tensor(p) else torch.stack(list(p))

@@ -668,7 +668,12 @@ def prefix_attention(query: torch.Tensor, prefix_k: torch.Tensor, prefix_v: torc
 # skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
 SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
 GEMM_NT_MAX_ROWS = int(_os.environ.get("BMA_GEMM_NT_MAX_ROWS", "96"))   # one 64- or 96-row tile: the shapes the kernel is built and measured for
-GEMM_NT_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_NT_MIN_K_OVER_N", "3"))   # routed only where the library must split K
+# Routed where the kernel measures faster than the tuned library (tools/gemm_bench.py, profiles/r4_gemm_bench.txt): the
+# products whose reduction is long against their width -- the library has to split K itself: the input gradients through
+# the transposed copies and down_proj -- and the widest forward product (gate/up, N >= 5 K), where the non-temporal weight
+# stream is worth a few percent.  0 for either bound routes every shape (tools, tests).
+GEMM_NT_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_NT_MIN_K_OVER_N", "2.5"))
+GEMM_NT_MIN_N_OVER_K = float(_os.environ.get("BMA_GEMM_NT_MIN_N_OVER_K", "5"))
 _GEMM_WS_BYTES = 64 << 20
 _GEMM_COUNTERS = 4096
 _GEMM_WS = {}
@@ -699,7 +704,9 @@ def gemm_nt_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     M = x.numel() // K if K else 0
     if K % 64 or N % 4 or not (0 < M <= GEMM_NT_MAX_ROWS) or not x.is_contiguous():
         return False
-    if K < GEMM_NT_MIN_K_OVER_N * N:
+    routed = GEMM_NT_MIN_K_OVER_N <= 0.0 or K >= GEMM_NT_MIN_K_OVER_N * N or \
+        (GEMM_NT_MIN_N_OVER_K > 0.0 and N >= GEMM_NT_MIN_N_OVER_K * K)
+    if not routed:
         return False                 # the library is as fast or faster there (csrc/gemm_nt.hip, "Measured")
     return lib.bma_gemm_nt_ws_bytes(M, N, K) <= _GEMM_WS_BYTES and lib.bma_gemm_nt_tiles(M, N, K) <= _GEMM_COUNTERS
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 105 /* 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 106 /* 0.1.6: bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -259,15 +259,23 @@ int bma_allgather_f32(const float* local, int64_t n_local, float* out, int rank,
 /* bma_gemm_nt: y[M][N] = x[M][K] . w[N][K]^T for the SKINNY products of the batch-1 gradient pass (a1, :953-1028: every
  *   linear layer of the language model applied to a handful of rows): bf16 / f16 operands with K contiguous, fp32
  *   accumulation on the matrix cores, one rounding to `dtype`.  Leading dimensions ldx/ldw/ldy in elements (multiples
- *   of 8 / 8 / 4); K a multiple of 64; any M (tiles of 64 or 96 rows), any N.  The weight is streamed once; the grid is
- *   (128-row slabs of w) x (splits of K), the split count chosen so that the workgroups fill the CUs in whole rounds.
+ *   of 8 / 8 / 4); K a multiple of 64; any M (tiles of 64 or 96 rows), any N.  The weight is streamed once (non-temporal
+ *   loads); the grid is (slabs of w rows) x (splits of K), slab height (<= 128 or 192 rows, a multiple of 4) and split
+ *   count chosen together so that the workgroups fill the 256 CUs in whole rounds (bma_gemm_nt_plan reports them).
  *   With more than one split the partial sums pass through `ws` (bma_gemm_nt_ws_bytes(M,N,K) bytes, 16-byte aligned)
  *   and a ticket per tile in `counters` (bma_gemm_nt_tiles(M,N,K) ints, ZERO before the first launch; every launch
  *   leaves them zero); the last workgroup of a tile adds the partials in split order, so the result does not depend on
  *   arrival order.  ws/counters may be NULL when bma_gemm_nt_ws_bytes returns 0.  Launches that share ws/counters
- *   must be ordered on one stream. */
+ *   must be ordered on one stream.
+ * bma_gemm_nt_plan: the decomposition bma_gemm_nt will use, out8 = {row tiles of 16 per workgroup, row-tile count,
+ *   16-row w tiles per wave, w rows per slab, slabs, K splits, splits of a tile kept on one XCD (0/1), non-temporal w
+ *   loads (0/1)}.  bma_gemm_nt_set_plan: measurement only (tools/gemm_bench.py --sweep) -- pins w tiles per wave /
+ *   rows per slab / splits (0 = the planner's choice) and the two flags (bit 0 XCD grouping, bit 1 non-temporal; -1 =
+ *   default) for every later call in the process; results never depend on it. */
 size_t bma_gemm_nt_ws_bytes(int M, int N, int K);
 int bma_gemm_nt_tiles(int M, int N, int K);
+int bma_gemm_nt_plan(int M, int N, int K, int* out8);
+void bma_gemm_nt_set_plan(int w_tiles_per_wave, int rows_per_slab, int splits, int flags);
 int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
                 int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream);
 

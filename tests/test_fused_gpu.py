@@ -884,8 +884,8 @@ def test_tower_qkv_as_one_product_matches_the_three():
     sh = Shell()
     sh.model, sh.device = tower, torch.device(DEV)
     sh.fuse_quick_gelu = sh.fuse_tower_qkv = True
-    sh._quick_gelus = sh._tower_attn = None
-    for name in ("quick_gelu_modules", "tower_attention_modules", "_tower_qkv_forwards", "_fused_activations"):
+    sh._quick_gelus = sh._tower_attn = sh._proj_norms = None
+    for name in ("quick_gelu_modules", "tower_attention_modules", "projector_norms", "_tower_qkv_forwards", "_fused_activations"):
         setattr(sh, name, getattr(HFAdapter, name).__get__(sh))
     assert len(sh.tower_attention_modules()) == 3 and len(sh.quick_gelu_modules()) == 3
 

@@ -383,6 +383,161 @@ def test_decoder_layer_structure_is_read_from_source():
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6) and not any("forward" in m.__dict__ for m in model.modules())
 
 
+def test_image_features_across_transformers_return_types():
+    """The reference pins transformers 4.50.2 (/root/reference/requirements.txt:4), where ``get_image_features`` returns
+    the (1,N,D) tensor the reference indexes (bimodal_attack.py:528-536, :877-884, :972-979); this image has 5.x, where
+    it returns an output object.  ``features_tensor`` takes every form a release has used, and ``HFAdapter`` calls the
+    plug-in with the reference's own keyword arguments for each processor family."""
+    from types import SimpleNamespace as NS
+    from bimodalattack_amd.hf_adapter import HFAdapter, features_tensor
+    t = torch.arange(24.0).reshape(1, 4, 6)
+    assert features_tensor(t) is t                                                          # 4.50.2
+    assert torch.equal(features_tensor([t[0]]), t) and torch.equal(features_tensor((t[0], t[0] + 1)), torch.stack([t[0], t[0] + 1]))
+    assert features_tensor(NS(pooler_output=t)) is t                                        # 5.x, Gemma-3
+    assert torch.equal(features_tensor(NS(pooler_output=[t[0]])), t)                        # 5.x, LLaVA: a list per image
+    hidden = torch.zeros(1, 9, 5)
+    assert features_tensor((hidden, t)) is t                                                # 5.x output object as a tuple
+    assert torch.equal(features_tensor((hidden, [t[0]])), t)
+    with pytest.raises(TypeError):
+        features_tensor(NS(last_hidden_state=hidden))
+    with pytest.raises(TypeError):
+        features_tensor(())
+
+    calls = []
+
+    class Stub450(torch.nn.Module):
+        """The plug-in surface of a 4.50.2 model: get_image_features(...) -> Tensor."""
+
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Embedding(11, 6)
+            self.config = NS(model_type="llava")
+            self.dtype, self.device = torch.float32, torch.device("cpu")
+
+        def get_input_embeddings(self):
+            return self.emb
+
+        def forward(self, inputs_embeds=None, logits_to_keep=0, past_key_values=None, use_cache=None):
+            raise AssertionError("not called here")
+
+        def get_image_features(self, pixel_values=None, **kw):
+            calls.append(sorted(kw))
+            return pixel_values.mean(dim=(2, 3), keepdim=False).reshape(1, 1, 3).repeat(1, 4, 2)
+
+    img = torch.rand(1, 3, 8, 8)
+    for proc_name, want_kw in (("LlavaProcessor", ["vision_feature_layer", "vision_feature_select_strategy"]),
+                               ("Gemma3Processor", [])):
+        proc = type(proc_name, (), {})()
+        hf = HFAdapter(Stub450(), proc, lambda x: x * 2.0)
+        got = hf.image_features(img)
+        assert got.shape == (1, 4, 6) and torch.allclose(got[0, 0, :3], (img * 2.0).mean(dim=(2, 3))[0])
+        assert calls[-1] == want_kw, (proc_name, calls[-1])
+        assert hf.emb_scale == 1.0 and hf.has_logits_to_keep and hf.projector_norms() == []
+
+
+def test_fused_structure_detection_steps_aside_on_4_50_style_layers():
+    """transformers 4.50.2's decoder layers return a TUPLE and unpack ``hidden_states, self_attn_weights = self.self_attn(``;
+    the fused layer forward restates 5.x's statements and returns a tensor, so on such a layer it must NOT be installed
+    (``_layer_kind`` reads the source) -- while the per-module fusions, which depend on attribute names only
+    (``*RMSNorm`` with ``variance_epsilon``, ``gate_proj``/``up_proj``/``down_proj``/``act_fn``, ``q_proj``/``k_proj``/``v_proj``/
+    ``o_proj`` with ``layer_idx``), are still admitted.  And without ``transformers.masking_utils`` (added after 4.50) the
+    attention-interface routes report themselves unavailable instead of failing."""
+    from bimodalattack_amd import fused
+
+    class StubRMSNorm(torch.nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.ones(d))
+            self.variance_epsilon = 1e-6
+
+        def forward(self, x):
+            return self.weight * x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.variance_epsilon)
+
+    class StubAttention(torch.nn.Module):
+        def __init__(self, d, idx):
+            super().__init__()
+            self.layer_idx, self.head_dim = idx, d // 2
+            self.q_proj, self.k_proj, self.v_proj, self.o_proj = (torch.nn.Linear(d, d, bias=False) for _ in range(4))
+
+        def forward(self, hidden_states, **kw):
+            return self.o_proj(self.q_proj(hidden_states) + self.k_proj(hidden_states) + self.v_proj(hidden_states)), None
+
+    class StubMLP(torch.nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.gate_proj, self.up_proj, self.down_proj = (torch.nn.Linear(d, 2 * d, bias=False), torch.nn.Linear(d, 2 * d, bias=False),
+                                                            torch.nn.Linear(2 * d, d, bias=False))
+            self.act_fn = torch.nn.SiLU()
+
+        def forward(self, x):
+            return self.down_proj(self.act_fn(self.gate_proj(x)) * self.up_proj(x))
+
+    class DecoderLayer450(torch.nn.Module):
+        def __init__(self, d, idx):
+            super().__init__()
+            self.self_attn, self.mlp = StubAttention(d, idx), StubMLP(d)
+            self.input_layernorm, self.post_attention_layernorm = StubRMSNorm(d), StubRMSNorm(d)
+
+        def forward(self, hidden_states, output_attentions=False, **kwargs):          # 4.50.2's statements
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+            hidden_states, self_attn_weights = self.self_attn(hidden_states=hidden_states, **kwargs)
+            hidden_states = residual + hidden_states
+            residual = hidden_states
+            hidden_states = self.post_attention_layernorm(hidden_states)
+            hidden_states = self.mlp(hidden_states)
+            hidden_states = residual + hidden_states
+            outputs = (hidden_states,)
+            if output_attentions:
+                outputs += (self_attn_weights,)
+            return outputs
+
+    class Stack(torch.nn.Module):
+        def __init__(self, d=8, n=2):
+            super().__init__()
+            self.layers = torch.nn.ModuleList(DecoderLayer450(d, i) for i in range(n))
+            self.norm = StubRMSNorm(d)
+
+        def forward(self, x):
+            for l in self.layers:
+                x = l(x)[0]
+            return self.norm(x)
+
+    model = Stack()
+    assert fused._layer_kind(model.layers[0]) is None
+    f = fused.FusedInference(model)
+    assert f.layers == [] and f.admitted["add_norm_layers"] == 0 and f.admitted["layer_kinds"] == []
+    assert f.admitted["rmsnorms"] == 5 and f.admitted["gated_mlps"] == 2 and f.admitted["transposed_copy_projections"] == 14
+    assert f.admitted["rotary_files"] == [] and f.admitted["qk_norm_in_rotary_blocks"] == 0
+    x = torch.randn(1, 5, 8)
+    want = model(x)
+    with f:                                   # on the CPU the kernels step aside; the 4.50-style tuple flows through untouched
+        got = model(x)
+    assert torch.equal(got, want) and not any("forward" in m.__dict__ for m in model.modules())
+
+    # transformers without masking_utils / AttentionInterface: register() says no, nothing raises
+    import builtins
+    import sys
+    from bimodalattack_amd import prefix_attention as pa
+    real_import = builtins.__import__
+
+    def no_masking_utils(name, *a, **kw):
+        if name == "transformers.masking_utils":
+            raise ImportError("No module named 'transformers.masking_utils'")
+        return real_import(name, *a, **kw)
+
+    saved, was = sys.modules.pop("transformers.masking_utils", None), dict(pa._REGISTERED)
+    pa._REGISTERED["done"] = False
+    builtins.__import__ = no_masking_utils
+    try:
+        assert pa.register() is False and pa._REGISTERED["done"] is False
+    finally:
+        builtins.__import__ = real_import
+        if saved is not None:
+            sys.modules["transformers.masking_utils"] = saved
+        pa._REGISTERED.update(was)
+
+
 def test_ragged_maps_fixed_layout_for_graph_replay():
     """``RaggedMaps`` with caps: whatever the draw's number of distinct candidates, the packed index maps have ONE byte
     layout (what lets a captured hipGraph read them from a static buffer): per-block arrays and ids padded with EMPTY
@@ -439,27 +594,46 @@ def test_derived_weight_copies_are_versioned():
 
 
 def test_gemm_nt_plan_and_routing_rule():
-    """Split-K planning of bma_gemm_nt through the C ABI (no launch): the workgroups of a product fill the CUs in whole
-    rounds, the workspace covers every partial tile, and ops.gemm_nt_ok routes only products the library must split."""
+    """Planning of bma_gemm_nt through the C ABI (no launch): slab height and split count are chosen together so that
+    the workgroups of a product fill the CUs in whole rounds where K is split, the workspace covers every partial tile,
+    and ops.gemm_nt_ok routes the products the kernel measures faster on."""
+    import ctypes
     from bimodalattack_amd import ops
     from bimodalattack_amd.native import lib
-    for M, N, K in ((65, 4096, 22016), (65, 4096, 12288), (44, 4096, 22016), (65, 22016, 4096), (96, 4096, 4096)):
-        tiles = lib.bma_gemm_nt_tiles(M, N, K)
-        assert tiles == -(-N // 128)
-        bm = 64 if M <= 64 else 96
-        ws = lib.bma_gemm_nt_ws_bytes(M, N, K)
-        assert ws % (tiles * bm * 128 * 4) == 0
-        S = ws // (tiles * bm * 128 * 4) if ws else 1
-        assert 1 <= S <= 16 and (tiles * S <= 256 or S == 1 or (tiles * S) % 256 < 256)
-        if N == 4096 and K >= 12288:
-            assert tiles * S == 256                         # 32 slabs x 8 splits: one full round
+    plan = (ctypes.c_int * 8)()
+    for M, N, K in ((65, 4096, 22016), (65, 4096, 12288), (44, 4096, 22016), (65, 22016, 4096), (96, 4096, 4096), (65, 12288, 4096),
+                    (65, 11008, 4096), (65, 4096, 11008), (19, 32064, 4096), (65, 20480, 2560)):
+        assert lib.bma_gemm_nt_plan(M, N, K, plan) == 0
+        mt, m_tiles, ntw, R, slabs, S, xcd, ntl = list(plan)
+        assert mt == (4 if M <= 64 else 6) and m_tiles == 1 and ntw in (2, 3) and 16 <= R <= 64 * ntw and R % 4 == 0
+        assert slabs == -(-N // R) and 1 <= S <= 16 and ntl == 1
+        assert lib.bma_gemm_nt_tiles(M, N, K) == slabs
+        assert lib.bma_gemm_nt_ws_bytes(M, N, K) == (0 if S == 1 else slabs * S * 16 * mt * 64 * ntw * 4)
+        assert lib.bma_gemm_nt_ws_bytes(M, N, K) <= ops._GEMM_WS_BYTES and slabs <= ops._GEMM_COUNTERS
+        assert slabs * S <= 256                                   # one round of the 256 CUs
+        if S > 1:
+            assert xcd == ((slabs * S) % 8 == 0)                  # a tile's splits on one XCD whenever the grid allows
+        if N == 4096 and K >= 11008:
+            assert (R, S) == (128, 8)                             # 32 slabs x 8 splits: one full round
+        if (N, K) == (22016, 4096):
+            assert (R, S) == (128, 1)                             # one pass, 172 CUs: splitting K cost more than it filled
+    # the tuning override pins a decomposition for every later call, and lets go again
+    lib.bma_gemm_nt_set_plan(3, 172, 2, 0)
+    assert lib.bma_gemm_nt_plan(65, 22016, 4096, plan) == 0 and list(plan)[2:8] == [3, 172, 128, 2, 0, 0]
+    lib.bma_gemm_nt_set_plan(0, 0, 0, -1)
+    assert lib.bma_gemm_nt_plan(65, 22016, 4096, plan) == 0 and list(plan)[2:6] == [2, 128, 172, 1]
+    assert lib.bma_gemm_nt_plan(65, 4096, 100, plan) == -1
     assert lib.bma_gemm_nt_ws_bytes(65, 4096, 100) == 0 and lib.bma_gemm_nt_tiles(0, 4096, 4096) == 0
     assert lib.bma_gemm_nt(16, 4096, 16, 4096, 16, 4096, 8, 4096, 100, 1, None, 0, None, 0, None) == -5     # K % 64
     assert lib.bma_gemm_nt(16, 4096, 16, 4096, 16, 4096, 8, 4096, 4096, 0, None, 0, None, 0, None) == -2    # fp32
     assert lib.bma_gemm_nt(None, 4096, 16, 4096, 16, 4096, 0, 4096, 4096, 1, None, 0, None, 0, None) == 0   # no rows
-    assert ops.GEMM_NT_MIN_K_OVER_N == 3.0 and ops.GEMM_NT_MAX_ROWS == 96
+    assert ops.GEMM_NT_MIN_K_OVER_N == 2.5 and ops.GEMM_NT_MIN_N_OVER_K == 5.0 and ops.GEMM_NT_MAX_ROWS == 96
     x = torch.zeros(65, 4096, dtype=torch.bfloat16)
     assert not ops.gemm_nt_ok(x, torch.zeros(4096, 4096, dtype=torch.bfloat16))          # (CPU tensors never qualify)
+    # the rule itself, on shapes alone: long reductions and the widest forward product
+    rule = lambda N, K: K >= ops.GEMM_NT_MIN_K_OVER_N * N or N >= ops.GEMM_NT_MIN_N_OVER_K * K      # noqa: E731
+    assert [rule(N, K) for N, K in ((4096, 22016), (4096, 12288), (4096, 11008), (22016, 4096), (12288, 4096), (11008, 4096),
+                                    (4096, 4096))] == [True, True, True, True, False, False, False]
 
 
 def test_bench_gemm_roles_and_extra_workloads():

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default=None, help="comma list of shape names")
+    ap.add_argument("--sweep", action="store_true", help="time the kernel under pinned decompositions (bma_gemm_nt_set_plan): "
+                    "the planner's choice with each flag combination, round 3's 128-row slabs, and neighbours")
     args = ap.parse_args()
     ops.GEMM_NT_MIN_K_OVER_N = 0.0                 # time the kernel on every shape, routed or not
     gemm_tuning.enable("auto", DEV)
@@ -68,6 +70,29 @@ def main():
                 to.append(graph_time(own_fn, len(ws)))
             nbytes = 2.0 * (M * K + N * K + M * N)
             l, o = statistics.median(tl), statistics.median(to)
+            if args.sweep:
+                import ctypes
+                from bimodalattack_amd.native import lib
+                plan = (ctypes.c_int * 8)()
+                lib.bma_gemm_nt_plan(M, N, K, plan)
+                _, _, ntw0, R0, _, S0, _, _ = list(plan)
+                T = K // 64
+                cands = [(0, 0, 0, f) for f in (0, 1, 2, 3)] + [(2, 128, 0, 3), (2, 128, 0, 0)]
+                cands += [(ntw0, R0, s_, 3) for s_ in sorted({max(1, S0 // 2), min(16, S0 * 2)}) if s_ != S0 and s_ <= T]
+                if ntw0 == 3:
+                    cands += [(3, 192, 0, 3), (2, 0, 0, 3)]
+                else:
+                    cands += [(3, 0, 0, 3)]
+                for ntw, R, S_, fl in cands:
+                    lib.bma_gemm_nt_set_plan(ntw, R, S_, fl)
+                    if lib.bma_gemm_nt_plan(M, N, K, plan) != 0 or lib.bma_gemm_nt_ws_bytes(M, N, K) > ops._GEMM_WS_BYTES \
+                            or lib.bma_gemm_nt_tiles(M, N, K) > ops._GEMM_COUNTERS:
+                        continue
+                    tt = statistics.median(graph_time(own_fn, len(ws)) for _ in range(3))
+                    pl = list(plan)
+                    print(f"      pinned ntw={ntw} R={R} S={S_} flags={fl} -> ntw={pl[2]} R={pl[3]} slabs={pl[4]} S={pl[5]} xcd={pl[6]} nt={pl[7]}: "
+                          f"{tt:7.1f} us ({nbytes / tt / 1e6:4.2f} TB/s)", flush=True)
+                lib.bma_gemm_nt_set_plan(0, 0, 0, -1)
             out[f"{name} M={M} N={N} K={K}"] = dict(library_us=l, kernel_us=o, library_TBps=nbytes / l / 1e6, kernel_TBps=nbytes / o / 1e6,
                                                     kernel_frac_of_8TBps=nbytes / o / 1e6 / 8.0, speedup=l / o, kernel_min_us=min(to), library_min_us=min(tl))
             print(f"{name:11s} M={M:3d} N={N:5d} K={K:5d}: library {l:7.1f} us ({nbytes / l / 1e6:4.2f} TB/s)   bma_gemm_nt {o:7.1f} us "
