@@ -231,7 +231,8 @@ class BimodalAttack:
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
         ops.SKINNY_GEMM = bool(self.opt.skinny_gemm)
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
-                                    self.opt.fuse_gate_up, self.opt.fuse_add_norm, self.opt.fuse_qk_rope)
+                                    self.opt.fuse_gate_up, self.opt.fuse_add_norm, self.opt.fuse_qk_rope,
+                                    self.opt.fuse_b1_attention)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         logger.info(f"Fused forward admitted: {self.fused.admitted}")
         if hasattr(model.config, "model_type"):

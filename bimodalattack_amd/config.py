@@ -145,6 +145,11 @@ class EngineOptions:
     # Gemma-3's per-head q_norm / k_norm inside the rotary launch of the no-grad scoring forward (bma_qknorm_rope2): one
     # pass over q and k instead of two
     fuse_qk_rope: bool = True
+    # batch-1 gradient pass over a short text-only prompt (<= 80 tokens; llama-style attention blocks with 128-wide heads and
+    # no grouped heads): rotary embedding + causal attention between the fused q/k/v projection and o_proj as ONE launch
+    # forward and ONE backward (bma_b1_attention) instead of HuggingFace's rotary + library attention and, under autograd,
+    # the library's attention backward, a counter fill, the rotary backward and a concatenation.
+    fuse_b1_attention: bool = True
     # batch-1 gradient pass: products with at most 96 rows (16-bit, bias-free decoder projections and their input
     # gradients through the transposed copies) on the hand-written weight-streaming kernel bma_gemm_nt instead of the
     # library (process-wide switch: ops.SKINNY_GEMM).
@@ -269,6 +274,8 @@ class EngineOptions:
             opts.skinny_gemm = env["BMA_SKINNY_GEMM"] not in ("0", "false", "False")
         if "BMA_FUSE_ADD_NORM" in env:
             opts.fuse_add_norm = env["BMA_FUSE_ADD_NORM"] not in ("0", "false", "False")
+        if "BMA_FUSE_B1_ATTENTION" in env:
+            opts.fuse_b1_attention = env["BMA_FUSE_B1_ATTENTION"] not in ("0", "false", "False")
         if "BMA_FUSE_QK_ROPE" in env:
             opts.fuse_qk_rope = env["BMA_FUSE_QK_ROPE"] not in ("0", "false", "False")
         if "BMA_BACKWARD_WEIGHT_COPIES" in env:

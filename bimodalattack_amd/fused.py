@@ -199,14 +199,45 @@ class DeferredNormMissed(RuntimeError):
     the forward again and gets the unfused norms."""
 
 
+_ATTN_SELF_LINES = ["self,", "hidden_shape = (*input_shape, -1, self.head_dim)",
+                    "query_states = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)",
+                    "key_states = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)",
+                    "value_states = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)",
+                    "key_states, value_states = past_key_values.update(key_states, value_states, self.layer_idx)",
+                    "self.config._attn_implementation, eager_attention_forward", "self,",
+                    "dropout=0.0 if not self.training else self.attention_dropout,", "scaling=self.scaling,",
+                    "attn_output = self.o_proj(attn_output)", "return attn_output, attn_weights"]
+
+
+def _plain_rotary_attention(attn) -> bool:
+    """Is the attention block's forward, statement for statement, projections -> rotary embedding -> (cache) -> attention
+    function -> o_proj with nothing else touching q, k or v (HuggingFace's LlamaAttention, read from its source)?  Only
+    then may the span between the projections and o_proj run as ONE launch (ops.B1AttentionFn)."""
+    import inspect
+    try:
+        lines = [ln.strip() for ln in inspect.getsource(type(attn).forward).splitlines()]
+    except (OSError, TypeError):
+        return False
+    if "query_states, key_states = apply_rotary_pos_emb(query_states, key_states, cos, sin)" not in lines or \
+            "cos, sin = position_embeddings" not in lines:
+        return False
+    # every line that touches `self` (the signature's and the attention function's `self,` included) or returns
+    seen = [t for t in lines if not t.startswith("#") and not t.startswith("def ") and ("self." in t or t.startswith("return") or t == "self,")]
+    return seen == _ATTN_SELF_LINES
+
+
 _TP_COLUMN = ("q_proj", "k_proj", "v_proj", "gate_proj", "up_proj")
 _TP_ROW = ("o_proj", "down_proj")
 
 
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
-                 fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True, fuse_qk_rope: bool = True):
+                 fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True, fuse_qk_rope: bool = True,
+                 fuse_b1_attention: bool = True):
         self.enabled = enabled
+        self.fuse_b1_attention = fuse_b1_attention
+        self.b1_attn: List[torch.nn.Module] = []     # attention blocks whose rotary + attention run as one launch in the batch-1 gradient pass
+        self._qkv_whole = {}                         # id(attention block) -> x -> the fused q/k/v product (made at __enter__)
         self.fuse_qk_rope = fuse_qk_rope
         self._rope_norms = {}                        # id(q_norm / k_norm module) of attention blocks whose forward rotates right behind them
         self.admitted = {}
@@ -284,12 +315,20 @@ class FusedInference:
             if sys.modules.get(type(m).__module__) in self.rope_modules:
                 self._rope_norms[id(m.q_norm)] = m.q_norm
                 self._rope_norms[id(m.k_norm)] = m.k_norm
+        if fuse_b1_attention:
+            for m in self.qkv:
+                cfg = getattr(m, "config", None)
+                if cfg is not None and hasattr(m, "o_proj") and hasattr(m, "scaling") and getattr(m, "head_dim", 0) == 128 \
+                        and getattr(cfg, "num_attention_heads", 0) == (getattr(cfg, "num_key_value_heads", None) or cfg.num_attention_heads) \
+                        and m.q_proj.out_features == cfg.num_attention_heads * 128 and _plain_rotary_attention(m):
+                    self.b1_attn.append(m)
         kinds = sorted({k for _, k, _ in self.layers})
         # what was admitted (the source-text checks above turn a fusion off silently on a transformers upgrade or a
         # .pyc-only install: the engine logs this and bench.py prints it with the engine state)
         self.admitted = dict(rmsnorms=len(self.norms), gated_mlps=len(self.mlps), fused_qkv_blocks=len(self.qkv),
                              transposed_copy_projections=len(self.linears), add_norm_layers=len(self.layers),
                              layer_kinds=kinds, rotary_files=[m.__name__.rsplit(".", 1)[-1] for m in self.rope_modules],
+                             b1_attention_blocks=len(self.b1_attn),
                              qk_norm_in_rotary_blocks=len(self._rope_norms) // 2,
                              qk_norm_blocks_not_admitted=len(norm_rope_blocks) - len(self._rope_norms) // 2)
 
@@ -417,27 +456,31 @@ class FusedInference:
                     w = self._copies.put(("wqkv", id(attn)), torch.cat([m.weight.detach() for m in mods], dim=0).contiguous(), srcs)
             return w
 
-        def first(x):
-            slot.clear()
+        def whole(x):
+            """The fused product itself, (.., q + k + v columns); None when it cannot be formed here."""
             w0 = mods[0].weight
             if not (x.is_cuda and x.dtype == w0.dtype and x.dim() >= 2):
-                return origs[0](x)
+                return None
             w = fused_weight()
             if w is None:
-                return origs[0](x)
+                return None
             if self._tracking(x):
                 if not self.weight_copies or x.numel() // x.shape[-1] > SKINNY_ROWS:
-                    y = torch.nn.functional.linear(x, w)
-                else:
-                    wt = self._copies.get(("wqkv_t", id(attn)), srcs)
-                    if wt is None:
-                        if torch.cuda.is_current_stream_capturing():
-                            return origs[0](x)
-                        with torch.no_grad():
-                            wt = self._copies.put(("wqkv_t", id(attn)), w.t().contiguous(), srcs)
-                    y = ops.FrozenLinearFn.apply(x, w, wt)
-            else:
-                y = torch.nn.functional.linear(x, w)
+                    return torch.nn.functional.linear(x, w)
+                wt = self._copies.get(("wqkv_t", id(attn)), srcs)
+                if wt is None:
+                    if torch.cuda.is_current_stream_capturing():
+                        return None
+                    with torch.no_grad():
+                        wt = self._copies.put(("wqkv_t", id(attn)), w.t().contiguous(), srcs)
+                return ops.FrozenLinearFn.apply(x, w, wt)
+            return torch.nn.functional.linear(x, w)
+
+        def first(x):
+            slot.clear()
+            y = whole(x)
+            if y is None:
+                return origs[0](x)
             # one split node: its backward is a single concatenation of the three gradients (three
             # independent slices would each zero-fill a full-width buffer and add)
             parts = torch.split(y, sizes, dim=-1)
@@ -455,7 +498,31 @@ class FusedInference:
                 return out
             return forward
 
-        return first, later(1), later(2)
+        return first, later(1), later(2), whole
+
+    def _attn_forward(self, attn, orig):
+        """The attention block between its (fused) q/k/v projection and o_proj as ONE launch forward and ONE backward --
+        rotary embedding, causal attention, the head transposes either side -- for the batch-1 gradient pass over a
+        short sequence (ops.B1AttentionFn; <= 80 tokens, 128-wide heads, no grouped heads).  Taken only when the engine
+        has switched the block to its mask-free causal attention for this forward (prefix_attention.causal_b1: plain
+        causal, no cache), autograd is recording, and the tensors qualify; HuggingFace's own forward otherwise."""
+        cfg = attn.config
+        heads = cfg.num_attention_heads
+
+        def forward(hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+            whole = self._qkv_whole.get(id(attn))
+            if whole is not None and position_embeddings is not None and attention_mask is None and past_key_values is None \
+                    and self.tp is None and getattr(cfg, "_attn_implementation", None) == "bma_causal_b1" \
+                    and hidden_states.dim() == 3 and hidden_states.shape[0] == 1 and self._tracking(hidden_states):
+                cos, sin = position_embeddings
+                if not (cos.requires_grad or sin.requires_grad) and cos.shape == (1, hidden_states.shape[1], 128):
+                    y = whole(hidden_states)
+                    if y is not None and ops.b1_attention_ok(y, cos, heads, heads, 128):
+                        out = ops.B1AttentionFn.apply(y, cos[0], sin[0], heads, float(attn.scaling))
+                        return attn.o_proj(out), None
+            return orig(hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
+                        past_key_values=past_key_values, **kwargs)
+        return forward
 
     def _gate_up_weight(self, m):
         """The chunk-interleaved [gate_proj; up_proj] weight of a 16-bit MLP (ops.interleave_gate_up), or None when
@@ -648,8 +715,11 @@ class FusedInference:
             for m, fn in self._linear_patches:
                 m.__dict__["forward"] = fn
             for attn in self.qkv:                      # after the per-projection patches: these win for q/k/v
-                fq, fk, fv = self._qkv_forwards(attn)
+                fq, fk, fv, whole = self._qkv_forwards(attn)
                 attn.q_proj.__dict__["forward"], attn.k_proj.__dict__["forward"], attn.v_proj.__dict__["forward"] = fq, fk, fv
+                self._qkv_whole[id(attn)] = whole
+            for attn in self.b1_attn:
+                attn.__dict__["forward"] = self._attn_forward(attn, type(attn).forward.__get__(attn))
         for mod in self.rope_modules:
             self._saved_rope[mod] = mod.apply_rotary_pos_emb
             mod.apply_rotary_pos_emb = self._rope(mod.apply_rotary_pos_emb)
@@ -668,6 +738,9 @@ class FusedInference:
         for attn in self.qkv:
             for m in (attn.q_proj, attn.k_proj, attn.v_proj):
                 m.__dict__.pop("forward", None)
+        for attn in self.b1_attn:
+            attn.__dict__.pop("forward", None)
+        self._qkv_whole.clear()
         for layer, _, _ in self.layers:
             layer.__dict__.pop("forward", None)
         for lin, _ in self._tp_roles.values():

@@ -91,6 +91,10 @@ PROTOTYPES = {
                                      c_void_p, c_void_p, c_void_p]),
     "bma_prefix_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                      c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "bma_b1_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p,
+                                 c_void_p]),
+    "bma_b1_attention_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int,
+                                     c_int, c_int, c_float, c_void_p, c_int64, c_void_p]),
     "bma_gemm_nt_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bma_gemm_nt_tiles": (c_int, [c_int, c_int, c_int]),
     "bma_gemm_nt_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
@@ -104,7 +108,7 @@ PROTOTYPES = {
 
 KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5,
               "ce_rows_grad": 6, "rmsnorm": 7, "swiglu": 8, "rope": 9, "attn_merge": 10, "gather_rows": 11,
-              "ragged_attn": 12, "prefix_attn": 13, "add_rmsnorm": 14, "gemm_nt": 15}
+              "ragged_attn": 12, "prefix_attn": 13, "add_rmsnorm": 14, "gemm_nt": 15, "b1_attn": 16}
 
 
 def profile_enable(on: bool) -> None:

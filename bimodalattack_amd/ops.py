@@ -665,6 +665,67 @@ def prefix_attention(query: torch.Tensor, prefix_k: torch.Tensor, prefix_v: torc
 
 
 # ---------------------------------------------------------------------------
+# rotary + causal attention of one short sequence, forward and backward (csrc/b1_attention.hip): the batch-1 gradient pass
+B1_ATTENTION_MAX_TOKENS = 80
+
+
+def b1_attention_ok(qkv: torch.Tensor, cos: torch.Tensor, heads: int, kv_heads: int, head_dim: int) -> bool:
+    """Can bma_b1_attention take this fused q/k/v projection output (.., S, (H + 2 Hk) * Dh)?"""
+    S = qkv.shape[-2] if qkv.dim() >= 2 else 0
+    return bool(qkv.is_cuda and qkv.dtype in (torch.bfloat16, torch.float16) and head_dim == 128 and heads == kv_heads
+                and qkv.numel() == S * 3 * heads * 128 and 1 <= S <= B1_ATTENTION_MAX_TOKENS and qkv.stride(-1) == 1
+                and qkv.stride(-2) % 8 == 0 and qkv.data_ptr() % 16 == 0 and cos.dtype == qkv.dtype
+                and cos.numel() == S * 128 and cos.shape[-1] == 128)
+
+
+def b1_attention(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, scale: float):
+    """(out (S, H*128), lse (H, S) fp32) of rotary + causal attention over qkv (S, 3*H*128) [q heads | k heads | v heads]
+    (include/bma.h: bma_b1_attention).  cos / sin (S, 128)."""
+    dev = _need_gpu(qkv, cos, sin)
+    S = qkv.shape[0]
+    cos, sin = cos.reshape(S, 128).contiguous(), sin.reshape(S, 128).contiguous()
+    out = torch.empty((S, heads * 128), dtype=qkv.dtype, device=dev)
+    lse = torch.empty((heads, S), dtype=torch.float32, device=dev)
+    check("bma_b1_attention", lib.bma_b1_attention(qkv.data_ptr(), qkv.stride(0), cos.data_ptr(), sin.data_ptr(), S, heads,
+                                                   _dt(qkv), float(scale), out.data_ptr(), out.stride(0), lse.data_ptr(),
+                                                   _stream(dev)))
+    return out, lse
+
+
+def b1_attention_bwd(qkv, cos, sin, out, lse, dout, heads: int, scale: float) -> torch.Tensor:
+    """d(qkv) (S, 3*H*128) from d(out) (S, H*128) (include/bma.h: bma_b1_attention_bwd)."""
+    dev = _need_gpu(qkv, cos, sin, out, lse, dout)
+    S = qkv.shape[0]
+    cos, sin = cos.reshape(S, 128).contiguous(), sin.reshape(S, 128).contiguous()
+    dout = dout.contiguous()
+    dqkv = torch.empty((S, 3 * heads * 128), dtype=qkv.dtype, device=dev)
+    check("bma_b1_attention_bwd", lib.bma_b1_attention_bwd(
+        qkv.data_ptr(), qkv.stride(0), cos.data_ptr(), sin.data_ptr(), out.data_ptr(), out.stride(0), lse.data_ptr(),
+        dout.data_ptr(), dout.stride(0), S, heads, _dt(qkv), float(scale), dqkv.data_ptr(), dqkv.stride(0), _stream(dev)))
+    return dqkv
+
+
+class B1AttentionFn(torch.autograd.Function):
+    """out = attention(rope(q), rope(k), v) for ONE sequence, straight from the fused q/k/v projection output and into the
+    layout o_proj reads; the backward hands d(qkv) back in the projection's layout -- two launches where the unfused
+    route has ten (bma_b1_attention)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, heads, scale):
+        q2 = qkv.reshape(qkv.shape[-2], qkv.shape[-1])
+        out, lse = b1_attention(q2, cos, sin, heads, scale)
+        ctx.save_for_backward(q2, cos, sin, out, lse)
+        ctx.heads, ctx.scale, ctx.shape = int(heads), float(scale), tuple(qkv.shape)
+        return out.view(*qkv.shape[:-1], heads * 128)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, cos, sin, out, lse = ctx.saved_tensors
+        d2 = dout.reshape(out.shape)
+        return b1_attention_bwd(q2, cos, sin, out, lse, d2, ctx.heads, ctx.scale).view(ctx.shape), None, None, None, None
+
+
+# ---------------------------------------------------------------------------
 # skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
 SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
 GEMM_NT_MAX_ROWS = int(_os.environ.get("BMA_GEMM_NT_MAX_ROWS", "96"))   # one 64- or 96-row tile: the shapes the kernel is built and measured for

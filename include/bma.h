@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 106 /* 0.1.6: bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 106 /* 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -279,6 +279,21 @@ void bma_gemm_nt_set_plan(int w_tiles_per_wave, int rows_per_slab, int splits, i
 int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
                 int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream);
 
+/* bma_b1_attention / bma_b1_attention_bwd: rotary embedding + causal self-attention of ONE short sequence, for the batch-1
+ *   gradient pass over a text-only prompt (a1, :953-1028: what HuggingFace's attention block does between the q/k/v
+ *   projections and o_proj, and autograd's backward of it).  qkv [S][ld_qkv] holds, per token, H query heads, H key heads
+ *   and H value heads of 128 (the fused projection's own output); cos / sin [S][128] contiguous, HuggingFace's duplicated-
+ *   halves tables (rotate_half convention); out [S][ld_out] = H heads of 128 in the layout o_proj reads; lse [H][S] fp32,
+ *   natural log.  The backward takes dout [S][ld_dout] and writes dqkv [S][ld_dqkv] in qkv's layout (the rotation's
+ *   backward applied).  S <= 80 (BMA_ELIMIT beyond), bf16 / f16, one workgroup per head; leading dimensions in elements,
+ *   multiples of 8; pointers 16-byte aligned.  Rounding points are those of bma_rope2 + a flash-attention kernel: the
+ *   rotated q / k, the probabilities and dS are rounded to `dtype` before their products, sums are fp32. */
+int bma_b1_attention(const void* qkv, int64_t ld_qkv, const void* cos, const void* sin, int S, int H, int dtype, float scale,
+                     void* out, int64_t ld_out, float* lse, void* stream);
+int bma_b1_attention_bwd(const void* qkv, int64_t ld_qkv, const void* cos, const void* sin, const void* out, int64_t ld_out,
+                         const float* lse, const void* dout, int64_t ld_dout, int S, int H, int dtype, float scale, void* dqkv,
+                         int64_t ld_dqkv, void* stream);
+
 /* bma_prefix_attention: N rows (q [N][H][Dh] through row/head strides) against the P keys/values of the SHARED
  *   prefix (pk/pv [P][Hk][Dh] through strides; grouped heads in place), no mask: out [N][H][Dh] contiguous of
  *   `dtype` and lse [H][N] fp32 (natural log) -- the partial that bma_ragged_attention merges (o1, lse1).  A
@@ -321,7 +336,7 @@ enum {
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
   BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11,
-  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_COUNT = 16
+  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_B1_ATTN = 16, BMA_K_COUNT = 17
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

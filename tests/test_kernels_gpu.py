@@ -484,3 +484,70 @@ def test_allgather_f32_world_of_one_through_rccl():
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+# ------------------------------------------------------------------ bma_b1_attention (round 4)
+def _rope_tables(S, dtype, gen):
+    ang = torch.rand((S, 64), generator=gen, device=DEV) * 6.28
+    return torch.cat([ang.cos(), ang.cos()], -1).to(dtype), torch.cat([ang.sin(), ang.sin()], -1).to(dtype)
+
+
+def _b1_reference(qkv, cos, sin, H, scale):
+    """HuggingFace's route on the same numbers: apply_rotary_pos_emb in the 16-bit type (its three roundings), then causal
+    attention in fp32 on the rotated 16-bit q / k -- with autograd through all of it."""
+    S = qkv.shape[0]
+    q, k, v = (t.view(S, H, 128).transpose(0, 1) for t in qkv.split(H * 128, dim=-1))       # (H,S,128)
+
+    def rot(x):
+        x1, x2 = x[..., :64], x[..., 64:]
+        return (x * cos) + (torch.cat((-x2, x1), dim=-1) * sin)
+    qr, kr = rot(q).float(), rot(k).float()
+    s = (qr @ kr.transpose(1, 2)) * scale
+    s = s.masked_fill(~torch.tril(torch.ones(S, S, dtype=torch.bool, device=qkv.device)), float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    out = torch.softmax(s, dim=-1) @ v.float()
+    return out.transpose(0, 1).reshape(S, H * 128), lse
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_b1_attention_forward_and_backward(dtype):
+    """Rotary + causal attention of one short sequence in one launch each way (the batch-1 gradient pass over a text-only
+    prompt) against HuggingFace's formulation with fp32 attention: outputs and log-sum-exp to the rounding of the 16-bit
+    probabilities, d(qkv) to a few percent of its scale element-wise and 1 % in norm; sequence lengths on and off the
+    16-row tiles up to the 80-token limit, one head and 32; row strides wider than the row (a view into a larger
+    buffer); same bits on repeated launches; beyond the limits the call refuses."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    g = torch.Generator(device=DEV).manual_seed(7)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for S, H in ((65, 32), (44, 32), (1, 2), (16, 1), (17, 3), (80, 4), (33, 32)):
+        scale = 128 ** -0.5
+        big = (torch.randn((S, 3 * H * 128 + 64), generator=g, device=DEV) * 1.5).to(dtype)
+        qkv = big[:, : 3 * H * 128]                            # row stride 3*H*128 + 64
+        cos, sin = _rope_tables(S, dtype, g)
+        assert ops.b1_attention_ok(qkv, cos, H, H, 128)
+        leaf = qkv.detach().clone().requires_grad_()
+        ref, ref_lse = _b1_reference(leaf, cos, sin, H, scale)
+        dout = (torch.randn((S, H * 128), generator=g, device=DEV)).to(dtype)
+        (ref_grad,) = torch.autograd.grad(ref, leaf, dout.float())
+        mine = qkv.detach().requires_grad_()
+        out = ops.B1AttentionFn.apply(mine, cos, sin, H, scale)
+        (grad,) = torch.autograd.grad(out, mine, dout)
+        out2, lse = ops.b1_attention(qkv, cos, sin, H, scale)
+        assert torch.equal(out2, out.detach()) and out.shape == (S, H * 128) and grad.shape == (S, 3 * H * 128)
+        err = (out.float() - ref).abs().max() / ref.abs().max()
+        assert float(err) < 6 * eps, (S, H, float(err))
+        assert float((lse - ref_lse).abs().max()) < 2e-3 * max(1.0, float(ref_lse.abs().max())), (S, H)
+        gerr = (grad.float() - ref_grad.float()).abs().max() / ref_grad.abs().max()
+        gnorm = (grad.float() - ref_grad.float()).norm() / ref_grad.float().norm()
+        assert float(gerr) < 16 * eps and float(gnorm) < 4 * eps, (S, H, float(gerr), float(gnorm))
+        (grad2,) = torch.autograd.grad(ops.B1AttentionFn.apply(mine, cos, sin, H, scale), mine, dout)
+        assert torch.equal(grad, grad2)
+    # what it does not take
+    x = torch.zeros((81, 3 * 128), device=DEV, dtype=dtype)
+    c = torch.zeros((81, 128), device=DEV, dtype=dtype)
+    assert not ops.b1_attention_ok(x, c, 1, 1, 128)
+    assert lib.bma_b1_attention(x.data_ptr(), 384, c.data_ptr(), c.data_ptr(), 81, 1, 1, 0.1, x.data_ptr(), 128, x.data_ptr(), None) == -5
+    assert not ops.b1_attention_ok(x[:8], c[:8], 2, 1, 128) and not ops.b1_attention_ok(x[:8].float(), c[:8].float(), 1, 1, 128)
+    assert lib.bma_b1_attention(x.data_ptr(), 384, c.data_ptr(), c.data_ptr(), 8, 1, 0, 0.1, x.data_ptr(), 128, x.data_ptr(), None) == -2
+    assert lib.bma_b1_attention(x.data_ptr(), 100, c.data_ptr(), c.data_ptr(), 8, 1, 1, 0.1, x.data_ptr(), 128, x.data_ptr(), None) == -1
