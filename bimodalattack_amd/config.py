@@ -104,7 +104,7 @@ class EngineOptions:
     # static buffer; at most `score_graphs` captures are kept.  OFF by default (0): measured on one GPU and as rank 0 of
     # an emulated eight it buys nothing -- the eager forward's ~9 ms of host enqueue hide behind the GPU work even at an
     # eighth of the rows -- while every capture costs 7-55 ms of host time once (profiles/r3_ab_engine_options.txt,
-    # DESIGN.md 7).  For hosts where eight ranks do contend for cores.
+    # NOTEBOOK.md r3 7).  For hosts where eight ranks do contend for cores.
     score_graphs: int = 0
     score_graph_after: int = 1          # capture a row count when it has been met this many times
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
@@ -156,7 +156,7 @@ class EngineOptions:
     skinny_gemm: bool = True
     # Several GPUs: run the batch-1 gradient pass TENSOR-PARALLEL over the ranks instead of redundantly on each --
     # q/k/v/gate/up cut by output rows (whole heads), o/down by input columns, two all-reduces per decoder layer and
-    # direction (540 KB each at LLaVA width) -- the one lever left on the serial quarter of an 8-GPU step (DESIGN.md 7).
+    # direction (540 KB each at LLaVA width) -- the one lever left on the serial quarter of an 8-GPU step (DESIGN.md 8).
     # Correctness is tested (2 ranks, equal to the replicated pass); its speed has never been measured on real xGMI
     # (this pool has one GPU per box), the pass runs eagerly (no hipGraph), so it is OFF by default.
     tp_gradient: bool = False

@@ -19,7 +19,7 @@ the HOST's ``ncclComm_t`` and calls ``ncclAllGather`` of the RCCL instance alrea
 created their communicator themselves (C, C++, Go).  This module does not go through it: torch.distributed owns the
 RCCL communicator of a PyTorch job, its stream ordering and its error handling, and does not hand the handle out; a
 second communicator inside libbma_hip.so would need its own bootstrap (unique-id exchange) for a <= 2 KiB payload.
-The boundary for the exchange under PyTorch is therefore this module (DESIGN.md 7).
+The boundary for the exchange under PyTorch is therefore this module (DESIGN.md 8).
 """
 
 from __future__ import annotations

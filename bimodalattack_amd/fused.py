@@ -515,7 +515,11 @@ class FusedInference:
                     and self.tp is None and getattr(cfg, "_attn_implementation", None) == "bma_causal_b1" \
                     and hidden_states.dim() == 3 and hidden_states.shape[0] == 1 and self._tracking(hidden_states):
                 cos, sin = position_embeddings
-                if not (cos.requires_grad or sin.requires_grad) and cos.shape == (1, hidden_states.shape[1], 128):
+                # (everything that can be known without the product is checked BEFORE it is formed: a refusal behind it
+                # would run the projection twice -- the 643-row image pass did, for one round-4 measurement)
+                if not (cos.requires_grad or sin.requires_grad) and cos.shape == (1, hidden_states.shape[1], 128) \
+                        and hidden_states.shape[1] <= ops.B1_ATTENTION_MAX_TOKENS and cos.dtype == hidden_states.dtype \
+                        and hidden_states.dtype in (torch.bfloat16, torch.float16) and hidden_states.is_cuda:
                     y = whole(hidden_states)
                     if y is not None and ops.b1_attention_ok(y, cos, heads, heads, 128):
                         out = ops.B1AttentionFn.apply(y, cos[0], sin[0], heads, float(attn.scaling))

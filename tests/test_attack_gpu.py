@@ -1211,6 +1211,52 @@ def test_text_gradient_pass_with_one_launch_attention_at_7b_width():
     assert e1 <= 1.5 * e0 + 2e-3 and cross <= 2.0 * e0 + 2e-3
 
 
+def test_image_gradient_pass_forms_each_projection_once():
+    """The one-launch attention (<= 80 tokens) must step aside for the 643-row image pass BEFORE it has formed the fused
+    q/k/v product -- a refusal behind it ran that projection twice per layer (round 4's first PGD-only measurement:
+    35.4 -> 37.5 ms).  Counted at the dispatcher: one forward product of width 3 x 4096 per layer, one input-gradient
+    product of that shape per layer."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+    layers = 2
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("pgd", dev, torch.bfloat16, layers)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=False,
+                              images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True, graph_gradient=False))
+    atk._prepare_prompt(messages, target)
+    assert atk.engine_state()["fusions"]["b1_attention_blocks"] == layers
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    img = image.detach().clone().requires_grad_()
+    atk._gradient_eager(ids, img)                       # derived weight copies made outside the count
+    seen = []
+
+    class Count(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = getattr(getattr(func, "overloadpacket", None), "__name__", "")
+            if name in ("mm", "addmm") and torch.is_tensor(args[-1]):
+                a, b = args[-2], args[-1]
+                seen.append((a.shape[0], b.shape[1], a.shape[1]))
+            return func(*args, **(kwargs or {}))
+
+    with Count():
+        atk._gradient_eager(ids, img.detach().clone().requires_grad_())
+    rows = 643
+    fwd = [s_ for s_ in seen if s_ == (rows, 3 * 4096, 4096)]
+    bwd = [s_ for s_ in seen if s_ == (rows, 4096, 3 * 4096)]
+    # (a forward product may reach the dispatcher under another name -- one layer's does -- but never more than once per
+    # layer; the doubled projection showed as 2 x layers here)
+    assert 1 <= len(fwd) <= layers and len(bwd) == layers, (len(fwd), len(bwd))
+    n_qkv_shaped = len([s_ for s_ in seen if s_[1] == 3 * 4096 and s_[2] == 4096])
+    assert n_qkv_shaped <= layers, seen
+
+
 def test_maskless_b1_attention_gradient_matches_masked():
     """The gradient pass of the image prompt (643 rows, LLaVA-1.5-7B width, 2 layers here) with the library
     attention asked for `is_causal` against the same pass handed HuggingFace's mask tensor: token and pixel

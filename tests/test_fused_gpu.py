@@ -351,6 +351,12 @@ def _ragged_attention_reference(q, k, v, pk, pv, plan, P, scale):
     (2, 3, 200, 7, 40, 3, 3, 256, False),
     (3, 5, 97, 9, 1, 6, 2, 128, False),
     (3, 4, 80, 10, 7, 4, 2, 256, False),      # 256-wide blocks below 96 tokens: the short kernel's two stretches
+    # keys ending ONE past a 32-key chunk (a last chunk of one key, seen by one query)
+    (5, 6, 44, 20, 21, 4, 4, 128, False),     # BASELINE's text-only layout: 21 prefix + 44 = 65 keys
+    (4, 5, 33, 6, 0, 4, 2, 64, False),        # 33 keys, no prefix, grouped heads
+    (3, 4, 33, 5, 64, 4, 4, 128, False),      # 97 keys
+    (4, 6, 33, 7, 40, 2, 2, 128, True),       # 33 keys behind a prefix partial merged in the epilogue
+    (3, 4, 65, 9, 32, 2, 1, 256, False),      # 256-wide heads, two stretches: the second ends at key 97 (64-query stretch + 1)
 ])
 def test_ragged_attention_kernel_vs_fp32_loops(dtype, m, n_opt, L, T, P, H, Hk, Dh, merge):
     from bimodalattack_amd import ops

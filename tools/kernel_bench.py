@@ -208,6 +208,16 @@ def cases():
             return ops.gemm_nt(x, ws[state["i"]])
         return go
 
+    def b1_attn(S, H, backward):
+        qkv = torch.randn((S, 3 * H * 128), generator=g, device=DEV).to(bf)
+        ang = torch.rand((S, 64), generator=g, device=DEV) * 6.28
+        cos, sin = torch.cat([ang.cos(), ang.cos()], -1).to(bf), torch.cat([ang.sin(), ang.sin()], -1).to(bf)
+        out, lse = ops.b1_attention(qkv, cos, sin, H, 128 ** -0.5)
+        dout = torch.randn((S, H * 128), generator=g, device=DEV).to(bf)
+        if backward:
+            return lambda: ops.b1_attention_bwd(qkv, cos, sin, out, lse, dout, H, 128 ** -0.5)
+        return lambda: ops.b1_attention(qkv, cos, sin, H, 128 ** -0.5)
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -259,6 +269,10 @@ def cases():
         "gemm_nt/gate_up_dX_65x4096x22016": ("gemm_nt", lambda: gemm_nt(65, 4096, 22016)),
         "gemm_nt/qkv_dX_65x4096x12288": ("gemm_nt", lambda: gemm_nt(65, 4096, 12288)),
         "gemm_nt/gate_up_65x22016x4096": ("gemm_nt", lambda: gemm_nt(65, 22016, 4096)),
+        "gemm_nt/down_65x4096x11008": ("gemm_nt", lambda: gemm_nt(65, 4096, 11008)),
+        # rotary + causal attention of the text-only gradient pass (65 rows, 32 heads of 128): latency-bound, one launch each way
+        "b1_attn/fwd_S65_H32": ("b1_attn", lambda: b1_attn(65, 32, False)),
+        "b1_attn/bwd_S65_H32": ("b1_attn", lambda: b1_attn(65, 32, True)),
         # the dominant kernel of a step: the fused gate/up product of the C3 ragged candidate forward
         "gemm/gate_up_17152x22016x4096": (None, lambda: gemm(17152, 22016, 4096)),
         "gemm/down_17152x4096x11008": (None, lambda: gemm(17152, 4096, 11008)),
