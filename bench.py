@@ -696,9 +696,6 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
             marks["stats"] = dict(attack.score_stats)
             marks["ids"] = attack._last["sampled"][:1].clone() if getattr(attack, "_last", None) else None
             if n_prof:
-                # the profiled steps run the scoring forward EAGERLY (the timed steps replay it from a hipGraph, which
-                # neither Python hooks nor the in-library brackets can see): same kernels, same order
-                attack.opt.score_graphs = 0
                 native.profile_enable(True)      # event brackets cost a few us per launch: kept OUT of the timing (resets the tallies)
                 gemms.on = True
         if i == total and n_prof:

@@ -208,9 +208,6 @@ class BimodalAttack:
         # through the model behind the shared prefix for `candidates` candidates; bench.py reads this
         self.score_stats = dict(candidates=0, rows=0, rows_needed=0, ragged_calls=0, padded_calls=0)
         self._rescore_graphs: Dict[tuple, object] = {}
-        self._score_graphs: Dict[tuple, object] = {}    # ragged candidate forward per row-count grid point (LRU, insertion-ordered)
-        self._score_pool = None                         # one memory pool for all of them (never replayed concurrently)
-        self._score_seen: Dict[tuple, int] = {}
         self._tp_checked: Optional[bool] = None         # tensor-parallel gradient pass applicable to this model / world size?
         self._tp_graph = None                           # its hipGraph (None: not tried; False: eager for good)
         self._gp = None                            # _GradPrefix: scoring prefix reused by the gradient pass (joint mode)
@@ -558,8 +555,7 @@ class BimodalAttack:
         if cfg.filter_ids and (self._filter_pin is None or self._filter_pin.numel() < sampled.numel()):
             self._filter_pin = torch.empty(max(sampled.numel(), cfg.search_width * sampled.shape[1]), dtype=sampled.dtype,
                                            pin_memory=True)
-        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids, threaded=self.opt.threaded_filter,
-                                  pinned=self._filter_pin)
+        return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids, pinned=self._filter_pin)
 
     # ------------------------------------------------------------ scoring
     def _segments(self, order, feats):
@@ -713,14 +709,12 @@ class BimodalAttack:
         return self._pins.upload(host, self.model.device)
 
     def _ragged_score(self, host_ids: np.ndarray, host_parent: np.ndarray, segs, L: int, P: int, cache,
-                      n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None, m_cap: Optional[int] = None,
-                      real=None):
+                      n_rows: Optional[int] = None, inverse: Optional[np.ndarray] = None, real=None):
         """(loss (m_out,) fp32, early-stop hit or None) of this rank's candidates through the ragged forward, or None
         when this draw does not fit the row count asked for (then the caller scores the padded block).  host_ids: this
         rank's DISTINCT candidates (host copy); inverse: which of them each candidate to report is (None: one each, in
-        order).  From the second ragged forward of an attack on, the whole forward of a row count -- row-list splice,
-        model, target cross-entropy -- is ONE hipGraph replay (``_ScoreGraph``); the host only plans and uploads the
-        index maps."""
+        order).  (Round 3 also kept the whole forward of a row count as one hipGraph; measured to buy nothing -- the
+        forward is GPU-bound even at an eighth of the rows -- and removed in round 4: NOTEBOOK.md r3 7.)"""
         hf, dev, cfg = self.hf, self.model.device, self.config
         from .prefix_attention import RaggedMaps, fused_ragged_route
         # the same predicate the attention function evaluates on the tensors: the library route needs the padded-block
@@ -739,15 +733,13 @@ class BimodalAttack:
         ids = np.concatenate([plan["cand"], host_parent.reshape(1, -1)])
         E = self.embedding_layer.weight
 
-        def forward(maps, blocks, segs_=segs, cache_=cache):
+        def forward(maps, blocks):
             # the row list straight from the segments and the table: the padded (blocks, L, D) block is never built
-            rows = ops.splice(segs_, blocks, E, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
-            logits = hf.target_logits_ragged(rows, self.T, cache_, maps)
+            rows = ops.splice(segs, blocks, E, maps.ids, hf.emb_scale, rows=maps.flat).unsqueeze(0)
+            logits = hf.target_logits_ragged(rows, self.T, cache, maps)
             loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
             return loss, hit
 
-        # (the first ragged forward of an attack runs eagerly; the prefix must be the recording kind, whose tensors the
-        # graph can keep and refresh)
         if real is not None:
             # host_ids are stand-ins (``_virtual_ids``): the maps go up without ids, the forward reads the device's
             maps = RaggedMaps(plan, dev, ids=None, stage=self._stage)
@@ -755,34 +747,6 @@ class BimodalAttack:
             if maps.ids.shape != (mu + 1, int(plan["n_opt"])):
                 raise RuntimeError("ragged scoring: gathered ids do not match the plan")
             return forward(maps, mu + 1)
-        graphs_on = bool(self.opt.score_graphs > 0 and fused and hf.ragged_ok and hasattr(cache, "k") and hasattr(cache, "v"))
-        if graphs_on:
-            cap_m = max(m_out, m_cap or 0)
-            cap_b2 = max(host_ids.shape[0], cap_m) + 1
-            shape_of = tuple((k_, None if t is None else tuple(t.shape)) for k_, t in segs)
-            key = (int(plan["N"]), cap_b2, cap_m, int(plan["n_opt"]), L, P, len(cache.k), shape_of, bool(cfg.early_stop))
-            g = self._score_graphs.get(key)
-            if g is None and self._score_graphs.get(("failed",)) is None:
-                seen = self._score_seen.get(key, 0) + 1
-                self._score_seen[key] = seen
-                if seen >= self.opt.score_graph_after:      # (1: capture at first sight -- a capture runs no kernel, the replay that follows does)
-                    try:
-                        g = _ScoreGraph(self, key, plan, ids, forward, cap_b2, cap_m, segs, cache)
-                        while len(self._score_graphs) >= self.opt.score_graphs:
-                            old = next(iter(self._score_graphs))
-                            del self._score_graphs[old]
-                            self.graphs_captured = [n for n in self.graphs_captured if n != f"score:{old[0]}"]
-                        self._score_graphs[key] = g
-                        self.graphs_captured.append(f"score:{key[0]}")
-                    except Exception as e:
-                        self._fallback("graph_score", e, "ragged scoring forward not captured into a graph; running eager")
-                        self._score_graphs[("failed",)] = False
-                        torch.cuda.synchronize(dev)
-                        g = None
-            if g is not None:
-                self._score_graphs[key] = self._score_graphs.pop(key)          # most recently used last
-                loss, hit = g(plan, ids, self._stage, segs, cache)
-                return loss[:m_out], (None if hit is None else hit[:m_out])
         maps = RaggedMaps(plan, dev, ids=ids, stage=self._stage)
         return forward(maps, mu + 1)
 
@@ -893,19 +857,18 @@ class BimodalAttack:
                 kv, x, logits, scored = None, None, None, None
                 if ragged:
                     try:
-                        n_rows, m_cap = None, None
+                        n_rows = None
                         if dealt is not None:
                             # every rank builds the row count of the rank with the most rows (they differ by
                             # a few rows after dealing): one set of GEMM shapes per step on all ranks
                             n_rows = self._dealt_rows(dealt, world, L, mine.shape[1])
-                            m_cap = -(-n // world)      # most candidates a rank can be dealt: the captured forward's fixed size
                         real = None
                         if pick is not None:
                             # the stand-ins planned it; the forward embeds the real ids, gathered on the device
                             # (dealt: `mine` IS that gather; else the first appearances within this rank's slice)
                             real = (mine if dealt is not None else mine.index_select(0, self._upload(pick)),
                                     parent.reshape(1, -1).to(sampled.device))
-                        scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, m_cap, real)
+                        scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, real)
                         hf.ragged_ok = True
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):
@@ -1269,7 +1232,7 @@ class BimodalAttack:
                             # still takes from it in the reference's order -- debug_output's generate() under a sampling
                             # generation_config (:745-777) -- so that mode keeps the plain order; and a step that turns
                             # out to stop the run (early_stop) gives its draws back, as if they had never been made
-                            if self.opt.early_plan and self.opt.score_graphs == 0 and cfg.gcg_attack and not cfg.debug_output:
+                            if self.opt.early_plan and cfg.gcg_attack and not cfg.debug_output:
                                 if cfg.early_stop:
                                     rng_before = self._rng_state()
                                 self._draw_ahead(i + 1, winner.shape[1])
@@ -1611,52 +1574,6 @@ class _GradPrefix:
         self.current = None
         a.graphs_captured.append("grad_prefix")
         a.graphs_captured.append("grad_tail")
-
-
-class _ScoreGraph:
-    """The ragged candidate forward of one row count -- row-list splice, the model on the row list, target cross-entropy
-    -- as one hipGraph.  What changes from step to step is data, not shape: the index maps of the step's plan go into a
-    static device buffer of a fixed byte layout (``RaggedMaps`` with caps), the losses come back in a static output.
-    Every other tensor the captured kernels read -- the prompt segments, the prefix keys/values of every layer -- is
-    HELD by this object (so its memory cannot be handed to anybody else) and compared by address on every call: the
-    attack's own long-lived tensors and the outputs of the prefix graphs are the same storage step after step and cost
-    nothing; a caller that built them afresh (eager prefix pass, eager image features) gets them copied into the
-    captured ones."""
-
-    def __init__(self, attack: "BimodalAttack", key, plan, ids, forward, cap_b2: int, cap_m: int, segs, cache):
-        from .prefix_attention import RaggedMaps, RecordingKV
-        dev = attack.model.device
-        probe = RaggedMaps(plan, dev, ids=ids, stage=attack._stage, b2_cap=cap_b2, m_cap=cap_m)
-        self.buf = torch.empty(probe.nbytes, dtype=torch.uint8, device=dev)
-        self.cap_b2, self.cap_m = cap_b2, cap_m
-        maps = RaggedMaps(plan, dev, ids=ids, stage=attack._stage, b2_cap=cap_b2, m_cap=cap_m, out=self.buf)
-        self.maps = maps                       # views into self.buf: what the captured kernels read
-        self.segs = list(segs)                 # (kind, tensor) as captured
-        self.cache = RecordingKV(len(cache.k))
-        self.cache.k, self.cache.v = list(cache.k), list(cache.v)
-        if attack._score_pool is None:
-            attack._score_pool = torch.cuda.graph_pool_handle()
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, pool=attack._score_pool, capture_error_mode=_CAPTURE_MODE):
-            self.loss, self.hit = forward(maps, cap_b2, self.segs, self.cache)
-
-    @staticmethod
-    def _refresh(held: Tensor, new: Tensor) -> None:
-        if new is not held and (new.data_ptr() != held.data_ptr() or new.shape != held.shape or new.stride() != held.stride()):
-            held.copy_(new)
-
-    def __call__(self, plan, ids, stage, segs, cache):
-        from .prefix_attention import RaggedMaps
-        with torch.no_grad():
-            for (_, held), (_, new) in zip(self.segs, segs):
-                if held is not None:
-                    self._refresh(held, new)
-            for held, new in zip(self.cache.k + self.cache.v, list(cache.k) + list(cache.v)):
-                self._refresh(held, new)
-        RaggedMaps(plan, self.buf.device, ids=ids, stage=stage, b2_cap=self.cap_b2, m_cap=self.cap_m, out=self.buf)
-        self.graph.replay()
-        return self.loss, self.hit
 
 
 class _GradientGraph:

@@ -99,14 +99,6 @@ class EngineOptions:
     # ... and for the per-step image-features + shared-prefix pass of joint scoring (vision tower
     # forward, then the prompt+image prefix through the LM with a recording cache).
     graph_prefix: bool = True
-    # ... and for the ragged candidate forward itself (splice of the row list, the model, the target cross-entropy): one
-    # hipGraph per row-count grid point (three or four at BASELINE's width), the step's index maps uploaded into a
-    # static buffer; at most `score_graphs` captures are kept.  OFF by default (0): measured on one GPU and as rank 0 of
-    # an emulated eight it buys nothing -- the eager forward's ~9 ms of host enqueue hide behind the GPU work even at an
-    # eighth of the rows -- while every capture costs 7-55 ms of host time once (profiles/r3_ab_engine_options.txt,
-    # NOTEBOOK.md r3 7).  For hosts where eight ranks do contend for cores.
-    score_graphs: int = 0
-    score_graph_after: int = 1          # capture a row count when it has been met this many times
     # Run RMSNorm / SwiGLU / rotary embedding of Llama-family models through the fused
     # one-pass kernels while scoring candidates (no autograd there); see fused.py.
     fused_elementwise: bool = True
@@ -124,10 +116,6 @@ class EngineOptions:
     # joint mode, image in front of the suffix: the scoring prefix pass runs with autograd and serves as the first
     # 599 rows of the next gradient pass, which then runs 44 rows forward instead of 644 (attack._GradPrefix)
     grad_prefix_reuse: bool = True
-    # retokenisation filter on a worker thread beside the forward's enqueue (utils.FilterJob) instead of on the main
-    # thread right after it.  Measured neutral to slightly slower (the two threads share the interpreter lock while
-    # the main one enqueues), so off; what mattered was keeping the host from blocking behind the forward at all.
-    threaded_filter: bool = False
     # vision towers whose head width is not a multiple of 32 (SigLIP: 72): zero-pad q/k/v to a width the library's
     # attention kernels are built for (prefix_attention.padded_heads_attention); same attention, faster kernels
     pad_vision_heads: bool = True
@@ -195,7 +183,7 @@ class EngineOptions:
     # made -- in the same order of the same generator -- before the pass is queued, copied to the host behind it, and
     # the host plans on "virtual" ids (the parent with a placeholder per drawn (position, rank)) that coincide exactly
     # where the real candidates must; the real ids never visit the host before the forward (the retokenisation filter
-    # still gets its copy, beside the forward), they are gathered on the device.  Off with score_graphs.
+    # still gets its copy, beside the forward), they are gathered on the device.
     early_plan: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
@@ -242,8 +230,6 @@ class EngineOptions:
             opts.graph_rescore = env["BMA_GRAPH_RESCORE"] not in ("0", "false", "False")
         if "BMA_GRAPH_PREFIX" in env:
             opts.graph_prefix = env["BMA_GRAPH_PREFIX"] not in ("0", "false", "False")
-        if "BMA_SCORE_GRAPHS" in env:
-            opts.score_graphs = max(0, int(env["BMA_SCORE_GRAPHS"]))
         if "BMA_GRAPH_GRADIENT" in env:
             opts.graph_gradient = env["BMA_GRAPH_GRADIENT"] not in ("0", "false", "False")
         if "BMA_FUSED_ELEMENTWISE" in env:
@@ -258,8 +244,6 @@ class EngineOptions:
             opts.maskless_b1_attention = env["BMA_MASKLESS_B1_ATTENTION"] not in ("0", "false", "False")
         if "BMA_GRAD_PREFIX_REUSE" in env:
             opts.grad_prefix_reuse = env["BMA_GRAD_PREFIX_REUSE"] not in ("0", "false", "False")
-        if "BMA_THREADED_FILTER" in env:
-            opts.threaded_filter = env["BMA_THREADED_FILTER"] not in ("0", "false", "False")
         if "BMA_PAD_VISION_HEADS" in env:
             opts.pad_vision_heads = env["BMA_PAD_VISION_HEADS"] not in ("0", "false", "False")
         if "BMA_FUSE_QUICK_GELU" in env:

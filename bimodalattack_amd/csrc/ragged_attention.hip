@@ -26,7 +26,9 @@
 // Algorithmic bytes per launch: q + k + v read once, o written once = 4 * N * H * Dh * es
 // (prefix and parent rows are re-read from L2).
 #include <cstdio>
+#ifdef BMA_LONG_STAMPS
 #include <cstdlib>
+#endif
 #include <type_traits>
 #include <vector>
 
@@ -887,25 +889,13 @@ __global__ __launch_bounds__(64 * TW * REP) void ragged_attn_long_kernel(const A
 #endif
 }
 
-// 0 = never, 1 = when the blocks are long enough (default)
-int long_blocks_mode() {
-  static const int mode = [] {
-    const char* e = getenv("BMA_RAGGED_LONG");
-    return e && *e ? atoi(e) : 1;
-  }();
-  return mode;
-}
-
-// shortest max_len that takes the long-block kernel (BMA_RAGGED_LONG_MIN overrides, for experiments: with 16 every
-// ragged test passes through it, and the LLaVA row list / padded blocks take 335 / 261 us instead of 156 / 167 -- items
-// of three stages are all start and end)
-int long_min() {
-  static const int v = [] {
-    const char* e = getenv("BMA_RAGGED_LONG_MIN");
-    return e && *e ? atoi(e) : kLongMin;
-  }();
-  return v;
-}
+// Which blocks take the long-block kernel: set by bma_ragged_attention_set_long (measurement only; the library reads no
+// environment).  mode 0 = never, 1 = when the blocks are long enough (default); min_len = shortest max_len that takes it
+// (with 16 every ragged test passes through it, and the LLaVA row list / padded blocks take 335 / 261 us instead of
+// 156 / 167 -- items of three stages are all start and end).
+int g_long_mode = 1, g_long_min = kLongMin;
+int long_blocks_mode() { return g_long_mode; }
+int long_min() { return g_long_min; }
 
 template <int DT, int DH, int REP, int QT, int TW>
 int launch_long_cfg(Args b, int max_len, hipStream_t st) {
@@ -998,6 +988,11 @@ int launch_dt(const Args& a, int max_len, int Dh, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void bma_ragged_attention_set_long(int mode, int min_len) {
+  g_long_mode = mode != 0 ? 1 : 0;
+  g_long_min = min_len > 0 ? min_len : kLongMin;
+}
 
 extern "C" int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs,
                                     int64_t k_hs, const void* v, int64_t v_rs, int64_t v_hs, const void* pk,

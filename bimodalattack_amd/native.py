@@ -89,6 +89,7 @@ PROTOTYPES = {
                                      c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
+    "bma_ragged_attention_set_long": (None, [c_int, c_int]),
     "bma_prefix_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
                                      c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bma_b1_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p,

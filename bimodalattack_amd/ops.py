@@ -637,6 +637,13 @@ def ragged_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor
     return out
 
 
+# Measurement knobs of the two attention kernels behind bma_ragged_attention (tools/fuzz_long_attn.py, tools/pmc_kernel.py):
+# the environment is read HERE, once, and handed to the library through its ABI -- the kernels read no environment.
+if "BMA_RAGGED_LONG" in _os.environ or "BMA_RAGGED_LONG_MIN" in _os.environ:
+    lib.bma_ragged_attention_set_long(int(_os.environ.get("BMA_RAGGED_LONG", "1") or 1),
+                                      int(_os.environ.get("BMA_RAGGED_LONG_MIN", "0") or 0))
+
+
 def prefix_attention_ok(query: torch.Tensor, key: torch.Tensor) -> bool:
     """Can bma_prefix_attention take these (.,H,N,Dh) queries / (1,Hk,P,Dh) prefix keys?"""
     return (query.is_cuda and query.dtype in (torch.bfloat16, torch.float16) and key.dtype == query.dtype

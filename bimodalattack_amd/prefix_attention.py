@@ -162,13 +162,7 @@ class RaggedMaps:
     _INT32 = ("flat", "cstart", "cfirst", "clen", "q_src", "kv_src")
     _INT64 = ("pos", "keep", "ids")
 
-    def __init__(self, plan: dict, device, ids=None, stage: Optional[dict] = None, b2_cap: Optional[int] = None,
-                 m_cap: Optional[int] = None, out: Optional[torch.Tensor] = None):
-        """`b2_cap` / `m_cap`: build the maps at FIXED sizes whatever this draw's count of distinct candidates is -- the
-        per-block arrays and the ids padded with empty blocks (length 0: the attention kernel's workgroups for them
-        return at once), the target-row index padded by repeating its last candidate (whose extra losses the caller
-        drops) -- so that the byte layout is the same every step and `out`, a device buffer a captured hipGraph reads,
-        can take the upload."""
+    def __init__(self, plan: dict, device, ids=None, stage: Optional[dict] = None):
         import numpy as np
         self.N, self.L, self.B2 = int(plan["N"]), int(plan["L"]), int(plan["m"]) + 1
         self.m_out = int(plan.get("m_out", plan["m"]))
@@ -176,21 +170,6 @@ class RaggedMaps:
         arrays = {k: plan[k] for k in self._INT32 + ("pos", "keep") if plan.get(k) is not None}
         if ids is not None:
             arrays["ids"] = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
-        if b2_cap is not None:
-            if b2_cap < self.B2 or arrays.get("q_src") is not None:
-                raise ValueError("b2_cap below the block count, or padded-block maps present (kernel route only)")
-            pad = b2_cap - self.B2
-            for k in ("cstart", "cfirst", "clen"):
-                arrays[k] = np.concatenate([arrays[k], np.zeros(pad, dtype=np.int32)])
-            if ids is not None:
-                arrays["ids"] = np.concatenate([arrays["ids"], np.zeros(pad * int(plan["n_opt"]), dtype=np.int64)])
-            self.B2 = b2_cap
-        if m_cap is not None:
-            T = arrays["keep"].size // self.m_out
-            if m_cap < self.m_out:
-                raise ValueError("m_cap below the candidate count")
-            arrays["keep"] = np.concatenate([arrays["keep"], np.tile(arrays["keep"][-T:], m_cap - self.m_out)])
-            self.m_out = m_cap
         # int64 arrays first: every piece stays aligned to its element size
         order = [k for k in self._INT64 if k in arrays] + [k for k in self._INT32 if k in arrays]
         sizes = [arrays[k].size * (8 if k in self._INT64 else 4) for k in order]
@@ -210,12 +189,7 @@ class RaggedMaps:
             where[k] = (at, nb)
             at += nb
         self.nbytes = total
-        if out is None:
-            dev = torch.empty(total, dtype=torch.uint8, device=device)
-        else:
-            if out.numel() != total or out.dtype != torch.uint8:
-                raise ValueError("static map buffer of another layout")
-            dev = out
+        dev = torch.empty(total, dtype=torch.uint8, device=device)
         dev.copy_(pin[:total], non_blocking=True)
         if stage is not None:
             # the staging buffer is rewritten next step: that copy must have left it by then

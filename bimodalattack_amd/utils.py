@@ -71,15 +71,14 @@ class FilterJob:
     their way to the host (pinned buffer, non-blocking copy) right after sampling, the
     GPU goes on to score EVERY sampled candidate, and the host runs the tokenizer round
     trip meanwhile: in ``result()``, called once the forward is enqueued (nothing on the
-    way there may block the host behind the stream -- see dist.dealt_index), or with
-    ``threaded`` on a worker thread from the start (measured no faster: both threads want
-    the interpreter lock while the main one enqueues).
+    way there may block the host behind the stream -- see dist.dealt_index).  (A worker
+    thread for it was measured no faster -- both threads want the interpreter lock while
+    the main one enqueues -- and removed in round 4.)
     ``result()`` returns the surviving indices; the caller masks the losses with them --
     the same candidates win as if they had been filtered first.  ``seconds`` is the round
     trip's own duration, ``waited`` what the caller actually spent blocked in ``result()``."""
 
-    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool, threaded: bool = False,
-                 pinned: Optional[torch.Tensor] = None):
+    def __init__(self, ids: torch.Tensor, tokenizer, enabled: bool, pinned: Optional[torch.Tensor] = None):
         self.n = ids.shape[0]
         self.tokenizer = tokenizer
         self.enabled = enabled
@@ -87,7 +86,6 @@ class FilterJob:
         self.waited = 0.0
         self._keep: Optional[List[int]] = None
         self._error: Optional[BaseException] = None
-        self._thread = None
         if enabled:
             # `pinned`: a block the caller keeps between steps.  A fresh pinned allocation per step is recycled by
             # PyTorch's host allocator only once the stream has passed the point where the previous one was dropped;
@@ -99,10 +97,6 @@ class FilterJob:
             self.host.copy_(ids, non_blocking=True)
             self.event = torch.cuda.Event()
             self.event.record(torch.cuda.current_stream(ids.device))
-            if threaded:
-                import threading
-                self._thread = threading.Thread(target=self._run, name="bma-filter", daemon=True)
-                self._thread.start()
 
     def _run(self) -> None:
         import time
@@ -121,10 +115,7 @@ class FilterJob:
             else:
                 import time
                 t0 = time.perf_counter()
-                if self._thread is not None:
-                    self._thread.join()
-                else:
-                    self._run()
+                self._run()
                 self.waited = time.perf_counter() - t0
         if self._error is not None:
             raise self._error

@@ -316,7 +316,10 @@ int bma_prefix_attention(const void* q, int64_t q_row_stride, int64_t q_head_str
  *   take a persistent flash-attention-style kernel -- one workgroup per CU, LDS-DMA ring, two query heads of a
  *   key/value head per workgroup; shorter blocks and the other head widths one workgroup per (candidate, head,
  *   64 queries).  Same arithmetic (32-key online-softmax steps, fp32 accumulation, one rounding), not bit-identical.
- *   BMA_RAGGED_LONG=0 in the environment keeps every shape on the second. */
+ *   bma_ragged_attention_set_long(mode, min_len) -- measurement only, process-wide: mode 0 keeps every shape on the
+ *   second kernel, 1 (default) routes by length; min_len > 0 moves the 96-token threshold (0 = default).  The library
+ *   reads no environment variables. */
+void bma_ragged_attention_set_long(int mode, int min_len);
 int bma_ragged_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
                          const void* v, int64_t v_rs, int64_t v_hs, const void* pk, int64_t pk_rs, int64_t pk_hs,
                          const void* pv, int64_t pv_rs, int64_t pv_hs, int P, const int* start, const int* first,

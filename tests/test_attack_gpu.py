@@ -793,67 +793,6 @@ def test_7b_scoring_fp32_within_1e_4(workload):
     assert got["ragged"][7] == got["ragged"][3]
 
 
-@pytest.mark.parametrize("workload", ["gcg", "joint"])
-def test_scoring_forward_graph_equals_eager(workload):
-    """The ragged scoring forward replayed from a hipGraph (``_ScoreGraph``) against the same forward run eagerly, bit
-    for bit, over a sequence of different draws on a 2-layer model of LLaVA-1.5-7B width (bf16: the kernel route the
-    graphs require): different candidates and duplicate counts every call (so different index maps in the static
-    buffer, different numbers of empty padding blocks), a parent change, and in joint mode a different IMAGE every
-    call with the prefix pass run eagerly -- fresh prefix key/value tensors each time, which the graph must notice and
-    copy into the ones it captured."""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bench import build_plugins
-    from bimodalattack_amd import BimodalAttackConfig
-    from bimodalattack_amd.attack import BimodalAttack
-    from bimodalattack_amd.config import EngineOptions
-    from bimodalattack_amd.layout import segment_order
-
-    dev = torch.device(DEV)
-    n = 96
-    model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, dev, torch.bfloat16, 2)
-    joint = workload == "joint"
-    cfg = BimodalAttackConfig(num_steps=1, search_width=n, seed=1, verbosity="ERROR", pgd_attack=joint, gcg_attack=True,
-                              joint_eval=joint, early_stop=True, images_folder=tempfile.mkdtemp())
-    order = segment_order("pgd", "llava", single=True) if joint else segment_order("gcg", "llava", no_joint_eval=True)
-    engines = {}
-    for name, kw in (("graph", dict(score_graphs=4)), ("eager", dict(score_graphs=0))):
-        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, loss_in_model_dtype=False,
-                                                                                strict=True, graph_prefix=False, **kw))
-        atk._prepare_prompt(messages, target)
-        engines[name] = atk
-    g = torch.Generator(device=DEV).manual_seed(3)
-    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
-    n_opt = ids.shape[1]
-    rows_seen = set()
-    for call in range(6):
-        parent = ids.clone()
-        if call >= 4:
-            parent[0, 3] = 777                                     # another parent suffix
-        cand = parent.repeat(n, 1)
-        pos = torch.randint(0 if call % 2 else 9, n_opt, (n,), generator=g, device=DEV)      # (late positions: fewer rows)
-        cand[torch.arange(n, device=DEV), pos] = torch.randint(5, 32000, (n,), generator=g, device=DEV)
-        cand[call + 1] = cand[0]                                   # duplicates: a varying number of distinct candidates
-        cand[2 * call + 10:2 * call + 14] = parent[0]
-        cand = cand.contiguous()
-        out = {}
-        with torch.no_grad():
-            img = None if not joint else (image * (0.5 + 0.1 * call)).clamp(0, 1)
-            for name, atk in engines.items():
-                feats = atk.hf.image_features(img) if joint else None
-                out[name] = (atk.score_candidates(cand, order, feats, parent=parent).float().cpu().numpy(),
-                             None if atk._match is None else atk._match.float().cpu().numpy())
-        assert np.array_equal(out["graph"][0], out["eager"][0]), call
-        assert (out["graph"][1] is None) == (out["eager"][1] is None) and \
-            (out["graph"][1] is None or np.array_equal(out["graph"][1], out["eager"][1]))
-        assert np.isfinite(out["graph"][0]).all() and out["graph"][0][call + 1] == out["graph"][0][0]
-        rows_seen.add(engines["graph"].score_stats["rows"])
-    ga = engines["graph"]
-    assert not ga.fallbacks and any(n_.startswith("score:") for n_ in ga.graphs_captured), ga.graphs_captured
-    assert not any(n_.startswith("score:") for n_ in engines["eager"].graphs_captured)
-    assert ga.score_stats["ragged_calls"] == 6 and ga.score_stats["padded_calls"] == 0
-
-
 def test_gemma3_4b_scoring_fp32_within_1e_4():
     """The same bar at BASELINE configs[4]'s width: Gemma-3-4b-it shape (D = 2560, 8 query heads on 4 key/value heads x
     256, FFN 10240, V = 262208, scaled embedding, q/k norms, sandwich norms, suffix in FRONT of the 256 image tokens:
@@ -1493,31 +1432,6 @@ def test_padded_vision_heads_same_features_and_pixel_gradient():
         assert float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
     big = g0.abs() > 0.1 * g0.abs().max()
     assert float((torch.sign(g1[big]) == torch.sign(g0[big])).float().mean()) > 0.98
-
-
-def test_filter_job_on_a_worker_thread_matches_inline():
-    """The retokenisation filter beside the forward (worker thread) keeps exactly what the inline one keeps, and
-    hands the reference's "nothing survives" error to the caller of result()."""
-    from bimodalattack_amd import synthetic as S
-    from bimodalattack_amd.utils import FilterJob, roundtrip_keep
-    tok = S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, S.TINY_UNRT)
-    g = torch.Generator().manual_seed(0)
-    ids = torch.randint(0, len(tok), (64, 8), generator=g).to(DEV)
-    want = None
-    try:
-        want = roundtrip_keep(ids.tolist(), tok)
-    except RuntimeError:
-        pass
-    assert want is not None and 0 < len(want) < 64           # the tiny vocabulary has words that do not round-trip
-    for threaded in (True, False):
-        job = FilterJob(ids, tok, True, threaded=threaded)
-        assert job.result() == want and job.result() is job.result() and job.seconds > 0
-    bad = ids[[i for i in range(64) if i not in want]][:4]
-    for threaded in (True, False):
-        job = FilterJob(bad, tok, True, threaded=threaded)
-        with pytest.raises(RuntimeError, match="No token sequences are the same"):
-            job.result()
-    assert FilterJob(ids, tok, False).result() == list(range(64))
 
 
 @pytest.mark.parametrize("graphs", [False, True])

@@ -538,49 +538,6 @@ def test_fused_structure_detection_steps_aside_on_4_50_style_layers():
         pa._REGISTERED.update(was)
 
 
-def test_ragged_maps_fixed_layout_for_graph_replay():
-    """``RaggedMaps`` with caps: whatever the draw's number of distinct candidates, the packed index maps have ONE byte
-    layout (what lets a captured hipGraph read them from a static buffer): per-block arrays and ids padded with EMPTY
-    blocks, the target-row index padded by repeating its last candidate."""
-    from bimodalattack_amd.layout import ragged_plan
-    from bimodalattack_amd.prefix_attention import RaggedMaps
-    n_opt, L, T, P, n = 6, 15, 4, 11, 12
-    parent = np.arange(n_opt)
-    rng = np.random.default_rng(0)
-    layouts = []
-    for distinct in (12, 7, 3):
-        cand = np.tile(parent, (n, 1))
-        for i in range(n):
-            cand[i, rng.integers(0, n_opt)] = 10 + (i % distinct)
-        uniq, inv = np.unique(cand, axis=0, return_inverse=True)
-        plan = ragged_plan(uniq, parent, L, T, P, n_rows=None, dedup=False, padded_maps=False, inverse=np.asarray(inv).reshape(-1))
-        assert plan is not None and plan["m"] == uniq.shape[0]
-        ids = np.concatenate([plan["cand"], parent[None]])
-        out = torch.zeros(0, dtype=torch.uint8)
-        probe = RaggedMaps(plan, "cpu", ids=ids, b2_cap=n + 1, m_cap=n)
-        out = torch.empty(probe.nbytes, dtype=torch.uint8)
-        maps = RaggedMaps(plan, "cpu", ids=ids, b2_cap=n + 1, m_cap=n, out=out)
-        # everything but the two per-row arrays (flat, pos: N entries each) has the caps' size
-        layouts.append((probe.nbytes - plan["N"] * (4 + 8), tuple(maps.ids.shape), maps.cstart.shape[0], maps.keep.shape[0]))
-        assert maps.flat.shape[0] == plan["N"] and maps.pos.shape == (1, plan["N"])
-        m = plan["m"]
-        assert maps.B2 == n + 1 and maps.m_out == n and maps.m_real == n
-        assert maps.clen[:m + 1].tolist() == plan["clen"].tolist() and maps.clen[m + 1:].tolist() == [0] * (n - m)
-        assert maps.ids[:m + 1].tolist() == ids.tolist() and int(maps.ids[m + 1:].abs().sum()) == 0
-        assert maps.keep.tolist() == plan["keep"].tolist()              # (already one entry per input candidate)
-        assert maps.flat.data_ptr() >= out.data_ptr() and maps.flat.data_ptr() < out.data_ptr() + out.numel()
-        with pytest.raises(ValueError):
-            RaggedMaps(plan, "cpu", ids=ids, b2_cap=m, m_cap=n)          # fewer blocks than the draw has
-    assert len(set(layouts)) == 1
-    # a dealt share: fewer candidates than the cap -> the index repeats its last candidate
-    cand = np.tile(parent, (5, 1))
-    cand[np.arange(5), [0, 1, 2, 3, 4]] = 50 + np.arange(5)
-    plan = ragged_plan(cand, parent, L, T, P, n_rows=None, dedup=False, padded_maps=False)
-    maps = RaggedMaps(plan, "cpu", ids=np.concatenate([plan["cand"], parent[None]]), b2_cap=9, m_cap=8)
-    assert maps.m_out == 8 and maps.m_real == 5 and maps.keep.shape[0] == 8 * T
-    assert maps.keep[5 * T:].tolist() == plan["keep"][-T:].tolist() * 3
-
-
 def test_derived_weight_copies_are_versioned():
     from bimodalattack_amd.fused import _CopyCache
     c = _CopyCache()
