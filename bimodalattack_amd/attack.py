@@ -46,7 +46,7 @@ from .dist import CandidateSharder
 from .fused import DeferredNormMissed, FusedInference
 from . import gemm_tuning
 from .hf_adapter import HFAdapter
-from .layout import ragged_plan, ragged_rows, dynamic_width, segment_order, split_at_suffix, unique_rows
+from .layout import expected_row_counts, ragged_plan, ragged_rows, dynamic_width, segment_order, split_at_suffix, unique_rows
 from .utils import INIT_CHARS, FilterJob, get_nonascii_toks, is_oom, plan_chunk
 
 logger = logging.getLogger("gcg")
@@ -259,6 +259,7 @@ class BimodalAttack:
         return dict(tuned_gemms=self.tuned_gemms, prefix_ok=hf.prefix_ok, shared_ok=hf.shared_ok, ragged_ok=hf.ragged_ok,
                     graphs_captured=list(self.graphs_captured), fallbacks=dict(self.fallbacks),
                     fused_elementwise=bool(self.fused.enabled), fusions=dict(self.fused.admitted), chunk_cap=self._chunk_cap,
+                    warmed_row_counts=list(getattr(self, "warmed", {}).get("row_counts", [])),
                     collectives=self.shard.n_collectives if self.shard.enabled else 0)
 
     # ------------------------------------------------------------------ setup
@@ -991,6 +992,54 @@ class BimodalAttack:
         loss, self._match = g(winner, feats)
         return loss
 
+    def _warm_gemms(self, n_opt: int) -> None:
+        """Touch every (row count, projection shape) pair the ragged scoring forwards of this run can meet, once, before
+        the first step (EngineOptions.warm_gemms): kernel choice and lazy code-object loading depend on the shape alone,
+        so zeros against the first decoder layer's own weights do."""
+        cfg, hf = self.config, self.hf
+        if not (self.opt.warm_gemms and cfg.gcg_attack and self.opt.ragged_suffix and self.opt.prefix_reuse
+                and self.opt.shared_prefix_attention and self.opt.target_rows_only and hf.shared_prefix_configs()
+                and self.model.dtype in (torch.bfloat16, torch.float16)):
+            return
+        order = segment_order("pgd" if (cfg.pgd_attack and cfg.joint_eval) else "gcg", hf.model_type, single=True) \
+            if cfg.pgd_attack else segment_order("gcg", hf.model_type, no_joint_eval=True)
+        prefix_names, tail = split_at_suffix(order)
+        if not tail or tail[0] != "optim" or "image" in tail:
+            return                               # (suffix in front of the image: padded chunks, another set of shapes)
+        L = n_opt + sum(self.seg[("target_in" if t == "target" else t)].shape[1] for t in tail if t != "optim")
+        world = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else self.shard.world
+        widths = {self._width(i) for i in range(cfg.num_steps)} if (cfg.dynamic_search or self.opt.width_override) else {cfg.search_width}
+        layer = next((l for l, _, _ in self.fused.layers), None)
+        if layer is None:
+            return
+        shapes = set()
+        attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+        lin = lambda m, n: getattr(m, n) if isinstance(getattr(m, n, None), torch.nn.Linear) else None    # noqa: E731
+        qkv = [lin(attn, n) for n in ("q_proj", "k_proj", "v_proj")]
+        if all(qkv):
+            if self.opt.fuse_qkv and attn in self.fused.qkv:
+                shapes.add((sum(l.out_features for l in qkv), qkv[0].in_features))
+            else:
+                shapes |= {(l.out_features, l.in_features) for l in qkv}
+        gu = [lin(mlp, n) for n in ("gate_proj", "up_proj")]
+        if all(gu):
+            if self.opt.fuse_gate_up:
+                shapes.add((gu[0].out_features + gu[1].out_features, gu[0].in_features))
+            else:
+                shapes |= {(l.out_features, l.in_features) for l in gu}
+        shapes |= {(l.out_features, l.in_features) for l in (lin(attn, "o_proj"), lin(mlp, "down_proj")) if l is not None}
+        counts = set()
+        for w_ in sorted(widths)[-8:] if len(widths) > 8 else widths:      # (a long width schedule: its widest steps)
+            counts |= set(expected_row_counts(w_, n_opt, L, cfg.n_replace, cfg.topk, (world,)))
+        dev, dt = self.model.device, self.model.dtype
+        with torch.no_grad():
+            for out_f, in_f in sorted(shapes):
+                w = torch.zeros((out_f, in_f), dtype=dt, device=dev)
+                for M in sorted(counts):
+                    torch.nn.functional.linear(torch.zeros((1, M, in_f), dtype=dt, device=dev), w)
+                del w
+        self.warmed = dict(row_counts=sorted(counts), shapes=sorted(shapes))
+
     # ------------------------------------------------------------ buffer init
     def init_buffer(self, image) -> AttackBuffer:
         cfg, tok, dev = self.config, self.tokenizer, self.model.device
@@ -1061,6 +1110,7 @@ class BimodalAttack:
         self._prepare_prompt(messages, target)
         buffer = self.init_buffer(image)
         optim_ids = buffer.get_best_ids()
+        self._warm_gemms(optim_ids.shape[1])
 
         losses: List[float] = []
         strings: List[str] = []

@@ -185,6 +185,10 @@ class EngineOptions:
     # where the real candidates must; the real ids never visit the host before the forward (the retokenisation filter
     # still gets its copy, beside the forward), they are gathered on the device.
     early_plan: bool = True
+    # Before the first step: one product of every decoder projection shape at every row count the run's ragged forwards
+    # can meet (layout.expected_row_counts), so that the library's lazy loading of a kernel it has not used in this process
+    # -- ~39 ms the first time a new row count shows up -- happens in set-up and not inside a step.
+    warm_gemms: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
     # Padded scoring (no ragged rows: Gemma-3's layout, fp32 models) runs chunks whose candidate count is a
@@ -276,6 +280,8 @@ class EngineOptions:
             opts.gradient_ahead = env["BMA_GRADIENT_AHEAD"] not in ("0", "false", "False")
         if "BMA_EARLY_PLAN" in env:
             opts.early_plan = env["BMA_EARLY_PLAN"] not in ("0", "false", "False")
+        if "BMA_WARM_GEMMS" in env:
+            opts.warm_gemms = env["BMA_WARM_GEMMS"] not in ("0", "false", "False")
         if "BMA_CHUNK_QUANTUM" in env:
             opts.chunk_quantum = max(1, int(env["BMA_CHUNK_QUANTUM"]))
         if "BMA_CHUNK" in env:

@@ -108,6 +108,29 @@ def ragged_rows(needed: int, cap: int) -> int:
     return min(-(-needed // gran) * gran, cap)
 
 
+def expected_row_counts(m: int, n_opt: int, L: int, n_replace: int, topk: int, worlds=(1,), sigmas: float = 4.5) -> list:
+    """The row counts (grid points of ``ragged_rows``) the ragged forwards of a run can meet: every grid point within
+    `sigmas` standard deviations of the expected count for `m` sampled candidates of `L` tokens behind the prefix --
+    first replaced positions and duplicates are random --, for one rank of each world size in `worlds`.  The GEMM
+    selection table is tuned over this set (tools/tune_rows.py) and the engine touches it once before the first step
+    (``BimodalAttack._warm_gemms``)."""
+    mean_p, var_p = first_diff_stats(n_opt, n_replace)
+    u, var_u = expected_unique(m, n_opt, n_replace, topk)
+    rows = L - mean_p
+    out = set()
+    for w in worlds:
+        mean = n_opt + u / w * rows
+        sd = (u / w * var_p + var_u / (w * w) * rows * rows) ** 0.5
+        lo, hi = int(mean - sigmas * sd), int(mean + sigmas * sd) + L
+        cap = n_opt + (-(-m // w)) * L
+        v = max(n_opt + 1, lo)
+        while v <= hi:
+            r = ragged_rows(v, cap)
+            out.add(r)
+            v = r + 1
+    return sorted(out)
+
+
 _HASH_MUL = None
 
 

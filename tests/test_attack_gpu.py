@@ -272,6 +272,30 @@ def test_device_rng_mode_and_16bit_run(kind, dtype):
         assert not (set(st["topk_idx"].reshape(-1).tolist()) & na)
 
 
+def test_gemm_shapes_are_touched_before_the_first_step():
+    """EngineOptions.warm_gemms: a GCG run on a llama-family model touches, in set-up, every row count its ragged forwards
+    can meet (so that the library's first-use loading of a kernel does not land inside a step); the run itself is the
+    one without the warm-up."""
+    from bimodalattack_amd import BimodalAttackConfig, synthetic as S
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import expected_row_counts
+    out = {}
+    for warm in (True, False):
+        model, tok, proc, _ = S.tiny_case("llava", dtype=torch.bfloat16, device=DEV)
+        cfg = BimodalAttackConfig(num_steps=3, search_width=24, topk=16, seed=5, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
+                                  images_folder=tempfile.mkdtemp())
+        atk = BimodalAttack(model, tok, proc, cfg, None, EngineOptions.from_env(rng_device="cpu", strict=True, warm_gemms=warm))
+        res = atk.run("tell me a story", "tell me a story", "Sure here is a story", None)
+        out[warm] = (res.losses, res.strings, atk.engine_state()["warmed_row_counts"], atk)
+    assert out[True][:2] == out[False][:2] and out[False][2] == []
+    atk = out[True][3]
+    n_opt = len(tok(S.TINY_OPTIM_INIT, add_special_tokens=False)["input_ids"])
+    L = n_opt + atk.seg["after"].shape[1] + atk.seg["target_in"].shape[1]
+    assert out[True][2] == expected_row_counts(24, n_opt, L, 1, 16, (1,)) and len(out[True][2]) >= 1
+    assert atk.score_stats["ragged_calls"] == 3
+
+
 def test_early_stop_and_errors():
     from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
     model, tok, proc, _ = S.tiny_case("opt", device=DEV)

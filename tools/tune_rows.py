@@ -20,22 +20,8 @@ sys.path.insert(0, REPO)
 
 
 def row_counts(m, n_opt, L, n_replace, topk, worlds=(1, 2, 4, 8), sigmas=4.5):
-    from bimodalattack_amd.layout import expected_unique, first_diff_stats, ragged_rows
-    mean_p, var_p = first_diff_stats(n_opt, n_replace)
-    u, var_u = expected_unique(m, n_opt, n_replace, topk)
-    rows = L - mean_p
-    out = set()
-    for w in worlds:
-        mean = n_opt + u / w * rows
-        sd = (u / w * var_p + var_u / (w * w) * rows * rows) ** 0.5
-        lo, hi = int(mean - sigmas * sd), int(mean + sigmas * sd) + L
-        cap = n_opt + (-(-m // w)) * L
-        v = max(n_opt + 1, lo)
-        while v <= hi:
-            r = ragged_rows(v, cap)
-            out.add(r)
-            v = r + 1
-    return sorted(out)
+    from bimodalattack_amd.layout import expected_row_counts
+    return expected_row_counts(m, n_opt, L, n_replace, topk, worlds, sigmas)
 
 
 def main():
