@@ -301,7 +301,7 @@ class FusedInference:
                 self.mlps.append(m)
             files.add(type(m).__module__)
         if next((True for p in model.parameters() if p.is_cuda), False):
-            ops.gemm_workspace(next(p for p in model.parameters() if p.is_cuda).device)   # before any capture needs it
+            ops.gemm_workspace_for_graphs(next(p for p in model.parameters() if p.is_cuda).device)   # before any capture needs it
         self._norm_info = {id(m): (eps, gemma) for m, eps, gemma in self.norms}
         if fuse_add_norm:
             self.layers = _decoder_layers(model, self._norm_info)

@@ -749,17 +749,32 @@ GEMM_NT_HOOK = None             # measurement: called as hook(x, w) for every pr
 
 
 def gemm_workspace(dev: torch.device):
-    """(partial-sum workspace, zeroed tile tickets) of the split-K reduction, one pair per device for the life of the
-    process: captured hipGraphs hold their addresses, so they are never freed or reallocated.  None while a capture is
-    running and the pair does not exist yet (allocate it beforehand: ``FusedInference`` does at construction)."""
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    """(partial-sum workspace, zeroed tile tickets) of the split-K reduction.  Launches that share a pair must be ordered
+    on one stream (the last arriver of a tile re-zeroes its ticket for the NEXT launch), so there is one pair per
+    (device, stream) for eager work -- two attack objects or a side stream on one device get their own -- and one per
+    device for everything captured into hipGraphs, whose replays the engine issues from one stream; captured graphs hold
+    the addresses, so pairs are never freed or reallocated.  None while a capture is running and its pair does not exist
+    yet (allocate it beforehand: ``FusedInference`` does at construction)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev.type, idx, "graphs" if capturing else torch.cuda.current_stream(dev).cuda_stream)
     ws = _GEMM_WS.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             return None
         ws = (torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=dev), torch.zeros(_GEMM_COUNTERS, dtype=torch.int32, device=dev))
         _GEMM_WS[key] = ws
     return ws
+
+
+def gemm_workspace_for_graphs(dev: torch.device):
+    """Allocate the pair captured launches use (call outside any capture)."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (dev.type, idx, "graphs")
+    if key not in _GEMM_WS and not torch.cuda.is_current_stream_capturing():
+        _GEMM_WS[key] = (torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=dev),
+                         torch.zeros(_GEMM_COUNTERS, dtype=torch.int32, device=dev))
+    return _GEMM_WS.get(key)
 
 
 def gemm_nt_ok(x: torch.Tensor, w: torch.Tensor) -> bool:

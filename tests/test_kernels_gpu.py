@@ -430,6 +430,13 @@ def test_gemm_nt_under_autograd_and_in_a_graph(monkeypatch):
         ops.gemm_nt(xs, w)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    # captured launches use the device's pair for graphs (allocated outside the capture), eager ones a pair per stream:
+    # an eager product on another stream cannot race a replay on partials and tickets
+    assert ops.gemm_workspace_for_graphs(torch.device(DEV)) is not None
+    main_pair = ops.gemm_workspace(torch.device(DEV))
+    with torch.cuda.stream(side):
+        side_pair = ops.gemm_workspace(torch.device(DEV))
+    assert main_pair[0].data_ptr() != side_pair[0].data_ptr() != ops.gemm_workspace_for_graphs(torch.device(DEV))[0].data_ptr()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         out = ops.gemm_nt(xs, w)

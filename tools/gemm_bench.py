@@ -56,6 +56,7 @@ def main():
     ops.GEMM_NT_MIN_K_OVER_N = 0.0                 # time the kernel on every shape, routed or not
     gemm_tuning.enable("auto", DEV)
     ops.gemm_workspace(DEV)
+    ops.gemm_workspace_for_graphs(DEV)
     out = {}
     gen = torch.Generator(device=DEV).manual_seed(0)
     for name, N, K in [s_ for s_ in SHAPES if args.only is None or s_[0] in args.only.split(",")]:

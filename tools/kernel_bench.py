@@ -199,6 +199,7 @@ def cases():
         # the skinny kernel over `layers` different weights (each launch streams its weight from HBM)
         ops.GEMM_NT_MIN_K_OVER_N = 0.0
         ops.gemm_workspace(torch.device(DEV))
+        ops.gemm_workspace_for_graphs(torch.device(DEV))
         x = torch.randn((1, M, K), generator=g, device=DEV).to(bf)
         ws = [(torch.randn((N, K), generator=g, device=DEV) * 0.02).to(bf) for _ in range(layers)]
         state = {"i": 0}
