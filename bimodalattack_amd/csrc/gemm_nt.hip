@@ -61,6 +61,7 @@ struct GemmArgs {
   int M, N, K, S, m_tiles;
   int R;                   // rows of w per slab (<= 64 * NTW, a multiple of 4)
   int xcd;                 // 1: workgroup ids remapped so that the splits of a tile share an XCD (grid a multiple of 8)
+  int dbg;                 // measurement only (bma_gemm_nt_set_plan flags bit 2): 1 = stop after publishing the partial (wrong result)
 };
 
 template <int DT>
@@ -196,41 +197,58 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
     f32x4* wsv = reinterpret_cast<f32x4*>(a.ws);
     const int64_t per = static_cast<int64_t>(kNW) * NTW * MT * 64;        // float4 per (tile, split)
     f32x4* mine = wsv + (static_cast<int64_t>(tile) * a.S + split) * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane;
+    // The partial leaves WRITE-THROUGH (agent-scope relaxed stores = global_store ... sc1, 8 bytes each): no release
+    // fence is needed behind them -- a fence would write back this XCD's L2 with 48 KB freshly dirtied per workgroup,
+    // most of the 10-12 us a split product spent behind its k-loop (cdna_hip_programming.md 6 Guideline 16, R1;
+    // MI355X_MICROARCH.md "publish-large": 8.2 vs 3.0 us) -- only every storing wave's drain, the barrier, the ticket.
+    // (16 bytes per lane through a raw buffer store with aux = sc1; as 8-byte atomic stores the publish was 2 us slower)
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    const int64_t mine_off = ((static_cast<int64_t>(tile) * a.S + split) * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane) * 16;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.ws) + mine_off - static_cast<int64_t>(lane) * 16, 0, NTW * MT * 1024, 0x00020000);
+    (void)mine;
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) mine[(j * MT + m) * 64] = acc[j][m];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int m = 0; m < MT; ++m)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[j][m]), rsrc, lane * 16 + (j * MT + m) * 1024, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its own stores
+    if (a.dbg) return;
     __syncthreads();                                            // (also: every wave is done with the stage ring)
     int* flag = reinterpret_cast<int*>(lds);
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int last = ticket == a.S - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      }
+      if (last) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       *flag = last;
     }
     __syncthreads();
     if (*flag == 0) return;
-    // every partial -- this workgroup's own too -- is read back in split order: all loads of a split are independent
-    // (a per-element "own registers or load" select would serialise them behind one wait each; issuing the loads of
-    // four splits together before adding, measured in round 4, was no faster)
-    const f32x4* base = wsv + static_cast<int64_t>(tile) * a.S * per + static_cast<int64_t>(wave) * NTW * MT * 64 + lane;
+    // Every partial -- this workgroup's own too -- is read back in split order, by sc1 loads (buffer_load_dwordx4 ... sc1:
+    // past this CU's L1, which may hold stale lines of the workspace from an earlier launch) INSTEAD of an agent-scope
+    // acquire in front of plain loads: valid because every byte was stored sc1, every storing wave drained before its
+    // workgroup's barrier and ticket add, the reducer learnt it is last from the value its own add returned, and its
+    // other waves load behind the barrier above (MI355X_MICROARCH.md, visibility: the hand-off table's third row);
+    // one workgroup per CU (the ring fills the LDS).  All loads of a split are independent (a per-element "own registers
+    // or load" select would serialise them behind one wait each).  What remains of the tail -- ~6 us -- is a latency
+    // chain (ticket round trip, barrier, read rounds, stores) and the arrival skew: issuing four splits' loads together,
+    // and leaving out the x tiles without a real row, were each measured in round 4 and moved nothing.
+    typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(a.ws) + (static_cast<int64_t>(tile) * a.S * per + static_cast<int64_t>(wave) * NTW * MT * 64) * 16, 0,
+        static_cast<int>(a.S * per * 16), 0x00020000);
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int s = 0; s < a.S; ++s) {
       f32x4 v[NTW][MT];
+      const int so = static_cast<int>(static_cast<int64_t>(s) * per * 16);
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) v[j][m] = base[static_cast<int64_t>(s) * per + (j * MT + m) * 64];
+        for (int m = 0; m < MT; ++m)
+          v[j][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16 + (j * MT + m) * 1024, so, 16));
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
@@ -268,7 +286,7 @@ constexpr int kMaxSplit = 16;
 constexpr int kCUs = 256;
 
 struct Plan {
-  int mt, m_tiles, ntw, R, slabs, S, xcd, ntl;
+  int mt, m_tiles, ntw, R, slabs, S, xcd, ntl, dbg;
 };
 
 // tuning override (bma_gemm_nt_set_plan): 0 = the planner's choice
@@ -277,7 +295,7 @@ int g_ntw = 0, g_R = 0, g_S = 0, g_flags = -1;
 // What one decomposition costs, in units of one stage of a 96 + 128-row image: the workgroups run in rounds of 256 (one
 // per CU, the ring fills the LDS); a round lasts (k-steps + pipeline fill) stages, a stage costs in proportion to the
 // rows of its image, and a split of K costs the partial-sum round trip
-// plus the reducer's tail -- a lot: calibrated on the round-4 sweep (profiles/r4_gemm_sweep.txt), where two splits of
+// plus the reducer's tail -- a lot: calibrated on the round-4 sweep (profiles/r4_gemm_sweep_flags_before_writethrough.txt), where two splits of
 // 172-row slabs on all 256 CUs (52 us) lost to one pass over 128-row slabs on 172 of them (42 us) for N = 22016, while
 // N = 4096 wants its eight splits.
 double plan_cost(int bm, int bn, int R, int wgs, int T, int S) {
@@ -325,6 +343,7 @@ bool make_plan(int M, int N, int K, Plan& p) {
   const int flags = g_flags >= 0 ? g_flags : 3;
   p.xcd = (flags & 1) && p.S > 1 && grid % 8 == 0;
   p.ntl = (flags & 2) ? 1 : 0;
+  p.dbg = (flags & 4) ? 1 : 0;
   return true;
 }
 
@@ -379,7 +398,7 @@ extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ld
   a.ws = static_cast<float*>(ws);
   a.cnt = counters;
   a.ldx = ldx; a.ldw = ldw; a.ldy = ldy;
-  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles; a.R = p.R; a.xcd = p.xcd;
+  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles; a.R = p.R; a.xcd = p.xcd; a.dbg = p.dbg;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(tiles * p.S)), block(256);
   BMA_PROF_BEGIN(BMA_K_GEMM_NT, st, 2.0 * (static_cast<double>(M) * K + static_cast<double>(N) * K + static_cast<double>(M) * N));

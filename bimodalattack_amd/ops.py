@@ -736,12 +736,13 @@ class B1AttentionFn(torch.autograd.Function):
 # skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
 SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
 GEMM_NT_MAX_ROWS = int(_os.environ.get("BMA_GEMM_NT_MAX_ROWS", "96"))   # one 64- or 96-row tile: the shapes the kernel is built and measured for
-# Routed where the kernel measures faster than the tuned library (tools/gemm_bench.py, profiles/r4_gemm_bench.txt): the
-# products whose reduction is long against their width -- the library has to split K itself: the input gradients through
-# the transposed copies and down_proj -- and the widest forward product (gate/up, N >= 5 K), where the non-temporal weight
-# stream is worth a few percent.  0 for either bound routes every shape (tools, tests).
+# Routed where the kernel measures faster than the tuned library (tools/gemm_bench.py, profiles/r4_gemm_bench.txt): every
+# product of the pass whose long side is at least 2.5x its short one -- long reductions (the library has to split K
+# itself: the input gradients through the transposed copies, down_proj: 1.3-1.5x) and wide outputs (gate/up, q/k/v, the
+# input gradient of down_proj: 1.0-1.13x); the square o_proj ties (0.98x) and stays with the library.  0 for either
+# bound routes every shape (tools, tests).
 GEMM_NT_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_NT_MIN_K_OVER_N", "2.5"))
-GEMM_NT_MIN_N_OVER_K = float(_os.environ.get("BMA_GEMM_NT_MIN_N_OVER_K", "5"))
+GEMM_NT_MIN_N_OVER_K = float(_os.environ.get("BMA_GEMM_NT_MIN_N_OVER_K", "2.5"))
 _GEMM_WS_BYTES = 64 << 20
 _GEMM_COUNTERS = 4096
 _GEMM_WS = {}

@@ -584,13 +584,13 @@ def test_gemm_nt_plan_and_routing_rule():
     assert lib.bma_gemm_nt(16, 4096, 16, 4096, 16, 4096, 8, 4096, 100, 1, None, 0, None, 0, None) == -5     # K % 64
     assert lib.bma_gemm_nt(16, 4096, 16, 4096, 16, 4096, 8, 4096, 4096, 0, None, 0, None, 0, None) == -2    # fp32
     assert lib.bma_gemm_nt(None, 4096, 16, 4096, 16, 4096, 0, 4096, 4096, 1, None, 0, None, 0, None) == 0   # no rows
-    assert ops.GEMM_NT_MIN_K_OVER_N == 2.5 and ops.GEMM_NT_MIN_N_OVER_K == 5.0 and ops.GEMM_NT_MAX_ROWS == 96
+    assert ops.GEMM_NT_MIN_K_OVER_N == 2.5 and ops.GEMM_NT_MIN_N_OVER_K == 2.5 and ops.GEMM_NT_MAX_ROWS == 96
     x = torch.zeros(65, 4096, dtype=torch.bfloat16)
     assert not ops.gemm_nt_ok(x, torch.zeros(4096, 4096, dtype=torch.bfloat16))          # (CPU tensors never qualify)
-    # the rule itself, on shapes alone: long reductions and the widest forward product
+    # the rule itself, on shapes alone: every product of the pass but the square o_proj
     rule = lambda N, K: K >= ops.GEMM_NT_MIN_K_OVER_N * N or N >= ops.GEMM_NT_MIN_N_OVER_K * K      # noqa: E731
     assert [rule(N, K) for N, K in ((4096, 22016), (4096, 12288), (4096, 11008), (22016, 4096), (12288, 4096), (11008, 4096),
-                                    (4096, 4096))] == [True, True, True, True, False, False, False]
+                                    (4096, 4096))] == [True, True, True, True, True, True, False]
 
 
 def test_bench_gemm_roles_and_extra_workloads():
