@@ -1107,6 +1107,7 @@ class BimodalAttack:
             raise ValueError("pgd_attack=True needs an image")
 
         self.n_scored: List[int] = []          # candidates scored at each step
+        self._warned_nonfinite = False
         self._prepare_prompt(messages, target)
         buffer = self.init_buffer(image)
         optim_ids = buffer.get_best_ids()
@@ -1394,6 +1395,13 @@ class BimodalAttack:
                         self._t_read = t_read
                     n = sampled.shape[0]
                     optim_ids = winner                      # greedy: accepted even when worse (:613, :638)
+                    if current_loss != current_loss or current_loss in (float("inf"), float("-inf")):
+                        # the reference would carry a NaN on silently (argmin then picks arbitrary winners and
+                        # sign(NaN) poisons the image for good); so does the engine -- but it says so, once per run
+                        if not getattr(self, "_warned_nonfinite", False):
+                            self._warned_nonfinite = True
+                            logger.warning(f"[Iteration {i}] non-finite loss ({current_loss}): the run continues as the reference's "
+                                           "would, but its results from here on are meaningless")
                     losses.append(current_loss)
                     strings.append(tok.batch_decode(optim_ids if ids_host is None else [ids_host])[0])
                     if buffer.size == 0 or current_loss < buffer.get_highest_loss():
