@@ -374,12 +374,17 @@ class GradPassProfile:
         def nt_hook(x, w):          # products the engine routes to its own skinny kernel never reach aten
             outer.calls.append(("gemm_nt", ops.gemm_nt, (x, w), {}))
 
+        def mid_hook(x, w):
+            outer.calls.append(("gemm_mid", ops.gemm_mid, (x, w), {}))
+
         ops.GEMM_NT_HOOK = nt_hook
+        ops.GEMM_MID_HOOK = mid_hook
         try:
             with Rec():
                 out = fn()
         finally:
             ops.GEMM_NT_HOOK = None
+            ops.GEMM_MID_HOOK = None
         torch.cuda.synchronize()
         return out
 
@@ -388,7 +393,7 @@ class GradPassProfile:
         a, b = args[-2], args[-1]
         if name == "bmm":
             return a.shape[0], a.shape[1], b.shape[2], a.shape[2]
-        if name == "gemm_nt":                       # (x (..., K), w (N, K))
+        if name in ("gemm_nt", "gemm_mid"):         # (x (..., K), w (N, K))
             return 1, a.numel() // a.shape[-1], b.shape[0], b.shape[1]
         return 1, a.shape[0], b.shape[1], a.shape[1]
 

@@ -125,6 +125,7 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_ADD_RMSNORM: return "add_rmsnorm_kernel";
     case BMA_K_GEMM_NT: return "gemm_nt_kernel";
     case BMA_K_B1_ATTN: return "b1_attn_kernel";
+    case BMA_K_GEMM_MID: return "gemm_mid_kernel";
     default: return "?";
   }
 }

@@ -817,10 +817,67 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return y
 
 
+# the same products at 599-644 rows (the pass with the image in the prompt) on csrc/gemm_mid.hip
+MID_GEMM = True                 # module switch (EngineOptions.mid_gemm / BMA_MID_GEMM)
+GEMM_MID_MIN_ROWS = int(_os.environ.get("BMA_GEMM_MID_MIN_ROWS", "449"))    # three 224-row tiles, the third at least begun
+GEMM_MID_MAX_ROWS = int(_os.environ.get("BMA_GEMM_MID_MAX_ROWS", "672"))
+# Routed where the kernel measures faster than the tuned library at 599-644 rows (tools/gemm_bench.py --mid,
+# profiles/r4_gemm_mid_bench.txt): long reductions (N = 4096 with K = 11008 / 12288 / 22016, where the library has to split
+# K itself: 1.25-1.65x) and the widest output (gate/up, N = 22016: 1.04-1.2x); q/k/v and the input gradient of down_proj
+# tie and the square o_proj loses (0.8x): those stay with the library.  0 for either bound routes every shape.
+GEMM_MID_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_MID_MIN_K_OVER_N", "2.5"))
+GEMM_MID_MIN_N_OVER_K = float(_os.environ.get("BMA_GEMM_MID_MIN_N_OVER_K", "4.0"))
+GEMM_MID_HOOK = None            # measurement: called as hook(x, w) for every product routed to the kernel (bench.py)
+
+
+def gemm_mid_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Can (and should) bma_gemm_mid compute linear(x, w)?  16-bit, K a multiple of 64, GEMM_MID_MIN_ROWS..MAX_ROWS
+    rows, 16-byte aligned rows, partial sums within the fixed workspace."""
+    if not (MID_GEMM and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and w.dim() == 2
+            and x.dim() >= 2 and x.shape[-1] == w.shape[1] and w.is_contiguous() and x.is_contiguous()):
+        return False
+    K, N = w.shape[1], w.shape[0]
+    M = x.numel() // K if K else 0
+    if K % 64 or N % 4 or not (GEMM_MID_MIN_ROWS <= M <= GEMM_MID_MAX_ROWS):
+        return False
+    routed = GEMM_MID_MIN_K_OVER_N <= 0.0 or K >= GEMM_MID_MIN_K_OVER_N * N or \
+        (GEMM_MID_MIN_N_OVER_K > 0.0 and N >= GEMM_MID_MIN_N_OVER_K * K)
+    if not routed:
+        return False
+    return lib.bma_gemm_mid_ws_bytes(M, N, K) <= _GEMM_WS_BYTES
+
+
+def gemm_mid(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """linear(x, w) = x @ w^T through bma_gemm_mid (include/bma.h); x (..., K) contiguous, w (N, K) contiguous."""
+    dev = _need_gpu(x, w)
+    if w.dim() != 2 or x.dim() < 1 or x.shape[-1] != w.shape[1] or x.dtype != w.dtype or x.dtype not in (torch.bfloat16, torch.float16) \
+            or not x.is_contiguous() or not w.is_contiguous() or w.shape[1] % 64:
+        raise ValueError("gemm_mid wants contiguous 16-bit x (..., K) and w (N, K) of one dtype with K a multiple of 64")
+    K, N = w.shape[1], w.shape[0]
+    M = x.numel() // K
+    need = lib.bma_gemm_mid_ws_bytes(M, N, K)
+    ws_ptr, ws_len = 0, 0
+    if need:
+        pair = gemm_workspace(dev)
+        if pair is None:
+            raise RuntimeError("bma_gemm_mid workspace requested inside a graph capture before it was allocated")
+        if need > pair[0].numel():
+            raise ValueError("product beyond the fixed split-K workspace")
+        ws_ptr, ws_len = pair[0].data_ptr(), pair[0].numel()
+    if GEMM_MID_HOOK is not None:
+        GEMM_MID_HOOK(x, w)
+    y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=dev)
+    check("bma_gemm_mid", lib.bma_gemm_mid(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws_ptr, ws_len,
+                                           _stream(dev)))
+    return y
+
+
 def linear_b1(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """x @ w^T for a bias-free weight: the hand-written skinny kernel where it applies, the library otherwise."""
+    """x @ w^T for a bias-free weight: the hand-written kernels where they apply, the library otherwise."""
     if gemm_nt_ok(x, w) and (gemm_workspace(x.device) is not None):
         return gemm_nt(x, w)
+    if gemm_mid_ok(x, w) and (gemm_workspace(x.device) is not None):
+        return gemm_mid(x, w)
     return torch.nn.functional.linear(x, w)
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 106 /* 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 107 /* 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -279,6 +279,25 @@ void bma_gemm_nt_set_plan(int w_tiles_per_wave, int rows_per_slab, int splits, i
 int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
                 int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream);
 
+/* bma_gemm_mid: y[M][N] = x[M][K] . w[N][K]^T for the products of the batch-1 gradient pass when the image is part of the
+ *   prompt (a1, :953-1028 with PGD on: 576 image rows + the text = 599-644 rows; the same shapes occur in the prefix
+ *   pass of joint candidate scoring, :605-612).  Operands, accumulation, rounding and leading dimensions as for
+ *   bma_gemm_nt; K a multiple of 64; any M (row tiles of 224), any N.  Tiles of 224 x {192, 256} on one workgroup per CU;
+ *   the tile width and a split of K -- of every tile, or of the last columns of tiles only -- are chosen so that the
+ *   grid fits the 256 CUs (bma_gemm_mid_plan reports them).  Split tiles pass their fp32 partials through `ws`
+ *   (bma_gemm_mid_ws_bytes(M,N,K) bytes, 16-byte aligned; may be NULL when that is 0) and a second launch on the same
+ *   stream adds them in split order: results do not depend on scheduling.
+ * bma_gemm_mid_plan: out8 = {16-row x fragments per wave, row-tile count, 16-row w fragments per wave, column-tile
+ *   count, K splits, XCD-contiguous tile order (0/1), workgroups, tiles that run unsplit}.  bma_gemm_mid_set_plan:
+ *   measurement only -- pins w fragments per wave / splits / columns of tiles that are split (0, 0, -1 = the planner's
+ *   choice; 0 columns = every tile) and the flags (bit 0 XCD order; -1 = default) for every later call in the process;
+ *   results never depend on it. */
+size_t bma_gemm_mid_ws_bytes(int M, int N, int K);
+int bma_gemm_mid_plan(int M, int N, int K, int* out8);
+void bma_gemm_mid_set_plan(int w_frags_per_wave, int splits, int tail_columns, int flags);
+int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
+                 int dtype, void* ws, size_t ws_bytes, void* stream);
+
 /* bma_b1_attention / bma_b1_attention_bwd: rotary embedding + causal self-attention of ONE short sequence, for the batch-1
  *   gradient pass over a text-only prompt (a1, :953-1028: what HuggingFace's attention block does between the q/k/v
  *   projections and o_proj, and autograd's backward of it).  qkv [S][ld_qkv] holds, per token, H query heads, H key heads
@@ -339,7 +358,7 @@ enum {
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
   BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11,
-  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_B1_ATTN = 16, BMA_K_COUNT = 17
+  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_B1_ATTN = 16, BMA_K_GEMM_MID = 17, BMA_K_COUNT = 18
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);

@@ -1178,7 +1178,7 @@ def test_image_gradient_pass_forms_each_projection_once():
     """The one-launch attention (<= 80 tokens) must step aside for the 643-row image pass BEFORE it has formed the fused
     q/k/v product -- a refusal behind it ran that projection twice per layer (round 4's first PGD-only measurement:
     35.4 -> 37.5 ms).  Counted at the dispatcher: one forward product of width 3 x 4096 per layer, one input-gradient
-    product of that shape per layer."""
+    product of that shape per layer (on bma_gemm_mid since round 4: counted through its hook)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from torch.utils._python_dispatch import TorchDispatchMode
@@ -1208,8 +1208,13 @@ def test_image_gradient_pass_forms_each_projection_once():
                 seen.append((a.shape[0], b.shape[1], a.shape[1]))
             return func(*args, **(kwargs or {}))
 
-    with Count():
-        atk._gradient_eager(ids, img.detach().clone().requires_grad_())
+    from bimodalattack_amd import ops
+    ops.GEMM_MID_HOOK = lambda x, w: seen.append((x.numel() // x.shape[-1], w.shape[0], w.shape[1]))   # products on bma_gemm_mid never reach aten
+    try:
+        with Count():
+            atk._gradient_eager(ids, img.detach().clone().requires_grad_())
+    finally:
+        ops.GEMM_MID_HOOK = None
     rows = 643
     fwd = [s_ for s_ in seen if s_ == (rows, 3 * 4096, 4096)]
     bwd = [s_ for s_ in seen if s_ == (rows, 4096, 3 * 4096)]

@@ -550,6 +550,48 @@ def test_derived_weight_copies_are_versioned():
     assert c.get(("wt", 1), (w.clone(),)) is None         # another tensor (another address) is another source
 
 
+def test_gemm_mid_plan_and_routing_rule():
+    """Planning of bma_gemm_mid through the C ABI (no launch): 224-row tiles, the tile width and the K split -- of every
+    tile, or of the last columns of tiles only -- chosen so that the grid fits the 256 CUs; the workspace covers the split
+    tiles' partials; ops.gemm_mid_ok routes the products the kernel measures faster on at 599-644 rows."""
+    import ctypes
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    plan = (ctypes.c_int * 8)()
+    want = {(644, 22016, 4096): (4, 86, 8, 279, 255),      # 85 columns of tiles whole + the 86th split 8 ways in their shadow
+            (644, 4096, 22016): (4, 16, 5, 240, 0), (644, 4096, 12288): (4, 16, 5, 240, 0), (599, 4096, 11008): (4, 16, 5, 240, 0),
+            (643, 12288, 4096): (3, 64, 1, 192, 192), (644, 11008, 4096): (3, 58, 1, 174, 174), (644, 4096, 4096): (4, 16, 5, 240, 0),
+            (450, 5120, 13824): (4, 20, 4, 240, 0), (200, 4096, 4096): (4, 16, 8, 128, 0)}
+    for (M, N, K), (nf, n_tiles, S, wgs, unsplit) in want.items():
+        assert lib.bma_gemm_mid_plan(M, N, K, plan) == 0
+        got = list(plan)
+        m_tiles = -(-M // 224)
+        assert got == [7, m_tiles, nf, n_tiles, S, 1, wgs, unsplit], ((M, N, K), got)
+        assert n_tiles == -(-N // (64 * nf)) and wgs == unsplit + (m_tiles * n_tiles - unsplit) * S
+        assert lib.bma_gemm_mid_ws_bytes(M, N, K) == (0 if S == 1 else (m_tiles * n_tiles - unsplit) * S * 224 * 64 * nf * 4)
+        assert lib.bma_gemm_mid_ws_bytes(M, N, K) <= ops._GEMM_WS_BYTES
+        assert unsplit <= 256 and (wgs <= 256 or unsplit > 0)         # one round, or short pieces behind a round of whole tiles
+    # the tuning override pins tile width / splits / split columns for every later call, and lets go again
+    lib.bma_gemm_mid_set_plan(3, 2, 0, 0)
+    assert lib.bma_gemm_mid_plan(644, 12288, 4096, plan) == 0 and list(plan)[2:8] == [3, 64, 2, 0, 384, 0]
+    lib.bma_gemm_mid_set_plan(4, 4, 2, -1)
+    assert lib.bma_gemm_mid_plan(644, 22016, 4096, plan) == 0 and list(plan)[2:8] == [4, 86, 4, 1, 252 + 6 * 4, 252]
+    lib.bma_gemm_mid_set_plan(5, 0, -1, -1)
+    assert lib.bma_gemm_mid_plan(644, 4096, 4096, plan) == -1                              # no such tile
+    lib.bma_gemm_mid_set_plan(0, 0, -1, -1)
+    assert lib.bma_gemm_mid_plan(644, 12288, 4096, plan) == 0 and list(plan)[2:5] == [3, 64, 1]
+    assert lib.bma_gemm_mid_plan(644, 4096, 96, plan) == -1 and lib.bma_gemm_mid_ws_bytes(644, 4096, 96) == 0
+    assert lib.bma_gemm_mid(16, 4096, 16, 4096, 16, 4096, 8, 4096, 96, 1, None, 0, None) == -5     # K % 64
+    assert lib.bma_gemm_mid(16, 4096, 16, 4096, 16, 4096, 8, 4096, 4096, 0, None, 0, None) == -2   # fp32
+    assert lib.bma_gemm_mid(None, 4096, 16, 4096, 16, 4096, 0, 4096, 4096, 1, None, 0, None) == 0  # no rows
+    assert lib.bma_gemm_mid(16, 4096, 16, 4096, 16, 4096, 644, 4096, 11008, 1, None, 0, None) == -1   # split plan without a workspace
+    assert (ops.GEMM_MID_MIN_ROWS, ops.GEMM_MID_MAX_ROWS, ops.GEMM_MID_MIN_K_OVER_N, ops.GEMM_MID_MIN_N_OVER_K) == (449, 672, 2.5, 4.0)
+    assert not ops.gemm_mid_ok(torch.zeros(644, 11008, dtype=torch.bfloat16), torch.zeros(4096, 11008, dtype=torch.bfloat16))   # (CPU tensors never qualify)
+    rule = lambda N, K: K >= ops.GEMM_MID_MIN_K_OVER_N * N or N >= ops.GEMM_MID_MIN_N_OVER_K * K      # noqa: E731
+    assert [rule(N, K) for N, K in ((4096, 22016), (4096, 12288), (4096, 11008), (22016, 4096), (12288, 4096), (11008, 4096),
+                                    (4096, 4096))] == [True, True, True, True, False, False, False]
+
+
 def test_gemm_nt_plan_and_routing_rule():
     """Planning of bma_gemm_nt through the C ABI (no launch): slab height and split count are chosen together so that
     the workgroups of a product fill the CUs in whole rounds where K is split, the workspace covers every partial tile,

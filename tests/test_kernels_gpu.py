@@ -405,6 +405,114 @@ def test_gemm_nt_matches_fp32_reference(dtype, monkeypatch):
                                                      torch.zeros((4096, 22016), device=DEV, dtype=dtype))
 
 
+# ------------------------------------------------------------------ bma_gemm_mid (round 4)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_mid_matches_fp32_reference(dtype, monkeypatch):
+    """y = x W^T on the 224-row-tile kernel against the product in fp32 (one rounding of the fp32 sum to the 16-bit type):
+    the seven products of a LLaVA-7B layer at the row counts of the pass with the image in the prompt (599 / 643 / 644:
+    every tile plan -- K split 5 ways, 192- and 256-wide tiles unsplit, the last column of tiles split 8 ways behind 255
+    whole ones), row counts on and off the 224-row tile and down to one row, N off the tile, off 64 and off 16, one and two
+    units of K; bitwise equal over repeated launches (the second launch adds the partials in split order).  ops.gemm_mid_ok
+    routes only the shapes where the kernel beats the library: lifted here."""
+    import ctypes
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    g = torch.Generator(device=DEV).manual_seed(321)
+    monkeypatch.setattr(ops, "GEMM_MID_MIN_K_OVER_N", 0.0)
+    monkeypatch.setattr(ops, "GEMM_MID_MIN_ROWS", 1)
+    shapes = [(644, 4096, 4096), (644, 22016, 4096), (599, 4096, 22016), (643, 12288, 4096), (644, 4096, 11008), (644, 11008, 4096),
+              (644, 4096, 12288), (672, 260, 64), (449, 132, 128), (1, 64, 64), (225, 200, 192), (448, 8, 64), (600, 1028, 4096),
+              (17, 32064, 64), (224, 256, 1024)]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    plan = (ctypes.c_int * 8)()
+    seen = set()
+    for M, N, K in shapes:
+        x = (torch.randn((M, K), generator=g, device=DEV)).to(dtype)
+        w = (torch.randn((N, K), generator=g, device=DEV) * 0.05).to(dtype)
+        assert ops.gemm_mid_ok(x, w)
+        assert lib.bma_gemm_mid_plan(M, N, K, plan) == 0
+        seen.add((plan[2], plan[4] > 1, 0 < plan[7] < plan[1] * plan[3]))
+        y = ops.gemm_mid(x, w)
+        ref = (x.double() @ w.double().t()).float()               # float64: the fp32 sums' own error is priced below
+        err = (y.float() - ref).abs()
+        # one rounding to the 16-bit type (1 ulp where the fp32 sum sits on a rounding boundary) + what K fp32 additions
+        # of terms of this size can have drifted (random walk, 8 sigma)
+        tol = 2.02 * eps * ref.abs() + 8.0 * K ** 0.5 * 2.0 ** -24 * ref.abs().max() + (2.0 ** -24 if dtype == torch.float16 else 0.0)
+        assert y.shape == (M, N) and bool((err <= tol).all()), (M, N, K, float(err.max()), float((err - tol).max()))
+        for _ in range(3):
+            assert torch.equal(ops.gemm_mid(x, w), y)
+        lib_y = torch.nn.functional.linear(x, w)
+        assert float((y.float() - lib_y.float()).abs().max()) <= 2.5 * eps * float(ref.abs().max())
+    assert {(4, True, False), (3, False, False), (4, True, True)} <= seen          # every kind of plan ran
+    # every pinned decomposition of one product gives the same rounding of the same sums up to the order of the K pieces
+    x = (torch.randn((644, 4096), generator=g, device=DEV)).to(dtype)
+    w = (torch.randn((1000, 4096), generator=g, device=DEV) * 0.05).to(dtype)
+    ref = x.float() @ w.float().t()
+    try:
+        for nf, S, tail in ((3, 1, 0), (4, 1, 0), (4, 3, 0), (3, 8, 0), (4, 2, 1), (3, 5, 2)):
+            lib.bma_gemm_mid_set_plan(nf, S, tail, -1)
+            y = ops.gemm_mid(x, w)
+            assert float((y.float() - ref).abs().max()) <= 2.5 * eps * float(ref.abs().max()), (nf, S, tail)
+            lib.bma_gemm_mid_set_plan(nf, S, tail, 0)                 # without the XCD-contiguous order: the same bits
+            assert torch.equal(ops.gemm_mid(x, w), y)
+    finally:
+        lib.bma_gemm_mid_set_plan(0, 0, -1, -1)
+    # padded leading dimensions through the C ABI (a view of a wider buffer on either side, a wider output)
+    from bimodalattack_amd.native import check
+    xb = torch.randn((500, 4096 + 64), generator=g, device=DEV).to(dtype)
+    wb = (torch.randn((300, 4096 + 128), generator=g, device=DEV) * 0.05).to(dtype)
+    yb = torch.full((500, 320), 7.0, device=DEV, dtype=dtype)
+    pair = ops.gemm_workspace(torch.device(DEV))
+    check("bma_gemm_mid", lib.bma_gemm_mid(xb.data_ptr(), 4096 + 64, wb.data_ptr(), 4096 + 128, yb.data_ptr(), 320, 500, 300, 4096,
+                                           1 if dtype == torch.bfloat16 else 2, pair[0].data_ptr(), pair[0].numel(),
+                                           torch.cuda.current_stream().cuda_stream))
+    ref = xb[:, :4096].float() @ wb[:, :4096].float().t()
+    assert float((yb[:, :300].float() - ref).abs().max()) <= 2.5 * eps * float(ref.abs().max())
+    assert bool((yb[:, 300:] == 7.0).all())                            # nothing written past N
+    # a 3-D activation, as the decoder hands it over; what it does not take goes to the library
+    x3 = torch.randn((1, 644, 11008), generator=g, device=DEV).to(dtype)
+    w3 = (torch.randn((4096, 11008), generator=g, device=DEV) * 0.05).to(dtype)
+    monkeypatch.undo()
+    assert ops.gemm_mid_ok(x3, w3) and ops.linear_b1(x3, w3).shape == (1, 644, 4096)
+    assert torch.equal(ops.linear_b1(x3, w3)[0], ops.gemm_mid(x3[0], w3))
+    assert not ops.gemm_mid_ok(x3[:, :300], w3) and not ops.gemm_mid_ok(torch.zeros((700, 11008), device=DEV, dtype=dtype), w3)
+    assert not ops.gemm_mid_ok(torch.zeros((644, 4096), device=DEV, dtype=dtype), torch.zeros((4096, 4096), device=DEV, dtype=dtype))
+    assert not ops.gemm_mid_ok(x3.float(), w3.float())
+    monkeypatch.setattr(ops, "MID_GEMM", False)
+    assert not ops.gemm_mid_ok(x3, w3)
+
+
+def test_gemm_mid_under_autograd_and_in_a_graph():
+    """FrozenLinearFn at 644 rows (forward on the library or the kernel as routed, the input gradient through the transposed
+    copy on the kernel) against autograd through the library, and the pair captured into a hipGraph and replayed."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.randn((1, 644, 4096), generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn((22016, 4096), generator=g, device=DEV) * 0.02).to(torch.bfloat16)
+    wt = w.t().contiguous()
+    dy = torch.randn((1, 644, 22016), generator=g, device=DEV).to(torch.bfloat16)
+    assert ops.gemm_mid_ok(x, w) and ops.gemm_mid_ok(dy, wt)
+    xa = x.clone().requires_grad_()
+    ya = ops.FrozenLinearFn.apply(xa, w, wt)
+    (ga,) = torch.autograd.grad(ya, xa, dy)
+    xb = x.clone().requires_grad_()
+    yb = torch.nn.functional.linear(xb, w)
+    (gb,) = torch.autograd.grad(yb, xb, dy)
+    assert float((ya.float() - yb.float()).abs().max()) <= 2 ** -7 * float(yb.float().abs().max())
+    assert float((ga.float() - gb.float()).abs().max()) <= 2 ** -7 * float(gb.float().abs().max())
+    assert ops.gemm_workspace_for_graphs(torch.device(DEV)) is not None
+    xs = x.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.gemm_mid(xs, w)
+        out2 = ops.gemm_mid(out, wt)
+    for k in range(3):
+        xs.copy_(x * (k + 1))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ops.gemm_mid(xs, w)) and torch.equal(out2, ops.gemm_mid(out, wt))
+
+
 def test_gemm_nt_under_autograd_and_in_a_graph(monkeypatch):
     """FrozenLinearFn on the skinny kernel (forward and the input gradient through the transposed copy) against autograd
     through the library, and the same pair captured into a hipGraph and replayed."""
