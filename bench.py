@@ -827,7 +827,8 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
             r = grad_profile["gemms"][int(top[5:])]
             mfma_bound = r["frac_of_mfma_peak"] >= r["frac_of_8TBps"]
             roofline = dict(bound="mfma" if mfma_bound else "hbm",
-                            kernel=f"hipBLASLt/rocBLAS GEMM of the batch-1 gradient pass: {r['role']}, M={r['M']} N={r['N']} K={r['K']} {r['dtype']}",
+                            kernel=(f"{'bma_' + r['op'] if r['op'] in ('gemm_nt', 'gemm_mid') else 'hipBLASLt/rocBLAS GEMM'} of the batch-1 gradient pass: "
+                                    f"{r['role']}, M={r['M']} N={r['N']} K={r['K']} {r['dtype']}"),
                             achieved=r["achieved_TFLOPs"] if mfma_bound else r["achieved_GBps"],
                             peak=MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS, unit="TFLOP/s" if mfma_bound else "GB/s",
                             frac=r["frac_of_mfma_peak"] if mfma_bound else r["frac_of_8TBps"],

@@ -51,6 +51,13 @@ constexpr int kBK = 64;           // k per ring unit: 128-byte rows
 constexpr int kRowB = kBK * 2;    // bytes per LDS row (16-bit types only)
 constexpr int kLds = 160 * 1024;
 constexpr int kNA = 2;            // ring slots of x
+// Timing experiments only (the loop with its MFMAs or its DMA compiled out): build with -DBMA_MID_DEBUG and
+// bma_gemm_mid_set_plan's flags bits 2-4 switch them on -- WRONG results.  The shipped library has no such switch.
+#ifdef BMA_MID_DEBUG
+constexpr bool kDbg = true;
+#else
+constexpr bool kDbg = false;
+#endif
 
 struct MidArgs {
   const char* x;
@@ -62,7 +69,7 @@ struct MidArgs {
   int t_full;              // tiles [0, t_full) run over all of K; the others are split S ways
   int S;
   int xcd;                 // 1: remap workgroup ids so that an XCD owns a contiguous run of tiles
-  int dbg;                 // measurement only (bma_gemm_mid_set_plan flags >> 2): bit 0 = no DMA after the prologue, bit 1 = no MFMA, bit 2 = every workgroup reads the same w rows (wrong results)
+  int dbg;                 // BMA_MID_DEBUG builds only (flags >> 2): bit 0 = no DMA after the prologue, bit 1 = no MFMA, bit 2 = every workgroup reads the same w rows
 };
 
 template <int DT>
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   } else {
 #pragma unroll
     for (int i = 0; i < CB; ++i) {
-      int n = ((a.dbg & 4) ? 0 : n0) + (wc + 4 * i) * 8 + prow;
+      int n = ((kDbg && (a.dbg & 4)) ? 0 : n0) + (wc + 4 * i) * 8 + prow;
       n = n < a.N ? n : a.N - 1;
       src[i] = a.w + (static_cast<int64_t>(n) * a.ldw) * 2 + pchunk * 16;
     }
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     }
   };
   auto compute = [&]() {
-    if (a.dbg & 2) {
+    if (kDbg && (a.dbg & 2)) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     int sa = 0, sb = 0;
     for (int k = 0; k < n_units; ++k) {
       read_frags(sa, sb);
-      if (k + 1 < n_units && !(a.dbg & 1)) issue_a(u0 + k + 1, sa ^ 1);   // slot of unit k-1: both halves read it a barrier ago
+      if (k + 1 < n_units && !(kDbg && (a.dbg & 1))) issue_a(u0 + k + 1, sa ^ 1);   // slot of unit k-1: both halves read it a barrier ago
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: slots may be refilled behind the barrier
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -245,14 +252,14 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     int sa = 0, sb = 0;
     for (int k = 0; k < n_units; ++k) {
       read_frags(sa, sb);
-      if (k + NB - 1 < n_units && !(a.dbg & 1)) {                 // into the slot of unit k-1
+      if (k + NB - 1 < n_units && !(kDbg && (a.dbg & 1))) {                 // into the slot of unit k-1
         int ns = sb + NB - 1;
         ns = ns >= NB ? ns - NB : ns;
         issue_b(u0 + k + NB - 1, ns);
       }
       {                                                          // w of unit k+1 landed: the units issued behind it may stay in flight
         const int behind = n_units - 2 - k;                      // min(behind, NB-2)
-        if (a.dbg & 1) wait_vm<0>();
+        if (kDbg && (a.dbg & 1)) wait_vm<0>();
         else if (behind >= NB - 2) wait_vm<CB * (NB - 2)>();
         else if (NB > 3 && behind == 1) wait_vm<CB>();
         else wait_vm<0>();
@@ -385,7 +392,7 @@ bool make_plan(int M, int N, int K, MidPlan& p) {
   p.t_full = S == 1 ? T : (tail > 0 ? T - tail * p.m_tiles : 0);
   const int flags = g_flags >= 0 ? g_flags : 1;
   p.xcd = flags & 1;
-  p.dbg = (flags >> 2) & 7;
+  p.dbg = kDbg ? (flags >> 2) & 7 : 0;
   return true;
 }
 
@@ -445,7 +452,6 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   if (dtype == BMA_BF16) BMA_MID_GO(BMA_BF16);
   else BMA_MID_GO(BMA_F16);
 #undef BMA_MID_GO
-  BMA_PROF_END(BMA_K_GEMM_MID, st);
   BMA_LAUNCH_CHECK();
   if (p.S > 1) {
     const int64_t n4 = static_cast<int64_t>(n_split_tiles) * kNW * p.mf * p.nf * 64;
@@ -454,5 +460,6 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
     else hipLaunchKernelGGL((gemm_mid_reduce_kernel<BMA_F16>), rgrid, rblock, 0, st, a, p.mf, p.nf);
     BMA_LAUNCH_CHECK();
   }
+  BMA_PROF_END(BMA_K_GEMM_MID, st);                             // both launches of a split product
   return BMA_OK;
 }

@@ -819,7 +819,7 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 # the same products at 599-644 rows (the pass with the image in the prompt) on csrc/gemm_mid.hip
 MID_GEMM = True                 # module switch (EngineOptions.mid_gemm / BMA_MID_GEMM)
-GEMM_MID_MIN_ROWS = int(_os.environ.get("BMA_GEMM_MID_MIN_ROWS", "449"))    # three 224-row tiles, the third at least begun
+GEMM_MID_MIN_ROWS = int(_os.environ.get("BMA_GEMM_MID_MIN_ROWS", "560"))    # three 224-row tiles, the third at least half full
 GEMM_MID_MAX_ROWS = int(_os.environ.get("BMA_GEMM_MID_MAX_ROWS", "672"))
 # Routed where the kernel measures faster than the tuned library at 599-644 rows (tools/gemm_bench.py --mid,
 # profiles/r4_gemm_mid_bench.txt): long reductions (N = 4096 with K = 11008 / 12288 / 22016, where the library has to split

@@ -585,7 +585,7 @@ def test_gemm_mid_plan_and_routing_rule():
     assert lib.bma_gemm_mid(16, 4096, 16, 4096, 16, 4096, 8, 4096, 4096, 0, None, 0, None) == -2   # fp32
     assert lib.bma_gemm_mid(None, 4096, 16, 4096, 16, 4096, 0, 4096, 4096, 1, None, 0, None) == 0  # no rows
     assert lib.bma_gemm_mid(16, 4096, 16, 4096, 16, 4096, 644, 4096, 11008, 1, None, 0, None) == -1   # split plan without a workspace
-    assert (ops.GEMM_MID_MIN_ROWS, ops.GEMM_MID_MAX_ROWS, ops.GEMM_MID_MIN_K_OVER_N, ops.GEMM_MID_MIN_N_OVER_K) == (449, 672, 2.5, 4.0)
+    assert (ops.GEMM_MID_MIN_ROWS, ops.GEMM_MID_MAX_ROWS, ops.GEMM_MID_MIN_K_OVER_N, ops.GEMM_MID_MIN_N_OVER_K) == (560, 672, 2.5, 4.0)
     assert not ops.gemm_mid_ok(torch.zeros(644, 11008, dtype=torch.bfloat16), torch.zeros(4096, 11008, dtype=torch.bfloat16))   # (CPU tensors never qualify)
     rule = lambda N, K: K >= ops.GEMM_MID_MIN_K_OVER_N * N or N >= ops.GEMM_MID_MIN_N_OVER_K * K      # noqa: E731
     assert [rule(N, K) for N, K in ((4096, 22016), (4096, 12288), (4096, 11008), (22016, 4096), (12288, 4096), (11008, 4096),

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""bma_gemm_nt against the library on the batch-1 shapes of the gradient pass, cold weights.
+"""bma_gemm_nt / bma_gemm_mid against the library on the batch-1 shapes of the gradient pass, cold weights.
 
     python tools/gemm_bench.py [--rows 65,44] [--layers 32] [--rounds 5] [--json out.json]
+    python tools/gemm_bench.py --mid [--rows 644,599] [--layers 16] [--sweep]      # the pass with the image in the prompt
 
 Each shape is timed the way the pass meets it: `layers` different weight tensors of the shape (32 x 180 MB does not
 fit the 256 MB Infinity Cache, so every launch streams its weight from HBM), launched back to back from ONE hipGraph
@@ -52,7 +53,11 @@ def main():
     ap.add_argument("--only", default=None, help="comma list of shape names")
     ap.add_argument("--sweep", action="store_true", help="time the kernel under pinned decompositions (bma_gemm_nt_set_plan): "
                     "the planner's choice with each flag combination, round 3's 128-row slabs, and neighbours")
+    ap.add_argument("--mid", action="store_true", help="bma_gemm_mid at a few hundred rows (default --rows 644,599 --layers 16) "
+                    "instead of bma_gemm_nt; with --sweep also pinned tile widths / K splits / split tail columns")
     args = ap.parse_args()
+    if args.mid:
+        return main_mid(args)
     ops.GEMM_NT_MIN_K_OVER_N = 0.0                 # time the kernel on every shape, routed or not
     gemm_tuning.enable("auto", DEV)
     ops.gemm_workspace(DEV)
@@ -99,6 +104,63 @@ def main():
             print(f"{name:11s} M={M:3d} N={N:5d} K={K:5d}: library {l:7.1f} us ({nbytes / l / 1e6:4.2f} TB/s)   bma_gemm_nt {o:7.1f} us "
                   f"({nbytes / o / 1e6:4.2f} TB/s = {nbytes / o / 1e6 / 8.0:4.2f} of 8)   x{l / o:4.2f}", flush=True)
         del ws
+    if args.json:
+        json.dump(out, open(args.json, "w"), indent=1)
+
+
+def main_mid(args):
+    import ctypes
+    from bimodalattack_amd.native import lib
+    rows = [int(r) for r in (args.rows if args.rows != "65,44" else "644,599").split(",")]
+    layers = args.layers if args.layers != 32 else 16
+    ops.GEMM_MID_MIN_K_OVER_N = 0.0                # time the kernel on every shape, routed or not
+    gemm_tuning.enable("auto", DEV)
+    ops.gemm_workspace(DEV)
+    ops.gemm_workspace_for_graphs(DEV)
+    out = {}
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    plan = (ctypes.c_int * 8)()
+    totals = {}
+    for name, N, K in [s_ for s_ in SHAPES if args.only is None or s_[0] in args.only.split(",")]:
+        ws = [(torch.randn((N, K), generator=gen, device=DEV) * 0.02).to(torch.bfloat16) for _ in range(layers)]
+        for M in rows:
+            x = torch.randn((1, M, K), generator=gen, device=DEV).to(torch.bfloat16)
+            lib_fn = lambda: [torch.nn.functional.linear(x, w) for w in ws]          # noqa: E731
+            own_fn = lambda: [ops.gemm_mid(x, w) for w in ws]                         # noqa: E731
+            tl, to = [], []
+            for _ in range(args.rounds):
+                tl.append(graph_time(lib_fn, len(ws)))
+                to.append(graph_time(own_fn, len(ws)))
+            l, o = statistics.median(tl), statistics.median(to)
+            flops = 2.0 * M * N * K
+            lib.bma_gemm_mid_plan(M, N, K, plan)
+            pl = list(plan)
+            # what every tile pulls L2 -> LDS: (224 + tile width) rows x K per tile, padding rows included
+            l2_bytes = 2.0 * pl[1] * pl[3] * (224 + 64 * pl[2]) * K
+            routed = K >= 2.5 * N or N >= 4.0 * K
+            t_ = totals.setdefault(M, [0.0, 0.0])
+            t_[0] += l
+            t_[1] += o if routed else l
+            out[f"{name} M={M} N={N} K={K}"] = dict(library_us=l, kernel_us=o, library_TFLOPs=flops / l / 1e6, kernel_TFLOPs=flops / o / 1e6,
+                                                    kernel_frac_of_mfma_peak=flops / o / 1e6 / 2500.0, speedup=l / o, routed=routed,
+                                                    plan=dict(tile_cols=64 * pl[2], col_tiles=pl[3], splits=pl[4], workgroups=pl[6], unsplit_tiles=pl[7]),
+                                                    l2_to_lds_TBps=l2_bytes / o / 1e6)
+            print(f"{name:11s} M={M:3d} N={N:5d} K={K:5d}: library {l:7.1f} us ({flops / l / 1e6:6.0f} TF/s)   bma_gemm_mid {o:7.1f} us "
+                  f"({flops / o / 1e6:6.0f} TF/s = {flops / o / 1e6 / 2500:4.2f} of MFMA peak; tiles 224x{64 * pl[2]} x{pl[3] * pl[1]}, "
+                  f"{pl[4]} splits, {pl[6]} workgroups; L2->LDS {l2_bytes / o / 1e6:4.1f} TB/s)   x{l / o:4.2f}{'' if routed else '   (not routed)'}", flush=True)
+            if args.sweep:
+                for nf, S_, tail in ((3, 1, 0), (4, 1, 0), (3, 3, 0), (4, 3, 0), (4, 4, 0), (4, 5, 0), (4, 6, 0), (4, 8, 1), (4, 4, 1), (4, 8, 2)):
+                    lib.bma_gemm_mid_set_plan(nf, S_, tail, -1)
+                    if lib.bma_gemm_mid_plan(M, N, K, plan) == 0 and lib.bma_gemm_mid_ws_bytes(M, N, K) <= ops._GEMM_WS_BYTES \
+                            and not (tail and plan[7] > 256):
+                        tt = statistics.median(graph_time(own_fn, len(ws)) for _ in range(3))
+                        p2 = list(plan)
+                        print(f"      pinned tiles 224x{64 * nf} splits={S_} split tail columns={tail} -> {p2[6]} workgroups, {p2[7]} unsplit tiles: "
+                              f"{tt:7.1f} us ({flops / tt / 1e6:6.0f} TF/s)", flush=True)
+                lib.bma_gemm_mid_set_plan(0, 0, -1, -1)
+        del ws
+    for M, (l, o) in totals.items():
+        print(f"per layer at {M} rows (forward + input gradients, as routed): library {l:.1f} us -> {o:.1f} us", flush=True)
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 

@@ -209,6 +209,20 @@ def cases():
             return ops.gemm_nt(x, ws[state["i"]])
         return go
 
+    def gemm_mid(M, N, K, layers=8):
+        # the 224-row-tile kernel over `layers` different weights (each launch streams its weight from HBM)
+        ops.GEMM_MID_MIN_K_OVER_N = 0.0
+        ops.gemm_workspace(torch.device(DEV))
+        ops.gemm_workspace_for_graphs(torch.device(DEV))
+        x = torch.randn((1, M, K), generator=g, device=DEV).to(bf)
+        ws = [(torch.randn((N, K), generator=g, device=DEV) * 0.02).to(bf) for _ in range(layers)]
+        state = {"i": 0}
+
+        def go():
+            state["i"] = (state["i"] + 1) % layers
+            return ops.gemm_mid(x, ws[state["i"]])
+        return go
+
     def b1_attn(S, H, backward):
         qkv = torch.randn((S, 3 * H * 128), generator=g, device=DEV).to(bf)
         ang = torch.rand((S, 64), generator=g, device=DEV) * 6.28
@@ -271,6 +285,10 @@ def cases():
         "gemm_nt/qkv_dX_65x4096x12288": ("gemm_nt", lambda: gemm_nt(65, 4096, 12288)),
         "gemm_nt/gate_up_65x22016x4096": ("gemm_nt", lambda: gemm_nt(65, 22016, 4096)),
         "gemm_nt/down_65x4096x11008": ("gemm_nt", lambda: gemm_nt(65, 4096, 11008)),
+        # round 4: the same products at 644 rows (the pass with the image in the prompt): MFMA work fed through L2 -> LDS
+        "gemm_mid/gate_up_dX_644x4096x22016": ("gemm_mid", lambda: gemm_mid(644, 4096, 22016)),
+        "gemm_mid/gate_up_644x22016x4096": ("gemm_mid", lambda: gemm_mid(644, 22016, 4096)),
+        "gemm_mid/down_644x4096x11008": ("gemm_mid", lambda: gemm_mid(644, 4096, 11008)),
         # rotary + causal attention of the text-only gradient pass (65 rows, 32 heads of 128): latency-bound, one launch each way
         "b1_attn/fwd_S65_H32": ("b1_attn", lambda: b1_attn(65, 32, False)),
         "b1_attn/bwd_S65_H32": ("b1_attn", lambda: b1_attn(65, 32, True)),
@@ -340,6 +358,13 @@ def main():
             tf = gf / 1e3 / (us * 1e-6)
             results[name].update(algorithmic_GFLOP=gf, achieved_TFLOPs=tf, frac_of_2500TFLOPs=tf / 2500.0)
             extra = f"  {gf:6.1f} GFLOP (causal) {tf:6.0f} TFLOP/s"
+        m = re.match(r"gemm_mid/\w+?_(\d+)x(\d+)x(\d+)$", name)
+        if m:                                 # MFMA work: 2 M N K flops
+            M_, N_, K_ = (int(v) for v in m.groups())
+            gf = 2.0 * M_ * N_ * K_ / 1e9
+            tf = gf / 1e3 / (us * 1e-6)
+            results[name].update(algorithmic_GFLOP=gf, achieved_TFLOPs=tf, frac_of_2500TFLOPs=tf / 2500.0)
+            extra = f"  {gf:6.1f} GFLOP {tf:6.0f} TFLOP/s = {tf / 2500.0:4.2f} of the MFMA peak"
         print(f"{name:40s} {us:9.1f} us  {mb:9.2f} MB  {gbs:8.0f} GB/s  {100 * gbs / 8000.0:5.1f}% of 8 TB/s{extra}", flush=True)
         del fn
         torch.cuda.empty_cache()

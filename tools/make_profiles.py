@@ -34,7 +34,7 @@ for w in ("gcg", "joint", "pgd", "gemma_joint"):  # the batch-1 gradient pass al
 for extra in ("bench_driver_detail.json", "bench_gcg_under_rocprof_detail.json", "bench_joint_under_rocprof_detail.json",
               "bench_pgd_under_rocprof_detail.json", "bench_gemma_joint_under_rocprof_detail.json", "bench_em8_detail.json",
               "bench_joint_em8_detail.json", "bench_opt125m_detail.json", "bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
-              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json", "gemm_bench.json", "gemm_bench.txt", "kernel_bench.txt"):
+              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json", "gemm_bench.json", "gemm_bench.txt", "gemm_mid_bench.json", "gemm_mid_bench.txt", "kernel_bench.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
 for c in ("fetch", "write"):
@@ -91,6 +91,8 @@ CASES = [
     ("splice/c3r_rows_17152_D4096", "splice", "splice_rows_kernel<1>/threads4390912", "C3 ragged row list: 17152 rows of 8 KiB straight from the segments and the table"),
     ("gemm_nt/gate_up_dX_65x4096x22016", "gemm_nt", "gemm_nt_kernel<1, 6, 2, 4, true>/threads65536", "bma_gemm_nt 65 x 4096 x 22016 bf16 (input gradient of the fused gate/up product, 8-way split-K)"),
     ("gemm_nt/qkv_dX_65x4096x12288", "gemm_nt", "gemm_nt_kernel<1, 6, 2, 4, true>/threads65536", "bma_gemm_nt 65 x 4096 x 12288 bf16 (input gradient of the fused q/k/v product, 8-way split-K)"),
+    ("gemm_mid/gate_up_dX_644x4096x22016", "gemm_mid", "gemm_mid_kernel<1, 7, 4, 3>/threads122880", "bma_gemm_mid 644 x 4096 x 22016 bf16 (input gradient of the fused gate/up product at 644 rows: 48 tiles of 224 x 256, K split 5 ways; the partials' second launch not included)"),
+    ("gemm_mid/gate_up_644x22016x4096", "gemm_mid", "gemm_mid_kernel<1, 7, 4, 3>/threads142848", "bma_gemm_mid 644 x 22016 x 4096 bf16 (fused gate/up product at 644 rows: 255 whole tiles + the last column split 8 ways)"),
     # library GEMMs (keys are matched by symbol prefix: the kernel name depends on the selection table)
     ("gemm/gate_up_17152x22016x4096", "gemm_gate_up_proj", "Cijk", "fused gate/up product of the C3 ragged candidate forward, 17152 x 22016 x 4096 bf16"),
     ("gemm/down_17152x4096x11008", "gemm_down_proj", "Cijk", "down_proj, 17152 x 4096 x 11008 bf16"),
