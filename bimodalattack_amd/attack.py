@@ -228,6 +228,7 @@ class BimodalAttack:
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
         ops.SKINNY_GEMM = bool(self.opt.skinny_gemm)
         ops.MID_GEMM = bool(self.opt.mid_gemm)
+        ops.CAUSAL_ATTENTION = bool(self.opt.causal_attention)
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
                                     self.opt.fuse_gate_up, self.opt.fuse_add_norm, self.opt.fuse_qk_rope,
                                     self.opt.fuse_b1_attention)

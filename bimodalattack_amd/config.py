@@ -142,6 +142,7 @@ class EngineOptions:
     # gradients through the transposed copies) on the hand-written weight-streaming kernel bma_gemm_nt instead of the
     # library (process-wide switch: ops.SKINNY_GEMM).
     skinny_gemm: bool = True
+    causal_attention: bool = True       # batch-1 causal attention of a long prompt (and of the rows behind a reused prefix) on csrc/causal_attention.hip, forward and backward
     mid_gemm: bool = True               # the 599-644-row products of the pass with the image in the prompt on csrc/gemm_mid.hip
     # Several GPUs: run the batch-1 gradient pass TENSOR-PARALLEL over the ranks instead of redundantly on each --
     # q/k/v/gate/up cut by output rows (whole heads), o/down by input columns, two all-reduces per decoder layer and
@@ -261,6 +262,8 @@ class EngineOptions:
             opts.tp_gradient = env["BMA_TP_GRADIENT"] not in ("0", "false", "False")
         if "BMA_SKINNY_GEMM" in env:
             opts.skinny_gemm = env["BMA_SKINNY_GEMM"] not in ("0", "false", "False")
+        if "BMA_CAUSAL_ATTENTION" in env:
+            opts.causal_attention = env["BMA_CAUSAL_ATTENTION"] not in ("0", "false", "False")
         if "BMA_MID_GEMM" in env:
             opts.mid_gemm = env["BMA_MID_GEMM"] not in ("0", "false", "False")
         if "BMA_FUSE_ADD_NORM" in env:

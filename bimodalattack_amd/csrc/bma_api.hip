@@ -126,6 +126,7 @@ extern "C" const char* bma_profile_kernel_name(int kernel) {
     case BMA_K_GEMM_NT: return "gemm_nt_kernel";
     case BMA_K_B1_ATTN: return "b1_attn_kernel";
     case BMA_K_GEMM_MID: return "gemm_mid_kernel";
+    case BMA_K_CAUSAL_ATTN: return "causal_attn_kernel";
     default: return "?";
   }
 }

@@ -1,0 +1,499 @@
+// a1 (gradient pass) -- causal self-attention of ONE long sequence at batch 1, forward and backward.
+//
+// With PGD on, the reference's compute_gradient (bimodal_attack.py:953-1028) runs the decoder over 576 image rows plus the
+// prompt at batch 1: per layer one causal attention of 599-644 tokens x 32 heads x 128 and its backward.  That is 3.4 + 8.5
+// GFLOP -- nothing -- and the library's kernels spend 51 us (forward) and ~100 us (backward + its helper launches) on
+// it because a (head, 64-query) grid of a few hundred workgroups walks its key tiles one latency at a time.  The same
+// shape occurs behind a reused prefix (joint mode: 44 new rows against 643 keys).
+//
+// Three launches, all built like prefix_attention.hip's flash forward (v_mfma_f32_16x16x32, 32-row chunks staged
+// L2 -> registers -> LDS while the previous chunk is multiplied, one barrier per chunk, the exponentiated accumulator
+// packed straight into the next product's B operand, `ds_read_b64_tr_b16` for the transposed operand):
+//   forward   (head, 64 queries): S^T = K Q^T, online softmax per query lane, O^T += V^T P^T; writes o and
+//             lse2 = m*scale*log2(e) + log2(l)
+//   dq        (head, 64 queries): S^T and dP^T = V dO^T recomputed per key chunk, dS^T = P^T (dP^T - delta) scale,
+//             dQ^T += K^T dS^T; also writes delta = rowsum(dO o) for the third launch
+//   dk, dv    (head, 64 keys), a wave per 16 keys: per 32-query chunk S = Q K^T and dP = dO V^T (queries as rows, so that
+//             P and dS come out as the B operands of) dV^T += dO^T P, dK^T += Q^T dS
+// No atomics: every output element has one owner, results are bitwise reproducible.
+//
+// Queries are the LAST Lq positions of the Lk keys (P = Lk - Lq keys of prefix in front): query i sees keys 0 .. P + i.
+// H query heads = H key/value heads of 128; q/k/v through (row, head) strides (views of a fused projection), o / dO /
+// dq / dk / dv [rows][H][128] contiguous.
+#include <type_traits>
+
+#include "bma_common.h"
+#include "bma_profile.h"
+
+namespace {
+
+using bma::uint4_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int DH = 128;
+constexpr int KS = DH / 32;       // k-steps of a product over the head dimension
+constexpr int NT = DH / 16;       // 16-dim tiles of an output
+constexpr int PITCH = DH + 16;    // elements per LDS row (row + 32 B: conflict-free row and transposing reads)
+constexpr int IMG = 32 * PITCH;   // one 32-row chunk image
+constexpr int NTHR = 256;         // 4 waves
+constexpr int ITEMS = 32 * (DH / 8) / NTHR;   // 16-byte pieces per thread per image (2)
+
+struct CArgs {
+  const uint16_t *q, *k, *v, *o, *d_o;
+  uint16_t *out, *dq, *dk, *dv;
+  float *lse2, *delta;            // [H][Lq]
+  int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs;
+  int Lq, Lk, H, P;
+  float scale, scale_log2e;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 cmfma(const uint4_t& a, const uint4_t& b, const f32x4& c) {
+  if (DT == BMA_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// all-reduce over the four 16-lane rows of a wave (prefix_attention.hip)
+__device__ __forceinline__ float rows_max(float x) {
+  u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = vmax(__uint_as_float(a.x), __uint_as_float(a.y));
+  u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return vmax(__uint_as_float(b.x), __uint_as_float(b.y));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float m = __uint_as_float(a.x) + __uint_as_float(a.y);
+  u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
+
+// ---- a 32-row chunk of a [rows][heads][128] tensor: L2 -> registers -> LDS image [32][PITCH] ---------------------------
+struct Chunk {
+  uint4_t reg[ITEMS];
+};
+__device__ __forceinline__ void fetch_chunk(Chunk& ch, const uint16_t* base, int64_t rs, int row0, int rows, int tid) {
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * NTHR;
+    int row = row0 + idx / (DH / 8);
+    const int piece = idx % (DH / 8);
+    row = row < rows ? row : rows - 1;                          // rows past the end repeat the last one (masked by the caller)
+    ch.reg[it] = *reinterpret_cast<const uint4_t*>(base + static_cast<int64_t>(row) * rs + 8 * piece);
+  }
+}
+__device__ __forceinline__ void stash_chunk(const Chunk& ch, uint16_t* img, int tid) {
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * NTHR;
+    *reinterpret_cast<uint4_t*>(img + (idx / (DH / 8)) * PITCH + 8 * (idx % (DH / 8))) = ch.reg[it];
+  }
+}
+// operand with the image's rows 16t .. 16t+15 as the M / N index and dims 32ks .. as k (lane: row r, dims 8g ..)
+__device__ __forceinline__ uint4_t row_frag(const uint16_t* img, int t, int ks, int r, int g) {
+  return *reinterpret_cast<const uint4_t*>(img + (16 * t + r) * PITCH + 8 * g + 32 * ks);
+}
+// operand with dims 16dt .. 16dt+15 as the M index and the image's 32 rows as k, in the order pack_acc() leaves them
+__device__ __forceinline__ uint4_t tr_frag(const uint16_t* img, int dt, int r, int g) {
+  const int q4 = r >> 2, p4 = r & 3;
+  const uint16_t* rd = img + (4 * g + q4) * PITCH + 4 * p4 + 16 * dt;
+  const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(rd));
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(rd + 16 * PITCH));
+  const bma::uint2_t l2 = __builtin_bit_cast(bma::uint2_t, lo), h2 = __builtin_bit_cast(bma::uint2_t, hi);
+  uint4_t f;
+  f.x = l2.x; f.y = l2.y; f.z = h2.x; f.w = h2.y;
+  return f;
+}
+// two accumulators (chunk rows 4g+rr and 16+4g+rr of one column) as the B operand whose k runs over the chunk's rows
+template <int DT>
+__device__ __forceinline__ uint4_t pack_acc(const float (&e)[2][4]) {
+  uint4_t p;
+  p.x = bma::pack16<DT>(e[0][0], e[0][1]);
+  p.y = bma::pack16<DT>(e[0][2], e[0][3]);
+  p.z = bma::pack16<DT>(e[1][0], e[1][1]);
+  p.w = bma::pack16<DT>(e[1][2], e[1][3]);
+  return p;
+}
+// this lane's 32 dims (8g + 32ks ..) of row `row` of a [rows][H][128] tensor, as the K-contiguous operand of its column
+__device__ __forceinline__ void load_row_frags(uint4_t (&f)[KS], const uint16_t* base, int64_t rs, int row, int g) {
+  const uint16_t* p = base + static_cast<int64_t>(row) * rs + 8 * g;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) f[ks] = *reinterpret_cast<const uint4_t*>(p + 32 * ks);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];      // two pairs of (K image, V image)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x % a.H, qb = blockIdx.x / a.H;
+  const int row0 = 64 * qb + 16 * w;                              // first query of this wave
+  const int qrow = row0 + r;                                      // this lane's query
+  const float NEG = -__builtin_inff();
+  uint4_t qf[KS];
+  load_row_frags(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qrow < a.Lq ? qrow : a.Lq - 1, g);
+  f32x4 oacc[NT];
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  float mrun = NEG, lsum = 0.0f;
+  const uint16_t* kb = a.k + static_cast<int64_t>(h) * a.k_hs;
+  const uint16_t* vb = a.v + static_cast<int64_t>(h) * a.v_hs;
+  int last = 64 * qb + 63;
+  last = last < a.Lq ? last : a.Lq - 1;
+  const int chunks = (a.P + last + 1 + 31) >> 5;                   // keys 0 .. P + last
+  Chunk kc, vc;
+  fetch_chunk(kc, kb, a.k_rs, 0, a.Lk, tid);
+  fetch_chunk(vc, vb, a.v_rs, 0, a.Lk, tid);
+  stash_chunk(kc, lds, tid);
+  stash_chunk(vc, lds + IMG, tid);
+  __syncthreads();
+  for (int c = 0; c < chunks; ++c) {
+    const uint16_t* kl = lds + 2 * IMG * (c & 1);
+    const uint16_t* vl = kl + IMG;
+    if (c + 1 < chunks) {
+      fetch_chunk(kc, kb, a.k_rs, 32 * (c + 1), a.Lk, tid);
+      fetch_chunk(vc, vb, a.v_rs, 32 * (c + 1), a.Lk, tid);
+    }
+    f32x4 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
+    }
+    float e[2][4];
+    const bool edge = 32 * c + 31 > a.P + row0;                   // wave-uniform: some key of the chunk is masked for some query
+    float cmax = NEG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float v = s[kt][rr];
+        if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) v = NEG;
+        e[kt][rr] = v;
+        cmax = vmax(cmax, v);
+      }
+    cmax = rows_max(cmax);
+    const float mnew = vmax(mrun, cmax);                            // finite from chunk 0 on: key 0 is visible to every query
+    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * a.scale_log2e);
+    const float mneg = -mnew * a.scale_log2e;
+    float rs = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        e[kt][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kt][rr], a.scale_log2e, mneg));
+        rs += e[kt][rr];
+      }
+    lsum = lsum * alpha + rs;
+    mrun = mnew;
+    const uint4_t pf = pack_acc<DT>(e);
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag(vl, dt, r, g), pf, oacc[dt]);
+    if (c + 1 < chunks) {
+      stash_chunk(kc, lds + 2 * IMG * ((c + 1) & 1), tid);
+      stash_chunk(vc, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
+    }
+    __syncthreads();
+  }
+  const float l = rows_sum(lsum);
+  if (qrow >= a.Lq) return;
+  const float inv = 1.0f / l;
+  if (g == 0) a.lse2[static_cast<int64_t>(h) * a.Lq + qrow] = mrun * a.scale_log2e + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
+  uint16_t* op = a.out + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) {
+    bma::uint2_t ow;
+    ow.x = bma::pack16<DT>(oacc[dt][0] * inv, oacc[dt][1] * inv);
+    ow.y = bma::pack16<DT>(oacc[dt][2] * inv, oacc[dt][3] * inv);
+    *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x % a.H, qb = blockIdx.x / a.H;
+  const int row0 = 64 * qb + 16 * w;
+  const int qrow = row0 + r;
+  const int qc = qrow < a.Lq ? qrow : a.Lq - 1;
+  uint4_t qf[KS], dof[KS];
+  load_row_frags(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qc, g);
+  load_row_frags(dof, a.d_o + static_cast<int64_t>(h) * DH, static_cast<int64_t>(a.H) * DH, qc, g);
+  float delta;
+  {
+    uint4_t of[KS];
+    load_row_frags(of, a.o + static_cast<int64_t>(h) * DH, static_cast<int64_t>(a.H) * DH, qc, g);
+    float acc = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t dw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w};
+      const uint32_t ow[4] = {of[ks].x, of[ks].y, of[ks].z, of[ks].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc += bma::unpack16<DT>(dw[j], 0) * bma::unpack16<DT>(ow[j], 0) + bma::unpack16<DT>(dw[j], 1) * bma::unpack16<DT>(ow[j], 1);
+    }
+    delta = rows_sum(acc);
+    if (g == 0 && qrow < a.Lq) a.delta[static_cast<int64_t>(h) * a.Lq + qrow] = delta;
+  }
+  const float lse2 = a.lse2[static_cast<int64_t>(h) * a.Lq + qc];
+  f32x4 dqacc[NT];
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) dqacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  const uint16_t* kb = a.k + static_cast<int64_t>(h) * a.k_hs;
+  const uint16_t* vb = a.v + static_cast<int64_t>(h) * a.v_hs;
+  int last = 64 * qb + 63;
+  last = last < a.Lq ? last : a.Lq - 1;
+  const int chunks = (a.P + last + 1 + 31) >> 5;
+  Chunk kc, vc;
+  fetch_chunk(kc, kb, a.k_rs, 0, a.Lk, tid);
+  fetch_chunk(vc, vb, a.v_rs, 0, a.Lk, tid);
+  stash_chunk(kc, lds, tid);
+  stash_chunk(vc, lds + IMG, tid);
+  __syncthreads();
+  for (int c = 0; c < chunks; ++c) {
+    const uint16_t* kl = lds + 2 * IMG * (c & 1);
+    const uint16_t* vl = kl + IMG;
+    if (c + 1 < chunks) {
+      fetch_chunk(kc, kb, a.k_rs, 32 * (c + 1), a.Lk, tid);
+      fetch_chunk(vc, vb, a.v_rs, 32 * (c + 1), a.Lk, tid);
+    }
+    f32x4 s[2], dp[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      dp[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
+        dp[kt] = cmfma<DT>(row_frag(vl, kt, ks, r, g), dof[ks], dp[kt]);
+      }
+    }
+    float e[2][4];
+    const bool edge = 32 * c + 31 > a.P + row0;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], a.scale_log2e, -lse2));
+        if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) p = 0.0f;
+        e[kt][rr] = p * (dp[kt][rr] - delta) * a.scale;
+      }
+    const uint4_t dsf = pack_acc<DT>(e);
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag(kl, dt, r, g), dsf, dqacc[dt]);
+    if (c + 1 < chunks) {
+      stash_chunk(kc, lds + 2 * IMG * ((c + 1) & 1), tid);
+      stash_chunk(vc, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
+    }
+    __syncthreads();
+  }
+  if (qrow >= a.Lq) return;
+  uint16_t* op = a.dq + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) {
+    bma::uint2_t ow;
+    ow.x = bma::pack16<DT>(dqacc[dt][0], dqacc[dt][1]);
+    ow.y = bma::pack16<DT>(dqacc[dt][2], dqacc[dt][3]);
+    *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];      // two pairs of (Q image, dO image)
+  __shared__ __attribute__((aligned(16))) float stat[2][64];          // per pair: lse2 of the chunk's 32 queries, then delta
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x % a.H, kblk = blockIdx.x / a.H;
+  const int key0 = 64 * kblk + 16 * w;                            // first key of this wave
+  const int key = key0 + r;                                       // this lane's key (a column of S)
+  uint4_t kf[KS], vf[KS];
+  load_row_frags(kf, a.k + static_cast<int64_t>(h) * a.k_hs, a.k_rs, key < a.Lk ? key : a.Lk - 1, g);
+  load_row_frags(vf, a.v + static_cast<int64_t>(h) * a.v_hs, a.v_rs, key < a.Lk ? key : a.Lk - 1, g);
+  f32x4 dkacc[NT], dvacc[NT];
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) {
+    dkacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    dvacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  const uint16_t* qbase = a.q + static_cast<int64_t>(h) * a.q_hs;
+  const uint16_t* dobase = a.d_o + static_cast<int64_t>(h) * DH;
+  const int64_t do_rs = static_cast<int64_t>(a.H) * DH;
+  // queries that see at least one key of this block: i >= 64*kblk - P
+  int c0 = 64 * kblk - a.P;
+  c0 = c0 > 0 ? c0 >> 5 : 0;
+  const int c1 = (a.Lq + 31) >> 5;
+  Chunk qc, dc;
+  float st = 0.0f;
+  auto fetch = [&](int c) {
+    fetch_chunk(qc, qbase, a.q_rs, 32 * c, a.Lq, tid);
+    fetch_chunk(dc, dobase, do_rs, 32 * c, a.Lq, tid);
+    if (tid < 64) {
+      int qi = 32 * c + (tid & 31);
+      qi = qi < a.Lq ? qi : a.Lq - 1;
+      st = (tid < 32 ? a.lse2 : a.delta)[static_cast<int64_t>(h) * a.Lq + qi];
+    }
+  };
+  auto stash = [&](int pair) {
+    stash_chunk(qc, lds + 2 * IMG * pair, tid);
+    stash_chunk(dc, lds + 2 * IMG * pair + IMG, tid);
+    if (tid < 64) stat[pair][tid] = st;
+  };
+  if (c0 < c1) {
+    fetch(c0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    const int pair = (c - c0) & 1;
+    const uint16_t* ql = lds + 2 * IMG * pair;
+    const uint16_t* dl = ql + IMG;
+    if (c + 1 < c1) fetch(c + 1);
+    f32x4 s[2], dp[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      s[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      dp[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s[qt] = cmfma<DT>(row_frag(ql, qt, ks, r, g), kf[ks], s[qt]);
+        dp[qt] = cmfma<DT>(row_frag(dl, qt, ks, r, g), vf[ks], dp[qt]);
+      }
+    }
+    float pe[2][4], de[2][4];
+    // masked: the chunk reaches past Lq, or some of its queries do not see some key of this wave
+    const bool edge = 32 * c + 32 > a.Lq || key0 + 15 > a.P + 32 * c;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[pair][16 * qt + 4 * g]);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[pair][32 + 16 * qt + 4 * g]);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int qi = 32 * c + 16 * qt + 4 * g + rr;
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][rr], a.scale_log2e, -l4[rr]));
+        if (edge && (qi >= a.Lq || key > a.P + qi)) p = 0.0f;
+        pe[qt][rr] = p;
+        de[qt][rr] = p * (dp[qt][rr] - d4[rr]) * a.scale;
+      }
+    }
+    const uint4_t pf = pack_acc<DT>(pe), dsf = pack_acc<DT>(de);
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      dvacc[dt] = cmfma<DT>(tr_frag(dl, dt, r, g), pf, dvacc[dt]);
+      dkacc[dt] = cmfma<DT>(tr_frag(ql, dt, r, g), dsf, dkacc[dt]);
+    }
+    if (c + 1 < c1) stash(pair ^ 1);
+    __syncthreads();
+  }
+  if (key >= a.Lk) return;
+  uint16_t* kp = a.dk + (static_cast<int64_t>(key) * a.H + h) * DH + 4 * g;
+  uint16_t* vp = a.dv + (static_cast<int64_t>(key) * a.H + h) * DH + 4 * g;
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt) {
+    bma::uint2_t ow;
+    ow.x = bma::pack16<DT>(dkacc[dt][0], dkacc[dt][1]);
+    ow.y = bma::pack16<DT>(dkacc[dt][2], dkacc[dt][3]);
+    *reinterpret_cast<bma::uint2_t*>(kp + 16 * dt) = ow;
+    ow.x = bma::pack16<DT>(dvacc[dt][0], dvacc[dt][1]);
+    ow.y = bma::pack16<DT>(dvacc[dt][2], dvacc[dt][3]);
+    *reinterpret_cast<bma::uint2_t*>(vp + 16 * dt) = ow;
+  }
+}
+
+int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
+                 const int64_t* strides, int n_strides) {
+  if (Lq < 0 || Lk < Lq || H <= 0) return BMA_EINVAL;
+  if (!q || !k || !v) return BMA_EINVAL;
+  if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
+  if (Dh != DH || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
+  for (int i = 0; i < n_strides; ++i)
+    if (strides[i] % 8) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) % 16) return BMA_EALIGN;
+  return BMA_OK;
+}
+
+}  // namespace
+
+extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
+                                    const void* v, int64_t v_rs, int64_t v_hs, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
+                                    float scale, void* out, float* lse2, void* stream) {
+  const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
+  const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
+  if (rc != BMA_OK) return rc;
+  if (Lq == 0) return BMA_OK;
+  if (!out || !lse2 || reinterpret_cast<uintptr_t>(out) % 16 || reinterpret_cast<uintptr_t>(lse2) % 4) return out && lse2 ? BMA_EALIGN : BMA_EINVAL;
+  CArgs a = {};
+  a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
+  a.out = static_cast<uint16_t*>(out); a.lse2 = lse2;
+  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs;
+  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = static_cast<int>(Lk - Lq);
+  a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>(H * ((Lq + 63) / 64)));
+  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) + 2.0 * static_cast<double>(Lk)) * H * DH);
+  if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16>), grid, dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16>), grid, dim3(NTHR), 0, st, a);
+  BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
+                                        const void* v, int64_t v_rs, int64_t v_hs, const void* out, const float* lse2,
+                                        const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype, float scale,
+                                        void* dq, void* dk, void* dv, float* delta, void* stream) {
+  const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
+  const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
+  if (rc != BMA_OK) return rc;
+  if (!out || !lse2 || !d_out || !dq || !dk || !dv || !delta) return BMA_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(dq) |
+       reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 ||
+      (reinterpret_cast<uintptr_t>(lse2) | reinterpret_cast<uintptr_t>(delta)) % 4)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (Lq == 0) {                                                  // no query: the keys' gradients are zero
+    if (Lk > 0) {
+      if (hipMemsetAsync(dk, 0, static_cast<size_t>(Lk) * H * DH * 2, st) != hipSuccess) return BMA_ELAUNCH;
+      if (hipMemsetAsync(dv, 0, static_cast<size_t>(Lk) * H * DH * 2, st) != hipSuccess) return BMA_ELAUNCH;
+    }
+    return BMA_OK;
+  }
+  CArgs a = {};
+  a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
+  a.o = static_cast<const uint16_t*>(out); a.d_o = static_cast<const uint16_t*>(d_out);
+  a.dq = static_cast<uint16_t*>(dq); a.dk = static_cast<uint16_t*>(dk); a.dv = static_cast<uint16_t*>(dv);
+  a.lse2 = const_cast<float*>(lse2); a.delta = delta;
+  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs;
+  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = static_cast<int>(Lk - Lq);
+  a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  const dim3 gq(static_cast<unsigned>(H * ((Lq + 63) / 64))), gk(static_cast<unsigned>(H * ((Lk + 63) / 64)));
+  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (4.0 * static_cast<double>(Lq) + 4.0 * static_cast<double>(Lk)) * H * DH);
+  if (dtype == BMA_BF16) {
+    hipLaunchKernelGGL((causal_dq_kernel<BMA_BF16>), gq, dim3(NTHR), 0, st, a);       // writes delta for the next launch
+    hipLaunchKernelGGL((causal_dkv_kernel<BMA_BF16>), gk, dim3(NTHR), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((causal_dq_kernel<BMA_F16>), gq, dim3(NTHR), 0, st, a);
+    hipLaunchKernelGGL((causal_dkv_kernel<BMA_F16>), gk, dim3(NTHR), 0, st, a);
+  }
+  BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 107
+ABI_VERSION = 108
 
 
 class BmaSegment(Structure):
@@ -102,6 +102,11 @@ PROTOTYPES = {
     "bma_gemm_nt_set_plan": (None, [c_int, c_int, c_int, c_int]),
     "bma_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                             c_size_t, c_void_p, c_int, c_void_p]),
+    "bma_causal_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
+                                     c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "bma_causal_attention_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
     "bma_gemm_mid_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bma_gemm_mid_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
     "bma_gemm_mid_set_plan": (None, [c_int, c_int, c_int, c_int]),
@@ -114,7 +119,7 @@ PROTOTYPES = {
 
 KERNEL_IDS = {"linf": 0, "ce_rows": 1, "ce_dlogits": 2, "mask_topk": 3, "sample_scatter": 4, "splice": 5,
               "ce_rows_grad": 6, "rmsnorm": 7, "swiglu": 8, "rope": 9, "attn_merge": 10, "gather_rows": 11,
-              "ragged_attn": 12, "prefix_attn": 13, "add_rmsnorm": 14, "gemm_nt": 15, "b1_attn": 16, "gemm_mid": 17}
+              "ragged_attn": 12, "prefix_attn": 13, "add_rmsnorm": 14, "gemm_nt": 15, "b1_attn": 16, "gemm_mid": 17, "causal_attn": 18}
 
 
 def profile_enable(on: bool) -> None:

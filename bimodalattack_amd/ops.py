@@ -733,6 +733,82 @@ class B1AttentionFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------
+# causal attention of one long sequence at batch 1, forward and backward (csrc/causal_attention.hip)
+CAUSAL_ATTENTION = True         # module switch (EngineOptions.causal_attention / BMA_CAUSAL_ATTENTION)
+CAUSAL_ATTENTION_MAX_TOKENS = 4096
+
+
+def _rows_heads(t: torch.Tensor):
+    """(row stride, head stride) in elements of a (L, H, 128) view whose last dim is contiguous."""
+    return t.stride(0), t.stride(1)
+
+
+def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
+    """q (Lq, H, 128), k / v (Lk, H, 128) views, 16-bit, last dim contiguous, strides multiples of 8, the same heads on
+    both sides, Lq <= Lk (the queries are the last Lq positions)."""
+    if not (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype):
+        return False
+    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[1:] != k.shape[1:] or q.shape[2] != 128:
+        return False
+    if not (0 < q.shape[0] <= k.shape[0] <= CAUSAL_ATTENTION_MAX_TOKENS):
+        return False
+    for t in (q, k, v):
+        if t.stride(2) != 1 or t.stride(0) % 8 or t.stride(1) % 8 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
+    """(out (Lq, H, 128) contiguous, lse2 (H, Lq) fp32) through bma_causal_attention (include/bma.h)."""
+    dev = _need_gpu(q, k, v)
+    if not causal_attention_ok(q, k, v):
+        raise ValueError("causal_attention wants 16-bit (L, H, 128) views with a contiguous last dim, Lq <= Lk")
+    Lq, H, _ = q.shape
+    Lk = k.shape[0]
+    out = torch.empty((Lq, H, 128), dtype=q.dtype, device=dev)
+    lse2 = torch.empty((H, Lq), dtype=torch.float32, device=dev)
+    check("bma_causal_attention", lib.bma_causal_attention(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
+                                                           *_rows_heads(v), Lq, Lk, H, 128, _dt(q), float(scale), out.data_ptr(),
+                                                           lse2.data_ptr(), _stream(dev)))
+    return out, lse2
+
+
+def causal_attention_bwd(q, k, v, out, lse2, d_out, scale: float):
+    """(dq (Lq, H, 128), dk, dv (Lk, H, 128)) contiguous through bma_causal_attention_bwd."""
+    dev = _need_gpu(q, k, v)
+    Lq, H, _ = q.shape
+    Lk = k.shape[0]
+    d_out = d_out.contiguous()
+    dq = torch.empty((Lq, H, 128), dtype=q.dtype, device=dev)
+    dk = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
+    dv = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
+    delta = torch.empty((H, Lq), dtype=torch.float32, device=dev)
+    check("bma_causal_attention_bwd", lib.bma_causal_attention_bwd(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
+                                                                   *_rows_heads(v), out.data_ptr(), lse2.data_ptr(), d_out.data_ptr(), Lq,
+                                                                   Lk, H, 128, _dt(q), float(scale), dq.data_ptr(), dk.data_ptr(),
+                                                                   dv.data_ptr(), delta.data_ptr(), _stream(dev)))
+    return dq, dk, dv
+
+
+class CausalAttentionFn(torch.autograd.Function):
+    """out (Lq, H, 128) = causal attention of q (Lq, H, 128) against k / v (Lk, H, 128), the queries being the last Lq
+    positions; the backward is two launches of the same library (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        out, lse2 = causal_attention(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, out, lse2)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q, k, v, out, lse2 = ctx.saved_tensors
+        dq, dk, dv = causal_attention_bwd(q, k, v, out, lse2, d_out, ctx.scale)
+        return dq, dk, dv, None
+
+
+# ---------------------------------------------------------------------------
 # skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
 SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
 GEMM_NT_MAX_ROWS = int(_os.environ.get("BMA_GEMM_NT_MAX_ROWS", "96"))   # one 64- or 96-row tile: the shapes the kernel is built and measured for

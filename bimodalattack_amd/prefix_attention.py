@@ -385,6 +385,9 @@ def causal_b1_attention(module, query, key, value, attention_mask=None, dropout:
     fp32 scores + hand-written causal-softmax row kernels), 1.8 ms slower than this per pass."""
     B, H, S, Dh = query.shape
     scale = float(scaling) if scaling is not None else Dh ** -0.5
+    out = _own_causal(query, key, value, scale, dropout)
+    if out is not None:
+        return out, None
     n_rep = H // key.shape[1]
     if n_rep > 1:
         key, value = key.repeat_interleave(n_rep, dim=1), value.repeat_interleave(n_rep, dim=1)
@@ -395,6 +398,23 @@ def causal_b1_attention(module, query, key, value, attention_mask=None, dropout:
                      set_priority=True):
         out = torch.nn.functional.scaled_dot_product_attention(query, key, value, is_causal=S > 1, scale=scale)
     return out.transpose(1, 2).contiguous(), None
+
+
+def _own_causal(query, key, value, scale: float, dropout: float):
+    """(1, Lq, H, 128) through the hand-written causal attention pair (csrc/causal_attention.hip: forward 25 us and
+    backward 58 us at 643 tokens x 32 heads, where the library's pair and its helper launches take ~150), or None when the
+    call is not its shape: batch 1, the same 128-wide heads on both sides, 16-bit, the queries being the last Lq of the Lk
+    key positions, no dropout."""
+    from . import ops
+    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] != key.shape[1] or query.shape[3] != 128:
+        return None
+    # (squeeze, not [0]: the backward of an index is a zero fill plus a copy per operand, of a squeeze nothing)
+    q3, k3, v3 = query.squeeze(0).transpose(0, 1), key.squeeze(0).transpose(0, 1), value.squeeze(0).transpose(0, 1)
+    if not ops.causal_attention_ok(q3, k3, v3):
+        return None
+    if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
+        return ops.CausalAttentionFn.apply(q3, k3, v3, scale).unsqueeze(0)
+    return ops.causal_attention(q3, k3, v3, scale)[0].unsqueeze(0)
 
 
 NAME_TAIL = "bma_tail_grad"
@@ -456,6 +476,9 @@ def tail_grad_attention(module, query, key, value, attention_mask=None, dropout:
     pk, pv = kv.k[module.layer_idx], kv.v[module.layer_idx]
     K = torch.cat([pk.expand(B, -1, -1, -1), key], dim=2)
     V = torch.cat([pv.expand(B, -1, -1, -1), value], dim=2)
+    out = _own_causal(query, K, V, scale, dropout)                # the queries are the last L of the P + L positions
+    if out is not None:
+        return out, None
     n_rep = H // K.shape[1]
     if n_rep > 1:
         K, V = K.repeat_interleave(n_rep, dim=1), V.repeat_interleave(n_rep, dim=1)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 107 /* 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 108 /* 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -279,6 +279,24 @@ void bma_gemm_nt_set_plan(int w_tiles_per_wave, int rows_per_slab, int splits, i
 int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
                 int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream);
 
+/* bma_causal_attention / bma_causal_attention_bwd: causal self-attention of ONE sequence at batch 1 and its backward, for the
+ *   gradient pass with the image in the prompt (a1, :953-1028 with PGD on: 599-644 tokens per layer) and for the rows
+ *   behind a reused prefix (joint mode: 44 new tokens against 643 keys).  The Lq queries are the LAST Lq positions of the
+ *   Lk keys: query i attends to keys 0 .. (Lk - Lq) + i.  q [Lq][H][128], k / v [Lk][H][128] through (row, head) strides in
+ *   elements (multiples of 8; views of a fused projection are fine), H query heads = H key/value heads, Dh = 128, bf16 /
+ *   f16, rotary already applied.  Forward: out [Lq][H][128] contiguous and lse2 [H][Lq] fp32 = log2 of the softmax
+ *   denominator in units of the scaled scores (an opaque token for the backward).  Backward: dq [Lq][H][128], dk / dv
+ *   [Lk][H][128] contiguous from d_out [Lq][H][128] contiguous; `delta` [H][Lq] fp32 is scratch.  Two launches (dq, then
+ *   dk and dv), every output element with one owner: no atomics, bitwise reproducible.  Probabilities and score
+ *   gradients are rounded to `dtype` before their products, as in a flash kernel. */
+int bma_causal_attention(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
+                         int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, int64_t Lq,
+                         int64_t Lk, int H, int Dh, int dtype, float scale, void* out, float* lse2, void* stream);
+int bma_causal_attention_bwd(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
+                             int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, const void* out,
+                             const float* lse2, const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
+                             float scale, void* dq, void* dk, void* dv, float* delta, void* stream);
+
 /* bma_gemm_mid: y[M][N] = x[M][K] . w[N][K]^T for the products of the batch-1 gradient pass when the image is part of the
  *   prompt (a1, :953-1028 with PGD on: 576 image rows + the text = 599-644 rows; the same shapes occur in the prefix
  *   pass of joint candidate scoring, :605-612).  Operands, accumulation, rounding and leading dimensions as for
@@ -358,7 +376,7 @@ enum {
   BMA_K_TOPK = 3, BMA_K_SCATTER = 4, BMA_K_SPLICE = 5,
   BMA_K_CE_ROWS_B1 = 6 /* B == 1: the gradient pass */, BMA_K_RMSNORM = 7, BMA_K_SWIGLU = 8,
   BMA_K_ROPE = 9, BMA_K_ATTN_MERGE = 10, BMA_K_GATHER_ROWS = 11,
-  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_B1_ATTN = 16, BMA_K_GEMM_MID = 17, BMA_K_COUNT = 18
+  BMA_K_RAGGED_ATTN = 12, BMA_K_PREFIX_ATTN = 13, BMA_K_ADD_RMSNORM = 14, BMA_K_GEMM_NT = 15, BMA_K_B1_ATTN = 16, BMA_K_GEMM_MID = 17, BMA_K_CAUSAL_ATTN = 18, BMA_K_COUNT = 19
 };
 int bma_profile_enable(int on);
 int bma_profile_read(int kernel, int64_t* launches, double* total_ms, double* total_bytes);
