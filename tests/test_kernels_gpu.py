@@ -405,6 +405,150 @@ def test_gemm_nt_matches_fp32_reference(dtype, monkeypatch):
                                                      torch.zeros((4096, 22016), device=DEV, dtype=dtype))
 
 
+# ------------------------------------------------------------------ bma_causal_attention (round 4)
+def _causal_reference(q, k, v, scale):
+    """float64 attention of q (Lq,H,D) -- the LAST Lq positions -- against k, v (Lk,H,D)."""
+    Lq, Lk = q.shape[0], k.shape[0]
+    s = torch.einsum("qhd,khd->hqk", q, k) * scale
+    hidden = torch.arange(Lk, device=q.device)[None, :] > (Lk - Lq + torch.arange(Lq, device=q.device))[:, None]
+    p = s.masked_fill(hidden[None], float("-inf")).softmax(-1)
+    return torch.einsum("hqk,khd->qhd", p, v)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_causal_attention_forward_and_backward_match_float64(dtype):
+    """bma_causal_attention / _bwd against float64 attention and its autograd on the same 16-bit operands: the image
+    prompt's 643 and 599 tokens, 44 new rows behind 599 prefix keys (joint mode), lengths on and off the 64-row block and
+    the 32-row chunk, a single query, 2 and 32 heads; q / k / v are strided views of one fused projection, as the decoder
+    hands them over.  Bounds: the output within 3 roundings of the 16-bit type, the gradients within what the library's
+    own flash pair shows against the same reference (P and dS rounded to 16 bits before their products) x 1.5.  Launches
+    repeat bit for bit (no atomics)."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for H, Lq, Lk in ((32, 643, 643), (32, 599, 599), (32, 44, 643), (2, 100, 100), (2, 1, 33), (4, 64, 64), (2, 65, 200), (2, 81, 81),
+                      (2, 33, 32 + 33), (32, 1, 1)):
+        qkv = torch.randn((Lk, 3 * H * 128), generator=g, device=DEV).to(dtype)
+        q = qkv[Lk - Lq:, :H * 128].view(Lq, H, 128)
+        k = qkv[:, H * 128:2 * H * 128].view(Lk, H, 128)
+        v = qkv[:, 2 * H * 128:].view(Lk, H, 128)
+        assert ops.causal_attention_ok(q, k, v)
+        scale = 128 ** -0.5
+        qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+        o_ref = _causal_reference(qd, kd, vd, scale)
+        do = torch.randn((Lq, H, 128), generator=g, device=DEV).to(dtype)
+        gq, gk, gv = torch.autograd.grad(o_ref, (qd, kd, vd), do.double())
+        out, lse2 = ops.causal_attention(q, k, v, scale)
+        dq, dk, dv = ops.causal_attention_bwd(q, k, v, out, lse2, do, scale)
+        # (a single visible key has exactly zero dq / dk: measured against a floor instead of against nothing)
+        rel = lambda a_, b_: float((a_.double() - b_).abs().max() / b_.abs().max().clamp_min(1e-2))      # noqa: E731
+        assert rel(out, o_ref.detach()) <= 3 * eps, (H, Lq, Lk, rel(out, o_ref.detach()))
+        for name, mine, want in (("dq", dq, gq), ("dk", dk, gk), ("dv", dv, gv)):
+            assert rel(mine, want) <= 6 * eps, (name, H, Lq, Lk, rel(mine, want))
+        if Lq == Lk and Lq > 1:
+            ql, kl, vl = (t.detach().clone().requires_grad_() for t in (q, k, v))
+            ol = torch.nn.functional.scaled_dot_product_attention(ql.transpose(0, 1)[None], kl.transpose(0, 1)[None], vl.transpose(0, 1)[None],
+                                                                  is_causal=True, scale=scale)[0].transpose(0, 1)
+            lq, lk_, lv = torch.autograd.grad(ol, (ql, kl, vl), do)
+            for name, mine, theirs, want in (("dq", dq, lq, gq), ("dk", dk, lk_, gk), ("dv", dv, lv, gv)):
+                assert rel(mine, want) <= 1.5 * rel(theirs, want) + eps, (name, H, Lq, Lk, rel(mine, want), rel(theirs, want))
+        out2, lse2b = ops.causal_attention(q, k, v, scale)
+        again = ops.causal_attention_bwd(q, k, v, out, lse2, do, scale)
+        assert torch.equal(out, out2) and torch.equal(lse2, lse2b) and all(torch.equal(a_, b_) for a_, b_ in zip(again, (dq, dk, dv)))
+        # the softmax denominator: lse2 = log2(sum exp(scaled score))
+        ref_lse2 = torch.logsumexp((torch.einsum("qhd,khd->hqk", qd, kd) * scale).masked_fill(
+            (torch.arange(Lk, device=DEV)[None, :] > (Lk - Lq + torch.arange(Lq, device=DEV))[:, None])[None], float("-inf")), -1) / 0.6931471805599453
+        assert float((lse2.double() - ref_lse2.detach()).abs().max()) <= 1e-3
+    # what it does not take
+    q64 = torch.zeros((10, 2, 64), device=DEV, dtype=dtype)
+    assert not ops.causal_attention_ok(q64, q64, q64)
+    q3 = torch.zeros((10, 2, 128), device=DEV, dtype=dtype)
+    assert not ops.causal_attention_ok(q3, q3[:5], q3[:5])                       # more queries than keys
+    assert not ops.causal_attention_ok(q3, torch.zeros((10, 1, 128), device=DEV, dtype=dtype), torch.zeros((10, 1, 128), device=DEV, dtype=dtype))
+    assert not ops.causal_attention_ok(q3.float(), q3.float(), q3.float())
+    assert not ops.causal_attention_ok(torch.zeros((10, 2, 256), device=DEV, dtype=dtype)[:, :, ::2], q3, q3)      # last dim not contiguous
+
+
+def test_causal_attention_under_autograd_in_a_graph_and_through_the_interface():
+    """CausalAttentionFn against autograd through the library on views of one fused projection; the pair captured into a
+    hipGraph and replayed; and the two attention-interface functions of the gradient pass (prefix_attention.py) handing
+    (1, H, L, 128) tensors to it -- full causal, and 44 rows behind keys/values with autograd history -- and stepping aside
+    for grouped heads, other head widths and dropout."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd import prefix_attention as pa
+    g = torch.Generator(device=DEV).manual_seed(12)
+    H, S = 32, 643
+    qkv = torch.randn((1, S, 3 * H * 128), generator=g, device=DEV).to(torch.bfloat16).requires_grad_()
+    do = torch.randn((1, S, H, 128), generator=g, device=DEV).to(torch.bfloat16)
+
+    def heads(x):
+        q, k, v = x.view(1, S, 3, H, 128).unbind(2)
+        return q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)        # (1, H, S, 128) views, as HuggingFace passes them
+    q, k, v = heads(qkv)
+    out, _ = pa.causal_b1_attention(None, q, k, v, scaling=128 ** -0.5)
+    assert out.shape == (1, S, H, 128) and type(out.grad_fn).__name__ != "TransposeBackward0"
+    (g_own,) = torch.autograd.grad(out, qkv, do)
+    try:
+        ops.CAUSAL_ATTENTION = False
+        out_l, _ = pa.causal_b1_attention(None, *heads(qkv), scaling=128 ** -0.5)
+        (g_lib,) = torch.autograd.grad(out_l, qkv, do)
+    finally:
+        ops.CAUSAL_ATTENTION = True
+    assert float((out.float() - out_l.float()).abs().max()) <= 2 ** -6 * float(out_l.float().abs().max())
+    assert float((g_own.float() - g_lib.float()).abs().max()) <= 2 ** -5 * float(g_lib.float().abs().max())
+    # refusals: grouped heads, 64-wide heads, dropout
+    assert pa._own_causal(q, k[:, :8], v[:, :8], 0.1, 0.0) is None
+    assert pa._own_causal(q[..., :64], k[..., :64], v[..., :64], 0.1, 0.0) is None
+    assert pa._own_causal(q, k, v, 0.1, 0.1) is None
+    # the tail behind a prefix with history: gradients reach the prefix keys/values and the new rows alike
+    P, L = 599, 44
+    pk = torch.randn((1, H, P, 128), generator=g, device=DEV).to(torch.bfloat16).requires_grad_()
+    pv = torch.randn((1, H, P, 128), generator=g, device=DEV).to(torch.bfloat16).requires_grad_()
+    tq, tk, tv = (torch.randn((1, H, L, 128), generator=g, device=DEV).to(torch.bfloat16).requires_grad_() for _ in range(3))
+    dt = torch.randn((1, L, H, 128), generator=g, device=DEV).to(torch.bfloat16)
+
+    class KV:
+        k, v = [pk], [pv]
+
+        @staticmethod
+        def bias(L_, dtype, device):
+            b = torch.zeros((L_, P + L_), dtype=dtype, device=device)
+            b[:, P:] = torch.full((L_, L_), float("-inf"), dtype=dtype, device=device).triu(1)
+            return b
+
+    class Mod:
+        layer_idx = 0
+    pa._ACTIVE.append(KV)
+    try:
+        o1, _ = pa.tail_grad_attention(Mod, tq, tk, tv, scaling=128 ** -0.5)
+        g1 = torch.autograd.grad(o1, (tq, tk, tv, pk, pv), dt)
+        ops.CAUSAL_ATTENTION = False
+        o2, _ = pa.tail_grad_attention(Mod, tq, tk, tv, scaling=128 ** -0.5)
+        g2 = torch.autograd.grad(o2, (tq, tk, tv, pk, pv), dt)
+    finally:
+        ops.CAUSAL_ATTENTION = True
+        pa._ACTIVE.pop()
+    assert float((o1.float() - o2.float()).abs().max()) <= 2 ** -6 * float(o2.float().abs().max())
+    for a_, b_ in zip(g1, g2):
+        assert float((a_.float() - b_.float()).abs().max()) <= 2 ** -5 * float(b_.float().abs().max())
+    # captured and replayed
+    q3, k3, v3 = (t.detach().squeeze(0).transpose(0, 1) for t in heads(qkv))
+    xs = qkv.detach().clone()
+    qs, ks, vs = (t.squeeze(0).transpose(0, 1) for t in (lambda x: (x.view(1, S, 3, H, 128).unbind(2)))(xs))
+    qs, ks, vs = (t.transpose(0, 1).transpose(0, 1) for t in (qs, ks, vs))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        o_g, l_g = ops.causal_attention(qs, ks, vs, 128 ** -0.5)
+        grads_g = ops.causal_attention_bwd(qs, ks, vs, o_g, l_g, do[0], 128 ** -0.5)
+    for kk in range(2):
+        xs.copy_(qkv.detach() * (0.5 + kk))
+        graph.replay()
+        torch.cuda.synchronize()
+        o_e, l_e = ops.causal_attention(qs, ks, vs, 128 ** -0.5)
+        grads_e = ops.causal_attention_bwd(qs, ks, vs, o_e, l_e, do[0], 128 ** -0.5)
+        assert torch.equal(o_g, o_e) and all(torch.equal(a_, b_) for a_, b_ in zip(grads_g, grads_e))
+
+
 # ------------------------------------------------------------------ bma_gemm_mid (round 4)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_mid_matches_fp32_reference(dtype, monkeypatch):
