@@ -130,6 +130,19 @@ __device__ __forceinline__ void load_row_frags(uint4_t (&f)[KS], const uint16_t*
   for (int ks = 0; ks < KS; ++ks) f[ks] = *reinterpret_cast<const uint4_t*>(p + 32 * ks);
 }
 
+// The operands a wave loads ONCE must have landed before the chunk loop is entered: hipcc's wait insertion otherwise carries
+// "still pending" into the loop and puts counted `s_waitcnt vmcnt` in front of their first uses INSIDE it -- waits which, from
+// the second trip on, drain the chunk prefetch that was issued a few instructions earlier (1.07 us per chunk instead of the
+// ~0.4 the chain of products and the softmax take).  A use in an empty asm statement makes it wait here.
+__device__ __forceinline__ void landed(const uint4_t (&f)[ITEMS]) {
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) asm volatile("" ::"v"(f[it]));
+}
+__device__ __forceinline__ void landed(const uint4_t (&f)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(f[ks]));
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
@@ -150,19 +163,26 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
   const int chunks = (a.P + last + 1 + 31) >> 5;                   // keys 0 .. P + last
-  Chunk kc, vc;
-  fetch_chunk(kc, kb, a.k_rs, 0, a.Lk, tid);
-  fetch_chunk(vc, vb, a.v_rs, 0, a.Lk, tid);
-  stash_chunk(kc, lds, tid);
-  stash_chunk(vc, lds + IMG, tid);
+  // chunk c is multiplied from LDS while chunk c+1 waits in registers and chunk c+2 travels (two register sets, named
+  // statically: the loop advances two chunks per trip)
+  Chunk kA, vA, kB, vB;
+  fetch_chunk(kA, kb, a.k_rs, 0, a.Lk, tid);
+  fetch_chunk(vA, vb, a.v_rs, 0, a.Lk, tid);
+  fetch_chunk(kB, kb, a.k_rs, 32, a.Lk, tid);
+  fetch_chunk(vB, vb, a.v_rs, 32, a.Lk, tid);
+  stash_chunk(kA, lds, tid);
+  stash_chunk(vA, lds + IMG, tid);
+  landed(qf);
+  landed(kB.reg);
+  landed(vB.reg);
   __syncthreads();
-  for (int c = 0; c < chunks; ++c) {
+  auto step = [&](int c, Chunk& kX, Chunk& vX, const Chunk& kY, const Chunk& vY) {
     const uint16_t* kl = lds + 2 * IMG * (c & 1);
     const uint16_t* vl = kl + IMG;
-    if (c + 1 < chunks) {
-      fetch_chunk(kc, kb, a.k_rs, 32 * (c + 1), a.Lk, tid);
-      fetch_chunk(vc, vb, a.v_rs, 32 * (c + 1), a.Lk, tid);
-    }
+    // (unconditional: rows past the end are clamped to the last one; under a branch hipcc merges the two paths' wait
+    // counts and the stash below would drain THIS fetch as well)
+    fetch_chunk(kX, kb, a.k_rs, 32 * (c + 2), a.Lk, tid);
+    fetch_chunk(vX, vb, a.v_rs, 32 * (c + 2), a.Lk, tid);
     f32x4 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -206,10 +226,14 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
 #pragma unroll
     for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag(vl, dt, r, g), pf, oacc[dt]);
     if (c + 1 < chunks) {
-      stash_chunk(kc, lds + 2 * IMG * ((c + 1) & 1), tid);
-      stash_chunk(vc, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
+      stash_chunk(kY, lds + 2 * IMG * ((c + 1) & 1), tid);
+      stash_chunk(vY, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
     }
     __syncthreads();
+  };
+  for (int c = 0; c < chunks; c += 2) {
+    step(c, kA, vA, kB, vB);
+    if (c + 1 < chunks) step(c + 1, kB, vB, kA, vA);
   }
   const float l = rows_sum(lsum);
   if (qrow >= a.Lq) return;
@@ -262,19 +286,28 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
   const int chunks = (a.P + last + 1 + 31) >> 5;
-  Chunk kc, vc;
-  fetch_chunk(kc, kb, a.k_rs, 0, a.Lk, tid);
-  fetch_chunk(vc, vb, a.v_rs, 0, a.Lk, tid);
-  stash_chunk(kc, lds, tid);
-  stash_chunk(vc, lds + IMG, tid);
+  // chunk c is multiplied from LDS while chunk c+1 waits in registers and chunk c+2 travels (two register sets, named
+  // statically: the loop advances two chunks per trip)
+  Chunk kA, vA, kB, vB;
+  fetch_chunk(kA, kb, a.k_rs, 0, a.Lk, tid);
+  fetch_chunk(vA, vb, a.v_rs, 0, a.Lk, tid);
+  fetch_chunk(kB, kb, a.k_rs, 32, a.Lk, tid);
+  fetch_chunk(vB, vb, a.v_rs, 32, a.Lk, tid);
+  stash_chunk(kA, lds, tid);
+  stash_chunk(vA, lds + IMG, tid);
+  landed(qf);
+  landed(dof);
+  asm volatile("" ::"v"(lse2));
+  landed(kB.reg);
+  landed(vB.reg);
   __syncthreads();
-  for (int c = 0; c < chunks; ++c) {
+  auto step = [&](int c, Chunk& kX, Chunk& vX, const Chunk& kY, const Chunk& vY) {
     const uint16_t* kl = lds + 2 * IMG * (c & 1);
     const uint16_t* vl = kl + IMG;
-    if (c + 1 < chunks) {
-      fetch_chunk(kc, kb, a.k_rs, 32 * (c + 1), a.Lk, tid);
-      fetch_chunk(vc, vb, a.v_rs, 32 * (c + 1), a.Lk, tid);
-    }
+    // (unconditional: rows past the end are clamped to the last one; under a branch hipcc merges the two paths' wait
+    // counts and the stash below would drain THIS fetch as well)
+    fetch_chunk(kX, kb, a.k_rs, 32 * (c + 2), a.Lk, tid);
+    fetch_chunk(vX, vb, a.v_rs, 32 * (c + 2), a.Lk, tid);
     f32x4 s[2], dp[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -300,10 +333,14 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 #pragma unroll
     for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag(kl, dt, r, g), dsf, dqacc[dt]);
     if (c + 1 < chunks) {
-      stash_chunk(kc, lds + 2 * IMG * ((c + 1) & 1), tid);
-      stash_chunk(vc, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
+      stash_chunk(kY, lds + 2 * IMG * ((c + 1) & 1), tid);
+      stash_chunk(vY, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
     }
     __syncthreads();
+  };
+  for (int c = 0; c < chunks; c += 2) {
+    step(c, kA, vA, kB, vB);
+    if (c + 1 < chunks) step(c + 1, kB, vB, kA, vA);
   }
   if (qrow >= a.Lq) return;
   uint16_t* op = a.dq + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
@@ -361,6 +398,8 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
     fetch(c0);
     stash(0);
   }
+  landed(kf);
+  landed(vf);
   __syncthreads();
   for (int c = c0; c < c1; ++c) {
     const int pair = (c - c0) & 1;
