@@ -7,8 +7,9 @@
 // shape occurs behind a reused prefix (joint mode: 44 new rows against 643 keys).
 //
 // Three launches, all built like prefix_attention.hip's flash forward (v_mfma_f32_16x16x32, 32-row chunks staged
-// L2 -> registers -> LDS while the previous chunk is multiplied, one barrier per chunk, the exponentiated accumulator
-// packed straight into the next product's B operand, `ds_read_b64_tr_b16` for the transposed operand):
+// L2 -> registers -> LDS while the previous ones are multiplied, the exponentiated accumulator packed straight into the
+// next product's B operand, `ds_read_b64_tr_b16` for the transposed operand); a workgroup is 8 waves, 4 row tiles x the
+// even / odd chunks of the other side, two chunks per barrier:
 //   forward   (head, 64 queries): S^T = K Q^T, online softmax per query lane, O^T += V^T P^T; writes o and
 //             lse2 = m*scale*log2(e) + log2(l)
 //   dq        (head, 64 queries): S^T and dP^T = V dO^T recomputed per key chunk, dS^T = P^T (dP^T - delta) scale,
@@ -39,8 +40,8 @@ constexpr int KS = DH / 32;       // k-steps of a product over the head dimensio
 constexpr int NT = DH / 16;       // 16-dim tiles of an output
 constexpr int PITCH = DH + 16;    // elements per LDS row (row + 32 B: conflict-free row and transposing reads)
 constexpr int IMG = 32 * PITCH;   // one 32-row chunk image
-constexpr int NTHR = 256;         // 4 waves
-constexpr int ITEMS = 32 * (DH / 8) / NTHR;   // 16-byte pieces per thread per image (2)
+constexpr int NTHR = 512;         // 8 waves
+constexpr int ITEMS = 32 * (DH / 8) / NTHR;   // 16-byte pieces per thread per image (1)
 
 struct CArgs {
   const uint16_t *q, *k, *v, *o, *d_o;
@@ -132,24 +133,42 @@ __device__ __forceinline__ void load_row_frags(uint4_t (&f)[KS], const uint16_t*
 
 // The operands a wave loads ONCE must have landed before the chunk loop is entered: hipcc's wait insertion otherwise carries
 // "still pending" into the loop and puts counted `s_waitcnt vmcnt` in front of their first uses INSIDE it -- waits which, from
-// the second trip on, drain the chunk prefetch that was issued a few instructions earlier (1.07 us per chunk instead of the
-// ~0.4 the chain of products and the softmax take).  A use in an empty asm statement makes it wait here.
-__device__ __forceinline__ void landed(const uint4_t (&f)[ITEMS]) {
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) asm volatile("" ::"v"(f[it]));
-}
+// the second trip on, drain the chunk prefetch that was issued a few instructions earlier.  A use in an empty asm statement
+// makes it wait here.
 __device__ __forceinline__ void landed(const uint4_t (&f)[KS]) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(f[ks]));
 }
 
+// A workgroup is 8 waves: wave w works on the 16 rows (w & 3) of the block, and the two halves (w >> 2) take the even and
+// the odd 32-row chunks of the other side -- a trip of the loop stages TWO chunks (one barrier) and each wave's chain of
+// dependent products and softmax steps is half as long as the sequence; the halves' partial results meet in LDS at the end.
+// (One wave per 16 rows over all chunks: 1.07 us per chunk, 25 us forward and 58 us backward at 643 tokens.)
+struct Pair {
+  Chunk x0, y0, x1, y1;                                          // (K, V) or (Q, dO) images of chunks 2t and 2t+1
+};
+__device__ __forceinline__ void fetch_pair(Pair& p, const uint16_t* xb, int64_t x_rs, const uint16_t* yb, int64_t y_rs, int t,
+                                           int rows, int tid) {
+  fetch_chunk(p.x0, xb, x_rs, 64 * t, rows, tid);
+  fetch_chunk(p.y0, yb, y_rs, 64 * t, rows, tid);
+  fetch_chunk(p.x1, xb, x_rs, 64 * t + 32, rows, tid);
+  fetch_chunk(p.y1, yb, y_rs, 64 * t + 32, rows, tid);
+}
+__device__ __forceinline__ void stash_pair(const Pair& p, uint16_t* buf, int tid) {
+  stash_chunk(p.x0, buf, tid);
+  stash_chunk(p.y0, buf + IMG, tid);
+  stash_chunk(p.x1, buf + 2 * IMG, tid);
+  stash_chunk(p.y1, buf + 3 * IMG, tid);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];      // two pairs of (K image, V image)
+  __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (K, V, K, V) images: chunks 2t, 2t+1
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int half = w >> 2, wq = w & 3;
   const int h = blockIdx.x % a.H, qb = blockIdx.x / a.H;
-  const int row0 = 64 * qb + 16 * w;                              // first query of this wave
+  const int row0 = 64 * qb + 16 * wq;                             // first query of this wave
   const int qrow = row0 + r;                                      // this lane's query
   const float NEG = -__builtin_inff();
   uint4_t qf[KS];
@@ -163,88 +182,93 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
   const int chunks = (a.P + last + 1 + 31) >> 5;                   // keys 0 .. P + last
-  // chunk c is multiplied from LDS while chunk c+1 waits in registers and chunk c+2 travels (two register sets, named
-  // statically: the loop advances two chunks per trip)
-  Chunk kA, vA, kB, vB;
-  fetch_chunk(kA, kb, a.k_rs, 0, a.Lk, tid);
-  fetch_chunk(vA, vb, a.v_rs, 0, a.Lk, tid);
-  fetch_chunk(kB, kb, a.k_rs, 32, a.Lk, tid);
-  fetch_chunk(vB, vb, a.v_rs, 32, a.Lk, tid);
-  stash_chunk(kA, lds, tid);
-  stash_chunk(vA, lds + IMG, tid);
+  const int trips = (chunks + 1) >> 1;
+  Pair pr;
+  fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
+  stash_pair(pr, lds, tid);
   landed(qf);
-  landed(kB.reg);
-  landed(vB.reg);
   __syncthreads();
-  auto step = [&](int c, Chunk& kX, Chunk& vX, const Chunk& kY, const Chunk& vY) {
-    const uint16_t* kl = lds + 2 * IMG * (c & 1);
+  for (int t = 0; t < trips; ++t) {
+    const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    // (unconditional: rows past the end are clamped to the last one; under a branch hipcc merges the two paths' wait
-    // counts and the stash below would drain THIS fetch as well)
-    fetch_chunk(kX, kb, a.k_rs, 32 * (c + 2), a.Lk, tid);
-    fetch_chunk(vX, vb, a.v_rs, 32 * (c + 2), a.Lk, tid);
-    f32x4 s[2];
+    if (t + 1 < trips) fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
+    const int c = 2 * t + half;
+    if (c < chunks) {
+      f32x4 s[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int kt = 0; kt < 2; ++kt) {
+        s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
-    }
-    float e[2][4];
-    const bool edge = 32 * c + 31 > a.P + row0;                   // wave-uniform: some key of the chunk is masked for some query
-    float cmax = NEG;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float v = s[kt][rr];
-        if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) v = NEG;
-        e[kt][rr] = v;
-        cmax = vmax(cmax, v);
+        for (int ks = 0; ks < KS; ++ks) s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
       }
-    cmax = rows_max(cmax);
-    const float mnew = vmax(mrun, cmax);                            // finite from chunk 0 on: key 0 is visible to every query
-    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * a.scale_log2e);
-    const float mneg = -mnew * a.scale_log2e;
-    float rs = 0.0f;
+      float e[2][4];
+      const bool edge = 32 * c + 31 > a.P + row0;                 // wave-uniform: some key of the chunk is masked for some query
+      float cmax = NEG;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        e[kt][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kt][rr], a.scale_log2e, mneg));
-        rs += e[kt][rr];
-      }
-    lsum = lsum * alpha + rs;
-    mrun = mnew;
-    const uint4_t pf = pack_acc<DT>(e);
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        for (int rr = 0; rr < 4; ++rr) {
+          float v = s[kt][rr];
+          if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) v = NEG;
+          e[kt][rr] = v;
+          cmax = vmax(cmax, v);
+        }
+      cmax = rows_max(cmax);
+      // (a wave whose 16 queries see none of this chunk's keys -- only in the block's last chunks -- keeps its state)
+      if (__builtin_amdgcn_ballot_w64(cmax > NEG) != 0) {
+        const float mnew = vmax(mrun, cmax);
+        const float msafe = mnew > NEG ? mnew : 0.0f;               // a query that has seen no key yet: exponents of -inf, no NaN
+        const float alpha = __builtin_amdgcn_exp2f((mrun - msafe) * a.scale_log2e);
+        const float mneg = -msafe * a.scale_log2e;
+        float rs = 0.0f;
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt) {
-        oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            e[kt][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kt][rr], a.scale_log2e, mneg));
+            rs += e[kt][rr];
+          }
+        lsum = lsum * alpha + rs;
+        mrun = mnew;
+        const uint4_t pf = pack_acc<DT>(e);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+          for (int dt = 0; dt < NT; ++dt) {
+            oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+          }
+        }
+#pragma unroll
+        for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag(vl, dt, r, g), pf, oacc[dt]);
       }
     }
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag(vl, dt, r, g), pf, oacc[dt]);
-    if (c + 1 < chunks) {
-      stash_chunk(kY, lds + 2 * IMG * ((c + 1) & 1), tid);
-      stash_chunk(vY, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
-    }
+    if (t + 1 < trips) stash_pair(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
     __syncthreads();
-  };
-  for (int c = 0; c < chunks; c += 2) {
-    step(c, kA, vA, kB, vB);
-    if (c + 1 < chunks) step(c + 1, kB, vB, kA, vA);
   }
-  const float l = rows_sum(lsum);
-  if (qrow >= a.Lq) return;
+  // ---- the odd-chunk half hands (m, l, o) over through LDS; the even half merges and stores -------------------------------
+  float* xch = reinterpret_cast<float*>(lds) + (wq * 64 + lane) * (4 + 4 * NT);     // 16-byte aligned rows: m, l, -, -, o[32]
+  const float lfull = rows_sum(lsum);
+  if (half == 1) {
+    xch[0] = mrun;
+    xch[1] = lfull;
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) *reinterpret_cast<f32x4*>(xch + 4 + 4 * dt) = oacc[dt];
+  }
+  __syncthreads();
+  if (half == 1 || qrow >= a.Lq) return;
+  const float m2 = xch[0], l2 = xch[1];
+  const float m = vmax(mrun, m2);                                   // finite: chunk 0 belongs to this half and shows key 0
+  const float a1 = __builtin_amdgcn_exp2f((mrun - m) * a.scale_log2e), a2 = __builtin_amdgcn_exp2f((m2 - m) * a.scale_log2e);
+  const float l = lfull * a1 + l2 * a2;
   const float inv = 1.0f / l;
-  if (g == 0) a.lse2[static_cast<int64_t>(h) * a.Lq + qrow] = mrun * a.scale_log2e + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
+  if (g == 0) a.lse2[static_cast<int64_t>(h) * a.Lq + qrow] = m * a.scale_log2e + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
   uint16_t* op = a.out + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
+  const float c1 = a1 * inv, c2 = a2 * inv;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
+    const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 + 4 * dt);
     bma::uint2_t ow;
-    ow.x = bma::pack16<DT>(oacc[dt][0] * inv, oacc[dt][1] * inv);
-    ow.y = bma::pack16<DT>(oacc[dt][2] * inv, oacc[dt][3] * inv);
+    ow.x = bma::pack16<DT>(oacc[dt][0] * c1 + o2[0] * c2, oacc[dt][1] * c1 + o2[1] * c2);
+    ow.y = bma::pack16<DT>(oacc[dt][2] * c1 + o2[2] * c2, oacc[dt][3] * c1 + o2[3] * c2);
     *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
   }
 }
@@ -252,10 +276,11 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];
+  __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int half = w >> 2, wq = w & 3;
   const int h = blockIdx.x % a.H, qb = blockIdx.x / a.H;
-  const int row0 = 64 * qb + 16 * w;
+  const int row0 = 64 * qb + 16 * wq;
   const int qrow = row0 + r;
   const int qc = qrow < a.Lq ? qrow : a.Lq - 1;
   uint4_t qf[KS], dof[KS];
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
         acc += bma::unpack16<DT>(dw[j], 0) * bma::unpack16<DT>(ow[j], 0) + bma::unpack16<DT>(dw[j], 1) * bma::unpack16<DT>(ow[j], 1);
     }
     delta = rows_sum(acc);
-    if (g == 0 && qrow < a.Lq) a.delta[static_cast<int64_t>(h) * a.Lq + qrow] = delta;
+    if (half == 0 && g == 0 && qrow < a.Lq) a.delta[static_cast<int64_t>(h) * a.Lq + qrow] = delta;
   }
   const float lse2 = a.lse2[static_cast<int64_t>(h) * a.Lq + qc];
   f32x4 dqacc[NT];
@@ -286,69 +311,62 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
   const int chunks = (a.P + last + 1 + 31) >> 5;
-  // chunk c is multiplied from LDS while chunk c+1 waits in registers and chunk c+2 travels (two register sets, named
-  // statically: the loop advances two chunks per trip)
-  Chunk kA, vA, kB, vB;
-  fetch_chunk(kA, kb, a.k_rs, 0, a.Lk, tid);
-  fetch_chunk(vA, vb, a.v_rs, 0, a.Lk, tid);
-  fetch_chunk(kB, kb, a.k_rs, 32, a.Lk, tid);
-  fetch_chunk(vB, vb, a.v_rs, 32, a.Lk, tid);
-  stash_chunk(kA, lds, tid);
-  stash_chunk(vA, lds + IMG, tid);
+  const int trips = (chunks + 1) >> 1;
+  Pair pr;
+  fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
+  stash_pair(pr, lds, tid);
   landed(qf);
   landed(dof);
   asm volatile("" ::"v"(lse2));
-  landed(kB.reg);
-  landed(vB.reg);
   __syncthreads();
-  auto step = [&](int c, Chunk& kX, Chunk& vX, const Chunk& kY, const Chunk& vY) {
-    const uint16_t* kl = lds + 2 * IMG * (c & 1);
+  for (int t = 0; t < trips; ++t) {
+    const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    // (unconditional: rows past the end are clamped to the last one; under a branch hipcc merges the two paths' wait
-    // counts and the stash below would drain THIS fetch as well)
-    fetch_chunk(kX, kb, a.k_rs, 32 * (c + 2), a.Lk, tid);
-    fetch_chunk(vX, vb, a.v_rs, 32 * (c + 2), a.Lk, tid);
-    f32x4 s[2], dp[2];
+    if (t + 1 < trips) fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
+    const int c = 2 * t + half;
+    if (c < chunks) {
+      f32x4 s[2], dp[2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      dp[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int kt = 0; kt < 2; ++kt) {
+        s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        dp[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
-        dp[kt] = cmfma<DT>(row_frag(vl, kt, ks, r, g), dof[ks], dp[kt]);
+        for (int ks = 0; ks < KS; ++ks) {
+          s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
+          dp[kt] = cmfma<DT>(row_frag(vl, kt, ks, r, g), dof[ks], dp[kt]);
+        }
       }
+      float e[2][4];
+      const bool edge = 32 * c + 31 > a.P + row0;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], a.scale_log2e, -lse2));
+          if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) p = 0.0f;
+          e[kt][rr] = p * (dp[kt][rr] - delta) * a.scale;
+        }
+      const uint4_t dsf = pack_acc<DT>(e);
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag(kl, dt, r, g), dsf, dqacc[dt]);
     }
-    float e[2][4];
-    const bool edge = 32 * c + 31 > a.P + row0;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], a.scale_log2e, -lse2));
-        if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) p = 0.0f;
-        e[kt][rr] = p * (dp[kt][rr] - delta) * a.scale;
-      }
-    const uint4_t dsf = pack_acc<DT>(e);
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag(kl, dt, r, g), dsf, dqacc[dt]);
-    if (c + 1 < chunks) {
-      stash_chunk(kY, lds + 2 * IMG * ((c + 1) & 1), tid);
-      stash_chunk(vY, lds + 2 * IMG * ((c + 1) & 1) + IMG, tid);
-    }
+    if (t + 1 < trips) stash_pair(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
     __syncthreads();
-  };
-  for (int c = 0; c < chunks; c += 2) {
-    step(c, kA, vA, kB, vB);
-    if (c + 1 < chunks) step(c + 1, kB, vB, kA, vA);
   }
-  if (qrow >= a.Lq) return;
+  float* xch = reinterpret_cast<float*>(lds) + (wq * 64 + lane) * (4 * NT);
+  if (half == 1) {
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) *reinterpret_cast<f32x4*>(xch + 4 * dt) = dqacc[dt];
+  }
+  __syncthreads();
+  if (half == 1 || qrow >= a.Lq) return;
   uint16_t* op = a.dq + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
+    const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 * dt);
     bma::uint2_t ow;
-    ow.x = bma::pack16<DT>(dqacc[dt][0], dqacc[dt][1]);
-    ow.y = bma::pack16<DT>(dqacc[dt][2], dqacc[dt][3]);
+    ow.x = bma::pack16<DT>(dqacc[dt][0] + o2[0], dqacc[dt][1] + o2[1]);
+    ow.y = bma::pack16<DT>(dqacc[dt][2] + o2[2], dqacc[dt][3] + o2[3]);
     *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
   }
 }
@@ -356,11 +374,12 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * IMG];      // two pairs of (Q image, dO image)
-  __shared__ __attribute__((aligned(16))) float stat[2][64];          // per pair: lse2 of the chunk's 32 queries, then delta
+  __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (Q, dO, Q, dO) images: query chunks 2t, 2t+1
+  __shared__ __attribute__((aligned(16))) float stat[2][2][64];       // per buffer and chunk: lse2 of its 32 queries, then delta
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int half = w >> 2, wk = w & 3;
   const int h = blockIdx.x % a.H, kblk = blockIdx.x / a.H;
-  const int key0 = 64 * kblk + 16 * w;                            // first key of this wave
+  const int key0 = 64 * kblk + 16 * wk;                           // first key of this wave
   const int key = key0 + r;                                       // this lane's key (a column of S)
   uint4_t kf[KS], vf[KS];
   load_row_frags(kf, a.k + static_cast<int64_t>(h) * a.k_hs, a.k_rs, key < a.Lk ? key : a.Lk - 1, g);
@@ -374,85 +393,95 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   const uint16_t* qbase = a.q + static_cast<int64_t>(h) * a.q_hs;
   const uint16_t* dobase = a.d_o + static_cast<int64_t>(h) * DH;
   const int64_t do_rs = static_cast<int64_t>(a.H) * DH;
-  // queries that see at least one key of this block: i >= 64*kblk - P
-  int c0 = 64 * kblk - a.P;
-  c0 = c0 > 0 ? c0 >> 5 : 0;
+  // queries that see at least one key of this block: i >= 64*kblk - P; chunk pairs t0 .. t1-1 of 64 queries
+  int q0 = 64 * kblk - a.P;
+  q0 = q0 > 0 ? q0 : 0;
+  const int t0 = q0 >> 6, t1 = (a.Lq + 63) >> 6;
   const int c1 = (a.Lq + 31) >> 5;
-  Chunk qc, dc;
+  Pair pr;
   float st = 0.0f;
-  auto fetch = [&](int c) {
-    fetch_chunk(qc, qbase, a.q_rs, 32 * c, a.Lq, tid);
-    fetch_chunk(dc, dobase, do_rs, 32 * c, a.Lq, tid);
-    if (tid < 64) {
-      int qi = 32 * c + (tid & 31);
+  auto fetch = [&](int t) {
+    fetch_pair(pr, qbase, a.q_rs, dobase, do_rs, t, a.Lq, tid);
+    if (tid < 128) {                                               // lse2 and delta of the pair's 64 queries
+      int qi = 64 * t + 32 * (tid >> 6) + (tid & 31);
       qi = qi < a.Lq ? qi : a.Lq - 1;
-      st = (tid < 32 ? a.lse2 : a.delta)[static_cast<int64_t>(h) * a.Lq + qi];
+      st = ((tid & 32) ? a.delta : a.lse2)[static_cast<int64_t>(h) * a.Lq + qi];
     }
   };
-  auto stash = [&](int pair) {
-    stash_chunk(qc, lds + 2 * IMG * pair, tid);
-    stash_chunk(dc, lds + 2 * IMG * pair + IMG, tid);
-    if (tid < 64) stat[pair][tid] = st;
+  auto stash = [&](int buf) {
+    stash_pair(pr, lds + 4 * IMG * buf, tid);
+    if (tid < 128) stat[buf][tid >> 6][tid & 63] = st;
   };
-  if (c0 < c1) {
-    fetch(c0);
-    stash(0);
-  }
+  fetch(t0);
+  stash(0);
   landed(kf);
   landed(vf);
   __syncthreads();
-  for (int c = c0; c < c1; ++c) {
-    const int pair = (c - c0) & 1;
-    const uint16_t* ql = lds + 2 * IMG * pair;
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    const uint16_t* ql = lds + 4 * IMG * buf + 2 * IMG * half;
     const uint16_t* dl = ql + IMG;
-    if (c + 1 < c1) fetch(c + 1);
-    f32x4 s[2], dp[2];
+    if (t + 1 < t1) fetch(t + 1);
+    const int c = 2 * t + half;
+    if (c < c1 && 32 * c + 31 + a.P >= key0) {                     // (a chunk whose queries all sit in front of this wave's keys adds nothing)
+      f32x4 s[2], dp[2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      s[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      dp[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int qt = 0; qt < 2; ++qt) {
+        s[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        dp[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s[qt] = cmfma<DT>(row_frag(ql, qt, ks, r, g), kf[ks], s[qt]);
-        dp[qt] = cmfma<DT>(row_frag(dl, qt, ks, r, g), vf[ks], dp[qt]);
+        for (int ks = 0; ks < KS; ++ks) {
+          s[qt] = cmfma<DT>(row_frag(ql, qt, ks, r, g), kf[ks], s[qt]);
+          dp[qt] = cmfma<DT>(row_frag(dl, qt, ks, r, g), vf[ks], dp[qt]);
+        }
+      }
+      float pe[2][4], de[2][4];
+      // masked: the chunk reaches past Lq, or some of its queries do not see some key of this wave
+      const bool edge = 32 * c + 32 > a.Lq || key0 + 15 > a.P + 32 * c;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[buf][half][16 * qt + 4 * g]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[buf][half][32 + 16 * qt + 4 * g]);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int qi = 32 * c + 16 * qt + 4 * g + rr;
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][rr], a.scale_log2e, -l4[rr]));
+          if (edge && (qi >= a.Lq || key > a.P + qi)) p = 0.0f;
+          pe[qt][rr] = p;
+          de[qt][rr] = p * (dp[qt][rr] - d4[rr]) * a.scale;
+        }
+      }
+      const uint4_t pf = pack_acc<DT>(pe), dsf = pack_acc<DT>(de);
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        dvacc[dt] = cmfma<DT>(tr_frag(dl, dt, r, g), pf, dvacc[dt]);
+        dkacc[dt] = cmfma<DT>(tr_frag(ql, dt, r, g), dsf, dkacc[dt]);
       }
     }
-    float pe[2][4], de[2][4];
-    // masked: the chunk reaches past Lq, or some of its queries do not see some key of this wave
-    const bool edge = 32 * c + 32 > a.Lq || key0 + 15 > a.P + 32 * c;
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[pair][16 * qt + 4 * g]);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[pair][32 + 16 * qt + 4 * g]);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int qi = 32 * c + 16 * qt + 4 * g + rr;
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][rr], a.scale_log2e, -l4[rr]));
-        if (edge && (qi >= a.Lq || key > a.P + qi)) p = 0.0f;
-        pe[qt][rr] = p;
-        de[qt][rr] = p * (dp[qt][rr] - d4[rr]) * a.scale;
-      }
-    }
-    const uint4_t pf = pack_acc<DT>(pe), dsf = pack_acc<DT>(de);
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) {
-      dvacc[dt] = cmfma<DT>(tr_frag(dl, dt, r, g), pf, dvacc[dt]);
-      dkacc[dt] = cmfma<DT>(tr_frag(ql, dt, r, g), dsf, dkacc[dt]);
-    }
-    if (c + 1 < c1) stash(pair ^ 1);
+    if (t + 1 < t1) stash(buf ^ 1);
     __syncthreads();
   }
-  if (key >= a.Lk) return;
+  float* xch = reinterpret_cast<float*>(lds) + (wk * 64 + lane) * (8 * NT);
+  if (half == 1) {
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      *reinterpret_cast<f32x4*>(xch + 8 * dt) = dkacc[dt];
+      *reinterpret_cast<f32x4*>(xch + 8 * dt + 4) = dvacc[dt];
+    }
+  }
+  __syncthreads();
+  if (half == 1 || key >= a.Lk) return;
   uint16_t* kp = a.dk + (static_cast<int64_t>(key) * a.H + h) * DH + 4 * g;
   uint16_t* vp = a.dv + (static_cast<int64_t>(key) * a.H + h) * DH + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt), v2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt + 4);
     bma::uint2_t ow;
-    ow.x = bma::pack16<DT>(dkacc[dt][0], dkacc[dt][1]);
-    ow.y = bma::pack16<DT>(dkacc[dt][2], dkacc[dt][3]);
+    ow.x = bma::pack16<DT>(dkacc[dt][0] + k2[0], dkacc[dt][1] + k2[1]);
+    ow.y = bma::pack16<DT>(dkacc[dt][2] + k2[2], dkacc[dt][3] + k2[3]);
     *reinterpret_cast<bma::uint2_t*>(kp + 16 * dt) = ow;
-    ow.x = bma::pack16<DT>(dvacc[dt][0], dvacc[dt][1]);
-    ow.y = bma::pack16<DT>(dvacc[dt][2], dvacc[dt][3]);
+    ow.x = bma::pack16<DT>(dvacc[dt][0] + v2[0], dvacc[dt][1] + v2[1]);
+    ow.y = bma::pack16<DT>(dvacc[dt][2] + v2[2], dvacc[dt][3] + v2[3]);
     *reinterpret_cast<bma::uint2_t*>(vp + 16 * dt) = ow;
   }
 }
