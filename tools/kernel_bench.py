@@ -233,6 +233,17 @@ def cases():
             return lambda: ops.b1_attention_bwd(qkv, cos, sin, out, lse, dout, H, 128 ** -0.5)
         return lambda: ops.b1_attention(qkv, cos, sin, H, 128 ** -0.5)
 
+    def causal_attn(Lq, Lk, H, backward):
+        qkv = torch.randn((Lk, 3 * H * 128), generator=g, device=DEV).to(bf)
+        q = qkv[Lk - Lq:, :H * 128].view(Lq, H, 128)
+        k = qkv[:, H * 128:2 * H * 128].view(Lk, H, 128)
+        v = qkv[:, 2 * H * 128:].view(Lk, H, 128)
+        out, lse2 = ops.causal_attention(q, k, v, 128 ** -0.5)
+        dout = torch.randn((Lq, H, 128), generator=g, device=DEV).to(bf)
+        if backward:
+            return lambda: ops.causal_attention_bwd(q, k, v, out, lse2, dout, 128 ** -0.5)
+        return lambda: ops.causal_attention(q, k, v, 128 ** -0.5)
+
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
         idx = torch.randint(0, N, (R,), generator=g, device=DEV).sort().values.to(torch.int32)
@@ -289,6 +300,11 @@ def cases():
         "gemm_mid/gate_up_dX_644x4096x22016": ("gemm_mid", lambda: gemm_mid(644, 4096, 22016)),
         "gemm_mid/gate_up_644x22016x4096": ("gemm_mid", lambda: gemm_mid(644, 22016, 4096)),
         "gemm_mid/down_644x4096x11008": ("gemm_mid", lambda: gemm_mid(644, 4096, 11008)),
+        # causal attention of the 643-token pass at batch 1 and of 44 rows behind a 599-key prefix: latency-bound (3.4 / 8.5 GFLOP)
+        "causal_attn/fwd_L643_H32": ("causal_attn", lambda: causal_attn(643, 643, 32, False)),
+        "causal_attn/bwd_L643_H32": ("causal_attn", lambda: causal_attn(643, 643, 32, True)),
+        "causal_attn/fwd_tail_L44_K643_H32": ("causal_attn", lambda: causal_attn(44, 643, 32, False)),
+        "causal_attn/bwd_tail_L44_K643_H32": ("causal_attn", lambda: causal_attn(44, 643, 32, True)),
         # rotary + causal attention of the text-only gradient pass (65 rows, 32 heads of 128): latency-bound, one launch each way
         "b1_attn/fwd_S65_H32": ("b1_attn", lambda: b1_attn(65, 32, False)),
         "b1_attn/bwd_S65_H32": ("b1_attn", lambda: b1_attn(65, 32, True)),
