@@ -231,7 +231,7 @@ class BimodalAttack:
         ops.CAUSAL_ATTENTION = bool(self.opt.causal_attention)
         self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
                                     self.opt.fuse_gate_up, self.opt.fuse_add_norm, self.opt.fuse_qk_rope,
-                                    self.opt.fuse_b1_attention)
+                                    self.opt.fuse_b1_attention, self.opt.causal_attention)
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         logger.info(f"Fused forward admitted: {self.fused.admitted}")
         if hasattr(model.config, "model_type"):

@@ -48,6 +48,7 @@ struct CArgs {
   uint16_t *out, *dq, *dk, *dv;
   float *lse2, *delta;            // [H][Lq]
   int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs;
+  int64_t d_rs;                   // row stride of dq / dk / dv (elements)
   int Lq, Lk, H, P;
   float scale, scale_log2e;
 };
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   }
   __syncthreads();
   if (half == 1 || qrow >= a.Lq) return;
-  uint16_t* op = a.dq + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
+  uint16_t* op = a.dq + static_cast<int64_t>(qrow) * a.d_rs + h * DH + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
     const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 * dt);
@@ -471,8 +472,8 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   }
   __syncthreads();
   if (half == 1 || key >= a.Lk) return;
-  uint16_t* kp = a.dk + (static_cast<int64_t>(key) * a.H + h) * DH + 4 * g;
-  uint16_t* vp = a.dv + (static_cast<int64_t>(key) * a.H + h) * DH + 4 * g;
+  uint16_t* kp = a.dk + static_cast<int64_t>(key) * a.d_rs + h * DH + 4 * g;
+  uint16_t* vp = a.dv + static_cast<int64_t>(key) * a.d_rs + h * DH + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
     const f32x4 k2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt), v2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt + 4);
@@ -527,11 +528,13 @@ extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, c
 extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
                                         const void* v, int64_t v_rs, int64_t v_hs, const void* out, const float* lse2,
                                         const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype, float scale,
-                                        void* dq, void* dk, void* dv, float* delta, void* stream) {
+                                        void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta, void* stream) {
   const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
   const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
   if (rc != BMA_OK) return rc;
   if (!out || !lse2 || !d_out || !dq || !dk || !dv || !delta) return BMA_EINVAL;
+  if (d_row_stride < static_cast<int64_t>(H) * DH) return BMA_EINVAL;
+  if (d_row_stride % 8) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(dq) |
        reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 ||
       (reinterpret_cast<uintptr_t>(lse2) | reinterpret_cast<uintptr_t>(delta)) % 4)
@@ -539,8 +542,8 @@ extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_h
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (Lq == 0) {                                                  // no query: the keys' gradients are zero
     if (Lk > 0) {
-      if (hipMemsetAsync(dk, 0, static_cast<size_t>(Lk) * H * DH * 2, st) != hipSuccess) return BMA_ELAUNCH;
-      if (hipMemsetAsync(dv, 0, static_cast<size_t>(Lk) * H * DH * 2, st) != hipSuccess) return BMA_ELAUNCH;
+      if (hipMemset2DAsync(dk, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * DH * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
+      if (hipMemset2DAsync(dv, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * DH * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
     }
     return BMA_OK;
   }
@@ -549,7 +552,7 @@ extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_h
   a.o = static_cast<const uint16_t*>(out); a.d_o = static_cast<const uint16_t*>(d_out);
   a.dq = static_cast<uint16_t*>(dq); a.dk = static_cast<uint16_t*>(dk); a.dv = static_cast<uint16_t*>(dv);
   a.lse2 = const_cast<float*>(lse2); a.delta = delta;
-  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs;
+  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs; a.d_rs = d_row_stride;
   a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = static_cast<int>(Lk - Lq);
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
   const dim3 gq(static_cast<unsigned>(H * ((Lq + 63) / 64))), gk(static_cast<unsigned>(H * ((Lk + 63) / 64)));

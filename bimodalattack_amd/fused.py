@@ -233,9 +233,10 @@ _TP_ROW = ("o_proj", "down_proj")
 class FusedInference:
     def __init__(self, model: torch.nn.Module, enabled: bool = True, weight_copies: bool = True,
                  fuse_qkv: bool = True, fuse_gate_up: bool = True, fuse_add_norm: bool = True, fuse_qk_rope: bool = True,
-                 fuse_b1_attention: bool = True):
+                 fuse_b1_attention: bool = True, long_attention: bool = True):
         self.enabled = enabled
         self.fuse_b1_attention = fuse_b1_attention
+        self.long_attention = long_attention          # the same blocks at 81 .. 4096 tokens: ops.RotaryCausalAttentionFn
         self.b1_attn: List[torch.nn.Module] = []     # attention blocks whose rotary + attention run as one launch in the batch-1 gradient pass
         self._qkv_whole = {}                         # id(attention block) -> x -> the fused q/k/v product (made at __enter__)
         self.fuse_qk_rope = fuse_qk_rope
@@ -523,6 +524,16 @@ class FusedInference:
                     y = whole(hidden_states)
                     if y is not None and ops.b1_attention_ok(y, cos, heads, heads, 128):
                         out = ops.B1AttentionFn.apply(y, cos[0], sin[0], heads, float(attn.scaling))
+                        return attn.o_proj(out), None
+                # the long sequence (the image prompt): rotary + the hand-written causal attention pair, gradients written
+                # straight into the fused projection's (ops.RotaryCausalAttentionFn)
+                elif self.long_attention and not (cos.requires_grad or sin.requires_grad) \
+                        and ops.B1_ATTENTION_MAX_TOKENS < hidden_states.shape[1] <= ops.CAUSAL_ATTENTION_MAX_TOKENS \
+                        and cos.shape == (1, hidden_states.shape[1], 128) and cos.dtype == hidden_states.dtype \
+                        and hidden_states.dtype in (torch.bfloat16, torch.float16) and hidden_states.is_cuda and ops.CAUSAL_ATTENTION:
+                    y = whole(hidden_states)
+                    if y is not None and ops.rotary_causal_attention_ok(y, cos, heads):
+                        out = ops.RotaryCausalAttentionFn.apply(y, cos[0], sin[0], heads, float(attn.scaling))
                         return attn.o_proj(out), None
             return orig(hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
                         past_key_values=past_key_values, **kwargs)

@@ -773,20 +773,29 @@ def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
     return out, lse2
 
 
-def causal_attention_bwd(q, k, v, out, lse2, d_out, scale: float):
-    """(dq (Lq, H, 128), dk, dv (Lk, H, 128)) contiguous through bma_causal_attention_bwd."""
+def causal_attention_bwd(q, k, v, out, lse2, d_out, scale: float, into=None):
+    """(dq (Lq, H, 128), dk, dv (Lk, H, 128)) through bma_causal_attention_bwd: fresh contiguous tensors, or -- `into` a
+    (Lk, 3, H, 128) buffer with Lq == Lk -- views of it, the three written straight into the gradient of a fused q/k/v
+    projection."""
     dev = _need_gpu(q, k, v)
     Lq, H, _ = q.shape
     Lk = k.shape[0]
     d_out = d_out.contiguous()
-    dq = torch.empty((Lq, H, 128), dtype=q.dtype, device=dev)
-    dk = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
-    dv = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
+    if into is None:
+        dq = torch.empty((Lq, H, 128), dtype=q.dtype, device=dev)
+        dk = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
+        dv = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
+        d_rs = H * 128
+    else:
+        if Lq != Lk or into.shape != (Lk, 3, H, 128) or not into.is_contiguous() or into.dtype != q.dtype:
+            raise ValueError("`into` must be a contiguous (L, 3, H, 128) buffer of the operands' type with Lq == Lk")
+        dq, dk, dv = into[:, 0], into[:, 1], into[:, 2]
+        d_rs = 3 * H * 128
     delta = torch.empty((H, Lq), dtype=torch.float32, device=dev)
     check("bma_causal_attention_bwd", lib.bma_causal_attention_bwd(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
                                                                    *_rows_heads(v), out.data_ptr(), lse2.data_ptr(), d_out.data_ptr(), Lq,
                                                                    Lk, H, 128, _dt(q), float(scale), dq.data_ptr(), dk.data_ptr(),
-                                                                   dv.data_ptr(), delta.data_ptr(), _stream(dev)))
+                                                                   dv.data_ptr(), d_rs, delta.data_ptr(), _stream(dev)))
     return dq, dk, dv
 
 
@@ -806,6 +815,46 @@ class CausalAttentionFn(torch.autograd.Function):
         q, k, v, out, lse2 = ctx.saved_tensors
         dq, dk, dv = causal_attention_bwd(q, k, v, out, lse2, d_out, ctx.scale)
         return dq, dk, dv, None
+
+
+class RotaryCausalAttentionFn(torch.autograd.Function):
+    """What HuggingFace's attention block does between its (fused) q/k/v projection and o_proj, for ONE long sequence at
+    batch 1: rotary embedding of q and k (one launch), causal attention (one launch), and backward: the attention's two
+    launches writing dq / dk / dv straight into the projection's gradient, the inverse rotation in place (one launch) --
+    no split, no concatenation, no transposed copies.  qkv (1, S, 3*H*128) as the fused projection leaves it; cos / sin
+    (S, 128).  Returns (1, S, H*128)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, heads, scale):
+        S = qkv.shape[1]
+        x = qkv.view(1, S, 3, heads, 128)
+        q4, k4 = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2)            # (1, H, S, 128) views
+        qo, ko = rope2(q4, k4, cos.unsqueeze(0), sin.unsqueeze(0))
+        q3, k3, v3 = qo[0].transpose(0, 1), ko[0].transpose(0, 1), x[0, :, 2]       # (S, H, 128)
+        out, lse2 = causal_attention(q3, k3, v3, scale)
+        ctx.save_for_backward(q3, k3, qkv, out, lse2, cos, sin)
+        ctx.heads, ctx.scale = int(heads), float(scale)
+        return out.view(1, S, heads * 128)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q3, k3, qkv, out, lse2, cos, sin = ctx.saved_tensors
+        S, H = qkv.shape[1], ctx.heads
+        v3 = qkv.view(S, 3, H, 128)[:, 2]
+        g = torch.empty((S, 3, H, 128), dtype=qkv.dtype, device=qkv.device)
+        dq, dk, _ = causal_attention_bwd(q3, k3, v3, out, lse2, d_out.reshape(S, H, 128), ctx.scale, into=g)
+        rope2(dq.transpose(0, 1).unsqueeze(0), dk.transpose(0, 1).unsqueeze(0), cos.unsqueeze(0), sin.unsqueeze(0), inverse=True,
+              inplace=True)
+        return g.view(1, S, 3 * H * 128), None, None, None, None
+
+
+def rotary_causal_attention_ok(qkv: torch.Tensor, cos: torch.Tensor, heads: int) -> bool:
+    """A contiguous 16-bit (1, S, 3*heads*128) projection with cos / sin (1, S, 128) of its type, S within the kernels'
+    range and beyond the one-launch kernel's."""
+    return bool(CAUSAL_ATTENTION and qkv.is_cuda and qkv.dim() == 3 and qkv.shape[0] == 1 and qkv.is_contiguous()
+                and qkv.dtype in (torch.bfloat16, torch.float16) and qkv.shape[2] == 3 * heads * 128
+                and B1_ATTENTION_MAX_TOKENS < qkv.shape[1] <= CAUSAL_ATTENTION_MAX_TOKENS
+                and cos.dtype == qkv.dtype and cos.shape == (1, qkv.shape[1], 128))
 
 
 # ---------------------------------------------------------------------------

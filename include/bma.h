@@ -286,7 +286,8 @@ int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y,
  *   elements (multiples of 8; views of a fused projection are fine), H query heads = H key/value heads, Dh = 128, bf16 /
  *   f16, rotary already applied.  Forward: out [Lq][H][128] contiguous and lse2 [H][Lq] fp32 = log2 of the softmax
  *   denominator in units of the scaled scores (an opaque token for the backward).  Backward: dq [Lq][H][128], dk / dv
- *   [Lk][H][128] contiguous from d_out [Lq][H][128] contiguous; `delta` [H][Lq] fp32 is scratch.  Two launches (dq, then
+ *   [Lk][H][128] with rows d_row_stride elements apart (H*128 when contiguous; 3*H*128 writes the three straight into
+ *   the gradient of a fused q/k/v projection) from d_out [Lq][H][128] contiguous; `delta` [H][Lq] fp32 is scratch.  Two launches (dq, then
  *   dk and dv), every output element with one owner: no atomics, bitwise reproducible.  Probabilities and score
  *   gradients are rounded to `dtype` before their products, as in a flash kernel. */
 int bma_causal_attention(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
@@ -295,7 +296,7 @@ int bma_causal_attention(const void* q, int64_t q_row_stride, int64_t q_head_str
 int bma_causal_attention_bwd(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
                              int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, const void* out,
                              const float* lse2, const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
-                             float scale, void* dq, void* dk, void* dv, float* delta, void* stream);
+                             float scale, void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta, void* stream);
 
 /* bma_gemm_mid: y[M][N] = x[M][K] . w[N][K]^T for the products of the batch-1 gradient pass when the image is part of the
  *   prompt (a1, :953-1028 with PGD on: 576 image rows + the text = 599-644 rows; the same shapes occur in the prefix

@@ -30,6 +30,33 @@ def test_library_exports_every_declared_symbol():
     assert native.strerror(0) == "ok" and "align" in native.strerror(-3)
 
 
+def test_prototype_table_matches_the_header_argument_for_argument():
+    """native.PROTOTYPES against include/bma.h: the same number of parameters per entry point, pointers where the header has
+    pointers, 64-bit integers where it has int64_t / size_t, floats where it has float (a table one argument short is a
+    segmentation fault on the first call, not an exception)."""
+    from bimodalattack_amd import native
+    text = open(os.path.join(REPO, "include", "bma.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = dict(re.findall(r"\b(bma_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(decls) == set(native.PROTOTYPES)
+    for name, params in decls.items():
+        params = " ".join(params.split())
+        args = [] if params in ("", "void") else [a.strip() for a in params.split(",")]
+        _, table = native.PROTOTYPES[name]
+        assert len(args) == len(table), (name, len(args), len(table))
+        for a, t in zip(args, table):
+            if "*" in a:
+                assert t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or t.__name__.startswith("LP_"), (name, a, t)
+            elif re.match(r"(const )?(int64_t|size_t)\b", a):
+                assert t in (ctypes.c_int64, ctypes.c_size_t, ctypes.c_uint64), (name, a, t)
+            elif re.match(r"(const )?float\b", a):
+                assert t is ctypes.c_float, (name, a, t)
+            elif re.match(r"(const )?double\b", a):
+                assert t is ctypes.c_double, (name, a, t)
+            elif re.match(r"(const )?(int|unsigned|uint32_t|int32_t)\b", a):
+                assert t in (ctypes.c_int, ctypes.c_uint, ctypes.c_uint32, ctypes.c_int32), (name, a, t)
+
+
 def test_argument_validation_launches_nothing():
     """Every entry point rejects bad arguments before touching the device."""
     from bimodalattack_amd.native import BmaSegment, lib

@@ -549,6 +549,33 @@ def test_causal_attention_under_autograd_in_a_graph_and_through_the_interface():
         assert torch.equal(o_g, o_e) and all(torch.equal(a_, b_) for a_, b_ in zip(grads_g, grads_e))
 
 
+def test_rotary_causal_attention_block_equals_its_parts():
+    """ops.RotaryCausalAttentionFn -- rotary, causal attention and the gradient written straight into the fused q/k/v
+    projection's -- against the same steps as separate autograd functions (RoPE2Fn on views, CausalAttentionFn, autograd's
+    own concatenation): the same bits forward and backward, at the image prompt's 643 tokens and at 100."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(13)
+    H = 32
+    for S in (643, 100):
+        qkv = torch.randn((1, S, 3 * H * 128), generator=g, device=DEV).to(torch.bfloat16)
+        ang = torch.rand((S, 64), generator=g, device=DEV) * 6.28
+        cos = torch.cat([ang.cos(), ang.cos()], -1).to(torch.bfloat16)
+        sin = torch.cat([ang.sin(), ang.sin()], -1).to(torch.bfloat16)
+        do = torch.randn((1, S, H * 128), generator=g, device=DEV).to(torch.bfloat16)
+        assert ops.rotary_causal_attention_ok(qkv, cos.unsqueeze(0), H)
+        a = qkv.clone().requires_grad_()
+        out_a = ops.RotaryCausalAttentionFn.apply(a, cos, sin, H, 128 ** -0.5)
+        (ga,) = torch.autograd.grad(out_a, a, do)
+        b = qkv.clone().requires_grad_()
+        x = b.view(1, S, 3, H, 128)
+        qo, ko = ops.RoPE2Fn.apply(x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), cos.unsqueeze(0), sin.unsqueeze(0))
+        out_b = ops.CausalAttentionFn.apply(qo.squeeze(0).transpose(0, 1), ko.squeeze(0).transpose(0, 1), x[0, :, 2], 128 ** -0.5)
+        (gb,) = torch.autograd.grad(out_b.reshape(1, S, H * 128), b, do)
+        assert torch.equal(out_a, out_b.reshape(1, S, H * 128)) and torch.equal(ga, gb)
+    assert not ops.rotary_causal_attention_ok(qkv[:, :80], cos[:80].unsqueeze(0), H)          # the one-launch kernel's range
+    assert not ops.rotary_causal_attention_ok(qkv.float(), cos.unsqueeze(0).float(), H)
+
+
 # ------------------------------------------------------------------ bma_gemm_mid (round 4)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gemm_mid_matches_fp32_reference(dtype, monkeypatch):
