@@ -35,13 +35,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int DH = 128;
-constexpr int KS = DH / 32;       // k-steps of a product over the head dimension
-constexpr int NT = DH / 16;       // 16-dim tiles of an output
-constexpr int PITCH = DH + 16;    // elements per LDS row (row + 32 B: conflict-free row and transposing reads)
-constexpr int IMG = 32 * PITCH;   // one 32-row chunk image
+// per head width DH (64 or 128): KS = DH / 32 k-steps of a product over the head dimension, NT = DH / 16 16-dim tiles of an
+// output, PITCH = DH + 16 elements per LDS row (row + 32 B: conflict-free row and transposing reads), IMG = 32 * PITCH one
+// 32-row chunk image; a chunk is 32 * DH / 8 16-byte pieces, at most one per thread
 constexpr int NTHR = 512;         // 8 waves
-constexpr int ITEMS = 32 * (DH / 8) / NTHR;   // 16-byte pieces per thread per image (1)
 
 struct CArgs {
   const uint16_t *q, *k, *v, *o, *d_o;
@@ -79,33 +76,32 @@ __device__ __forceinline__ float rows_sum(float x) {
   return __uint_as_float(b.x) + __uint_as_float(b.y);
 }
 
-// ---- a 32-row chunk of a [rows][heads][128] tensor: L2 -> registers -> LDS image [32][PITCH] ---------------------------
+// ---- a 32-row chunk of a [rows][heads][DH] tensor: L2 -> registers -> LDS image [32][PITCH] ----------------------------
 struct Chunk {
-  uint4_t reg[ITEMS];
+  uint4_t reg;
 };
+template <int DH>
 __device__ __forceinline__ void fetch_chunk(Chunk& ch, const uint16_t* base, int64_t rs, int row0, int rows, int tid) {
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int idx = tid + it * NTHR;
-    int row = row0 + idx / (DH / 8);
-    const int piece = idx % (DH / 8);
-    row = row < rows ? row : rows - 1;                          // rows past the end repeat the last one (masked by the caller)
-    ch.reg[it] = *reinterpret_cast<const uint4_t*>(base + static_cast<int64_t>(row) * rs + 8 * piece);
-  }
+  if (32 * (DH / 8) < NTHR && tid >= 32 * (DH / 8)) return;
+  int row = row0 + tid / (DH / 8);
+  const int piece = tid % (DH / 8);
+  row = row < rows ? row : rows - 1;                            // rows past the end repeat the last one (masked by the caller)
+  ch.reg = *reinterpret_cast<const uint4_t*>(base + static_cast<int64_t>(row) * rs + 8 * piece);
 }
+template <int DH>
 __device__ __forceinline__ void stash_chunk(const Chunk& ch, uint16_t* img, int tid) {
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int idx = tid + it * NTHR;
-    *reinterpret_cast<uint4_t*>(img + (idx / (DH / 8)) * PITCH + 8 * (idx % (DH / 8))) = ch.reg[it];
-  }
+  if (32 * (DH / 8) < NTHR && tid >= 32 * (DH / 8)) return;
+  *reinterpret_cast<uint4_t*>(img + (tid / (DH / 8)) * (DH + 16) + 8 * (tid % (DH / 8))) = ch.reg;
 }
 // operand with the image's rows 16t .. 16t+15 as the M / N index and dims 32ks .. as k (lane: row r, dims 8g ..)
+template <int DH>
 __device__ __forceinline__ uint4_t row_frag(const uint16_t* img, int t, int ks, int r, int g) {
-  return *reinterpret_cast<const uint4_t*>(img + (16 * t + r) * PITCH + 8 * g + 32 * ks);
+  return *reinterpret_cast<const uint4_t*>(img + (16 * t + r) * (DH + 16) + 8 * g + 32 * ks);
 }
 // operand with dims 16dt .. 16dt+15 as the M index and the image's 32 rows as k, in the order pack_acc() leaves them
+template <int DH>
 __device__ __forceinline__ uint4_t tr_frag(const uint16_t* img, int dt, int r, int g) {
+  constexpr int PITCH = DH + 16;
   const int q4 = r >> 2, p4 = r & 3;
   const uint16_t* rd = img + (4 * g + q4) * PITCH + 4 * p4 + 16 * dt;
   const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(rd));
@@ -125,7 +121,8 @@ __device__ __forceinline__ uint4_t pack_acc(const float (&e)[2][4]) {
   p.w = bma::pack16<DT>(e[1][2], e[1][3]);
   return p;
 }
-// this lane's 32 dims (8g + 32ks ..) of row `row` of a [rows][H][128] tensor, as the K-contiguous operand of its column
+// this lane's dims (8g + 32ks ..) of row `row` of a [rows][H][DH] tensor, as the K-contiguous operand of its column
+template <int KS>
 __device__ __forceinline__ void load_row_frags(uint4_t (&f)[KS], const uint16_t* base, int64_t rs, int row, int g) {
   const uint16_t* p = base + static_cast<int64_t>(row) * rs + 8 * g;
 #pragma unroll
@@ -136,6 +133,7 @@ __device__ __forceinline__ void load_row_frags(uint4_t (&f)[KS], const uint16_t*
 // "still pending" into the loop and puts counted `s_waitcnt vmcnt` in front of their first uses INSIDE it -- waits which, from
 // the second trip on, drain the chunk prefetch that was issued a few instructions earlier.  A use in an empty asm statement
 // makes it wait here.
+template <int KS>
 __device__ __forceinline__ void landed(const uint4_t (&f)[KS]) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(f[ks]));
@@ -148,23 +146,27 @@ __device__ __forceinline__ void landed(const uint4_t (&f)[KS]) {
 struct Pair {
   Chunk x0, y0, x1, y1;                                          // (K, V) or (Q, dO) images of chunks 2t and 2t+1
 };
+template <int DH>
 __device__ __forceinline__ void fetch_pair(Pair& p, const uint16_t* xb, int64_t x_rs, const uint16_t* yb, int64_t y_rs, int t,
                                            int rows, int tid) {
-  fetch_chunk(p.x0, xb, x_rs, 64 * t, rows, tid);
-  fetch_chunk(p.y0, yb, y_rs, 64 * t, rows, tid);
-  fetch_chunk(p.x1, xb, x_rs, 64 * t + 32, rows, tid);
-  fetch_chunk(p.y1, yb, y_rs, 64 * t + 32, rows, tid);
+  fetch_chunk<DH>(p.x0, xb, x_rs, 64 * t, rows, tid);
+  fetch_chunk<DH>(p.y0, yb, y_rs, 64 * t, rows, tid);
+  fetch_chunk<DH>(p.x1, xb, x_rs, 64 * t + 32, rows, tid);
+  fetch_chunk<DH>(p.y1, yb, y_rs, 64 * t + 32, rows, tid);
 }
+template <int DH>
 __device__ __forceinline__ void stash_pair(const Pair& p, uint16_t* buf, int tid) {
-  stash_chunk(p.x0, buf, tid);
-  stash_chunk(p.y0, buf + IMG, tid);
-  stash_chunk(p.x1, buf + 2 * IMG, tid);
-  stash_chunk(p.y1, buf + 3 * IMG, tid);
+  constexpr int IMG = 32 * (DH + 16);
+  stash_chunk<DH>(p.x0, buf, tid);
+  stash_chunk<DH>(p.y0, buf + IMG, tid);
+  stash_chunk<DH>(p.x1, buf + 2 * IMG, tid);
+  stash_chunk<DH>(p.y1, buf + 3 * IMG, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int DH>
 __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
+  constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (K, V, K, V) images: chunks 2t, 2t+1
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
   const int half = w >> 2, wq = w & 3;
@@ -182,17 +184,18 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   const uint16_t* vb = a.v + static_cast<int64_t>(h) * a.v_hs;
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
-  const int chunks = (a.P + last + 1 + 31) >> 5;                   // keys 0 .. P + last
+  int chunks = (a.P + last + 1 + 31) >> 5;                         // keys 0 .. P + last
+  chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;   // (not causal: P is past every key)
   const int trips = (chunks + 1) >> 1;
   Pair pr;
-  fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
-  stash_pair(pr, lds, tid);
+  fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
+  stash_pair<DH>(pr, lds, tid);
   landed(qf);
   __syncthreads();
   for (int t = 0; t < trips; ++t) {
     const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    if (t + 1 < trips) fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
+    if (t + 1 < trips) fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
     const int c = 2 * t + half;
     if (c < chunks) {
       f32x4 s[2];
@@ -200,17 +203,17 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
       for (int kt = 0; kt < 2; ++kt) {
         s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
+        for (int ks = 0; ks < KS; ++ks) s[kt] = cmfma<DT>(row_frag<DH>(kl, kt, ks, r, g), qf[ks], s[kt]);
       }
       float e[2][4];
-      const bool edge = 32 * c + 31 > a.P + row0;                 // wave-uniform: some key of the chunk is masked for some query
+      const bool edge = 32 * c + 31 > a.P + row0 || 32 * c + 31 >= a.Lk;   // wave-uniform: some key of the chunk is masked for some query
       float cmax = NEG;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           float v = s[kt][rr];
-          if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) v = NEG;
+          if (edge && (32 * c + 16 * kt + 4 * g + rr > a.P + qrow || 32 * c + 16 * kt + 4 * g + rr >= a.Lk)) v = NEG;
           e[kt][rr] = v;
           cmax = vmax(cmax, v);
         }
@@ -239,10 +242,10 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
           }
         }
 #pragma unroll
-        for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag(vl, dt, r, g), pf, oacc[dt]);
+        for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag<DH>(vl, dt, r, g), pf, oacc[dt]);
       }
     }
-    if (t + 1 < trips) stash_pair(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
+    if (t + 1 < trips) stash_pair<DH>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
     __syncthreads();
   }
   // ---- the odd-chunk half hands (m, l, o) over through LDS; the even half merges and stores -------------------------------
@@ -275,8 +278,9 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int DH>
 __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
+  constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
   const int half = w >> 2, wq = w & 3;
@@ -311,11 +315,12 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   const uint16_t* vb = a.v + static_cast<int64_t>(h) * a.v_hs;
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
-  const int chunks = (a.P + last + 1 + 31) >> 5;
+  int chunks = (a.P + last + 1 + 31) >> 5;
+  chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;
   const int trips = (chunks + 1) >> 1;
   Pair pr;
-  fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
-  stash_pair(pr, lds, tid);
+  fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
+  stash_pair<DH>(pr, lds, tid);
   landed(qf);
   landed(dof);
   asm volatile("" ::"v"(lse2));
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   for (int t = 0; t < trips; ++t) {
     const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    if (t + 1 < trips) fetch_pair(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
+    if (t + 1 < trips) fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
     const int c = 2 * t + half;
     if (c < chunks) {
       f32x4 s[2], dp[2];
@@ -333,25 +338,25 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
         dp[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          s[kt] = cmfma<DT>(row_frag(kl, kt, ks, r, g), qf[ks], s[kt]);
-          dp[kt] = cmfma<DT>(row_frag(vl, kt, ks, r, g), dof[ks], dp[kt]);
+          s[kt] = cmfma<DT>(row_frag<DH>(kl, kt, ks, r, g), qf[ks], s[kt]);
+          dp[kt] = cmfma<DT>(row_frag<DH>(vl, kt, ks, r, g), dof[ks], dp[kt]);
         }
       }
       float e[2][4];
-      const bool edge = 32 * c + 31 > a.P + row0;
+      const bool edge = 32 * c + 31 > a.P + row0 || 32 * c + 31 >= a.Lk;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], a.scale_log2e, -lse2));
-          if (edge && 32 * c + 16 * kt + 4 * g + rr > a.P + qrow) p = 0.0f;
+          if (edge && (32 * c + 16 * kt + 4 * g + rr > a.P + qrow || 32 * c + 16 * kt + 4 * g + rr >= a.Lk)) p = 0.0f;
           e[kt][rr] = p * (dp[kt][rr] - delta) * a.scale;
         }
       const uint4_t dsf = pack_acc<DT>(e);
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag(kl, dt, r, g), dsf, dqacc[dt]);
+      for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag<DH>(kl, dt, r, g), dsf, dqacc[dt]);
     }
-    if (t + 1 < trips) stash_pair(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
+    if (t + 1 < trips) stash_pair<DH>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
     __syncthreads();
   }
   float* xch = reinterpret_cast<float*>(lds) + (wq * 64 + lane) * (4 * NT);
@@ -373,8 +378,9 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int DH>
 __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
+  constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (Q, dO, Q, dO) images: query chunks 2t, 2t+1
   __shared__ __attribute__((aligned(16))) float stat[2][2][64];       // per buffer and chunk: lse2 of its 32 queries, then delta
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   Pair pr;
   float st = 0.0f;
   auto fetch = [&](int t) {
-    fetch_pair(pr, qbase, a.q_rs, dobase, do_rs, t, a.Lq, tid);
+    fetch_pair<DH>(pr, qbase, a.q_rs, dobase, do_rs, t, a.Lq, tid);
     if (tid < 128) {                                               // lse2 and delta of the pair's 64 queries
       int qi = 64 * t + 32 * (tid >> 6) + (tid & 31);
       qi = qi < a.Lq ? qi : a.Lq - 1;
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
     }
   };
   auto stash = [&](int buf) {
-    stash_pair(pr, lds + 4 * IMG * buf, tid);
+    stash_pair<DH>(pr, lds + 4 * IMG * buf, tid);
     if (tid < 128) stat[buf][tid >> 6][tid & 63] = st;
   };
   fetch(t0);
@@ -432,8 +438,8 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
         dp[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          s[qt] = cmfma<DT>(row_frag(ql, qt, ks, r, g), kf[ks], s[qt]);
-          dp[qt] = cmfma<DT>(row_frag(dl, qt, ks, r, g), vf[ks], dp[qt]);
+          s[qt] = cmfma<DT>(row_frag<DH>(ql, qt, ks, r, g), kf[ks], s[qt]);
+          dp[qt] = cmfma<DT>(row_frag<DH>(dl, qt, ks, r, g), vf[ks], dp[qt]);
         }
       }
       float pe[2][4], de[2][4];
@@ -455,8 +461,8 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
       const uint4_t pf = pack_acc<DT>(pe), dsf = pack_acc<DT>(de);
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) {
-        dvacc[dt] = cmfma<DT>(tr_frag(dl, dt, r, g), pf, dvacc[dt]);
-        dkacc[dt] = cmfma<DT>(tr_frag(ql, dt, r, g), dsf, dkacc[dt]);
+        dvacc[dt] = cmfma<DT>(tr_frag<DH>(dl, dt, r, g), pf, dvacc[dt]);
+        dkacc[dt] = cmfma<DT>(tr_frag<DH>(ql, dt, r, g), dsf, dkacc[dt]);
       }
     }
     if (t + 1 < t1) stash(buf ^ 1);
@@ -492,7 +498,7 @@ int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_
   if (Lq < 0 || Lk < Lq || H <= 0) return BMA_EINVAL;
   if (!q || !k || !v) return BMA_EINVAL;
   if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
-  if (Dh != DH || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
+  if ((Dh != 64 && Dh != 128) || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
   for (int i = 0; i < n_strides; ++i)
     if (strides[i] % 8) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) % 16) return BMA_EALIGN;
@@ -501,9 +507,11 @@ int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_
 
 }  // namespace
 
+constexpr int kAllVisible = 1 << 28;      // CArgs::P when the attention is not causal: past every key
+
 extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
                                     const void* v, int64_t v_rs, int64_t v_hs, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
-                                    float scale, void* out, float* lse2, void* stream) {
+                                    int causal, float scale, void* out, float* lse2, void* stream) {
   const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
   const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
   if (rc != BMA_OK) return rc;
@@ -513,13 +521,15 @@ extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
   a.out = static_cast<uint16_t*>(out); a.lse2 = lse2;
   a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs;
-  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = static_cast<int>(Lk - Lq);
+  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = causal ? static_cast<int>(Lk - Lq) : kAllVisible;
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(H * ((Lq + 63) / 64)));
-  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) + 2.0 * static_cast<double>(Lk)) * H * DH);
-  if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16>), grid, dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16>), grid, dim3(NTHR), 0, st, a);
+  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) + 2.0 * static_cast<double>(Lk)) * H * Dh);
+  if (dtype == BMA_BF16 && Dh == 128) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 128>), grid, dim3(NTHR), 0, st, a);
+  else if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 64>), grid, dim3(NTHR), 0, st, a);
+  else if (Dh == 128) hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 128>), grid, dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 64>), grid, dim3(NTHR), 0, st, a);
   BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
@@ -527,13 +537,14 @@ extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, c
 
 extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
                                         const void* v, int64_t v_rs, int64_t v_hs, const void* out, const float* lse2,
-                                        const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype, float scale,
-                                        void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta, void* stream) {
+                                        const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype, int causal,
+                                        float scale, void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta,
+                                        void* stream) {
   const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
   const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
   if (rc != BMA_OK) return rc;
   if (!out || !lse2 || !d_out || !dq || !dk || !dv || !delta) return BMA_EINVAL;
-  if (d_row_stride < static_cast<int64_t>(H) * DH) return BMA_EINVAL;
+  if (d_row_stride < static_cast<int64_t>(H) * Dh) return BMA_EINVAL;
   if (d_row_stride % 8) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(dq) |
        reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 ||
@@ -542,8 +553,8 @@ extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_h
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (Lq == 0) {                                                  // no query: the keys' gradients are zero
     if (Lk > 0) {
-      if (hipMemset2DAsync(dk, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * DH * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
-      if (hipMemset2DAsync(dv, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * DH * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
+      if (hipMemset2DAsync(dk, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * Dh * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
+      if (hipMemset2DAsync(dv, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * Dh * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
     }
     return BMA_OK;
   }
@@ -553,17 +564,20 @@ extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_h
   a.dq = static_cast<uint16_t*>(dq); a.dk = static_cast<uint16_t*>(dk); a.dv = static_cast<uint16_t*>(dv);
   a.lse2 = const_cast<float*>(lse2); a.delta = delta;
   a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs; a.d_rs = d_row_stride;
-  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = static_cast<int>(Lk - Lq);
+  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = causal ? static_cast<int>(Lk - Lq) : kAllVisible;
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
   const dim3 gq(static_cast<unsigned>(H * ((Lq + 63) / 64))), gk(static_cast<unsigned>(H * ((Lk + 63) / 64)));
-  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (4.0 * static_cast<double>(Lq) + 4.0 * static_cast<double>(Lk)) * H * DH);
-  if (dtype == BMA_BF16) {
-    hipLaunchKernelGGL((causal_dq_kernel<BMA_BF16>), gq, dim3(NTHR), 0, st, a);       // writes delta for the next launch
-    hipLaunchKernelGGL((causal_dkv_kernel<BMA_BF16>), gk, dim3(NTHR), 0, st, a);
-  } else {
-    hipLaunchKernelGGL((causal_dq_kernel<BMA_F16>), gq, dim3(NTHR), 0, st, a);
-    hipLaunchKernelGGL((causal_dkv_kernel<BMA_F16>), gk, dim3(NTHR), 0, st, a);
-  }
+  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (4.0 * static_cast<double>(Lq) + 4.0 * static_cast<double>(Lk)) * H * Dh);
+#define BMA_CAUSAL_BWD(DT_, DH_)                                                                                          \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL((causal_dq_kernel<DT_, DH_>), gq, dim3(NTHR), 0, st, a); /* writes delta for the next launch */   \
+    hipLaunchKernelGGL((causal_dkv_kernel<DT_, DH_>), gk, dim3(NTHR), 0, st, a);                                          \
+  } while (0)
+  if (dtype == BMA_BF16 && Dh == 128) BMA_CAUSAL_BWD(BMA_BF16, 128);
+  else if (dtype == BMA_BF16) BMA_CAUSAL_BWD(BMA_BF16, 64);
+  else if (Dh == 128) BMA_CAUSAL_BWD(BMA_F16, 128);
+  else BMA_CAUSAL_BWD(BMA_F16, 64);
+#undef BMA_CAUSAL_BWD
   BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;

@@ -103,9 +103,9 @@ PROTOTYPES = {
     "bma_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                             c_size_t, c_void_p, c_int, c_void_p]),
     "bma_causal_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
-                                     c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+                                     c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bma_causal_attention_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
-                                         c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),
     "bma_gemm_mid_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bma_gemm_mid_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),

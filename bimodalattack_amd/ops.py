@@ -744,11 +744,11 @@ def _rows_heads(t: torch.Tensor):
 
 
 def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
-    """q (Lq, H, 128), k / v (Lk, H, 128) views, 16-bit, last dim contiguous, strides multiples of 8, the same heads on
-    both sides, Lq <= Lk (the queries are the last Lq positions)."""
+    """q (Lq, H, Dh), k / v (Lk, H, Dh) views with Dh 64 or 128, 16-bit, last dim contiguous, strides multiples of 8, the
+    same heads on both sides, Lq <= Lk (causal: the queries are the last Lq positions)."""
     if not (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype):
         return False
-    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[1:] != k.shape[1:] or q.shape[2] != 128:
+    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[1:] != k.shape[1:] or q.shape[2] not in (64, 128):
         return False
     if not (0 < q.shape[0] <= k.shape[0] <= CAUSAL_ATTENTION_MAX_TOKENS):
         return False
@@ -758,63 +758,64 @@ def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bo
     return True
 
 
-def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
-    """(out (Lq, H, 128) contiguous, lse2 (H, Lq) fp32) through bma_causal_attention (include/bma.h)."""
+def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, causal: bool = True):
+    """(out (Lq, H, Dh) contiguous, lse2 (H, Lq) fp32) through bma_causal_attention (include/bma.h); ``causal=False``: every
+    query sees every key (a vision tower)."""
     dev = _need_gpu(q, k, v)
     if not causal_attention_ok(q, k, v):
-        raise ValueError("causal_attention wants 16-bit (L, H, 128) views with a contiguous last dim, Lq <= Lk")
-    Lq, H, _ = q.shape
+        raise ValueError("causal_attention wants 16-bit (L, H, 64 | 128) views with a contiguous last dim, Lq <= Lk")
+    Lq, H, Dh = q.shape
     Lk = k.shape[0]
-    out = torch.empty((Lq, H, 128), dtype=q.dtype, device=dev)
+    out = torch.empty((Lq, H, Dh), dtype=q.dtype, device=dev)
     lse2 = torch.empty((H, Lq), dtype=torch.float32, device=dev)
     check("bma_causal_attention", lib.bma_causal_attention(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
-                                                           *_rows_heads(v), Lq, Lk, H, 128, _dt(q), float(scale), out.data_ptr(),
-                                                           lse2.data_ptr(), _stream(dev)))
+                                                           *_rows_heads(v), Lq, Lk, H, Dh, _dt(q), 1 if causal else 0, float(scale),
+                                                           out.data_ptr(), lse2.data_ptr(), _stream(dev)))
     return out, lse2
 
 
-def causal_attention_bwd(q, k, v, out, lse2, d_out, scale: float, into=None):
-    """(dq (Lq, H, 128), dk, dv (Lk, H, 128)) through bma_causal_attention_bwd: fresh contiguous tensors, or -- `into` a
-    (Lk, 3, H, 128) buffer with Lq == Lk -- views of it, the three written straight into the gradient of a fused q/k/v
+def causal_attention_bwd(q, k, v, out, lse2, d_out, scale: float, into=None, causal: bool = True):
+    """(dq (Lq, H, Dh), dk, dv (Lk, H, Dh)) through bma_causal_attention_bwd: fresh contiguous tensors, or -- `into` a
+    (Lk, 3, H, Dh) buffer with Lq == Lk -- views of it, the three written straight into the gradient of a fused q/k/v
     projection."""
     dev = _need_gpu(q, k, v)
-    Lq, H, _ = q.shape
+    Lq, H, Dh = q.shape
     Lk = k.shape[0]
     d_out = d_out.contiguous()
     if into is None:
-        dq = torch.empty((Lq, H, 128), dtype=q.dtype, device=dev)
-        dk = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
-        dv = torch.empty((Lk, H, 128), dtype=q.dtype, device=dev)
-        d_rs = H * 128
+        dq = torch.empty((Lq, H, Dh), dtype=q.dtype, device=dev)
+        dk = torch.empty((Lk, H, Dh), dtype=q.dtype, device=dev)
+        dv = torch.empty((Lk, H, Dh), dtype=q.dtype, device=dev)
+        d_rs = H * Dh
     else:
-        if Lq != Lk or into.shape != (Lk, 3, H, 128) or not into.is_contiguous() or into.dtype != q.dtype:
-            raise ValueError("`into` must be a contiguous (L, 3, H, 128) buffer of the operands' type with Lq == Lk")
+        if Lq != Lk or into.shape != (Lk, 3, H, Dh) or not into.is_contiguous() or into.dtype != q.dtype:
+            raise ValueError("`into` must be a contiguous (L, 3, H, Dh) buffer of the operands' type with Lq == Lk")
         dq, dk, dv = into[:, 0], into[:, 1], into[:, 2]
-        d_rs = 3 * H * 128
+        d_rs = 3 * H * Dh
     delta = torch.empty((H, Lq), dtype=torch.float32, device=dev)
     check("bma_causal_attention_bwd", lib.bma_causal_attention_bwd(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
                                                                    *_rows_heads(v), out.data_ptr(), lse2.data_ptr(), d_out.data_ptr(), Lq,
-                                                                   Lk, H, 128, _dt(q), float(scale), dq.data_ptr(), dk.data_ptr(),
-                                                                   dv.data_ptr(), d_rs, delta.data_ptr(), _stream(dev)))
+                                                                   Lk, H, Dh, _dt(q), 1 if causal else 0, float(scale), dq.data_ptr(),
+                                                                   dk.data_ptr(), dv.data_ptr(), d_rs, delta.data_ptr(), _stream(dev)))
     return dq, dk, dv
 
 
 class CausalAttentionFn(torch.autograd.Function):
-    """out (Lq, H, 128) = causal attention of q (Lq, H, 128) against k / v (Lk, H, 128), the queries being the last Lq
-    positions; the backward is two launches of the same library (no atomics)."""
+    """out (Lq, H, Dh) = attention of q (Lq, H, Dh) against k / v (Lk, H, Dh) -- causal with the queries as the last Lq
+    positions, or (``causal=False``) every key visible; the backward is two launches of the same library (no atomics)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
-        out, lse2 = causal_attention(q, k, v, scale)
+    def forward(ctx, q, k, v, scale, causal=True):
+        out, lse2 = causal_attention(q, k, v, scale, causal)
         ctx.save_for_backward(q, k, v, out, lse2)
-        ctx.scale = float(scale)
+        ctx.scale, ctx.causal = float(scale), bool(causal)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         q, k, v, out, lse2 = ctx.saved_tensors
-        dq, dk, dv = causal_attention_bwd(q, k, v, out, lse2, d_out, ctx.scale)
-        return dq, dk, dv, None
+        dq, dk, dv = causal_attention_bwd(q, k, v, out, lse2, d_out, ctx.scale, causal=ctx.causal)
+        return dq, dk, dv, None, None
 
 
 class RotaryCausalAttentionFn(torch.autograd.Function):

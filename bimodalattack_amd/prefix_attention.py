@@ -400,21 +400,21 @@ def causal_b1_attention(module, query, key, value, attention_mask=None, dropout:
     return out.transpose(1, 2).contiguous(), None
 
 
-def _own_causal(query, key, value, scale: float, dropout: float):
-    """(1, Lq, H, 128) through the hand-written causal attention pair (csrc/causal_attention.hip: forward 25 us and
-    backward 58 us at 643 tokens x 32 heads, where the library's pair and its helper launches take ~150), or None when the
-    call is not its shape: batch 1, the same 128-wide heads on both sides, 16-bit, the queries being the last Lq of the Lk
-    key positions, no dropout."""
+def _own_causal(query, key, value, scale: float, dropout: float, causal: bool = True):
+    """(1, Lq, H, Dh) through the hand-written attention pair (csrc/causal_attention.hip: forward 18 us and backward 53 us
+    at 643 tokens x 32 heads x 128, where the library's pair and its helper launches take ~150), or None when the call is not
+    its shape: batch 1, the same 64- or 128-wide heads on both sides, 16-bit, no dropout; causal with the queries as the
+    last Lq of the Lk key positions, or every key visible (a vision tower)."""
     from . import ops
-    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] != key.shape[1] or query.shape[3] != 128:
+    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] != key.shape[1] or query.shape[3] not in (64, 128):
         return None
     # (squeeze, not [0]: the backward of an index is a zero fill plus a copy per operand, of a squeeze nothing)
     q3, k3, v3 = query.squeeze(0).transpose(0, 1), key.squeeze(0).transpose(0, 1), value.squeeze(0).transpose(0, 1)
     if not ops.causal_attention_ok(q3, k3, v3):
         return None
     if torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad):
-        return ops.CausalAttentionFn.apply(q3, k3, v3, scale).unsqueeze(0)
-    return ops.causal_attention(q3, k3, v3, scale)[0].unsqueeze(0)
+        return ops.CausalAttentionFn.apply(q3, k3, v3, scale, causal).unsqueeze(0)
+    return ops.causal_attention(q3, k3, v3, scale, causal)[0].unsqueeze(0)
 
 
 NAME_TAIL = "bma_tail_grad"
@@ -490,6 +490,7 @@ def tail_grad_attention(module, query, key, value, attention_mask=None, dropout:
 NAME_VIS = "bma_padded_heads"
 PAD_HEADS_MIN_TOKENS = int(os.environ.get("BMA_PAD_HEADS_MIN_TOKENS", "1024"))
 TOWER_EFFICIENT_FIRST = os.environ.get("BMA_TOWER_EFFICIENT_FIRST", "1") not in ("0", "false", "False")
+OWN_TOWER_MAX_TOKENS = int(os.environ.get("BMA_OWN_TOWER_MAX_TOKENS", "1024"))
 
 
 def padded_width(head_dim: int, grad: bool) -> int:
@@ -514,6 +515,12 @@ def padded_heads_attention(module, query, key, value, attention_mask=None, dropo
     W = padded_width(Dh, grad) if S >= PAD_HEADS_MIN_TOKENS else Dh
     causal = bool(is_causal) and attention_mask is None and S > 1
     if W == Dh:
+        if attention_mask is None and B == 1 and S <= OWN_TOWER_MAX_TOKENS:
+            # CLIP's 577 tokens x 16 heads of 64 at batch 1: the hand-written pair (latency-bound shapes; a tower of
+            # thousands of tokens is arithmetic and stays with the library)
+            own = _own_causal(query, key, value, scale, dropout, causal=causal)
+            if own is not None:
+                return own, None
         if TOWER_EFFICIENT_FIRST and grad and attention_mask is None and query.dtype in (torch.bfloat16, torch.float16):
             # CLIP's 577 tokens x 16 heads of 64 with autograd: the efficient backend's forward + backward pair measures
             # 89 us against 101 us for the flash pair (MI355X)

@@ -282,21 +282,23 @@ int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y,
 /* bma_causal_attention / bma_causal_attention_bwd: causal self-attention of ONE sequence at batch 1 and its backward, for the
  *   gradient pass with the image in the prompt (a1, :953-1028 with PGD on: 599-644 tokens per layer) and for the rows
  *   behind a reused prefix (joint mode: 44 new tokens against 643 keys).  The Lq queries are the LAST Lq positions of the
- *   Lk keys: query i attends to keys 0 .. (Lk - Lq) + i.  q [Lq][H][128], k / v [Lk][H][128] through (row, head) strides in
- *   elements (multiples of 8; views of a fused projection are fine), H query heads = H key/value heads, Dh = 128, bf16 /
- *   f16, rotary already applied.  Forward: out [Lq][H][128] contiguous and lse2 [H][Lq] fp32 = log2 of the softmax
- *   denominator in units of the scaled scores (an opaque token for the backward).  Backward: dq [Lq][H][128], dk / dv
- *   [Lk][H][128] with rows d_row_stride elements apart (H*128 when contiguous; 3*H*128 writes the three straight into
- *   the gradient of a fused q/k/v projection) from d_out [Lq][H][128] contiguous; `delta` [H][Lq] fp32 is scratch.  Two launches (dq, then
+ *   Lk keys: query i attends to keys 0 .. (Lk - Lq) + i.  q [Lq][H][Dh], k / v [Lk][H][Dh] through (row, head) strides in
+ *   elements (multiples of 8; views of a fused projection are fine), H query heads = H key/value heads, Dh = 64 or 128, bf16 /
+ *   f16, rotary already applied.  causal = 0: every query sees every key (a vision tower's attention: CLIP's 577 tokens x 16
+ *   heads of 64).  Forward: out [Lq][H][Dh] contiguous and lse2 [H][Lq] fp32 = log2 of the softmax
+ *   denominator in units of the scaled scores (an opaque token for the backward).  Backward: dq [Lq][H][Dh], dk / dv
+ *   [Lk][H][Dh] with rows d_row_stride elements apart (H*128 when contiguous; 3*H*128 writes the three straight into
+ *   the gradient of a fused q/k/v projection) from d_out [Lq][H][Dh] contiguous; `delta` [H][Lq] fp32 is scratch.  Two launches (dq, then
  *   dk and dv), every output element with one owner: no atomics, bitwise reproducible.  Probabilities and score
  *   gradients are rounded to `dtype` before their products, as in a flash kernel. */
 int bma_causal_attention(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
                          int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, int64_t Lq,
-                         int64_t Lk, int H, int Dh, int dtype, float scale, void* out, float* lse2, void* stream);
+                         int64_t Lk, int H, int Dh, int dtype, int causal, float scale, void* out, float* lse2, void* stream);
 int bma_causal_attention_bwd(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
                              int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, const void* out,
                              const float* lse2, const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
-                             float scale, void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta, void* stream);
+                             int causal, float scale, void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta,
+                             void* stream);
 
 /* bma_gemm_mid: y[M][N] = x[M][K] . w[N][K]^T for the products of the batch-1 gradient pass when the image is part of the
  *   prompt (a1, :953-1028 with PGD on: 576 image rows + the text = 599-644 rows; the same shapes occur in the prefix

@@ -406,13 +406,69 @@ def test_gemm_nt_matches_fp32_reference(dtype, monkeypatch):
 
 
 # ------------------------------------------------------------------ bma_causal_attention (round 4)
-def _causal_reference(q, k, v, scale):
+def _causal_reference(q, k, v, scale, causal=True):
     """float64 attention of q (Lq,H,D) -- the LAST Lq positions -- against k, v (Lk,H,D)."""
     Lq, Lk = q.shape[0], k.shape[0]
     s = torch.einsum("qhd,khd->hqk", q, k) * scale
-    hidden = torch.arange(Lk, device=q.device)[None, :] > (Lk - Lq + torch.arange(Lq, device=q.device))[:, None]
-    p = s.masked_fill(hidden[None], float("-inf")).softmax(-1)
-    return torch.einsum("hqk,khd->qhd", p, v)
+    if causal:
+        hidden = torch.arange(Lk, device=q.device)[None, :] > (Lk - Lq + torch.arange(Lq, device=q.device))[:, None]
+        s = s.masked_fill(hidden[None], float("-inf"))
+    return torch.einsum("hqk,khd->qhd", s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_tower_attention_64_wide_heads_every_key_visible(dtype):
+    """The same kernels at head width 64 and with every key visible (causal = 0): CLIP's 577 tokens x 16 heads, lengths on and
+    off the block and chunk sizes, a causal 64-wide case; forward and backward against float64 on the same 16-bit
+    operands, the gradients also against the library's pair; bit-equal over repeated launches."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(14)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for H, L, Dh, causal in ((16, 577, 64, False), (2, 64, 64, False), (2, 33, 64, False), (2, 130, 128, False), (4, 100, 64, True),
+                             (2, 1, 64, False)):
+        qkv = torch.randn((L, 3 * H * Dh), generator=g, device=DEV).to(dtype)
+        q, k, v = (qkv[:, i * H * Dh:(i + 1) * H * Dh].view(L, H, Dh) for i in range(3))
+        assert ops.causal_attention_ok(q, k, v)
+        scale = Dh ** -0.5
+        qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+        o_ref = _causal_reference(qd, kd, vd, scale, causal)
+        do = torch.randn((L, H, Dh), generator=g, device=DEV).to(dtype)
+        gq, gk, gv = torch.autograd.grad(o_ref, (qd, kd, vd), do.double())
+        out, lse2 = ops.causal_attention(q, k, v, scale, causal)
+        dq, dk, dv = ops.causal_attention_bwd(q, k, v, out, lse2, do, scale, causal=causal)
+        rel = lambda a_, b_: float((a_.double() - b_).abs().max() / b_.abs().max().clamp_min(1e-2))      # noqa: E731
+        assert rel(out, o_ref.detach()) <= 3 * eps, (H, L, Dh, causal, rel(out, o_ref.detach()))
+        for name, mine, want in (("dq", dq, gq), ("dk", dk, gk), ("dv", dv, gv)):
+            assert rel(mine, want) <= 6 * eps, (name, H, L, Dh, causal, rel(mine, want))
+        if L > 1:
+            ql, kl, vl = (t.detach().clone().requires_grad_() for t in (q, k, v))
+            ol = torch.nn.functional.scaled_dot_product_attention(ql.transpose(0, 1)[None], kl.transpose(0, 1)[None], vl.transpose(0, 1)[None],
+                                                                  is_causal=causal, scale=scale)[0].transpose(0, 1)
+            lq, lk_, lv = torch.autograd.grad(ol, (ql, kl, vl), do)
+            for name, mine, theirs, want in (("dq", dq, lq, gq), ("dk", dk, lk_, gk), ("dv", dv, lv, gv)):
+                assert rel(mine, want) <= 1.5 * rel(theirs, want) + eps, (name, H, L, Dh, causal, rel(mine, want), rel(theirs, want))
+        again = ops.causal_attention_bwd(q, k, v, out, lse2, do, scale, causal=causal)
+        assert torch.equal(out, ops.causal_attention(q, k, v, scale, causal)[0]) and all(torch.equal(a_, b_) for a_, b_ in zip(again, (dq, dk, dv)))
+    # through the tower's attention-interface function: (1, H, S, 64) views of a fused projection, with and without autograd
+    from bimodalattack_amd import prefix_attention as pa
+    H, S = 16, 577
+    qkv = torch.randn((1, S, 3 * H * 64), generator=g, device=DEV).to(dtype).requires_grad_()
+    heads = lambda x: tuple(t.transpose(1, 2) for t in x.view(1, S, 3, H, 64).unbind(2))      # noqa: E731
+    do = torch.randn((1, S, H, 64), generator=g, device=DEV).to(dtype)
+    out, _ = pa.padded_heads_attention(None, *heads(qkv), scaling=0.125)
+    (g_own,) = torch.autograd.grad(out, qkv, do)
+    try:
+        ops.CAUSAL_ATTENTION = False
+        out_l, _ = pa.padded_heads_attention(None, *heads(qkv), scaling=0.125)
+        (g_lib,) = torch.autograd.grad(out_l, qkv, do)
+    finally:
+        ops.CAUSAL_ATTENTION = True
+    assert out.shape == (1, S, H, 64)
+    assert float((out.float() - out_l.float()).abs().max()) <= 4 * eps * float(out_l.float().abs().max())
+    assert float((g_own.float() - g_lib.float()).abs().max()) <= 8 * eps * float(g_lib.float().abs().max())
+    with torch.no_grad():
+        out_n, _ = pa.padded_heads_attention(None, *heads(qkv), scaling=0.125)
+    assert torch.equal(out_n, out.detach())
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -460,8 +516,8 @@ def test_causal_attention_forward_and_backward_match_float64(dtype):
             (torch.arange(Lk, device=DEV)[None, :] > (Lk - Lq + torch.arange(Lq, device=DEV))[:, None])[None], float("-inf")), -1) / 0.6931471805599453
         assert float((lse2.double() - ref_lse2.detach()).abs().max()) <= 1e-3
     # what it does not take
-    q64 = torch.zeros((10, 2, 64), device=DEV, dtype=dtype)
-    assert not ops.causal_attention_ok(q64, q64, q64)
+    q32 = torch.zeros((10, 2, 32), device=DEV, dtype=dtype)
+    assert not ops.causal_attention_ok(q32, q32, q32)                         # head widths 64 and 128 only
     q3 = torch.zeros((10, 2, 128), device=DEV, dtype=dtype)
     assert not ops.causal_attention_ok(q3, q3[:5], q3[:5])                       # more queries than keys
     assert not ops.causal_attention_ok(q3, torch.zeros((10, 1, 128), device=DEV, dtype=dtype), torch.zeros((10, 1, 128), device=DEV, dtype=dtype))
@@ -473,7 +529,7 @@ def test_causal_attention_under_autograd_in_a_graph_and_through_the_interface():
     """CausalAttentionFn against autograd through the library on views of one fused projection; the pair captured into a
     hipGraph and replayed; and the two attention-interface functions of the gradient pass (prefix_attention.py) handing
     (1, H, L, 128) tensors to it -- full causal, and 44 rows behind keys/values with autograd history -- and stepping aside
-    for grouped heads, other head widths and dropout."""
+    for grouped heads, head widths other than 64 / 128 and dropout."""
     from bimodalattack_amd import ops
     from bimodalattack_amd import prefix_attention as pa
     g = torch.Generator(device=DEV).manual_seed(12)
@@ -496,9 +552,9 @@ def test_causal_attention_under_autograd_in_a_graph_and_through_the_interface():
         ops.CAUSAL_ATTENTION = True
     assert float((out.float() - out_l.float()).abs().max()) <= 2 ** -6 * float(out_l.float().abs().max())
     assert float((g_own.float() - g_lib.float()).abs().max()) <= 2 ** -5 * float(g_lib.float().abs().max())
-    # refusals: grouped heads, 64-wide heads, dropout
+    # refusals: grouped heads, 32-wide heads, dropout
     assert pa._own_causal(q, k[:, :8], v[:, :8], 0.1, 0.0) is None
-    assert pa._own_causal(q[..., :64], k[..., :64], v[..., :64], 0.1, 0.0) is None
+    assert pa._own_causal(q[..., :32], k[..., :32], v[..., :32], 0.1, 0.0) is None
     assert pa._own_causal(q, k, v, 0.1, 0.1) is None
     # the tail behind a prefix with history: gradients reach the prefix keys/values and the new rows alike
     P, L = 599, 44
