@@ -227,6 +227,12 @@ void ragged_attn_kernel(const Args a) {
     }
   };
   fetch(0);
+  // The Q fragments must have LANDED before the loop: behind the lane-masked stores below hipcc's wait insertion still
+  // counts them as pending and puts `s_waitcnt vmcnt(3..0)` in front of the first S products of EVERY chunk -- waits which
+  // drain the next chunk's fetch, issued a few instructions earlier, before the current one is multiplied (round 4, seen in
+  // the ISA of csrc/causal_attention.hip first).  A use in an empty asm statement makes it wait here, once.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
   for (int c = 0; c < chunks; ++c) {
     if (c) __syncthreads();                               // the previous chunk's readers are done
 #pragma unroll
