@@ -483,7 +483,7 @@ def test_causal_attention_forward_and_backward_match_float64(dtype):
     g = torch.Generator(device=DEV).manual_seed(11)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     for H, Lq, Lk in ((32, 643, 643), (32, 599, 599), (32, 44, 643), (2, 100, 100), (2, 1, 33), (4, 64, 64), (2, 65, 200), (2, 81, 81),
-                      (2, 33, 32 + 33), (32, 1, 1)):
+                      (2, 33, 32 + 33), (32, 1, 1), (40, 700, 700), (1, 4096, 4096), (3, 17, 2049)):
         qkv = torch.randn((Lk, 3 * H * 128), generator=g, device=DEV).to(dtype)
         q = qkv[Lk - Lq:, :H * 128].view(Lq, H, 128)
         k = qkv[:, H * 128:2 * H * 128].view(Lk, H, 128)
