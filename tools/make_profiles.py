@@ -93,7 +93,7 @@ CASES = [
     ("gemm_nt/qkv_dX_65x4096x12288", "gemm_nt", "gemm_nt_kernel<1, 6, 2, 4, true>/threads65536", "bma_gemm_nt 65 x 4096 x 12288 bf16 (input gradient of the fused q/k/v product, 8-way split-K)"),
     ("gemm_mid/gate_up_dX_644x4096x22016", "gemm_mid", "gemm_mid_kernel<1, 7, 4, 3>/threads122880", "bma_gemm_mid 644 x 4096 x 22016 bf16 (input gradient of the fused gate/up product at 644 rows: 48 tiles of 224 x 256, K split 5 ways; the partials' second launch not included)"),
     ("gemm_mid/gate_up_644x22016x4096", "gemm_mid", "gemm_mid_kernel<1, 7, 4, 3>/threads142848", "bma_gemm_mid 644 x 22016 x 4096 bf16 (fused gate/up product at 644 rows: 255 whole tiles + the last column split 8 ways)"),
-    ("causal_attn/fwd_L643_H32", "causal_attn", "causal_fwd_kernel<1>/threads180224", "causal attention forward, 643 tokens x 32 heads x 128 at batch 1 (3.4 GFLOP: latency-bound)"),
+    ("causal_attn/fwd_L643_H32", "causal_attn", "causal_fwd_kernel<1, 128>/threads180224", "causal attention forward, 643 tokens x 32 heads x 128 at batch 1 (3.4 GFLOP: latency-bound)"),
     # library GEMMs (keys are matched by symbol prefix: the kernel name depends on the selection table)
     ("gemm/gate_up_17152x22016x4096", "gemm_gate_up_proj", "Cijk", "fused gate/up product of the C3 ragged candidate forward, 17152 x 22016 x 4096 bf16"),
     ("gemm/down_17152x4096x11008", "gemm_down_proj", "Cijk", "down_proj, 17152 x 4096 x 11008 bf16"),
