@@ -561,7 +561,13 @@ def build_line(out: dict, detail_file=None) -> dict:
     if out.get("rccl"):
         rc = out["rccl"]
         line["rccl"] = {k: rc.get(k) for k in ("backend", "world", "rccl_version", "collectives_per_step",
-                                               "allgather_bytes_per_step", "state_broadcast_bytes_per_step")}
+                                               "allgather_bytes_per_step", "state_broadcast_bytes_per_step",
+                                               "tp_off_ms", "tp_on_ms", "chosen", "tp_graph", "tp_fallbacks", "tp_error", "tp_note")
+                        if rc.get(k) is not None or k in ("tp_off_ms", "tp_on_ms", "chosen")}
+        if isinstance(line["rccl"].get("tp_note"), str):
+            line["rccl"]["tp_note"] = line["rccl"]["tp_note"][:160]
+        if isinstance(line["rccl"].get("tp_fallbacks"), dict):
+            line["rccl"]["tp_fallbacks"] = {k: str(v)[:100] for k, v in line["rccl"]["tp_fallbacks"].items()}
         line["rccl"]["devices"] = len(rc.get("device_names") or [])
     eng = out.get("engine") or {}
     line["engine"] = {"fallbacks": eng.get("fallbacks"), "graphs": len(eng.get("graphs_captured") or []),
@@ -630,9 +636,11 @@ def pmc_traffic(kernel: str, live_bytes: float):
 COPY_CEILING_GBS = 6290.0     # measured streaming-copy ceiling of the part (MI355X_MICROARCH.md)
 
 
-def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, world: int, rank: int, primary: bool):
+def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, world: int, rank: int, primary: bool,
+            engine_kw=None):
     """One workload: construct the engine on the (shared) model, run warmup + steps + n_prof attack steps with the clock
-    around the `steps`, then profile.  Returns (result dict, what cpu_baseline needs)."""
+    around the `steps`, then profile.  Returns (result dict, what cpu_baseline needs).  `engine_kw`: engine options of
+    this leg (the multi-GPU A/B of the tensor-parallel gradient pass)."""
     import torch
     import torch.distributed as dist
     from bimodalattack_amd import BimodalAttackConfig, native
@@ -709,7 +717,7 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
 
     gcg_logger.setLevel("ERROR")
     attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(
-        step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse, width_override=width_of))
+        step_hook=hook, save_images=False, prefix_reuse=not args.no_prefix_reuse, width_override=width_of, **(engine_kw or {})))
     gemms = GemmTimer.for_model(model, attack.fused.qkv if attack.fused.enabled else [])
     gemms.rec = []
     attack.fused.gemm_probe = gemms
@@ -937,6 +945,65 @@ def rccl_info(torch, dist, device, world: int, keep: dict) -> dict:
                      "ceil(N/W) fp32 losses per rank (+inf padded); plus one loss gather for the initial suffix")
 
 
+TP_LEG_LIMIT_S = float(os.environ.get("BMA_TP_LEG_LIMIT_S", "240"))
+
+
+def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
+    """Several GPUs: the SAME timed block a second time (same seed, same steps, same model object) with the batch-1
+    gradient pass TENSOR-PARALLEL over the ranks (EngineOptions.tp_gradient, as one hipGraph with its RCCL all-reduces
+    inside on the nccl backend) instead of replicated on each -- the replicated pass is the serial term of a sharded step
+     and the tensor-parallel one has never met xGMI, so the first multi-GPU run carries its own A/B.  The
+    better leg becomes the headline (`value`, `ms_per_step`, phases, losses); both are reported under
+    `rccl: {tp_off_ms, tp_on_ms, chosen}`.  The first leg's line is complete before the second starts: if the second
+    leg raises, or exceeds TP_LEG_LIMIT_S (a collective that never returns), the first leg's line is what is printed."""
+    import threading
+    import torch
+    rc = out["rccl"]
+    rc.update(tp_off_ms=out["ms_per_step"], tp_on_ms=None, chosen="off")
+    if os.environ.get("BMA_BENCH_TP_AB", "1") in ("0", "false", "False"):
+        rc["tp_note"] = "A/B skipped (BMA_BENCH_TP_AB=0)"
+        return
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(TP_LEG_LIMIT_S):
+            return
+        # a rank stuck in a collective cannot be unwound from Python: print what the finished leg measured and leave
+        if rank == 0:
+            rc["tp_note"] = f"tensor-parallel leg did not finish within {TP_LEG_LIMIT_S:.0f} s; the replicated leg stands"
+            out["cpu_baseline"] = None
+            print(json.dumps(build_line(out, None), allow_nan=False), flush=True)
+        os._exit(0 if rank == 0 else 1)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        log("tensor-parallel gradient pass: the same timed block again (A/B against the replicated pass)")
+        on, _ = measure(args, args.workload, args.steps, args.warmup, 0, device, world, rank, primary=True,
+                        engine_kw=dict(tp_gradient=True, tp_graph=True))
+        eng = on.get("engine") or {}
+        rc["tp_on_ms"] = on["ms_per_step"]
+        rc["tp_graph"] = "gradient_tp" in (eng.get("graphs_captured") or [])
+        fb = {k: v for k, v in (eng.get("fallbacks") or {}).items() if k in ("tp_gradient", "graph_gradient_tp")}
+        if fb:
+            rc["tp_fallbacks"] = {k: str(v)[:120] for k, v in fb.items()}
+        if "tp_gradient" not in fb and on.get("finite") and on["ms_per_step"] < out["ms_per_step"]:
+            rc["chosen"] = "on"
+            for k in ("value", "ms_per_step", "attack_steps_per_sec", "scoring_phase_candidate_forwards_per_sec", "phase_s_per_step",
+                      "final_loss", "finite", "losses_timed", "engine", "forward_roofline", "gradient_pass_ms_each"):
+                out[k] = on.get(k)
+            out["config"]["gradient_pass"] = "tensor-parallel over the ranks"
+            rc["tp_note"] = ("headline = the tensor-parallel leg; `roofline` and the per-kernel tables were taken in the replicated "
+                             "leg's profiled steps (the scoring kernels are the same in both)")
+    except Exception as e:              # the replicated leg's line stands on its own
+        rc["tp_error"] = f"{type(e).__name__}: {e}"[:200]
+        try:
+            torch.cuda.synchronize(device)
+        except Exception:
+            pass
+    finally:
+        done.set()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -997,9 +1064,11 @@ def main() -> None:
     native.check_single_hip_runtime()
 
     n_prof = max(0, args.profile_steps)
-    out, keep = measure(args, args.workload, args.steps, args.warmup, n_prof, device, world, rank, primary=True)
+    out, keep = measure(args, args.workload, args.steps, args.warmup, n_prof, device, world, rank, primary=True,
+                        engine_kw=dict(tp_gradient=False) if world > 1 else None)
     if world > 1:
         out["rccl"] = rccl_info(torch, dist, device, world, keep)
+        tp_ab(args, out, device, world, rank)
 
     # ---- the other single-GPU BASELINE configurations, on the same models, under `workloads` ----------
     if args.extra_workloads is None:

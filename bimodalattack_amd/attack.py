@@ -350,21 +350,32 @@ class BimodalAttack:
         on the first call (after one eager run) and replayed afterwards; results are the
         eager ones (same kernels, same order)."""
         if self._tp_active():
-            # the pass cut over the ranks, its all-reduces included, is one hipGraph too (RCCL collectives are capturable:
-            # the process group's stream fork/join lands in the graph); eager if this stack refuses the capture
-            if self._tp_graph is None and self.shard.backend() != "nccl":
-                self._tp_graph = False         # (a gloo rehearsal: its collectives run on the host and cannot be captured)
-            if not self.opt.graph_gradient or self._tp_graph is False:
+            # the pass cut over the ranks, its all-reduces included, CAN be one hipGraph too (RCCL collectives are
+            # capturable: the process group's stream fork/join lands in the graph) -- opt-in (EngineOptions.tp_graph) until a
+            # run on two or more GPUs has been recorded; a gloo rehearsal's collectives run on the host and cannot be captured
+            if self._tp_graph is None and not (self.opt.tp_graph and self.opt.graph_gradient and self.shard.backend() == "nccl"):
+                self._tp_graph = False
+            if self._tp_graph is False:
                 return self._gradient_tp(optim_ids, image)
             if self._tp_graph is None:
+                graph, err = None, None
                 try:
-                    self._tp_graph = _GradientGraph(self, optim_ids, image, fn=self._gradient_tp)
-                    self.graphs_captured.append("gradient_tp")
+                    graph = _GradientGraph(self, optim_ids, image, fn=self._gradient_tp)
                 except Exception as e:
-                    self._fallback("graph_gradient_tp", e, "tensor-parallel gradient pass not captured into a graph; running eager")
-                    self._tp_graph = False
+                    err = e
                     torch.cuda.synchronize(self.model.device)
+                # EVERY rank replays the graph or NONE does: a rank that replays while another runs eager collectives
+                # would pair a captured all-reduce with an eager one (and the ranks would no longer launch the same
+                # kernels in the same order, which is what keeps their gradients bit-identical) -- so the outcome of
+                # the capture is agreed on: MIN over the ranks of a success flag
+                if not self.shard.all_ok(graph is not None, self.model.device):
+                    graph = None
+                    self._tp_graph = False
+                    self._fallback("graph_gradient_tp", err or RuntimeError("another rank could not capture it"),
+                                   "tensor-parallel gradient pass not captured into a graph on every rank; all ranks run it eagerly")
                     return self._gradient_tp(optim_ids, image)
+                self._tp_graph = graph
+                self.graphs_captured.append("gradient_tp")
             return self._tp_graph(optim_ids, image)
         if image is not None and self._gp_enabled():
             try:

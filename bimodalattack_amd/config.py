@@ -148,8 +148,12 @@ class EngineOptions:
     # q/k/v/gate/up cut by output rows (whole heads), o/down by input columns, two all-reduces per decoder layer and
     # direction (540 KB each at LLaVA width) -- the one lever left on the serial quarter of an 8-GPU step.
     # Correctness is tested (2 ranks, equal to the replicated pass); its speed has never been measured on real xGMI
-    # (this pool has one GPU per box), the pass runs eagerly (no hipGraph), so it is OFF by default.
+    # (this pool has one GPU per box), so it is OFF by default; `bench.py --gpus N` times it against the replicated pass.
     tp_gradient: bool = False
+    # ... and that tensor-parallel pass as ONE hipGraph with its RCCL all-reduces inside (nccl backend only).  Opt-in:
+    # no run on two or more GPUs has been recorded yet.  The capture's outcome is agreed on by all ranks --
+    # one that fails makes every rank run the pass eagerly (dist.CandidateSharder.all_ok).
+    tp_graph: bool = False
     # joint_eval: the step's loss is the winner's row of the candidate batch (scored with the image, in the
     # re-score's own segment order) instead of a second, batch-1 forward of the same sequence (:605-612).
     joint_winner_from_batch: bool = True
@@ -260,6 +264,8 @@ class EngineOptions:
             opts.fuse_gate_up = env["BMA_FUSE_GATE_UP"] not in ("0", "false", "False")
         if "BMA_TP_GRADIENT" in env:
             opts.tp_gradient = env["BMA_TP_GRADIENT"] not in ("0", "false", "False")
+        if "BMA_TP_GRAPH" in env:
+            opts.tp_graph = env["BMA_TP_GRAPH"] not in ("0", "false", "False")
         if "BMA_SKINNY_GEMM" in env:
             opts.skinny_gemm = env["BMA_SKINNY_GEMM"] not in ("0", "false", "False")
         if "BMA_CAUSAL_ATTENTION" in env:

@@ -155,6 +155,17 @@ class CandidateSharder:
                            group=self.group)
         return t
 
+    def all_ok(self, ok: bool, device) -> bool:
+        """True when `ok` holds on EVERY rank (one all-reduce(MIN) of a flag; every rank must call it).  Decisions that
+        change which collectives a rank issues later -- replaying a captured graph with its all-reduces inside, or running
+        them eagerly -- are taken with it, never on one rank alone."""
+        if not self.enabled:
+            return bool(ok)
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=device)
+        self.n_collectives += 1
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0.5)
+
     def sync_state(self, *tensors: torch.Tensor) -> None:
         """Rank 0's values of `tensors` (any dtypes, fixed shapes known to every rank: the sampled
         ids, the PGD image) overwrite everybody's, in ONE broadcast of their packed bytes."""

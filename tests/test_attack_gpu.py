@@ -24,13 +24,15 @@ with open(os.path.join(os.path.dirname(__file__), "golden", "g5_meta.json")) as 
     META = json.load(_f)
 
 
-def run_case(name, **engine):
+def run_case(name, cfg_over=None, **engine):
+    """The golden case `name` through the engine; `cfg_over`: config fields changed for runs that are compared with each
+    other instead of with the golden (the many-rank rehearsal)."""
     from bimodalattack_amd import BimodalAttackConfig, run, synthetic as S
     m = META["cases"][name]
     model, tok, proc, image = S.tiny_case(m["kind"], device=DEV)
     tmp = tempfile.mkdtemp(prefix="bma_gpu_")
     cfg = BimodalAttackConfig(seed=1, verbosity="ERROR", optim_str_init=m["optim_str_init"], images_folder=tmp,
-                              **m["config"])
+                              **dict(m["config"], **(cfg_over or {})))
     trace = []
     engine.setdefault("strict", True)        # a fast path that silently gives up on these models is a failure
     res = run(model, tok, proc, m["goal"], m["goal"], m["target"], image, cfg,
@@ -64,6 +66,7 @@ def check_against_golden(golden_dir, name, m, res, trace, tmp, png=True):
     eps, alpha, k = cfg.get("eps", 0), cfg.get("alpha", 0), cfg.get("topk", 256)
     na = K.nonascii_tokens(S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, S.TINY_UNRT))
     diverged = False
+    diverged_at = None           # the step whose near-tied winner differs from the golden's: nothing after it is compared
     for i, st in enumerate(trace):
         # ---- (1) in-situ kernel parity -------------------------------------------------
         if "sampled" in st:
@@ -110,6 +113,7 @@ def check_against_golden(golden_dir, name, m, res, trace, tmp, png=True):
         nxt = z[f"s{i + 1}_optim_ids_in"] if i + 1 < m["steps"] else None
         if not exact and nxt is not None and not np.array_equal(trace[i + 1]["optim_ids_in"], nxt):
             diverged = True            # a near-tied candidate won: both continuations are valid
+            diverged_at = i
         if not diverged:
             np.testing.assert_allclose(st["current_loss"], z["losses"][i], rtol=1e-4)
     if not diverged:
@@ -128,12 +132,33 @@ def check_against_golden(golden_dir, name, m, res, trace, tmp, png=True):
         want = np.load(png)["png"]
         assert got.shape == want.shape and (got != want).mean() <= 0.005
         assert sorted(os.listdir(tmp)) == sorted(f"{i}.png" for i in range(m["steps"]))
+    _ALL_RUNS.append((name, diverged_at, len(trace)))
+    return diverged_at
+
+
+# how each base trajectory ended on THIS device: None = compared to its last step, i = the escape hatch opened at step i
+# (a near-tied candidate won and every later step went unchecked); audited by the test behind the parametrised one
+_DIVERGED_AT = {}
+_ALL_RUNS = []          # (case, diverged_at, steps) of EVERY check_against_golden call of the session (the last test of the file audits it)
 
 
 @pytest.mark.parametrize("name", sorted(META["cases"]))
 def test_trajectory_matches_reference(golden_dir, name):
     m, res, trace, tmp = run_case(name)
-    check_against_golden(golden_dir, name, m, res, trace, tmp)
+    _DIVERGED_AT[name] = check_against_golden(golden_dir, name, m, res, trace, tmp)
+
+
+def test_most_base_trajectories_are_compared_to_their_last_step():
+    """VERDICT r4 "What's weak" 2: `check_against_golden` stops comparing once a near-tied candidate wins a step
+    (legitimate: SURVEY.md 7 "argmin flips") -- so count how often that happens on this device.  At least 10 of the 13
+    base trajectories must be held to the reference to their LAST step; otherwise the goldens need regenerating with
+    margin.  (Runs behind the parametrised test above; skipped when that was deselected.)"""
+    if len(_DIVERGED_AT) < len(META["cases"]):
+        pytest.skip("the base trajectories were not all run in this session")
+    ended_early = {k: v for k, v in _DIVERGED_AT.items() if v is not None}
+    print(f"trajectories compared to their last step: {len(_DIVERGED_AT) - len(ended_early)} of {len(_DIVERGED_AT)}; "
+          f"diverged (near-tied winner) at: {ended_early}")
+    assert len(_DIVERGED_AT) - len(ended_early) >= min(10, len(_DIVERGED_AT)), ended_early
 
 
 @pytest.mark.parametrize("name", ["llava_joint", "opt_gcg", "gemma3_joint", "llava_pgd_gcg"])
@@ -500,7 +525,7 @@ def test_weights_changed_between_runs_are_picked_up():
 
 
 # ------------------------------------------------------------------ sharded engine, 2 ranks on one GPU
-def _sharded_worker(rank, world, port, name, out, backend="gloo"):
+def _sharded_worker(rank, world, port, name, out, backend="gloo", cfg_over=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if backend == "nccl":                                                 # RCCL: one GPU per rank
@@ -513,7 +538,7 @@ def _sharded_worker(rank, world, port, name, out, backend="gloo"):
     try:
         if backend != "nccl":
             torch.cuda.set_device(0)
-        m, res, trace, tmp = run_case(name)
+        m, res, trace, tmp = run_case(name, cfg_over)
         out.put((rank, res.losses, res.strings, [st["n_scored"] for st in trace],
                  [st["losses"][0].tolist() for st in trace if st["losses"]]))
     finally:
@@ -547,6 +572,47 @@ def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
         for a, b in zip(cand_losses, [st["losses"][0] for st in trace1 if st["losses"]]):
             np.testing.assert_allclose(a, b, rtol=1e-5)
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2]          # ranks agree bit for bit
+
+
+# Ranks of the many-rank rehearsal.  The driver's node has 8; a GPU box of this pool lets at most 6 processes use its one
+# card at a time and the test runner is one of them, so the rehearsal runs 4 ranks on a width that decays BELOW 4: the
+# same code paths as 8 ranks on a width decayed to 8 and thinned by the filter -- `per` = 1, empty
+# shares, the contiguous partition taking over from the dealt one.  The 8-rank partition / gather arithmetic itself runs
+# on the CPU (tests/test_dist_gloo.py::test_sharded_scoring_gloo[8]).
+MANY_RANKS = 4
+
+
+@pytest.mark.parametrize("name", ["llava_joint_dyn", "gemma3_joint_dyn", "llava_gcg"])
+def test_sharded_engine_more_ranks_than_candidates(name):
+    """BASELINE configs[3]/[4]'s tail in miniature: a dynamic width that decays to fewer candidates than there are ranks
+    (12, 10, 8, 6, 4, 2 over 4 ranks; the retokenisation filter thins it further): every rank returns the single-process
+    run -- strings, losses, candidates scored per step, every candidate's loss."""
+    import socket
+    import torch.multiprocessing as mp
+    over = dict(num_steps=6, search_width=12, dynamic_search=True, min_search_width=2, early_stop=False)
+    m, res1, trace1, _ = run_case(name, over)
+    widths = [st["sampled"].shape[0] for st in trace1]
+    assert widths == [12, 10, 8, 6, 4, 2] and min(st["n_scored"] for st in trace1) <= 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, MANY_RANKS, port, name, out, "gloo", over)) for r in range(MANY_RANKS)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, losses, strings, n_scored, cand_losses in got:
+        assert strings == res1.strings, f"rank {rank}"
+        np.testing.assert_allclose(losses, res1.losses, rtol=1e-5)
+        assert n_scored == [st["n_scored"] for st in trace1]
+        for a, b in zip(cand_losses, [st["losses"][0] for st in trace1 if st["losses"]]):
+            np.testing.assert_allclose(a, b, rtol=1e-5)
+    assert all(g[1] == got[0][1] and g[2] == got[0][2] for g in got)      # ranks agree bit for bit
 
 
 def _tp_worker(rank, world, port, name, out):
@@ -635,9 +701,16 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert d["finite"] is True and d["rccl"]["world"] == 2 and d["rccl"]["backend"] == "gloo"
     assert d["detail_file"] and os.path.exists(os.path.join(repo, d["detail_file"]))
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "candidates/2" and d["scaling"] == "strong"
-    # one loss gather for the initial suffix, then two collectives per step (ids broadcast + loss gather), 4 steps;
-    # from the second step on the draws made ahead of the gradient pass are broadcast as well (early_plan: 8 KB)
-    assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) + 3 and not d["engine"]["fallbacks"]
+    # the line carries its own A/B of the tensor-parallel gradient pass: both legs ran, one was chosen
+    rc = d["rccl"]
+    assert rc["tp_off_ms"] > 0 and rc["tp_on_ms"] > 0 and rc["chosen"] in ("off", "on") and "tp_error" not in rc, rc
+    assert rc.get("tp_graph") is False                     # (gloo: its collectives run on the host, nothing to capture)
+    assert d["ms_per_step"] == pytest.approx(min(rc["tp_off_ms"], rc["tp_on_ms"]) if rc["chosen"] == "on" else rc["tp_off_ms"], rel=1e-3)
+    if rc["chosen"] == "off":
+        # one loss gather for the initial suffix, then two collectives per step (ids broadcast + loss gather), 4 steps;
+        # from the second step on the draws made ahead of the gradient pass are broadcast as well (early_plan: 8 KB)
+        assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) + 3
+    assert not d["engine"]["fallbacks"]
     assert d["roofline"]["bound"] in ("mfma", "hbm") and d["value"] > 0
 
 
@@ -1017,6 +1090,226 @@ def test_gemma3_4b_gradient_matches_reference_call_shape():
           f"{err_img:.3e}, reference-bf16 {noise_img:.3e}")
     assert abs(float(first[2]) - f_loss) <= 1.5 * abs(b_loss - f_loss) + 2e-2 * abs(f_loss)
     assert err_tok <= 1.5 * noise_tok + 2e-3 and err_img <= 1.5 * noise_img + 2e-3
+
+
+def _plain_hf_gradient(model, atk, ids, image, norm):
+    """The reference's gradient pass (:953-1028) on the UNPATCHED HuggingFace modules: `model.get_image_features` called
+    as the reference calls it (:972-979) with the stock attention (no engine context of any kind), one-hot @ E.weight,
+    the llava segment order, full (1,S,V) logits, torch's mean cross-entropy on the shifted target slice."""
+    from bimodalattack_amd.hf_adapter import features_tensor
+    assert not any("forward" in m.__dict__ for m in model.modules()), "an engine patch is still on the model"
+    E = atk.embedding_layer
+    dt = E.weight.dtype
+    onehot = torch.nn.functional.one_hot(ids, num_classes=E.num_embeddings).to(dt).requires_grad_()
+    optim_embeds = onehot @ E.weight
+    img = image.detach().clone().requires_grad_()
+    feats = features_tensor(model.get_image_features(pixel_values=norm(img), vision_feature_layer=-2,
+                                                     vision_feature_select_strategy="default"))
+    parts = [atk.seg["before_img"].to(dt), feats.to(dt), atk.seg["before_suffix"].to(dt), optim_embeds, atk.seg["after"].to(dt),
+             atk.seg["target"].to(dt)]
+    x = torch.cat(parts, dim=1)
+    logits = model(inputs_embeds=x, use_cache=False).logits
+    shift = x.shape[1] - atk.T
+    loss = torch.nn.functional.cross_entropy(logits[0, shift - 1:-1, :], atk.target_ids[0])
+    g_tok, g_img = torch.autograd.grad(loss, [onehot, img])
+    return g_tok[0].detach().float(), g_img.detach().float(), float(loss.detach())
+
+
+class _KernelSpy:
+    """Counts what reaches the hand-written kernels' torch-side entry points while a block runs."""
+
+    def __init__(self):
+        from bimodalattack_amd import ops
+        self.ops, self.seen = ops, dict(causal_fwd=[], causal_bwd=[], gemm_mid=[], gemm_nt=[])
+
+    def __enter__(self):
+        ops, seen = self.ops, self.seen
+        self._fwd, self._bwd = ops.causal_attention, ops.causal_attention_bwd
+
+        def fwd(q, k, v, scale, causal=True):
+            seen["causal_fwd"].append((q.shape[0], k.shape[0], q.shape[1], q.shape[2], bool(causal)))
+            return self._fwd(q, k, v, scale, causal)
+
+        def bwd(q, k, v, *a, **kw):
+            seen["causal_bwd"].append((q.shape[0], k.shape[0], q.shape[1], q.shape[2], bool(kw.get("causal", True))))
+            return self._bwd(q, k, v, *a, **kw)
+
+        ops.causal_attention, ops.causal_attention_bwd = fwd, bwd
+        ops.GEMM_MID_HOOK = lambda x, w: seen["gemm_mid"].append((x.numel() // x.shape[-1], w.shape[0], w.shape[1]))
+        ops.GEMM_NT_HOOK = lambda x, w: seen["gemm_nt"].append((x.numel() // x.shape[-1], w.shape[0], w.shape[1]))
+        return self
+
+    def __exit__(self, *exc):
+        ops = self.ops
+        ops.causal_attention, ops.causal_attention_bwd = self._fwd, self._bwd
+        ops.GEMM_MID_HOOK = ops.GEMM_NT_HOOK = None
+        return False
+
+
+@pytest.mark.parametrize("workload", ["pgd", "joint"])
+def test_7b_image_gradient_bf16_matches_reference_call_shape(workload):
+    """the round-4 hot-path kernels IN COMPOSITION at BASELINE size (configs[1] and [3]) against the
+    reference's own formulation of the gradient pass (:953-1028) -- LLaVA-1.5-7B shape, bf16, 32 decoder layers, the
+    24-layer CLIP tower, the 643-row image prompt.  Engine = `compute_gradient` as the attack runs it (strict; hipGraph
+    replay; PGD-only: the one-sequence pass, joint: scoring prefix with history + tail), with the launches counted:
+    `bma_gemm_mid` (the 599-644-row products), `bma_causal_attention` at 128-wide heads causal (decoder) AND at 64-wide
+    heads with every key visible (the tower), `bma_gemm_nt` (joint: the 44-row tail).  Reference = the unpatched
+    HuggingFace modules called as the reference calls them, in bf16 and -- after `model.float()` -- in fp32.
+    Bars (measured yardstick, as for scoring): relative L2 of engine-vs-fp32 <= 1.5 x reference-bf16-vs-fp32 + 2e-3 for
+    the pixel gradient (and the token gradient in joint mode), the loss likewise, and the SIGN of the pixel gradient --
+    which is the PGD step (:1033) -- agrees with fp32's on the pixels that matter at least as often as the reference's
+    own bf16 pass does (-2 %), and with the reference-bf16 pass's on > 90 % of them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig, native
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+    joint = workload == "joint"
+    model, tok, proc, messages, goal, target, image, norm = build_plugins(workload, dev, torch.bfloat16, 32)
+    cfg = BimodalAttackConfig(num_steps=1, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=joint,
+                              joint_eval=joint, eps=64 / 255, alpha=4 / 255, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True))
+    atk._prepare_prompt(messages, target)
+    ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+    img = image.detach().clone().requires_grad_()
+
+    # ---- the engine, as the attack runs it: first call = eager warm-up (counted) + capture + replay; second = a replay
+    native.profile_enable(True)
+    with _KernelSpy() as spy, torch.enable_grad():
+        # (joint: the pass makes its own scoring prefix current for this image -- what step t's scoring call does in a run)
+        first = [None if t is None else t.detach().clone() for t in atk.compute_gradient(ids, img)]
+    torch.cuda.synchronize()
+    prof = native.profile_read()
+    native.profile_enable(False)
+    with torch.enable_grad():
+        again = atk.compute_gradient(ids, img)
+    assert not atk.fallbacks, atk.fallbacks
+    assert ({"grad_prefix", "grad_tail"} if joint else {"gradient"}) <= set(atk.graphs_captured), atk.graphs_captured
+    for a, b in zip(first, again):
+        if a is not None:                                   # no atomics on these routes: a replay reproduces the first run
+            assert bool(torch.isfinite(a.float()).all()) and torch.equal(a, b)
+    seen = spy.seen
+    dec_fwd = [c for c in seen["causal_fwd"] if c[3] == 128 and c[4]]
+    tower_fwd = [c for c in seen["causal_fwd"] if c[3] == 64 and not c[4]]
+    dec_bwd = [c for c in seen["causal_bwd"] if c[3] == 128 and c[4]]
+    tower_bwd = [c for c in seen["causal_bwd"] if c[3] == 64 and not c[4]]
+    # (eager warm-up + capture each run the pass once: counts are per pass x 2; the tower runs its first 23 layers --
+    # vision_feature_layer = -2 -- or all 24, depending on the transformers version)
+    n_pass = 2
+    assert len(tower_fwd) in (23 * n_pass, 24 * n_pass) and all(c[:3] == (577, 577, 16) for c in tower_fwd), tower_fwd[:3]
+    assert len(tower_bwd) == 23 * n_pass, len(tower_bwd)      # (the features come from layer -2: the last layer has no backward)
+    if joint:
+        assert len(dec_fwd) == 2 * 32 * n_pass and sorted(set(c[:2] for c in dec_fwd)) == [(44, 643), (599, 599)]
+        assert len([c for c in seen["gemm_nt"] if c[0] == 44]) >= 4 * 32 * n_pass
+        assert len([c for c in seen["gemm_mid"] if c[0] == 599]) >= 3 * 32 * n_pass
+    else:
+        assert len(dec_fwd) == 32 * n_pass and set(c[:3] for c in dec_fwd) == {(643, 643, 32)}
+        assert len([c for c in seen["gemm_mid"] if c[0] == 643]) >= 3 * 32 * n_pass
+    # (joint: the prefix rows' LAST-layer attention output feeds nothing -- the tail reads that layer's keys/values only --
+    # so it has no backward)
+    assert len(dec_bwd) == len(dec_fwd) - (n_pass if joint else 0), (len(dec_bwd), len(dec_fwd))
+    assert prof["gemm_mid"]["launches"] > 0 and prof["causal_attn"]["launches"] > 0
+    assert (prof["gemm_nt"]["launches"] > 0) == joint
+    g_tok = None if first[0] is None else first[0][0].float()
+    g_img, g_loss = first[1].float(), float(first[2])
+    del atk._grad_graph, atk._gp
+    atk._grad_graph = atk._gp = None
+
+    # ---- the reference's formulation on the same bf16 model, then on the same weights in fp32 ----------------------
+    with torch.enable_grad():
+        b_tok, b_img, b_loss = _plain_hf_gradient(model, atk, ids, image, norm)
+        segs16 = atk.seg
+        model.float()
+        atk.seg = {k_: v_.float() for k_, v_ in segs16.items()}
+        f_tok, f_img, f_loss = _plain_hf_gradient(model, atk, ids, image, norm)
+        atk.seg = segs16
+    rel = lambda a, b: float((a - b).norm() / b.norm())              # noqa: E731
+    big = f_img.abs() > 0.05 * f_img.abs().max()
+    agree = lambda a, b: float((torch.sign(a[big]) == torch.sign(b[big])).float().mean())   # noqa: E731
+    noise_img, err_img = rel(b_img, f_img), rel(g_img, f_img)
+    s_ref, s_eng, s_cross = agree(b_img, f_img), agree(g_img, f_img), agree(g_img, b_img)
+    msg = (f"7B image gradient pass, bf16, {workload}: loss engine {g_loss:.4f} reference-bf16 {b_loss:.4f} fp32 {f_loss:.4f}; pixel "
+           f"gradient rel-L2 vs fp32: engine {err_img:.3e}, reference-bf16 {noise_img:.3e}; sign agreement on {int(big.sum())} "
+           f"pixels > 5 % of max: engine-vs-fp32 {s_eng:.4f}, reference-bf16-vs-fp32 {s_ref:.4f}, engine-vs-reference-bf16 {s_cross:.4f}")
+    if joint:
+        noise_tok, err_tok = rel(b_tok, f_tok), rel(g_tok, f_tok)
+        msg += f"; token gradient rel-L2 vs fp32: engine {err_tok:.3e}, reference-bf16 {noise_tok:.3e}"
+    print(msg)
+    assert abs(g_loss - f_loss) <= 1.5 * abs(b_loss - f_loss) + 2e-2 * abs(f_loss)
+    assert err_img <= 1.5 * noise_img + 2e-3, (err_img, noise_img)
+    if joint:
+        assert err_tok <= 1.5 * noise_tok + 2e-3, (err_tok, noise_tok)
+    assert s_eng >= s_ref - 0.02 and s_cross > 0.90, (s_eng, s_ref, s_cross)
+    if s_ref > 0.99:
+        assert s_eng > 0.98, (s_eng, s_ref)
+
+
+def test_7b_pgd_only_steps():
+    """VERDICT r4 item 1, second half: BASELINE configs[1]'s own settings (PGD-only, eps 64/255, alpha 4/255) for six
+    steps at FULL size -- (A) the default engine (`bma_gemm_mid`, `bma_causal_attention` for decoder and tower, fused
+    PGD-only loop, hipGraph) against (B) the same engine with every round-4 kernel and the graph switched off
+    (library products, library attention, eager) and (C) the reference's loop itself on the plain HuggingFace modules
+    (:953-1037: gradient, x <- clamp(clamp(x - a*e*sign(g), x0 +- e), 0, 1), loss of the updated image).  Three bf16
+    computations of one function: A must sit as close to C as B does (x1.5 + margin) in the per-step losses and in the
+    share of pixels that took a different turn, every image stays within eps of the original and inside [0, 1]."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+
+    dev = torch.device(DEV)
+    steps, eps, alpha = 6, 64 / 255, 4 / 255
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("pgd", dev, torch.bfloat16, 32)
+    x0 = image.detach().clone()
+    runs = {}
+    for name, opts in (("default", {}),
+                       ("library", dict(mid_gemm=False, causal_attention=False, fuse_b1_attention=False, skinny_gemm=False,
+                                        graph_gradient=False))):
+        cfg = BimodalAttackConfig(num_steps=steps, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=False,
+                                  eps=eps, alpha=alpha, images_folder=tempfile.mkdtemp())
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True, **opts))
+        with _KernelSpy() as spy:
+            res = atk.run(messages, goal, target, x0.clone())
+        assert not atk.fallbacks, atk.fallbacks
+        n_own = len(spy.seen["gemm_mid"]) + len(spy.seen["causal_fwd"])
+        assert (n_own > 0) == (name == "default"), (name, n_own)
+        assert ("gradient" in atk.graphs_captured) == (name == "default")
+        runs[name] = (np.asarray(res.losses, dtype=np.float64), atk.final_image.detach().clone())
+        ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
+        keep = atk
+        del atk
+    # (C) the reference's loop on the plain modules: loss_i = loss of the image AFTER step i's update (:605-612)
+    x = x0.clone()
+    ref_losses = []
+    with torch.enable_grad():
+        for i in range(steps + 1):
+            _, g, loss = _plain_hf_gradient(model, keep, ids, x, norm)
+            if i > 0:
+                ref_losses.append(float(torch.tensor(loss).to(torch.bfloat16)))
+            if i < steps:
+                x = torch.clamp(torch.clamp(x - alpha * eps * torch.sign(g), x0 - eps, x0 + eps), 0, 1)
+    ref_losses = np.asarray(ref_losses)
+    la, lb = runs["default"][0], runs["library"][0]
+    xa, xb = runs["default"][1], runs["library"][1]
+    frac = lambda a, b: float((a != b).float().mean())              # noqa: E731
+    d_ac, d_bc, d_ab = frac(xa, x), frac(xb, x), frac(xa, xb)
+    e_a, e_b = np.abs(la - ref_losses).max(), np.abs(lb - ref_losses).max()
+    print(f"7B PGD-only, {steps} steps: losses default {la.round(4).tolist()} library {lb.round(4).tolist()} reference {ref_losses.round(4).tolist()}; "
+          f"pixels that differ after {steps} steps: default-vs-reference {d_ac:.4f}, library-vs-reference {d_bc:.4f}, default-vs-library {d_ab:.4f}")
+    for xi in (xa, xb):
+        assert bool(torch.isfinite(xi).all()) and float(xi.min()) >= 0.0 and float(xi.max()) <= 1.0
+        assert float((xi - x0).abs().max()) <= eps + 1e-6
+    assert np.isfinite(la).all() and np.isfinite(lb).all() and la.shape == (steps,)
+    assert e_a <= 1.5 * e_b + 2e-2 * np.abs(ref_losses).max(), (e_a, e_b)
+    assert d_ac <= 1.5 * d_bc + 0.005, (d_ac, d_bc)
+    # the trajectory goes somewhere: six steps of sign descent do not raise the loss (bf16 losses near 10: one unit in the last place is 0.0625)
+    assert la[-1] <= la[0] + 0.0625 and ref_losses[-1] <= ref_losses[0] + 0.0625
+    assert d_ab > 0.0 or np.array_equal(la, lb)      # (two different kernel sets: identical images would mean the switch did nothing)
 
 
 @pytest.mark.parametrize("width", [64, 512])
@@ -1542,8 +1835,9 @@ def test_tensor_parallel_gradient_pass_replays_from_a_hipgraph_under_rccl():
     """VERDICT r3 item 6(b).  ``tp_gradient`` (the batch-1 gradient pass cut over the ranks, two all-reduces per decoder
     layer and direction) captured into a hipGraph WITH its RCCL collectives inside, and replayed: one rank (RCCL cannot
     put two on one GPU) with the sharder's collective paths forced on, so every all-reduce is a real RCCL call on a
-    live communicator.  The graph is captured, no fallback is taken, and the run equals the same attack without a
-    process group.  Still off by default: its speed has never met xGMI."""
+    live communicator.  The graph is captured (opt-in: `tp_graph`; its outcome is agreed on by an all-reduce(MIN) over the
+    ranks), no fallback is taken, and the run equals the same attack without a process group.  Still off by default: its
+    speed has never met xGMI."""
     import socket
     import subprocess
     import sys
@@ -1568,7 +1862,7 @@ for grouped in (False, True):
                               eps=64 / 255, alpha=4 / 255, seed=3, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
                               early_stop=False, images_folder=tempfile.mkdtemp())
     atk = BimodalAttack(model, tok, proc, cfg, S.Normalize(S.CLIP_MEAN, S.CLIP_STD),
-                        EngineOptions.from_env(rng_device="cpu", strict=True, tp_gradient=grouped))
+                        EngineOptions.from_env(rng_device="cpu", strict=True, tp_gradient=grouped, tp_graph=grouped))
     if grouped:
         atk.shard.enabled = True
     res = atk.run("tell me a story", "tell me a story", "Sure here is a story", image)
@@ -1640,3 +1934,22 @@ print("RESULT " + json.dumps({str(k): v for k, v in out.items()}))
     assert "grad_tail" in b["graphs"] and "grad_prefix" in b["graphs"] and b["collectives"] >= 2 * 4
     assert a["strings"] == b["strings"]
     np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-5)
+
+
+def test_zz_every_golden_comparison_of_the_session_is_audited():
+    """The audit of `check_against_golden`'s escape hatch over the WHOLE session (the 13 base trajectories and the ~90
+    parametrised restructurings / sharded runs of this file): how many comparisons ran to their last step, how many ended
+    at a near-tied winner and where.  At least 80 % must run to the end, and the steps actually compared must be at least
+    85 % of the steps run."""
+    if len(_ALL_RUNS) < 20:
+        pytest.skip("too few golden comparisons in this session to audit")
+    early = [(n, d, s_) for n, d, s_ in _ALL_RUNS if d is not None]
+    steps = sum(s_ for _, _, s_ in _ALL_RUNS)
+    compared = sum((s_ if d is None else d + 1) for _, d, s_ in _ALL_RUNS)
+    by_case = {}
+    for n, d, _ in early:
+        by_case.setdefault(n, []).append(d)
+    print(f"golden comparisons: {len(_ALL_RUNS)}, to the last step: {len(_ALL_RUNS) - len(early)}; steps compared {compared} of {steps}; "
+          f"ended at a near-tied winner: {by_case}")
+    assert len(early) <= 0.2 * len(_ALL_RUNS), by_case
+    assert compared >= 0.85 * steps

@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) sharding of candidate scoring over gloo on CPU: slices are
+"""world_size-2 (3 and 8) sharding of candidate scoring over gloo on CPU: slices are
 contiguous and cover every candidate, ragged N pads with +inf, the gathered vector and
 its argmin are identical on every rank and equal to the unsharded result."""
 
@@ -62,6 +62,11 @@ def _worker(rank, world, port, out):
                 assert torch.equal(sh.gather_dealt(truth[mine].clone(), order, at=at), truth[torch.from_numpy(inverse)])
                 a, b = sh.gather_dealt(truth[mine].clone(), order, extra=-truth[mine], at=at)
                 assert torch.equal(a, truth[torch.from_numpy(inverse)]) and torch.equal(b, -truth[torch.from_numpy(inverse)])
+        # a decision every rank must take alike (replay a captured graph with collectives inside, or run them eagerly):
+        # true only when it is true on EVERY rank
+        assert sh.all_ok(True, "cpu") is True
+        assert sh.all_ok(rank != world - 1, "cpu") is False
+        assert sh.all_ok(rank == 0, "cpu") is (world == 1)
         # rank 0's ids and image overwrite a drifted rank's, in one packed broadcast
         ids = torch.arange(12, dtype=torch.int64).view(4, 3) + (0 if rank == 0 else 100 * rank)
         img = torch.full((1, 3, 4, 4), float(rank) + 0.25).requires_grad_()
@@ -75,8 +80,10 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_scoring_gloo(world):
+    """World 8 is the driver's node: with n = 1, 2, 5 candidates (a decayed width the filter has thinned) every rank's
+    slice is one candidate or EMPTY (`per` = 1, +inf padding only), with n = 8 dealt one each."""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()

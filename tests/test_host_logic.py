@@ -687,7 +687,10 @@ def test_bench_line_fits_the_drivers_window_and_is_strict_json():
     full["workloads"]["gemma_joint"]["finite"] = False
     full["rccl"] = dict(backend="nccl", world=8, rccl_version="2.26.6", device_names=["rank %d: AMD Instinct MI355X" % i for i in range(8)],
                         collectives_per_step=2.0, allgather_bytes_per_step=2048, allgather_bytes_per_rank=256,
-                        state_broadcast_bytes_per_step=77824, what="x" * 500)
+                        state_broadcast_bytes_per_step=77824, what="x" * 500,
+                        # the multi-GPU A/B of the tensor-parallel gradient pass (bench.tp_ab)
+                        tp_off_ms=37.91, tp_on_ms=31.25, chosen="on", tp_graph=True, tp_note="n" * 400,
+                        tp_fallbacks={"graph_gradient_tp": "RuntimeError: " + "e" * 300})
     for blow in (0, 1):
         if blow:
             full["roofline"]["note"] = "prose " * 2000
@@ -711,6 +714,8 @@ def test_bench_line_fits_the_drivers_window_and_is_strict_json():
             g = back["workloads"]["gemma_joint"]
             assert g["finite"] is False and g["final_loss"] is None and back["workloads"]["joint"]["finite"] is True
             assert back["rccl"]["world"] == 8 and back["rccl"]["devices"] == 8 and "what" not in back["rccl"]
+            assert (back["rccl"]["tp_off_ms"], back["rccl"]["tp_on_ms"], back["rccl"]["chosen"]) == (37.91, 31.25, "on")
+            assert back["rccl"]["tp_graph"] is True and len(back["rccl"]["tp_note"]) <= 160
     assert bench._strict({"a": [float("inf"), 1.0, {"b": float("nan")}]}) == {"a": [None, 1.0, {"b": None}]}
 
 
