@@ -1635,6 +1635,7 @@ class _GradPrefix:
             self._tail_fn()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        a.fused.register_gemm_chain()
         g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, capture_error_mode=_CAPTURE_MODE):
             feats, rec = self._prefix_fn()
@@ -1663,6 +1664,7 @@ class _GradientGraph:
             fn(self.ids, self.image)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        attack.fused.register_gemm_chain()     # the derived weight copies exist now: every skinny product learns its successor
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.out = fn(self.ids, self.image)

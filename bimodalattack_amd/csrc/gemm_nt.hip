@@ -61,8 +61,18 @@ struct GemmArgs {
   int M, N, K, S, m_tiles;
   int R;                   // rows of w per slab (<= 64 * NTW, a multiple of 4)
   int xcd;                 // 1: workgroup ids remapped so that the splits of a tile share an XCD (grid a multiple of 8)
-  int dbg;                 // measurement only (bma_gemm_nt_set_plan flags bit 2): 1 = stop after publishing the partial (wrong result)
+  int dbg;                 // -DBMA_NT_DEBUG builds only (bma_gemm_nt_set_plan flags bit 2): 1 = stop after publishing the partial (wrong result)
+  int fenced;              // bma_gemm_nt_set_plan flags bit 3: the split-K hand-off with an agent-scope release / acquire fence pair as well
+  // cross-product prefetch (bma_gemm_nt_next): the weight of the NEXT product of the chain and the decomposition its launch
+  // will use -- workgroups that leave early (every split of a tile but the last arriver) pull the first stages of the next
+  // launch's workgroups on their own XCD into the L2 while the reducers finish; nw == nullptr: none
+  const char* nw;
+  int64_t nldw;
+  int nN, nT, nS, nR, n_mtiles, nGrid, nXcd;
+  int main_grid;           // workgroups that compute; an unsplit launch that leaves CUs idle appends prefetch-only workgroups behind them
 };
+
+constexpr int kPrefetchStages = 4;      // the ring depth of the consumer: what its prologue and first step ask for
 
 template <int DT>
 __device__ __forceinline__ f32x4 mfma16(const uint4_t& a, const uint4_t& b, const f32x4& c) {
@@ -74,6 +84,36 @@ __device__ __forceinline__ f32x4 mfma16(const uint4_t& a, const uint4_t& b, cons
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// The first kPrefetchStages stages (128-byte lines) of the weight rows of every workgroup b' = blockIdx.x, blockIdx.x + grid,
+// ... of the NEXT launch: b' is congruent to this workgroup's id modulo 8, i.e. it will run on this XCD (workgroups are dealt
+// to the 8 XCDs round-robin), so the lines land in the L2 that will be asked for them; whatever that L2 drops before the
+// next launch starts is still in the Infinity Cache.  One 4-byte load per line, results discarded (the wave's end waits
+// for them: this workgroup has nothing else to do; the reducers it leaves behind are the launch's critical path).
+__device__ __forceinline__ void prefetch_next(const GemmArgs& a, int first, int stride) {
+  const int tid = threadIdx.x;
+  for (int b2 = first; b2 < a.nGrid; b2 += stride) {
+    int bid = b2;
+    if (a.nXcd) bid = (b2 & 7) * (a.nGrid >> 3) + (b2 >> 3);
+    const int split = bid % a.nS, tile = bid / a.nS;
+    const int n0 = (tile / a.n_mtiles) * a.nR;
+    int rows = a.nN - n0;
+    rows = rows < a.nR ? rows : a.nR;
+    const int t0 = static_cast<int>(static_cast<int64_t>(a.nT) * split / a.nS);
+    const int t1 = static_cast<int>(static_cast<int64_t>(a.nT) * (split + 1) / a.nS);
+    int st = t1 - t0;
+    st = st < kPrefetchStages ? st : kPrefetchStages;
+    if (rows <= 0 || st <= 0 || (tile % a.n_mtiles) != 0) continue;      // (a second row tile re-reads the first one's lines)
+    const int lines = rows * st;
+    for (int i = tid; i < lines; i += kNW * 64) {
+      const int r = i / st, k = i - r * st;
+      const char* p = a.nw + (static_cast<int64_t>(n0 + r) * a.nldw) * 2 + static_cast<int64_t>(t0 + k) * kRowB;
+      unsigned int sink;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // MT row tiles of x (64 or 96 rows), NTW 16-row tiles of w per wave (slabs of up to 128 or 192 rows), ST ring stages,
@@ -94,6 +134,13 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int bid = blockIdx.x;
+  if (bid >= a.main_grid) {
+    // a prefetch-only workgroup on a CU the unsplit product leaves idle: the e-th of them sits on XCD (main_grid + e) % 8
+    // and takes every (extra / 8)-th of the next launch's workgroups on that XCD
+    const int e = bid - a.main_grid, per_xcd = (static_cast<int>(gridDim.x) - a.main_grid) >> 3;
+    prefetch_next(a, (bid & 7) + 8 * (e >> 3), 8 * per_xcd);
+    return;
+  }
   if (a.xcd) bid = (bid & 7) * (static_cast<int>(gridDim.x) >> 3) + (bid >> 3);   // blocks b, b+8, ... share an XCD: one tile's splits
   const int split = bid % a.S;
   const int tile = bid / a.S;
@@ -213,7 +260,14 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
       for (int m = 0; m < MT; ++m)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, acc[j][m]), rsrc, lane * 16 + (j * MT + m) * 1024, 0, 16);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its own stores
+#ifdef BMA_NT_DEBUG
     if (a.dbg) return;
+#endif
+    // (the fenced variant -- flags bit 3 -- adds what the HIP memory model asks for on top: a release fence behind the
+    // stores and an acquire in front of the reducer's loads.  The default relies on gfx942 / gfx950 cache behaviour --
+    // sc1 stores are written through to the device-coherent level, sc1 loads bypass the CU's L1 -- and is held to the
+    // fenced one by tests/test_kernels_gpu.py::test_gemm_nt_split_k_handoff_under_alternating_operands.)
+    if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();                                            // (also: every wave is done with the stage ring)
     int* flag = reinterpret_cast<int*>(lds);
     if (tid == 0) {
@@ -223,7 +277,11 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
       *flag = last;
     }
     __syncthreads();
-    if (*flag == 0) return;
+    if (*flag == 0) {
+      if (a.nw) prefetch_next(a, blockIdx.x, gridDim.x);
+      return;
+    }
+    if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // Every partial -- this workgroup's own too -- is read back in split order, by sc1 loads (buffer_load_dwordx4 ... sc1:
     // past this CU's L1, which may hold stale lines of the workspace from an earlier launch) INSTEAD of an agent-scope
     // acquire in front of plain loads: valid because every byte was stored sc1, every storing wave drained before its
@@ -283,10 +341,20 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
 }
 
 constexpr int kMaxSplit = 16;
-constexpr int kCUs = 256;
+
+// compute units of the device the process runs on (256 on an MI355X; asked once -- the planner fills whole rounds of them)
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
 
 struct Plan {
-  int mt, m_tiles, ntw, R, slabs, S, xcd, ntl, dbg;
+  int mt, m_tiles, ntw, R, slabs, S, xcd, ntl, dbg, fenced;
 };
 
 // tuning override (bma_gemm_nt_set_plan): 0 = the planner's choice
@@ -299,6 +367,7 @@ int g_ntw = 0, g_R = 0, g_S = 0, g_flags = -1;
 // 172-row slabs on all 256 CUs (52 us) lost to one pass over 128-row slabs on 172 of them (42 us) for N = 22016, while
 // N = 4096 wants its eight splits.
 double plan_cost(int bm, int bn, int R, int wgs, int T, int S) {
+  const int kCUs = cu_count();
   const int rounds = (wgs + kCUs - 1) / kCUs;
   const double steps = static_cast<double>((T + S - 1) / S);
   (void)R;
@@ -322,7 +391,7 @@ bool make_plan(int M, int N, int K, Plan& p) {
     for (int S = 1; S <= kMaxSplit && S <= T; ++S) {
       if (g_S && S != g_S) continue;
       for (int rounds = 1; rounds <= 3; ++rounds) {
-        const int want = rounds * kCUs / (S * p.m_tiles);       // slabs that fill `rounds` rounds exactly
+        const int want = rounds * cu_count() / (S * p.m_tiles); // slabs that fill `rounds` rounds exactly
         for (int pass = 0; pass < 2; ++pass) {
           // (a slab shorter than the tile only to spread ONE pass over more CUs does not pay -- 251 slabs of 88 rows
           // measured slower than 172 of 128: the padding rows are fetched all the same -- so balanced heights only
@@ -344,6 +413,7 @@ bool make_plan(int M, int N, int K, Plan& p) {
   p.xcd = (flags & 1) && p.S > 1 && grid % 8 == 0;
   p.ntl = (flags & 2) ? 1 : 0;
   p.dbg = (flags & 4) ? 1 : 0;
+  p.fenced = (flags & 8) ? 1 : 0;
   return true;
 }
 
@@ -374,8 +444,11 @@ extern "C" int bma_gemm_nt_tiles(int M, int N, int K) {
   return p.slabs * p.m_tiles;
 }
 
-extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N,
-                           int K, int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream) {
+namespace {
+
+int launch_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K, int dtype,
+                   void* ws, size_t ws_bytes, int* counters, int n_counters, const void* next_w, int64_t next_ldw, int next_N,
+                   int next_K, void* stream) {
   if (M < 0 || N < 0 || K <= 0 || ldx < K || ldw < K || ldy < N) return BMA_EINVAL;
   if (M == 0 || N == 0) return BMA_OK;
   if (!x || !w || !y) return BMA_EINVAL;
@@ -391,16 +464,35 @@ extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ld
   if (p.S > 1) {
     if (!ws || !counters || ws_bytes < bma_gemm_nt_ws_bytes(M, N, K) || n_counters < tiles) return BMA_EINVAL;
   }
-  GemmArgs a;
+  int extra = 0;
+  GemmArgs a = {};
   a.x = static_cast<const char*>(x);
   a.w = static_cast<const char*>(w);
   a.y = static_cast<char*>(y);
   a.ws = static_cast<float*>(ws);
   a.cnt = counters;
   a.ldx = ldx; a.ldw = ldw; a.ldy = ldy;
-  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles; a.R = p.R; a.xcd = p.xcd; a.dbg = p.dbg;
+  a.M = M; a.N = N; a.K = K; a.S = p.S; a.m_tiles = p.m_tiles; a.R = p.R; a.xcd = p.xcd; a.dbg = p.dbg; a.fenced = p.fenced;
+  if (next_w) {
+    // the decomposition the NEXT launch will use (the same rows M: one pass, one row count)
+    if (next_N <= 0 || next_K <= 0 || next_K % kBK || next_ldw < next_K || (next_ldw * 2) % 16 ||
+        reinterpret_cast<uintptr_t>(next_w) % 16)
+      return BMA_EINVAL;
+    Plan q;
+    if (!make_plan(M, next_N, next_K, q)) return BMA_EINVAL;
+    // who prefetches: the workgroups a split launch lets go early (every split of a tile but its last arriver), or -- an
+    // unsplit launch on fewer workgroups than CUs (gate/up: 172 of 256) -- prefetch-only workgroups on the idle CUs
+    extra = p.S == 1 ? (cu_count() - tiles) / 8 * 8 : 0;
+    if (extra < 0) extra = 0;
+    if (p.S > 1 || extra > 0) {
+      a.nw = static_cast<const char*>(next_w);
+      a.nldw = next_ldw; a.nN = next_N; a.nT = next_K / kBK; a.nS = q.S; a.nR = q.R; a.n_mtiles = q.m_tiles;
+      a.nGrid = q.slabs * q.m_tiles * q.S; a.nXcd = q.xcd;
+    }
+  }
+  a.main_grid = tiles * p.S;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 grid(static_cast<unsigned>(tiles * p.S)), block(256);
+  const dim3 grid(static_cast<unsigned>(tiles * p.S + extra)), block(256);
   BMA_PROF_BEGIN(BMA_K_GEMM_NT, st, 2.0 * (static_cast<double>(M) * K + static_cast<double>(N) * K + static_cast<double>(M) * N));
 #define BMA_GEMM_GO3(DT_, MT_, NTW_)                                                                    \
   do {                                                                                                  \
@@ -421,4 +513,18 @@ extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ld
   BMA_PROF_END(BMA_K_GEMM_NT, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+}  // namespace
+
+extern "C" int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N,
+                           int K, int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream) {
+  return launch_gemm_nt(x, ldx, w, ldw, y, ldy, M, N, K, dtype, ws, ws_bytes, counters, n_counters, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int bma_gemm_nt_next(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N,
+                                int K, int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, const void* next_w,
+                                int64_t next_ldw, int next_N, int next_K, void* stream) {
+  return launch_gemm_nt(x, ldx, w, ldw, y, ldy, M, N, K, dtype, ws, ws_bytes, counters, n_counters, next_w, next_ldw, next_N,
+                        next_K, stream);
 }

@@ -418,6 +418,25 @@ class FusedInference:
             return y if m.bias is None else y + m.bias
         return forward
 
+    def register_gemm_chain(self) -> int:
+        """Tell ops.gemm_nt which weight FOLLOWS which in the batch-1 gradient pass (cross-product weight prefetch,
+        bma_gemm_nt_next): forward, per decoder layer, fused q/k/v -> fused gate/up -> down -> the next layer's q/k/v;
+        backward the transposed copies in reverse (down -> gate/up -> q/k/v -> the layer below's down).  o_proj sits
+        between q/k/v and gate/up on the library and is stepped over.  Called once the derived copies exist (after the
+        first eager pass, before a capture: a captured launch carries its successor's address).  Returns the links made."""
+        if not (self.enabled and self.layers and self.weight_copies and ops.GEMM_NT_PREFETCH):
+            return 0
+        fwd, bwd = [], []
+        for layer, _, _ in self.layers:
+            attn, mlp = getattr(layer, "self_attn", None), getattr(layer, "mlp", None)
+            down = getattr(getattr(mlp, "down_proj", None), "weight", None)
+            down = down if (torch.is_tensor(down) and down.is_cuda) else None
+            fwd += [self._copies.get(("wqkv", id(attn))), self._copies.get(("wgu", id(mlp))), down]
+            bwd.append([self._copies.get(("wt", id(getattr(mlp, "down_proj", None)))), self._copies.get(("wgu_t", id(mlp))),
+                        self._copies.get(("wqkv_t", id(attn)))])
+        back = [w for trio in reversed(bwd) for w in trio]
+        return ops.gemm_nt_chain(fwd) + ops.gemm_nt_chain(back)
+
     def tp_ok(self, world: int) -> bool:
         """Can the gradient pass be cut `world` ways?  Known layer structure (the fused layer forward carries the f
         operator), every projection width and head count divisible."""

@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 108
+ABI_VERSION = 109
 
 
 class BmaSegment(Structure):
@@ -102,6 +102,8 @@ PROTOTYPES = {
     "bma_gemm_nt_set_plan": (None, [c_int, c_int, c_int, c_int]),
     "bma_gemm_nt": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                             c_size_t, c_void_p, c_int, c_void_p]),
+    "bma_gemm_nt_next": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                 c_size_t, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "bma_causal_attention": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                      c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bma_causal_attention_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,

@@ -921,8 +921,41 @@ def gemm_nt_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
     return lib.bma_gemm_nt_ws_bytes(M, N, K) <= _GEMM_WS_BYTES and lib.bma_gemm_nt_tiles(M, N, K) <= _GEMM_COUNTERS
 
 
-def gemm_nt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """linear(x, w) = x @ w^T through bma_gemm_nt (include/bma.h); x (..., K) contiguous, w (N, K) contiguous."""
+# Cross-product weight prefetch (bma_gemm_nt_next): weight (by data pointer) -> the weight of the NEXT product of the
+# gradient pass's chain, registered by fused.FusedInference (forward: qkv -> gate/up -> down -> the next layer's qkv; backward:
+# the transposed copies in reverse).  Weights do not depend on activations, so the workgroups a split launch lets go early
+# load the first stages of the next launch's weight rows.  A hint only; empty = plain bma_gemm_nt.
+GEMM_NT_PREFETCH = _os.environ.get("BMA_GEMM_NT_PREFETCH", "1") not in ("0", "false", "False")
+_GEMM_NT_NEXT = {}
+
+
+def gemm_nt_chain(weights) -> int:
+    """Register `weights` (contiguous 16-bit (N, K) tensors, in launch order; None entries are skipped) as one chain: each
+    one's successor is prefetched by its launch.  Successors are held weakly (a derived weight copy that is rebuilt drops
+    out by itself); returns the number of links made."""
+    import weakref
+    ws = [w for w in weights if w is not None and w.dim() == 2 and w.is_contiguous() and w.shape[1] % 64 == 0
+          and w.dtype in (torch.bfloat16, torch.float16)]
+    for a, b in zip(ws[:-1], ws[1:]):
+        _GEMM_NT_NEXT[a.data_ptr()] = weakref.ref(b)
+    return max(0, len(ws) - 1)
+
+
+def gemm_nt_chain_clear() -> None:
+    _GEMM_NT_NEXT.clear()
+
+
+def _next_weight(w: torch.Tensor):
+    ref = _GEMM_NT_NEXT.get(w.data_ptr())
+    nxt = None if ref is None else ref()
+    if ref is not None and nxt is None:
+        del _GEMM_NT_NEXT[w.data_ptr()]
+    return nxt
+
+
+def gemm_nt(x: torch.Tensor, w: torch.Tensor, next_w: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear(x, w) = x @ w^T through bma_gemm_nt (include/bma.h); x (..., K) contiguous, w (N, K) contiguous.  `next_w`
+    (or the registered successor of `w`, ``gemm_nt_chain``): the weight of the next product, prefetched (bma_gemm_nt_next)."""
     dev = _need_gpu(x, w)
     if w.dim() != 2 or x.dim() < 1 or x.shape[-1] != w.shape[1] or x.dtype != w.dtype or x.dtype not in (torch.bfloat16, torch.float16) \
             or not x.is_contiguous() or not w.is_contiguous() or w.shape[1] % 64:
@@ -938,6 +971,14 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     if GEMM_NT_HOOK is not None:
         GEMM_NT_HOOK(x, w)
     y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=dev)
+    if next_w is None and GEMM_NT_PREFETCH:
+        next_w = _next_weight(w)
+    if next_w is not None and next_w.dtype == w.dtype and next_w.device == w.device and next_w.dim() == 2 and next_w.is_contiguous() \
+            and next_w.shape[1] % 64 == 0:
+        check("bma_gemm_nt_next", lib.bma_gemm_nt_next(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws.data_ptr(),
+                                                       ws.numel(), cnt.data_ptr(), cnt.numel(), next_w.data_ptr(), next_w.shape[1],
+                                                       next_w.shape[0], next_w.shape[1], _stream(dev)))
+        return y
     check("bma_gemm_nt", lib.bma_gemm_nt(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws.data_ptr(),
                                          ws.numel(), cnt.data_ptr(), cnt.numel(), _stream(dev)))
     return y

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 108 /* 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 109 /* 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -271,13 +271,26 @@ int bma_allgather_f32(const float* local, int64_t n_local, float* out, int rank,
  *   16-row w tiles per wave, w rows per slab, slabs, K splits, splits of a tile kept on one XCD (0/1), non-temporal w
  *   loads (0/1)}.  bma_gemm_nt_set_plan: measurement only (tools/gemm_bench.py --sweep) -- pins w tiles per wave /
  *   rows per slab / splits (0 = the planner's choice) and the two flags (bit 0 XCD grouping, bit 1 non-temporal; -1 =
- *   default) for every later call in the process; results never depend on it. */
+ *   default; bit 3: the split-K hand-off with an agent-scope release / acquire fence pair on top of the write-through
+ *   stores -- the form the HIP memory model asks for, ~2 us per split launch slower; the default relies on gfx942 /
+ *   gfx950 cache behaviour) for every later call in the process; results never depend on it.  Process-global and not
+ *   synchronised: not to be called while another thread sizes or launches a product.
+ * bma_gemm_nt_next: bma_gemm_nt that also knows the NEXT product of the caller's chain -- its weight next_w [next_N][next_ldw]
+ *   (next_K columns used), applied to the same M rows (the gradient pass walks qkv -> gate/up -> down -> the next layer's
+ *   qkv, and the transposed copies in reverse, bimodal_attack.py:1003, :1016-1025; weights do not depend on activations).
+ *   Workgroups of a split launch that leave early -- every split of a tile but the last arriver -- load the first four
+ *   64-column stages of the weight rows the next launch's workgroups on the same XCD will start with, so that launch finds
+ *   them in the L2 / Infinity Cache instead of ramping HBM up from idle.  A hint: results are those of bma_gemm_nt;
+ *   next_w == NULL is bma_gemm_nt.  Only addresses inside next_w [0, next_N) x [0, next_K) are touched. */
 size_t bma_gemm_nt_ws_bytes(int M, int N, int K);
 int bma_gemm_nt_tiles(int M, int N, int K);
 int bma_gemm_nt_plan(int M, int N, int K, int* out8);
 void bma_gemm_nt_set_plan(int w_tiles_per_wave, int rows_per_slab, int splits, int flags);
 int bma_gemm_nt(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
                 int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, void* stream);
+int bma_gemm_nt_next(const void* x, int64_t ldx, const void* w, int64_t ldw, void* y, int64_t ldy, int M, int N, int K,
+                     int dtype, void* ws, size_t ws_bytes, int* counters, int n_counters, const void* next_w,
+                     int64_t next_ldw, int next_N, int next_K, void* stream);
 
 /* bma_causal_attention / bma_causal_attention_bwd: causal self-attention of ONE sequence at batch 1 and its backward, for the
  *   gradient pass with the image in the prompt (a1, :953-1028 with PGD on: 599-644 tokens per layer) and for the rows

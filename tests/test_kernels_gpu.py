@@ -405,6 +405,91 @@ def test_gemm_nt_matches_fp32_reference(dtype, monkeypatch):
                                                      torch.zeros((4096, 22016), device=DEV, dtype=dtype))
 
 
+def test_gemm_nt_split_k_handoff_under_alternating_operands():
+    """the split-K hand-off has no release / acquire fence -- partials leave as write-through (sc1)
+    stores, the reducer reads them with sc1 loads -- which is sound under gfx950's cache behaviour, not under the HIP
+    memory model; and a test that re-runs IDENTICAL operands would pass on a stale partial of the previous launch.  So:
+    the same shape and plan with DIFFERENT operands on consecutive launches (two activations x two weights, alternating,
+    the workspace reused each time), splits 2..16, with the XCD grouping OFF (producer and reducer on different XCD L2s)
+    and on, thousands of launches; every result must equal, bit for bit, what the FENCED variant of the kernel (flags
+    bit 3: agent-scope release behind the stores, acquire in front of the reducer's loads) gives for those operands --
+    and a stale partial of the other operand pair could not."""
+    import ctypes
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    dev = torch.device(DEV)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, N, K = 65, 4096, 8192
+    xs = [torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16) for _ in range(2)]
+    ws = [(torch.randn((N, K), generator=g, device=DEV) * 0.05).to(torch.bfloat16) for _ in range(2)]
+    plan = (ctypes.c_int * 8)()
+    launches = 0
+    try:
+        for S in (2, 3, 4, 7, 8, 16):
+            want = {}
+            lib.bma_gemm_nt_set_plan(2, 128, S, 2 | 8)                     # fenced, no XCD grouping: the reference bits
+            assert lib.bma_gemm_nt_plan(M, N, K, plan) == 0 and plan[5] == S and plan[6] == 0
+            for i in range(2):
+                for j in range(2):
+                    want[i, j] = ops.gemm_nt(xs[i], ws[j]).clone()
+                    ref = xs[i].float() @ ws[j].float().t()
+                    assert float((want[i, j].float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+            assert not torch.equal(want[0, 0], want[1, 1]) and not torch.equal(want[0, 0], want[0, 1])
+            for flags in (2, 3):                                            # unfenced: XCD grouping off, then on
+                lib.bma_gemm_nt_set_plan(2, 128, S, flags)
+                lib.bma_gemm_nt_plan(M, N, K, plan)
+                assert plan[5] == S and plan[6] == (1 if (flags & 1) and (32 * S) % 8 == 0 else 0)
+                outs = []
+                n_iter = 400
+                for it in range(n_iter):
+                    i, j = it & 1, (it >> 1) & 1
+                    outs.append(((i, j), ops.gemm_nt(xs[i], ws[j])))
+                    if len(outs) == 50:                                     # compare in batches: the launches stay back to back
+                        for key, y in outs:
+                            assert torch.equal(y, want[key]), (S, flags, key)
+                        outs = []
+                launches += n_iter
+                _, cnt = ops.gemm_workspace(dev)
+                assert int(cnt.sum()) == 0
+    finally:
+        lib.bma_gemm_nt_set_plan(0, 0, 0, -1)
+    assert launches >= 4000
+
+
+def test_gemm_nt_next_weight_prefetch_changes_nothing():
+    """bma_gemm_nt_next: a launch told about the next product of its chain -- the workgroups a split
+    launch lets go early, or prefetch-only workgroups on the CUs an unsplit one leaves idle, load the first stages of the
+    next weight -- returns exactly what bma_gemm_nt returns, for every (this, next) pair of the pass's shapes (and odd ones:
+    a next weight smaller than one slab, fewer stages than the prefetch depth).  The hint reads rows [0, next_N) x columns
+    [0, next_K) of the next weight only, by construction (csrc/gemm_nt.hip prefetch_next: rows clipped to the slab's real
+    rows, stages to the split's own range); the weights here are views that start inside a larger block, so that a wrong
+    row pitch or base would at least read foreign data -- which cannot change a result either: the loads are discarded."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shapes = [(12288, 4096), (22016, 4096), (4096, 11008), (11008, 4096), (4096, 22016), (4096, 12288), (132, 128), (8, 64)]
+    for M in (65, 44, 1):
+        mats = {}
+        for N, K in shapes:
+            # carve the weight out of the END of a bigger block: rows past N do not belong to it
+            block = (torch.randn(((N + 7) * K,), generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+            mats[N, K] = block[7 * K:].view(N, K)
+        for (N, K), w in mats.items():
+            x = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
+            plain = ops.gemm_nt(x, w)
+            for (N2, K2), w2 in mats.items():
+                assert torch.equal(ops.gemm_nt(x, w, next_w=w2), plain), (M, N, K, N2, K2)
+    torch.cuda.synchronize()
+    # the registry form: a chain registered once, looked up by the weight's address
+    ws = [mats[12288, 4096], mats[22016, 4096], mats[4096, 11008]]
+    assert ops.gemm_nt_chain([ws[0], None, ws[1], ws[2]]) == 2
+    try:
+        x = torch.randn((65, 4096), generator=g, device=DEV).to(torch.bfloat16)
+        assert ops._next_weight(ws[0]) is ws[1] and ops._next_weight(ws[2]) is None
+        assert torch.equal(ops.gemm_nt(x, ws[0]), ops.gemm_nt(x, ws[0], next_w=ws[1]))
+    finally:
+        ops.gemm_nt_chain_clear()
+
+
 # ------------------------------------------------------------------ bma_causal_attention (round 4)
 def _causal_reference(q, k, v, scale, causal=True):
     """float64 attention of q (Lq,H,D) -- the LAST Lq positions -- against k, v (Lk,H,D)."""

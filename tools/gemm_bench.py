@@ -53,11 +53,16 @@ def main():
     ap.add_argument("--only", default=None, help="comma list of shape names")
     ap.add_argument("--sweep", action="store_true", help="time the kernel under pinned decompositions (bma_gemm_nt_set_plan): "
                     "the planner's choice with each flag combination, round 3's 128-row slabs, and neighbours")
+    ap.add_argument("--chain", action="store_true", help="the pass's own chain of skinny products (per layer forward qkv -> gate/up -> down, "
+                    "then backward through the transposed shapes in reverse) from one hipGraph, with and without the cross-product "
+                    "weight prefetch of bma_gemm_nt_next; per-product figures of the same-shape chains as well")
     ap.add_argument("--mid", action="store_true", help="bma_gemm_mid at a few hundred rows (default --rows 644,599 --layers 16) "
                     "instead of bma_gemm_nt; with --sweep also pinned tile widths / K splits / split tail columns")
     args = ap.parse_args()
     if args.mid:
         return main_mid(args)
+    if args.chain:
+        return main_chain(args)
     ops.GEMM_NT_MIN_K_OVER_N = 0.0                 # time the kernel on every shape, routed or not
     gemm_tuning.enable("auto", DEV)
     ops.gemm_workspace(DEV)
@@ -104,6 +109,60 @@ def main():
             print(f"{name:11s} M={M:3d} N={N:5d} K={K:5d}: library {l:7.1f} us ({nbytes / l / 1e6:4.2f} TB/s)   bma_gemm_nt {o:7.1f} us "
                   f"({nbytes / o / 1e6:4.2f} TB/s = {nbytes / o / 1e6 / 8.0:4.2f} of 8)   x{l / o:4.2f}", flush=True)
         del ws
+    if args.json:
+        json.dump(out, open(args.json, "w"), indent=1)
+
+
+def main_chain(args):
+    """A/B of the cross-product weight prefetch: (1) per product shape, `layers` different weights back to
+    back, each launch given its successor; (2) the pass's own order -- per layer qkv, gate/up, down forward, then per layer in
+    reverse down dX, gate/up dX, qkv dX -- as one hipGraph.  Kernel launches only (no norms / attention in between): an upper
+    bound on what the hint can buy in the pass."""
+    ops.GEMM_NT_MIN_K_OVER_N = 0.0
+    ops.GEMM_NT_PREFETCH = False                    # successors are passed explicitly here
+    gemm_tuning.enable("auto", DEV)
+    ops.gemm_workspace(DEV)
+    ops.gemm_workspace_for_graphs(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    rows = [int(r) for r in args.rows.split(",")]
+    layers = args.layers
+    names = ["qkv", "gate_up", "down", "down dX", "gate_up dX", "qkv dX"]
+    shapes = {n: (N, K) for n, N, K in SHAPES}
+    W = {n: [(torch.randn(shapes[n], generator=gen, device=DEV) * 0.02).to(torch.bfloat16) for _ in range(layers)] for n in names}
+    out = {}
+    for M in rows:
+        X = {K: torch.randn((1, M, K), generator=gen, device=DEV).to(torch.bfloat16) for K in {k for _, k in shapes.values()}}
+        for n in names:
+            ws = W[n]
+            x = X[shapes[n][1]]
+            plain = lambda: [ops.gemm_nt(x, w) for w in ws]                                              # noqa: E731
+            hinted = lambda: [ops.gemm_nt(x, w, next_w=ws[i + 1] if i + 1 < len(ws) else None) for i, w in enumerate(ws)]   # noqa: E731
+            tp, th = [], []
+            for _ in range(args.rounds):
+                tp.append(graph_time(plain, len(ws)))
+                th.append(graph_time(hinted, len(ws)))
+            a, b = statistics.median(tp), statistics.median(th)
+            nbytes = 2.0 * (M * shapes[n][1] + shapes[n][0] * shapes[n][1] + M * shapes[n][0])
+            out[f"{n} M={M}"] = dict(plain_us=a, prefetch_us=b, plain_TBps=nbytes / a / 1e6, prefetch_TBps=nbytes / b / 1e6)
+            print(f"{n:11s} M={M:3d}: plain {a:6.1f} us ({nbytes / a / 1e6:4.2f} TB/s)   with next-weight prefetch {b:6.1f} us "
+                  f"({nbytes / b / 1e6:4.2f} TB/s)   x{a / b:5.3f}", flush=True)
+        seq = []
+        for l in range(layers):
+            seq += [("qkv", l), ("gate_up", l), ("down", l)]
+        for l in reversed(range(layers)):
+            seq += [("down dX", l), ("gate_up dX", l), ("qkv dX", l)]
+        wl = [W[n][l] for n, l in seq]
+        xs = [X[shapes[n][1]] for n, _ in seq]
+        plain = lambda: [ops.gemm_nt(x, w) for x, w in zip(xs, wl)]                                       # noqa: E731
+        hinted = lambda: [ops.gemm_nt(x, w, next_w=wl[i + 1] if i + 1 < len(wl) else None) for i, (x, w) in enumerate(zip(xs, wl))]   # noqa: E731
+        tp, th = [], []
+        for _ in range(args.rounds):
+            tp.append(graph_time(plain, 1))
+            th.append(graph_time(hinted, 1))
+        a, b = statistics.median(tp), statistics.median(th)
+        out[f"pass chain M={M}"] = dict(plain_us=a, prefetch_us=b, launches=len(seq))
+        print(f"the pass's chain at {M} rows ({len(seq)} launches, {layers} layers): plain {a / 1e3:6.3f} ms   with prefetch {b / 1e3:6.3f} ms   "
+              f"x{a / b:5.3f}  ({(a - b) / len(seq):+.2f} us per launch)", flush=True)
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 
