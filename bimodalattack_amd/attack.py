@@ -57,6 +57,14 @@ if not logger.hasHandlers():
     logger.setLevel(logging.INFO)
 logger.propagate = False
 
+# Filter policy (reference :166-186 filters BEFORE it scores, :930-941).  Scoring every sampled candidate while the host runs
+# the tokenizer round trip, and masking afterwards, is free as long as (almost) every candidate survives; with a tokenizer
+# that rejects a share r of them, r of the scoring phase is wasted, while filtering first leaves the GPU idle for the round
+# trip.  Break-even survivor rate = 1 - world * (filter seconds / scoring seconds of one GPU): 4.5 ms against 168 ms at
+# search width 512 on an MI355X (profiles/r4_bench_driver.json: phase_s_per_step) -- 0.973 on one GPU, 0.79 on eight.
+FILTER_COST_RATIO = float(os.environ.get("BMA_FILTER_COST_RATIO", "0.027"))
+FILTER_RATE_STEPS = 4            # the survivor rate is the mean over this many steps
+
 TEMPLATE_PGD = "USER: <image>\n{{ messages[0]['content'][0]['text'] }} \nASSISTANT: "
 TEMPLATE_GCG = "{% for message in messages %}{{ message['content'] }}{% endfor %}"
 
@@ -570,6 +578,32 @@ class BimodalAttack:
             self._filter_pin = torch.empty(max(sampled.numel(), cfg.search_width * sampled.shape[1]), dtype=sampled.dtype,
                                            pin_memory=True)
         return sampled, FilterJob(sampled, self.tokenizer, cfg.filter_ids, pinned=self._filter_pin)
+
+    # ------------------------------------------------------------ filter policy
+    def _filter_first_now(self) -> bool:
+        """Run the retokenisation filter BEFORE scoring at this step?  ``EngineOptions.filter_first``: True / False force
+        it; None (default) decides from the survivor rate of the last FILTER_RATE_STEPS steps -- a quantity every rank
+        computes alike (all ranks filter the same ids), so sharded runs stay in step without a collective."""
+        cfg, mode = self.config, self.opt.filter_first
+        if not (cfg.gcg_attack and cfg.filter_ids):
+            return False
+        if mode is not None:
+            return bool(mode)
+        recent = self._keep_rates[-FILTER_RATE_STEPS:]
+        if not recent:
+            return False
+        world = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else self.shard.world
+        return sum(recent) / len(recent) < 1.0 - world * FILTER_COST_RATIO
+
+    def _filter_now(self, sampled: Tensor, job: FilterJob):
+        """The reference's order (:930-941, :166-186): the round trip runs NOW -- the host waits for the sampled ids --
+        and only the survivors go on to be scored.  Returns (survivors, a job that has nothing left to drop, the round
+        trip's own seconds)."""
+        keep = job.result()
+        self._keep_rates.append(len(keep) / max(1, sampled.shape[0]))
+        if len(keep) < sampled.shape[0]:
+            sampled = sampled.index_select(0, self._upload(np.asarray(keep, dtype=np.int64)))
+        return sampled, _AlreadyFiltered(sampled.shape[0]), job.seconds
 
     # ------------------------------------------------------------ scoring
     def _segments(self, order, feats):
@@ -1120,6 +1154,8 @@ class BimodalAttack:
             raise ValueError("pgd_attack=True needs an image")
 
         self.n_scored: List[int] = []          # candidates scored at each step
+        self.filter_first_steps: List[int] = []    # steps that ran the retokenisation filter BEFORE scoring (filter policy)
+        self._keep_rates: List[float] = []     # survivor rate of the filter, step by step
         self._warned_nonfinite = False
         self._prepare_prompt(messages, target)
         buffer = self.init_buffer(image)
@@ -1244,6 +1280,20 @@ class BimodalAttack:
                                                                image if (cfg.pgd_attack and not image_synced) else None)
                     if cfg.gcg_attack:
                         samp_time = self._sync() - t0
+                if self._filter_first_now():
+                    # a tokenizer that rejects a real share of the candidates: filter first, score the survivors only.  (In
+                    # joint mode the image features and the prefix pass -- which need no ids -- are queued in front of the
+                    # wait, so the GPU has that much to do while the host runs the round trip.)
+                    if cfg.pgd_attack and cfg.joint_eval and self._gp_enabled() and self._gp not in (None, False):
+                        with torch.no_grad():
+                            self.scoring_features(image)       # (cached: the scoring call below gets the same tensors back)
+                    sampled_all, job, filt_s = self._filter_now(sampled_all, job)
+                    self.filter_first_steps.append(i)
+                    virtual = None              # the plan made from the draws counted candidates that are gone now
+                    if flying is not None:
+                        flying = (flying[0], flying[1] + filt_s, flying[2])
+                    else:
+                        samp_time += filt_s
                 if cfg.gcg_attack:
                     if st is not None:
                         st["sampled"] = self._last["sampled"].cpu().numpy()
@@ -1259,6 +1309,8 @@ class BimodalAttack:
                         scored, to the losses: the reference's filtered vector, in order.  `defer_hit`: the
                         early-stop verdict is handed back as a device tensor instead of being read here."""
                         keep = job.result()
+                        if getattr(job, "enabled", False):
+                            self._keep_rates.append(len(keep) / max(1, loss_all.shape[0]))
                         if len(keep) == loss_all.shape[0]:
                             idx = None
                             out = loss_all, sampled_all
@@ -1701,6 +1753,18 @@ class _ReplayGraph:
                 dst.copy_(src)
         self.graph.replay()
         return self.out
+
+
+class _AlreadyFiltered:
+    """Stands in for the step's FilterJob once the round trip has run (filter-first): every candidate left is a survivor."""
+    seconds = waited = 0.0
+    enabled = False
+
+    def __init__(self, n: int):
+        self.n = n
+
+    def result(self) -> List[int]:
+        return list(range(self.n))
 
 
 class _Solo:

@@ -191,6 +191,11 @@ class EngineOptions:
     # where the real candidates must; the real ids never visit the host before the forward (the retokenisation filter
     # still gets its copy, beside the forward), they are gathered on the device.
     early_plan: bool = True
+    # The retokenisation filter (reference :166-186) BEFORE scoring, as the reference runs it, instead of beside it with the
+    # losses masked afterwards: True / False force one order; None (default) picks per step from the filter's survivor rate
+    # over the last steps -- score-everything while (almost) everything survives, filter-first once a real share is
+    # rejected (attack.FILTER_COST_RATIO: below 97 % on one GPU, 79 % on eight).  Same winners either way.
+    filter_first: Optional[bool] = None
     # Before the first step: one product of every decoder projection shape at every row count the run's ragged forwards
     # can meet (layout.expected_row_counts), so that the library's lazy loading of a kernel it has not used in this process
     # -- ~39 ms the first time a new row count shows up -- happens in set-up and not inside a step.
@@ -292,6 +297,8 @@ class EngineOptions:
             opts.gradient_ahead = env["BMA_GRADIENT_AHEAD"] not in ("0", "false", "False")
         if "BMA_EARLY_PLAN" in env:
             opts.early_plan = env["BMA_EARLY_PLAN"] not in ("0", "false", "False")
+        if "BMA_FILTER_FIRST" in env:
+            opts.filter_first = env["BMA_FILTER_FIRST"] not in ("0", "false", "False")
         if "BMA_WARM_GEMMS" in env:
             opts.warm_gemms = env["BMA_WARM_GEMMS"] not in ("0", "false", "False")
         if "BMA_CHUNK_QUANTUM" in env:

@@ -80,18 +80,30 @@ __device__ __forceinline__ float rows_sum(float x) {
 struct Chunk {
   uint4_t reg;
 };
-template <int DH>
+// (DR: the head's REAL width in memory, DH: the width of its LDS image and of the products -- DR = 72, SigLIP's heads, rides
+// in 96-wide images whose last 24 columns are zero: zero dims add nothing to q.k and give zero outputs, which are not stored)
+template <int DH, int DR>
 __device__ __forceinline__ void fetch_chunk(Chunk& ch, const uint16_t* base, int64_t rs, int row0, int rows, int tid) {
-  if (32 * (DH / 8) < NTHR && tid >= 32 * (DH / 8)) return;
-  int row = row0 + tid / (DH / 8);
-  const int piece = tid % (DH / 8);
+  if (32 * (DR / 8) < NTHR && tid >= 32 * (DR / 8)) return;
+  int row = row0 + tid / (DR / 8);
+  const int piece = tid % (DR / 8);
   row = row < rows ? row : rows - 1;                            // rows past the end repeat the last one (masked by the caller)
   ch.reg = *reinterpret_cast<const uint4_t*>(base + static_cast<int64_t>(row) * rs + 8 * piece);
 }
-template <int DH>
+template <int DH, int DR>
 __device__ __forceinline__ void stash_chunk(const Chunk& ch, uint16_t* img, int tid) {
-  if (32 * (DH / 8) < NTHR && tid >= 32 * (DH / 8)) return;
-  *reinterpret_cast<uint4_t*>(img + (tid / (DH / 8)) * (DH + 16) + 8 * (tid % (DH / 8))) = ch.reg;
+  if (32 * (DR / 8) < NTHR && tid >= 32 * (DR / 8)) return;
+  *reinterpret_cast<uint4_t*>(img + (tid / (DR / 8)) * (DH + 16) + 8 * (tid % (DR / 8))) = ch.reg;
+}
+// the columns DR .. DH-1 of `n_img` chunk images, once, before the first stash (a stash never touches them)
+template <int DH, int DR>
+__device__ __forceinline__ void zero_pad_columns(uint16_t* lds, int n_img, int tid) {
+  if (DR == DH) return;
+  constexpr int PP = (DH - DR) / 8;                              // 16-byte pad pieces per row
+  for (int i = tid; i < n_img * 32 * PP; i += NTHR) {
+    const int row = i / PP, piece = i % PP;                      // row over all images: the images are contiguous, 32 rows each
+    *reinterpret_cast<uint4_t*>(lds + row * (DH + 16) + DR + 8 * piece) = uint4_t{0u, 0u, 0u, 0u};
+  }
 }
 // operand with the image's rows 16t .. 16t+15 as the M / N index and dims 32ks .. as k (lane: row r, dims 8g ..)
 template <int DH>
@@ -122,11 +134,14 @@ __device__ __forceinline__ uint4_t pack_acc(const float (&e)[2][4]) {
   return p;
 }
 // this lane's dims (8g + 32ks ..) of row `row` of a [rows][H][DH] tensor, as the K-contiguous operand of its column
-template <int KS>
+template <int KS, int DR>
 __device__ __forceinline__ void load_row_frags(uint4_t (&f)[KS], const uint16_t* base, int64_t rs, int row, int g) {
   const uint16_t* p = base + static_cast<int64_t>(row) * rs + 8 * g;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) f[ks] = *reinterpret_cast<const uint4_t*>(p + 32 * ks);
+  for (int ks = 0; ks < KS; ++ks) {
+    if (32 * ks + 32 <= DR || 8 * g + 32 * ks < DR) f[ks] = *reinterpret_cast<const uint4_t*>(p + 32 * ks);
+    else f[ks] = uint4_t{0u, 0u, 0u, 0u};                        // dims past the real width: the image's zero columns
+  }
 }
 
 // The operands a wave loads ONCE must have landed before the chunk loop is entered: hipcc's wait insertion otherwise carries
@@ -146,25 +161,30 @@ __device__ __forceinline__ void landed(const uint4_t (&f)[KS]) {
 struct Pair {
   Chunk x0, y0, x1, y1;                                          // (K, V) or (Q, dO) images of chunks 2t and 2t+1
 };
-template <int DH>
+template <int DH, int DR>
 __device__ __forceinline__ void fetch_pair(Pair& p, const uint16_t* xb, int64_t x_rs, const uint16_t* yb, int64_t y_rs, int t,
                                            int rows, int tid) {
-  fetch_chunk<DH>(p.x0, xb, x_rs, 64 * t, rows, tid);
-  fetch_chunk<DH>(p.y0, yb, y_rs, 64 * t, rows, tid);
-  fetch_chunk<DH>(p.x1, xb, x_rs, 64 * t + 32, rows, tid);
-  fetch_chunk<DH>(p.y1, yb, y_rs, 64 * t + 32, rows, tid);
+  fetch_chunk<DH, DR>(p.x0, xb, x_rs, 64 * t, rows, tid);
+  fetch_chunk<DH, DR>(p.y0, yb, y_rs, 64 * t, rows, tid);
+  fetch_chunk<DH, DR>(p.x1, xb, x_rs, 64 * t + 32, rows, tid);
+  fetch_chunk<DH, DR>(p.y1, yb, y_rs, 64 * t + 32, rows, tid);
 }
-template <int DH>
+template <int DH, int DR>
 __device__ __forceinline__ void stash_pair(const Pair& p, uint16_t* buf, int tid) {
   constexpr int IMG = 32 * (DH + 16);
-  stash_chunk<DH>(p.x0, buf, tid);
-  stash_chunk<DH>(p.y0, buf + IMG, tid);
-  stash_chunk<DH>(p.x1, buf + 2 * IMG, tid);
-  stash_chunk<DH>(p.y1, buf + 3 * IMG, tid);
+  stash_chunk<DH, DR>(p.x0, buf, tid);
+  stash_chunk<DH, DR>(p.y0, buf + IMG, tid);
+  stash_chunk<DH, DR>(p.x1, buf + 2 * IMG, tid);
+  stash_chunk<DH, DR>(p.y1, buf + 3 * IMG, tid);
+}
+// does this lane's 4-dim group of output tile dt (dims 16dt + 4g ..) exist in memory?
+template <int DR>
+__device__ __forceinline__ bool dims_real(int dt, int g) {
+  return 16 * dt + 16 <= DR || 16 * dt + 4 * g < DR;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT, int DH>
+template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (K, V, K, V) images: chunks 2t, 2t+1
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   const int qrow = row0 + r;                                      // this lane's query
   const float NEG = -__builtin_inff();
   uint4_t qf[KS];
-  load_row_frags(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qrow < a.Lq ? qrow : a.Lq - 1, g);
+  load_row_frags<KS, DR>(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qrow < a.Lq ? qrow : a.Lq - 1, g);
   f32x4 oacc[NT];
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -188,14 +208,15 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;   // (not causal: P is past every key)
   const int trips = (chunks + 1) >> 1;
   Pair pr;
-  fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
-  stash_pair<DH>(pr, lds, tid);
+  fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
+  zero_pad_columns<DH, DR>(lds, 8, tid);
+  stash_pair<DH, DR>(pr, lds, tid);
   landed(qf);
   __syncthreads();
   for (int t = 0; t < trips; ++t) {
     const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    if (t + 1 < trips) fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
+    if (t + 1 < trips) fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
     const int c = 2 * t + half;
     if (c < chunks) {
       f32x4 s[2];
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
         for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag<DH>(vl, dt, r, g), pf, oacc[dt]);
       }
     }
-    if (t + 1 < trips) stash_pair<DH>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
+    if (t + 1 < trips) stash_pair<DH, DR>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
     __syncthreads();
   }
   // ---- the odd-chunk half hands (m, l, o) over through LDS; the even half merges and stores -------------------------------
@@ -265,10 +286,11 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   const float l = lfull * a1 + l2 * a2;
   const float inv = 1.0f / l;
   if (g == 0) a.lse2[static_cast<int64_t>(h) * a.Lq + qrow] = m * a.scale_log2e + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
-  uint16_t* op = a.out + (static_cast<int64_t>(qrow) * a.H + h) * DH + 4 * g;
+  uint16_t* op = a.out + (static_cast<int64_t>(qrow) * a.H + h) * DR + 4 * g;
   const float c1 = a1 * inv, c2 = a2 * inv;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
+    if (!dims_real<DR>(dt, g)) continue;
     const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 + 4 * dt);
     bma::uint2_t ow;
     ow.x = bma::pack16<DT>(oacc[dt][0] * c1 + o2[0] * c2, oacc[dt][1] * c1 + o2[1] * c2);
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT, int DH>
+template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];
@@ -289,12 +311,12 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   const int qrow = row0 + r;
   const int qc = qrow < a.Lq ? qrow : a.Lq - 1;
   uint4_t qf[KS], dof[KS];
-  load_row_frags(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qc, g);
-  load_row_frags(dof, a.d_o + static_cast<int64_t>(h) * DH, static_cast<int64_t>(a.H) * DH, qc, g);
+  load_row_frags<KS, DR>(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qc, g);
+  load_row_frags<KS, DR>(dof, a.d_o + static_cast<int64_t>(h) * DR, static_cast<int64_t>(a.H) * DR, qc, g);
   float delta;
   {
     uint4_t of[KS];
-    load_row_frags(of, a.o + static_cast<int64_t>(h) * DH, static_cast<int64_t>(a.H) * DH, qc, g);
+    load_row_frags<KS, DR>(of, a.o + static_cast<int64_t>(h) * DR, static_cast<int64_t>(a.H) * DR, qc, g);
     float acc = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -319,8 +341,9 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;
   const int trips = (chunks + 1) >> 1;
   Pair pr;
-  fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
-  stash_pair<DH>(pr, lds, tid);
+  fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
+  zero_pad_columns<DH, DR>(lds, 8, tid);
+  stash_pair<DH, DR>(pr, lds, tid);
   landed(qf);
   landed(dof);
   asm volatile("" ::"v"(lse2));
@@ -328,7 +351,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   for (int t = 0; t < trips; ++t) {
     const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    if (t + 1 < trips) fetch_pair<DH>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
+    if (t + 1 < trips) fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
     const int c = 2 * t + half;
     if (c < chunks) {
       f32x4 s[2], dp[2];
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) dqacc[dt] = cmfma<DT>(tr_frag<DH>(kl, dt, r, g), dsf, dqacc[dt]);
     }
-    if (t + 1 < trips) stash_pair<DH>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
+    if (t + 1 < trips) stash_pair<DH, DR>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
     __syncthreads();
   }
   float* xch = reinterpret_cast<float*>(lds) + (wq * 64 + lane) * (4 * NT);
@@ -366,9 +389,10 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   }
   __syncthreads();
   if (half == 1 || qrow >= a.Lq) return;
-  uint16_t* op = a.dq + static_cast<int64_t>(qrow) * a.d_rs + h * DH + 4 * g;
+  uint16_t* op = a.dq + static_cast<int64_t>(qrow) * a.d_rs + h * DR + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
+    if (!dims_real<DR>(dt, g)) continue;
     const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 * dt);
     bma::uint2_t ow;
     ow.x = bma::pack16<DT>(dqacc[dt][0] + o2[0], dqacc[dt][1] + o2[1]);
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT, int DH>
+template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (Q, dO, Q, dO) images: query chunks 2t, 2t+1
@@ -389,8 +413,8 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   const int key0 = 64 * kblk + 16 * wk;                           // first key of this wave
   const int key = key0 + r;                                       // this lane's key (a column of S)
   uint4_t kf[KS], vf[KS];
-  load_row_frags(kf, a.k + static_cast<int64_t>(h) * a.k_hs, a.k_rs, key < a.Lk ? key : a.Lk - 1, g);
-  load_row_frags(vf, a.v + static_cast<int64_t>(h) * a.v_hs, a.v_rs, key < a.Lk ? key : a.Lk - 1, g);
+  load_row_frags<KS, DR>(kf, a.k + static_cast<int64_t>(h) * a.k_hs, a.k_rs, key < a.Lk ? key : a.Lk - 1, g);
+  load_row_frags<KS, DR>(vf, a.v + static_cast<int64_t>(h) * a.v_hs, a.v_rs, key < a.Lk ? key : a.Lk - 1, g);
   f32x4 dkacc[NT], dvacc[NT];
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
@@ -398,8 +422,8 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
     dvacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
   const uint16_t* qbase = a.q + static_cast<int64_t>(h) * a.q_hs;
-  const uint16_t* dobase = a.d_o + static_cast<int64_t>(h) * DH;
-  const int64_t do_rs = static_cast<int64_t>(a.H) * DH;
+  const uint16_t* dobase = a.d_o + static_cast<int64_t>(h) * DR;
+  const int64_t do_rs = static_cast<int64_t>(a.H) * DR;
   // queries that see at least one key of this block: i >= 64*kblk - P; chunk pairs t0 .. t1-1 of 64 queries
   int q0 = 64 * kblk - a.P;
   q0 = q0 > 0 ? q0 : 0;
@@ -408,7 +432,7 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   Pair pr;
   float st = 0.0f;
   auto fetch = [&](int t) {
-    fetch_pair<DH>(pr, qbase, a.q_rs, dobase, do_rs, t, a.Lq, tid);
+    fetch_pair<DH, DR>(pr, qbase, a.q_rs, dobase, do_rs, t, a.Lq, tid);
     if (tid < 128) {                                               // lse2 and delta of the pair's 64 queries
       int qi = 64 * t + 32 * (tid >> 6) + (tid & 31);
       qi = qi < a.Lq ? qi : a.Lq - 1;
@@ -416,10 +440,11 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
     }
   };
   auto stash = [&](int buf) {
-    stash_pair<DH>(pr, lds + 4 * IMG * buf, tid);
+    stash_pair<DH, DR>(pr, lds + 4 * IMG * buf, tid);
     if (tid < 128) stat[buf][tid >> 6][tid & 63] = st;
   };
   fetch(t0);
+  zero_pad_columns<DH, DR>(lds, 8, tid);
   stash(0);
   landed(kf);
   landed(vf);
@@ -478,10 +503,11 @@ __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
   }
   __syncthreads();
   if (half == 1 || key >= a.Lk) return;
-  uint16_t* kp = a.dk + static_cast<int64_t>(key) * a.d_rs + h * DH + 4 * g;
-  uint16_t* vp = a.dv + static_cast<int64_t>(key) * a.d_rs + h * DH + 4 * g;
+  uint16_t* kp = a.dk + static_cast<int64_t>(key) * a.d_rs + h * DR + 4 * g;
+  uint16_t* vp = a.dv + static_cast<int64_t>(key) * a.d_rs + h * DR + 4 * g;
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) {
+    if (!dims_real<DR>(dt, g)) continue;
     const f32x4 k2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt), v2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt + 4);
     bma::uint2_t ow;
     ow.x = bma::pack16<DT>(dkacc[dt][0] + k2[0], dkacc[dt][1] + k2[1]);
@@ -498,7 +524,7 @@ int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_
   if (Lq < 0 || Lk < Lq || H <= 0) return BMA_EINVAL;
   if (!q || !k || !v) return BMA_EINVAL;
   if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
-  if ((Dh != 64 && Dh != 128) || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
+  if ((Dh != 64 && Dh != 72 && Dh != 128) || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
   for (int i = 0; i < n_strides; ++i)
     if (strides[i] % 8) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) % 16) return BMA_EALIGN;
@@ -527,8 +553,10 @@ extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   const dim3 grid(static_cast<unsigned>(H * ((Lq + 63) / 64)));
   BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) + 2.0 * static_cast<double>(Lk)) * H * Dh);
   if (dtype == BMA_BF16 && Dh == 128) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 128>), grid, dim3(NTHR), 0, st, a);
+  else if (dtype == BMA_BF16 && Dh == 72) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 96, 72>), grid, dim3(NTHR), 0, st, a);
   else if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 64>), grid, dim3(NTHR), 0, st, a);
   else if (Dh == 128) hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 128>), grid, dim3(NTHR), 0, st, a);
+  else if (Dh == 72) hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 96, 72>), grid, dim3(NTHR), 0, st, a);
   else hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 64>), grid, dim3(NTHR), 0, st, a);
   BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
   BMA_LAUNCH_CHECK();
@@ -568,15 +596,17 @@ extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_h
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
   const dim3 gq(static_cast<unsigned>(H * ((Lq + 63) / 64))), gk(static_cast<unsigned>(H * ((Lk + 63) / 64)));
   BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (4.0 * static_cast<double>(Lq) + 4.0 * static_cast<double>(Lk)) * H * Dh);
-#define BMA_CAUSAL_BWD(DT_, DH_)                                                                                          \
-  do {                                                                                                                    \
-    hipLaunchKernelGGL((causal_dq_kernel<DT_, DH_>), gq, dim3(NTHR), 0, st, a); /* writes delta for the next launch */   \
-    hipLaunchKernelGGL((causal_dkv_kernel<DT_, DH_>), gk, dim3(NTHR), 0, st, a);                                          \
+#define BMA_CAUSAL_BWD(DT_, DH_, DR_)                                                                                          \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL((causal_dq_kernel<DT_, DH_, DR_>), gq, dim3(NTHR), 0, st, a); /* writes delta for the next launch */   \
+    hipLaunchKernelGGL((causal_dkv_kernel<DT_, DH_, DR_>), gk, dim3(NTHR), 0, st, a);                                          \
   } while (0)
-  if (dtype == BMA_BF16 && Dh == 128) BMA_CAUSAL_BWD(BMA_BF16, 128);
-  else if (dtype == BMA_BF16) BMA_CAUSAL_BWD(BMA_BF16, 64);
-  else if (Dh == 128) BMA_CAUSAL_BWD(BMA_F16, 128);
-  else BMA_CAUSAL_BWD(BMA_F16, 64);
+  if (dtype == BMA_BF16 && Dh == 128) BMA_CAUSAL_BWD(BMA_BF16, 128, 128);
+  else if (dtype == BMA_BF16 && Dh == 72) BMA_CAUSAL_BWD(BMA_BF16, 96, 72);
+  else if (dtype == BMA_BF16) BMA_CAUSAL_BWD(BMA_BF16, 64, 64);
+  else if (Dh == 128) BMA_CAUSAL_BWD(BMA_F16, 128, 128);
+  else if (Dh == 72) BMA_CAUSAL_BWD(BMA_F16, 96, 72);
+  else BMA_CAUSAL_BWD(BMA_F16, 64, 64);
 #undef BMA_CAUSAL_BWD
   BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
   BMA_LAUNCH_CHECK();

@@ -93,6 +93,11 @@ __device__ __forceinline__ void wait_vm() {
 // for them: this workgroup has nothing else to do; the reducers it leaves behind are the launch's critical path).
 __device__ __forceinline__ void prefetch_next(const GemmArgs& a, int first, int stride) {
   const int tid = threadIdx.x;
+  // ONE destination register for every load, threaded through the asm statements as an in/out operand and "used" by the
+  // final wait: the compiler must not hand a register with a load still in flight to anything else (a plain output
+  // operand is free for reuse the moment the statement is over -- the returning load then overwrote the NEXT address:
+  // a memory access fault on the first run of this function).
+  unsigned int sink = 0;
   for (int b2 = first; b2 < a.nGrid; b2 += stride) {
     int bid = b2;
     if (a.nXcd) bid = (b2 & 7) * (a.nGrid >> 3) + (b2 >> 3);
@@ -109,11 +114,10 @@ __device__ __forceinline__ void prefetch_next(const GemmArgs& a, int first, int 
     for (int i = tid; i < lines; i += kNW * 64) {
       const int r = i / st, k = i - r * st;
       const char* p = a.nw + (static_cast<int64_t>(n0 + r) * a.nldw) * 2 + static_cast<int64_t>(t0 + k) * kRowB;
-      unsigned int sink;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(p) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
 }
 
 // MT row tiles of x (64 or 96 rows), NTW 16-row tiles of w per wave (slabs of up to 128 or 192 rows), ST ring stages,

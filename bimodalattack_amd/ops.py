@@ -744,11 +744,12 @@ def _rows_heads(t: torch.Tensor):
 
 
 def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
-    """q (Lq, H, Dh), k / v (Lk, H, Dh) views with Dh 64 or 128, 16-bit, last dim contiguous, strides multiples of 8, the
-    same heads on both sides, Lq <= Lk (causal: the queries are the last Lq positions)."""
+    """q (Lq, H, Dh), k / v (Lk, H, Dh) views with Dh 64, 72 (SigLIP; computed in 96-wide LDS images) or 128, 16-bit, last
+    dim contiguous, strides multiples of 8, the same heads on both sides, Lq <= Lk (causal: the queries are the last Lq
+    positions)."""
     if not (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype):
         return False
-    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[1:] != k.shape[1:] or q.shape[2] not in (64, 128):
+    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[1:] != k.shape[1:] or q.shape[2] not in (64, 72, 128):
         return False
     if not (0 < q.shape[0] <= k.shape[0] <= CAUSAL_ATTENTION_MAX_TOKENS):
         return False
@@ -763,7 +764,7 @@ def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
     query sees every key (a vision tower)."""
     dev = _need_gpu(q, k, v)
     if not causal_attention_ok(q, k, v):
-        raise ValueError("causal_attention wants 16-bit (L, H, 64 | 128) views with a contiguous last dim, Lq <= Lk")
+        raise ValueError("causal_attention wants 16-bit (L, H, 64 | 72 | 128) views with a contiguous last dim, Lq <= Lk")
     Lq, H, Dh = q.shape
     Lk = k.shape[0]
     out = torch.empty((Lq, H, Dh), dtype=q.dtype, device=dev)

@@ -406,7 +406,7 @@ def _own_causal(query, key, value, scale: float, dropout: float, causal: bool = 
     its shape: batch 1, the same 64- or 128-wide heads on both sides, 16-bit, no dropout; causal with the queries as the
     last Lq of the Lk key positions, or every key visible (a vision tower)."""
     from . import ops
-    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] != key.shape[1] or query.shape[3] not in (64, 128):
+    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] != key.shape[1] or query.shape[3] not in (64, 72, 128):
         return None
     # (squeeze, not [0]: the backward of an index is a zero fill plus a copy per operand, of a squeeze nothing)
     q3, k3, v3 = query.squeeze(0).transpose(0, 1), key.squeeze(0).transpose(0, 1), value.squeeze(0).transpose(0, 1)
@@ -491,6 +491,10 @@ NAME_VIS = "bma_padded_heads"
 PAD_HEADS_MIN_TOKENS = int(os.environ.get("BMA_PAD_HEADS_MIN_TOKENS", "1024"))
 TOWER_EFFICIENT_FIRST = os.environ.get("BMA_TOWER_EFFICIENT_FIRST", "1") not in ("0", "false", "False")
 OWN_TOWER_MAX_TOKENS = int(os.environ.get("BMA_OWN_TOWER_MAX_TOKENS", "1024"))
+# ... and SigLIP's 72-wide heads (Gemma-3: 4096 tokens x 16 heads) on the same kernels, which take the real width and pad it
+# to 96 in their LDS images only: no zero-padded copies of q / k / v, no slice of the output, and a backward of two launches
+# where the library's padded pair took 719 us + the pad / slice copies per layer (profiles/r4_bench_gemma_joint_kernel_by_grid.txt)
+OWN_TOWER_72 = os.environ.get("BMA_OWN_TOWER_72", "1") not in ("0", "false", "False")
 
 
 def padded_width(head_dim: int, grad: bool) -> int:
@@ -531,6 +535,10 @@ def padded_heads_attention(module, query, key, value, attention_mask=None, dropo
         out = F.scaled_dot_product_attention(query, key, value, attn_mask=attention_mask, dropout_p=dropout,
                                              is_causal=causal, scale=scale)
         return out.transpose(1, 2).contiguous(), None
+    if OWN_TOWER_72 and Dh == 72 and attention_mask is None and B == 1 and S <= ops.CAUSAL_ATTENTION_MAX_TOKENS:
+        own = _own_causal(query, key, value, scale, dropout, causal=causal)
+        if own is not None:
+            return own, None
     q, k, v = (F.pad(t, (0, W - Dh)) for t in (query, key, value))
     from torch.nn.attention import SDPBackend, sdpa_kernel
     order = [SDPBackend.EFFICIENT_ATTENTION, SDPBackend.FLASH_ATTENTION, SDPBackend.MATH]

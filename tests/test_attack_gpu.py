@@ -375,6 +375,61 @@ def test_oom_halving_recovers_and_remembers(golden_dir):
     check_against_golden(golden_dir, name, m, res, trace, tmp)
 
 
+@pytest.mark.parametrize("mode", ["gcg", "joint"])
+def test_filter_first_policy_with_a_tokenizer_that_rejects_a_third(mode):
+    """VERDICT r4 item 5 / "What's missing" 3: the reference filters BEFORE it scores (:166-186, :930-941).  With a
+    tokenizer whose round trip rejects a real share of the candidates (80 of 256 words contain a space: ~30 % of the
+    sampled candidates fail) the engine must not spend the scoring phase on them.  Three runs of one attack on the tiny
+    LLaVA (fp32, CPU draws): filter beside the forward + mask afterwards (`filter_first=False`), the reference's order
+    (`True`), and the default policy (None: score-everything at the first step, filter-first from then on because the
+    survivor rate sits far below the break-even).  Same sampled ids, survivors, losses, strings in all three -- and in
+    the oracle loop, which filters first like the reference -- while the candidates actually scored drop by the rejected
+    share."""
+    from bimodalattack_amd import BimodalAttackConfig, synthetic as S
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from oracle.attack_loop import run_oracle
+    joint = mode == "joint"
+    steps = 5
+    kw = dict(num_steps=steps, search_width=32, topk=64, seed=3, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
+              pgd_attack=joint, gcg_attack=True, joint_eval=joint, eps=64 / 255, alpha=4 / 255)
+    norm = S.Normalize(S.CLIP_MEAN, S.CLIP_STD)
+    n_unrt = 80
+    out = {}
+    for ff in (False, True, None):
+        model, _, proc, image = S.tiny_case("llava", device=DEV)
+        tok = S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, n_unrt)
+        proc = S.SyntheticProcessor(tok)
+        trace = []
+        atk = BimodalAttack(model, tok, proc, BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw), norm,
+                            EngineOptions.from_env(rng_device="cpu", trace=trace, strict=True, filter_first=ff, save_images=False))
+        res = atk.run("tell me a story", "tell me a story", "Sure here is", image if joint else None)
+        assert not atk.fallbacks, atk.fallbacks
+        out[ff] = (res, trace, atk.score_stats["candidates"], list(atk.filter_first_steps), list(atk._keep_rates))
+    cmodel, _, _, cimage = S.tiny_case("llava")
+    ctok = S.build_tokenizer(S.TINY_WORDS, S.TINY_NONASCII, n_unrt)
+    want, wtrace, _ = run_oracle(cmodel, ctok, S.SyntheticProcessor(ctok), "tell me a story", "tell me a story", "Sure here is",
+                                 cimage if joint else None, BimodalAttackConfig(images_folder=tempfile.mkdtemp(), **kw), normalize=norm)
+    base = out[False]
+    rates = base[4]
+    assert len(rates) == steps and 0.4 < sum(rates) / steps < 0.9, rates           # a real share is rejected every step
+    for ff, (res, trace, scored, first_steps, _) in out.items():
+        for a, b, c in zip(trace, base[1], wtrace):
+            assert np.array_equal(a["sampled"], b["sampled"]) and np.array_equal(a["sampled"], c["sampled"])
+            assert np.array_equal(a["filtered"], b["filtered"]) and np.array_equal(a["filtered"], c["filtered"])
+            np.testing.assert_allclose(a["losses"][0], b["losses"][0], rtol=1e-5)
+            np.testing.assert_allclose(a["losses"][0], c["losses"][0], rtol=1e-4)
+        assert res.strings == base[0].strings == want["strings"]
+        np.testing.assert_allclose(res.losses, base[0].losses, rtol=1e-5)
+        assert [st["n_scored"] for st in trace] == [st["n_scored"] for st in base[1]]
+    sampled_total = sum(st["sampled"].shape[0] for st in base[1])
+    kept_total = sum(st["n_scored"] for st in base[1])
+
+    assert out[False][3] == [] and out[True][3] == list(range(steps)) and out[None][3] == list(range(1, steps))
+    assert out[False][2] == sampled_total and out[True][2] == kept_total, (out[False][2], out[True][2], sampled_total, kept_total)
+    assert kept_total < out[None][2] < sampled_total and kept_total < 0.9 * sampled_total
+
+
 def test_long_suffix_matches_oracle():
     """A 70-token suffix (the reference takes any optim_str_init; round 1's position sampler stopped at 64):
     two GCG steps on the tiny OPT, HIP engine against the oracle loop, same CPU draws."""
@@ -1713,10 +1768,11 @@ def test_16bit_engine_paths_agree(dtype):
 
 
 def test_padded_vision_heads_same_features_and_pixel_gradient():
-    """SigLIP-So400m-shaped tower (4096 patches, 16 heads x 72; 3 layers here): image features and the pixel
-    gradient through the padded-head attention (72 -> 96 forward-only, -> 128 with a backward) against the
-    library's own 72-wide route -- same attention, different kernels, bf16 noise apart."""
-    from bimodalattack_amd import prefix_attention as pa, synthetic as S
+    """SigLIP-So400m-shaped tower (4096 patches, 16 heads x 72; 3 layers here): image features and the pixel gradient
+    through (a) the hand-written attention pair at the REAL head width (round 5: 72 in memory, 96-wide images in LDS; no
+    padded copies, no library call at all), (b) the padded-head library route it replaces (72 -> 96 forward-only, -> 128
+    with a backward) and (c) the library's own 72-wide route -- same attention, three sets of kernels, bf16 noise apart."""
+    from bimodalattack_amd import ops, prefix_attention as pa, synthetic as S
     from bimodalattack_amd.hf_adapter import HFAdapter
 
     dev = torch.device(DEV)
@@ -1726,34 +1782,51 @@ def test_padded_vision_heads_same_features_and_pixel_gradient():
     assert len(hf.vision_configs()) == 1 and pa.padded_width(72, True) == 128
     image = S.synthetic_image(896, 896, seed=0, device=dev)
     w = torch.randn(256, 256, device=dev, dtype=torch.bfloat16, generator=torch.Generator(device=DEV).manual_seed(1))
-    seen = []
+    seen, own = [], []
     orig = torch.nn.functional.scaled_dot_product_attention
+    keep_fwd, keep_bwd = ops.causal_attention, ops.causal_attention_bwd
 
     def spy(q, *a, **k):
         seen.append(int(q.shape[-1]))
         return orig(q, *a, **k)
 
+    def own_fwd(q, *a, **k):
+        own.append(("fwd",) + tuple(q.shape))
+        return keep_fwd(q, *a, **k)
+
+    def own_bwd(q, *a, **k):
+        own.append(("bwd",) + tuple(q.shape))
+        return keep_bwd(q, *a, **k)
+
     out = {}
     torch.nn.functional.scaled_dot_product_attention = spy
+    ops.causal_attention, ops.causal_attention_bwd = own_fwd, own_bwd
     try:
-        for pad in (True, False):
-            hf.pad_vision_heads = pad
+        for route in ("own", "padded", "plain"):
+            hf.pad_vision_heads = route != "plain"
+            pa.OWN_TOWER_72 = route == "own"
             seen.clear()
+            own.clear()
             img = image.clone().requires_grad_()
             feats = hf.image_features(img)
             (g,) = torch.autograd.grad((feats[0].to(torch.bfloat16) * w).sum().float(), img)
             with torch.no_grad():
                 f2 = hf.image_features(image)
-            out[pad] = (feats.detach().float(), g.float(), f2.float(), list(seen))
+            out[route] = (feats.detach().float(), g.float(), f2.float(), list(seen), list(own))
     finally:
         torch.nn.functional.scaled_dot_product_attention = orig
-    assert out[True][3] == [128] * 3 + [96] * 3 and out[False][3] == [72] * 6
+        ops.causal_attention, ops.causal_attention_bwd = keep_fwd, keep_bwd
+        pa.OWN_TOWER_72 = True
+    assert out["own"][3] == [] and out["own"][4] == [("fwd", 4096, 16, 72)] * 3 + [("bwd", 4096, 16, 72)] * 3 + [("fwd", 4096, 16, 72)] * 3
+    assert out["padded"][3] == [128] * 3 + [96] * 3 and out["plain"][3] == [72] * 6 and out["padded"][4] == out["plain"][4] == []
     assert model.config.vision_config._attn_implementation == "sdpa"            # restored
-    (f1, g1, n1, _), (f0, g0, n0, _) = out[True], out[False]
-    for a, b in ((f1, f0), (n1, n0), (g1, g0)):
-        assert float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
-    big = g0.abs() > 0.1 * g0.abs().max()
-    assert float((torch.sign(g1[big]) == torch.sign(g0[big])).float().mean()) > 0.98
+    f0, g0, n0 = out["plain"][:3]
+    for route in ("own", "padded"):
+        f1, g1, n1 = out[route][:3]
+        for a, b in ((f1, f0), (n1, n0), (g1, g0)):
+            assert float((a - b).abs().max()) <= 4e-2 * float(b.abs().max()), (route, float((a - b).abs().max()) / float(b.abs().max()))
+        big = g0.abs() > 0.1 * g0.abs().max()
+        assert float((torch.sign(g1[big]) == torch.sign(g0[big])).float().mean()) > 0.98, route
 
 
 @pytest.mark.parametrize("graphs", [False, True])

@@ -504,13 +504,16 @@ def _causal_reference(q, k, v, scale, causal=True):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_tower_attention_64_wide_heads_every_key_visible(dtype):
     """The same kernels at head width 64 and with every key visible (causal = 0): CLIP's 577 tokens x 16 heads, lengths on and
-    off the block and chunk sizes, a causal 64-wide case; forward and backward against float64 on the same 16-bit
-    operands, the gradients also against the library's pair; bit-equal over repeated launches."""
+    off the block and chunk sizes, a causal 64-wide case; and at SigLIP's head width 72 (round 5: the real width in memory,
+    96-wide images with zero columns in LDS) -- Gemma-3's 4096 tokens x 16 heads, short and odd lengths, a causal case;
+    forward and backward against float64 on the same 16-bit operands, the gradients also against the library's pair;
+    bit-equal over repeated launches."""
     from bimodalattack_amd import ops
     g = torch.Generator(device=DEV).manual_seed(14)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     for H, L, Dh, causal in ((16, 577, 64, False), (2, 64, 64, False), (2, 33, 64, False), (2, 130, 128, False), (4, 100, 64, True),
-                             (2, 1, 64, False)):
+                             (2, 1, 64, False), (16, 4096, 72, False), (2, 100, 72, False), (3, 65, 72, False), (2, 33, 72, True),
+                             (2, 1, 72, False), (1, 700, 72, True)):
         qkv = torch.randn((L, 3 * H * Dh), generator=g, device=DEV).to(dtype)
         q, k, v = (qkv[:, i * H * Dh:(i + 1) * H * Dh].view(L, H, Dh) for i in range(3))
         assert ops.causal_attention_ok(q, k, v)
@@ -554,6 +557,31 @@ def test_tower_attention_64_wide_heads_every_key_visible(dtype):
     with torch.no_grad():
         out_n, _ = pa.padded_heads_attention(None, *heads(qkv), scaling=0.125)
     assert torch.equal(out_n, out.detach())
+    # SigLIP's tower (4096 tokens x 16 heads of 72, views of the fused q/k/v product): the own pair against the library's
+    # zero-padded route (pad to 128 with autograd / 96 without, slice the output)
+    H, S, Dh = 16, 4096, 72
+    qkv = torch.randn((1, S, 3 * H * Dh), generator=g, device=DEV).to(dtype).requires_grad_()
+    heads72 = lambda x: tuple(t.transpose(1, 2) for t in x.view(1, S, 3, H, Dh).unbind(2))      # noqa: E731
+    do = torch.randn((1, S, H, Dh), generator=g, device=DEV).to(dtype)
+    calls = []
+    keep = ops.causal_attention
+    ops.causal_attention = lambda q_, *a_, **k_: (calls.append(tuple(q_.shape)), keep(q_, *a_, **k_))[1]
+    try:
+        out, _ = pa.padded_heads_attention(None, *heads72(qkv), scaling=Dh ** -0.5)
+        (g_own,) = torch.autograd.grad(out, qkv, do)
+        with torch.no_grad():
+            out_n, _ = pa.padded_heads_attention(None, *heads72(qkv), scaling=Dh ** -0.5)
+    finally:
+        ops.causal_attention = keep
+    assert calls == [(S, H, Dh)] * 2 and out.shape == (1, S, H, Dh) and torch.equal(out_n, out.detach())
+    try:
+        pa.OWN_TOWER_72 = False
+        out_l, _ = pa.padded_heads_attention(None, *heads72(qkv), scaling=Dh ** -0.5)
+        (g_lib,) = torch.autograd.grad(out_l, qkv, do)
+    finally:
+        pa.OWN_TOWER_72 = True
+    assert float((out.float() - out_l.float()).abs().max()) <= 4 * eps * float(out_l.float().abs().max())
+    assert float((g_own.float() - g_lib.float()).abs().max()) <= 8 * eps * float(g_lib.float().abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -602,7 +630,7 @@ def test_causal_attention_forward_and_backward_match_float64(dtype):
         assert float((lse2.double() - ref_lse2.detach()).abs().max()) <= 1e-3
     # what it does not take
     q32 = torch.zeros((10, 2, 32), device=DEV, dtype=dtype)
-    assert not ops.causal_attention_ok(q32, q32, q32)                         # head widths 64 and 128 only
+    assert not ops.causal_attention_ok(q32, q32, q32)                         # head widths 64, 72 and 128 only
     q3 = torch.zeros((10, 2, 128), device=DEV, dtype=dtype)
     assert not ops.causal_attention_ok(q3, q3[:5], q3[:5])                       # more queries than keys
     assert not ops.causal_attention_ok(q3, torch.zeros((10, 1, 128), device=DEV, dtype=dtype), torch.zeros((10, 1, 128), device=DEV, dtype=dtype))
