@@ -734,7 +734,7 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
         elapsed = float(t.item())
     timed = attack.n_scored[warmup:timed_end]
     n_cand = sum(timed)
-    emulate = attack.opt.emulate_world if (attack.opt.emulate_world > 1 and world == 1) else 0
+    emulate = attack.emulate_world if (attack.emulate_world > 1 and world == 1) else 0
     ss = marks.get("stats", attack.score_stats)
     # with BMA_EMULATE_WORLD=W this process scores rank 0's share only: `value` counts the candidates ACTUALLY scored,
     # the whole-job figure a W-GPU run would print is a projection and is labelled as one
@@ -979,7 +979,7 @@ def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
     try:
         log("tensor-parallel gradient pass: the same timed block again (A/B against the replicated pass)")
         on, _ = measure(args, args.workload, args.steps, args.warmup, 0, device, world, rank, primary=True,
-                        engine_kw=dict(tp_gradient=True, tp_graph=True))
+                        engine_kw=dict(tp_gradient="graph"))
         eng = on.get("engine") or {}
         rc["tp_on_ms"] = on["ms_per_step"]
         rc["tp_graph"] = "gradient_tp" in (eng.get("graphs_captured") or [])

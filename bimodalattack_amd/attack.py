@@ -65,6 +65,22 @@ logger.propagate = False
 FILTER_COST_RATIO = float(os.environ.get("BMA_FILTER_COST_RATIO", "0.027"))
 FILTER_RATE_STEPS = 4            # the survivor rate is the mean over this many steps
 
+_OFF = ("0", "false", "False")
+# Switches that exist for A/B measurements (tools/, NOTEBOOK.md), read from the environment ONCE -- engine options until
+# round 4, module constants since (options are what a test or bench.py flips; tests that need one of
+# these monkeypatch the constant):
+# gradient pass: ask the library attention for `is_causal` instead of handing it the (1,1,S,S) mask tensor HuggingFace
+# builds for inputs_embeds calls (model families with plain causal text attention only: -3 ms per pass at 643 tokens)
+MASKLESS_B1_ATTENTION = os.environ.get("BMA_MASKLESS_B1_ATTENTION", "1") not in _OFF
+# padded scoring (no ragged rows: Gemma-3's layout, fp32 models) runs chunks whose candidate count is a multiple of this
+# -- a short last chunk is padded with copies of its last candidate, whose losses are dropped -- so a decaying search
+# width (reference :919-923) meets a handful of GEMM shapes, not hundreds.  1 switches it off.
+CHUNK_QUANTUM = max(1, int(os.environ.get("BMA_CHUNK_QUANTUM", "8")))
+# GEMM tuning aid (tools/tune_gemms.py): in a single process, score only what rank 0 of an N-rank run would score, with
+# that run's row budget -- the exact GEMM shapes of the multi-GPU run.  Results of the attack are meaningless with it.
+EMULATE_WORLD = int(os.environ.get("BMA_EMULATE_WORLD", "0") or 0)
+SHARED_PREFIX_MIN_TOKENS = 1     # shortest prefix worth the shared-prefix attention route
+
 TEMPLATE_PGD = "USER: <image>\n{{ messages[0]['content'][0]['text'] }} \nASSISTANT: "
 TEMPLATE_GCG = "{% for message in messages %}{{ message['content'] }}{% endfor %}"
 
@@ -201,14 +217,13 @@ class BimodalAttack:
                 f"bimodalattack_amd runs on an AMD GPU only (model is on {model.device}); there is no CPU path. "
                 "Move the model to the device first.")
         self.hf = HFAdapter(model, processor, normalize)
-        self.hf.pad_vision_heads = bool(self.opt.pad_vision_heads)
-        self.hf.fuse_quick_gelu = bool(self.opt.fuse_quick_gelu)
-        self.hf.fuse_tower_qkv = bool(self.opt.fuse_tower_qkv)
         self.embedding_layer = self.hf.embedding
         self.not_allowed_ids = None if config.allow_non_ascii else get_nonascii_toks(tokenizer, device=model.device)
         self.mask_bits = ops.build_mask_bits(self.not_allowed_ids, self.embedding_layer.num_embeddings, model.device)
         self.stop_flag = False
-        self.shard = CandidateSharder(self.opt.group)
+        self.shard = CandidateSharder()
+        self.emulate_world = EMULATE_WORLD             # (tools: rank 0's share of an N-rank run in one process)
+        self.score_log: Optional[list] = None          # debugging aid (tools/nan_bisect.py): one dict per scoring call when set to a list
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
         self._grad_graph = None                    # None: not tried yet; False: eager for good
         self._prefix_cache: Dict[tuple, tuple] = {}
@@ -234,14 +249,16 @@ class BimodalAttack:
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
-        ops.SKINNY_GEMM = bool(self.opt.skinny_gemm)
-        ops.MID_GEMM = bool(self.opt.mid_gemm)
-        ops.CAUSAL_ATTENTION = bool(self.opt.causal_attention)
-        self.fused = FusedInference(model, self.opt.fused_elementwise, self.opt.backward_weight_copies, self.opt.fuse_qkv,
-                                    self.opt.fuse_gate_up, self.opt.fuse_add_norm, self.opt.fuse_qk_rope,
-                                    self.opt.fuse_b1_attention, self.opt.causal_attention)
+        own = bool(self.opt.own_b1_kernels)               # the hand-written batch-1 kernels: one option, four process-wide switches
+        ops.SKINNY_GEMM = own and ops.OWN_KERNELS["skinny_gemm"]
+        ops.MID_GEMM = own and ops.OWN_KERNELS["mid_gemm"]
+        ops.CAUSAL_ATTENTION = own and ops.OWN_KERNELS["causal_attention"]
+        copies = bool(self.opt.derived_weight_copies)
+        from .fused import FUSE_QK_ROPE
+        self.fused = FusedInference(model, self.opt.fused_elementwise, copies, copies, copies, self.opt.fuse_add_norm, FUSE_QK_ROPE,
+                                    own and ops.OWN_KERNELS["b1_attention"], own and ops.OWN_KERNELS["causal_attention"])
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
-        logger.info(f"Fused forward admitted: {self.fused.admitted}")
+        logger.info(f"Fused forward admitted: {self.fused.admitted}; refused: {self.fused.refused}")
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
         if model.dtype in (torch.float32, torch.float64):
@@ -268,7 +285,9 @@ class BimodalAttack:
         hf = self.hf
         return dict(tuned_gemms=self.tuned_gemms, prefix_ok=hf.prefix_ok, shared_ok=hf.shared_ok, ragged_ok=hf.ragged_ok,
                     graphs_captured=list(self.graphs_captured), fallbacks=dict(self.fallbacks),
-                    fused_elementwise=bool(self.fused.enabled), fusions=dict(self.fused.admitted), chunk_cap=self._chunk_cap,
+                    fused_elementwise=bool(self.fused.enabled), fusions=dict(self.fused.admitted),
+                    refused=dict(self.fused.refused), filter_first_steps=len(getattr(self, "filter_first_steps", [])),
+                    chunk_cap=self._chunk_cap,
                     warmed_row_counts=list(getattr(self, "warmed", {}).get("row_counts", [])),
                     collectives=self.shard.n_collectives if self.shard.enabled else 0)
 
@@ -359,9 +378,9 @@ class BimodalAttack:
         eager ones (same kernels, same order)."""
         if self._tp_active():
             # the pass cut over the ranks, its all-reduces included, CAN be one hipGraph too (RCCL collectives are
-            # capturable: the process group's stream fork/join lands in the graph) -- opt-in (EngineOptions.tp_graph) until a
+            # capturable: the process group's stream fork/join lands in the graph) -- opt-in (tp_gradient="graph") until a
             # run on two or more GPUs has been recorded; a gloo rehearsal's collectives run on the host and cannot be captured
-            if self._tp_graph is None and not (self.opt.tp_graph and self.opt.graph_gradient and self.shard.backend() == "nccl"):
+            if self._tp_graph is None and not (self.opt.tp_gradient == "graph" and self.opt.graph_gradient and self.shard.backend() == "nccl"):
                 self._tp_graph = False
             if self._tp_graph is False:
                 return self._gradient_tp(optim_ids, image)
@@ -500,7 +519,7 @@ class BimodalAttack:
         families the shared-prefix scheme knows (plain causal attention; a sliding window at least as long as
         the sequence), nothing otherwise."""
         import contextlib
-        cfgs = self.hf.shared_prefix_configs(seq_len) if (self.opt.maskless_b1_attention and seq_len >= self.opt_b1_min) else []
+        cfgs = self.hf.shared_prefix_configs(seq_len) if (MASKLESS_B1_ATTENTION and seq_len >= self.opt_b1_min) else []
         if not cfgs:
             return contextlib.nullcontext()
         from . import prefix_attention as pa
@@ -592,7 +611,7 @@ class BimodalAttack:
         recent = self._keep_rates[-FILTER_RATE_STEPS:]
         if not recent:
             return False
-        world = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else self.shard.world
+        world = self.emulate_world if (self.emulate_world > 1 and not self.shard.enabled) else self.shard.world
         return sum(recent) / len(recent) < 1.0 - world * FILTER_COST_RATIO
 
     def _filter_now(self, sampled: Tensor, job: FilterJob):
@@ -653,7 +672,7 @@ class BimodalAttack:
                 self._fallback("grad_prefix_reuse", e, "gradient pass does not reuse the scoring prefix; running the full pass")
                 self._gp = False
                 torch.cuda.synchronize(self.model.device)
-        if not self.opt.graph_prefix or self._feat_graph is False:
+        if not self.opt.graph_scoring or self._feat_graph is False:
             return self.image_features(image)
         if self._feat_graph is None:
             try:
@@ -671,7 +690,7 @@ class BimodalAttack:
         # (KV concat); P=599: 288 ms vs 714 ms
         hf = self.hf
         return bool(self.opt.shared_prefix_attention and hf.shared_ok is not False
-                    and P >= self.opt.shared_prefix_min_tokens and hf.shared_prefix_configs(total_len))
+                    and P >= SHARED_PREFIX_MIN_TOKENS and hf.shared_prefix_configs(total_len))
 
     def _prefix(self, prefix_names: List[str], feats: Optional[Tensor], total_len: int = 0):
         """Keys/values of the segments in front of the suffix.  They depend on nothing but
@@ -697,10 +716,14 @@ class BimodalAttack:
                 if self._wants_shared(P, total_len):
                     try:
                         cache = self._recorded_prefix(key, cat_prefix, feats)
+                    except DeferredNormMissed:
+                        raise                          # (only the norm deferral is at fault: score_candidates retries without it)
                     except Exception as e:
                         self._fallback("recorded_prefix", e, "recording prefix pass failed; using the HF cache")
                 if cache is None:
                     cache = hf.build_prefix(cat_prefix(feats))
+            except DeferredNormMissed:
+                raise
             except Exception as e:  # a model without cache support: remember, use the full sequence
                 self._fallback("prefix_reuse", e, "prefix reuse disabled")
             hf.prefix_ok = cache is not None
@@ -719,7 +742,7 @@ class BimodalAttack:
             with self._b1_attention(x.shape[1]):          # one sequence, nothing cached in front of it: plain causal
                 return hf.build_prefix_recording(x)
 
-        if feats is None or not self.opt.graph_prefix or self._prefix_graphs.get(key) is False:
+        if feats is None or not self.opt.graph_scoring or self._prefix_graphs.get(key) is False:
             return build(feats)
         g = self._prefix_graphs.get(key)
         if g is None:
@@ -810,7 +833,7 @@ class BimodalAttack:
         cfg, hf = self.config, self.hf
         n = sampled.shape[0]
         dealt = None           # (order over distinct candidates, device index candidate -> gathered slot, distinct count, first positions) when dealing
-        emulate = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else 0
+        emulate = self.emulate_world if (self.emulate_world > 1 and not self.shard.enabled) else 0
         world = emulate or self.shard.world
         # `plan_ok` depends on options and the model family only -- never on what one rank learnt at run time --
         # because it also decides HOW candidates are partitioned over ranks, which every rank must decide alike
@@ -888,7 +911,7 @@ class BimodalAttack:
 
         free = torch.cuda.mem_get_info(self.model.device)[0] if m > 1 else (1 << 40)   # one candidate always fits
         fixed = cfg.batch_size if cfg.batch_size is not None else self.opt.chunk
-        quantum = self.opt.chunk_quantum if (fixed is None and m > self.opt.chunk_quantum > 1) else 1
+        quantum = CHUNK_QUANTUM if (fixed is None and m > CHUNK_QUANTUM > 1) else 1
         chunk = plan_chunk(max(m, 1), L, P if (use_prefix and not shared) else 0, hf.kv_bytes_per_token,
                            hf.act_bytes_per_token, free, fixed, quantum=quantum)
         if self._chunk_cap is not None:
@@ -918,6 +941,8 @@ class BimodalAttack:
                                     parent.reshape(1, -1).to(sampled.device))
                         scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, real)
                         hf.ragged_ok = True
+                    except DeferredNormMissed:
+                        raise                          # (a missed deferral costs the deferral, not the ragged path)
                     except Exception as e:
                         if hf.ragged_ok or is_oom(e):
                             raise
@@ -942,6 +967,8 @@ class BimodalAttack:
                     try:
                         logits = hf.target_logits_shared_prefix(x, self.T, cache)
                         hf.shared_ok = True
+                    except DeferredNormMissed:
+                        raise
                     except Exception as e:
                         if hf.shared_ok or is_oom(e):
                             raise
@@ -961,8 +988,8 @@ class BimodalAttack:
                     loss, hit = scored
                 else:
                     loss, hit, _, _ = ops.ce_target(logits, self.labels, want_match=cfg.early_stop)
-                if self.opt.score_log is not None and logits is not None:
-                    self.opt.score_log.append(dict(chunk_at=s, b=b, logits_bad=(~torch.isfinite(logits.float())).sum(),
+                if self.score_log is not None and logits is not None:
+                    self.score_log.append(dict(chunk_at=s, b=b, logits_bad=(~torch.isfinite(logits.float())).sum(),
                                                    x_bad=None if x is None else (~torch.isfinite(x.float())).sum()))
                 losses[s:s + b] = loss[:b]       # (the padding's losses are dropped)
                 if match is not None:
@@ -990,7 +1017,7 @@ class BimodalAttack:
             full, self._match = self.shard.gather2(losses, match, n)
         if self.opt.loss_in_model_dtype:
             full = full.to(self.model.dtype)        # the reference's CE returns the model dtype
-        if self.opt.score_log is not None:
+        if self.score_log is not None:
             # debugging aid (tools/nan_bisect.py): which route scored this call and whether every loss is finite -- kept
             # as device scalars, read by the owner of the list after the run, so that nothing here stops the host
             extra = {}
@@ -1002,7 +1029,7 @@ class BimodalAttack:
             for k_, t in segs:
                 if t is not None and k_ == "shared":
                     extra["segs_bad"] = extra.get("segs_bad", 0) + (~torch.isfinite(t.float())).sum()
-            self.opt.score_log.append(dict(n=n, m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared), **extra,
+            self.score_log.append(dict(n=n, m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared), **extra,
                                            use_prefix=bool(use_prefix), rows=self.score_stats["rows"],
                                            bad=(~torch.isfinite(full.float())).sum(),
                                            first_bad=(~torch.isfinite(full.float())).to(torch.int32).argmax()))
@@ -1021,7 +1048,7 @@ class BimodalAttack:
                 self.shard = keep
 
         key = tuple(order)
-        if not self.opt.graph_rescore or self._rescore_graphs.get(key) is False:
+        if not self.opt.graph_scoring or self._rescore_graphs.get(key) is False:
             return eager(winner, feats)[0]
         g = self._rescore_graphs.get(key)
         if g is None:
@@ -1054,7 +1081,7 @@ class BimodalAttack:
         if not tail or tail[0] != "optim" or "image" in tail:
             return                               # (suffix in front of the image: padded chunks, another set of shapes)
         L = n_opt + sum(self.seg[("target_in" if t == "target" else t)].shape[1] for t in tail if t != "optim")
-        world = self.opt.emulate_world if (self.opt.emulate_world > 1 and not self.shard.enabled) else self.shard.world
+        world = self.emulate_world if (self.emulate_world > 1 and not self.shard.enabled) else self.shard.world
         widths = {self._width(i) for i in range(cfg.num_steps)} if (cfg.dynamic_search or self.opt.width_override) else {cfg.search_width}
         layer = next((l for l, _, _ in self.fused.layers), None)
         if layer is None:
@@ -1064,13 +1091,13 @@ class BimodalAttack:
         lin = lambda m, n: getattr(m, n) if isinstance(getattr(m, n, None), torch.nn.Linear) else None    # noqa: E731
         qkv = [lin(attn, n) for n in ("q_proj", "k_proj", "v_proj")]
         if all(qkv):
-            if self.opt.fuse_qkv and attn in self.fused.qkv:
+            if self.opt.derived_weight_copies and attn in self.fused.qkv:
                 shapes.add((sum(l.out_features for l in qkv), qkv[0].in_features))
             else:
                 shapes |= {(l.out_features, l.in_features) for l in qkv}
         gu = [lin(mlp, n) for n in ("gate_proj", "up_proj")]
         if all(gu):
-            if self.opt.fuse_gate_up:
+            if self.opt.derived_weight_copies:
                 shapes.add((gu[0].out_features + gu[1].out_features, gu[0].in_features))
             else:
                 shapes |= {(l.out_features, l.in_features) for l in gu}
@@ -1545,7 +1572,7 @@ class _GradPrefix:
     ``gradient(ids, image)`` -- step t+1: the 44 tokens behind the prefix run forward against those keys/values
                             (prefix_attention.tail_grad_attention), the loss back-propagates through both parts.
 
-    With hipGraphs (options graph_gradient and graph_prefix): two captures sharing one autograd graph, as
+    With hipGraphs (options graph_gradient and graph_scoring): two captures sharing one autograd graph, as
     torch.cuda.make_graphed_callables does for a forward and its backward -- G1 = the prefix forward, G2 = the tail
     forward + the whole backward.  Each keeps its own memory pool, so what G1's replay writes (saved activations,
     keys/values) is read by G2's replay and by scoring and touched by nobody else.  The same maths as the full pass up
@@ -1565,7 +1592,7 @@ class _GradPrefix:
         self.g1 = self.g2 = self.g3 = None
         self.ids3 = self.out3 = None
         self._feats_out = None
-        self.graphs = bool(attack.opt.graph_gradient and attack.opt.graph_prefix)
+        self.graphs = bool(attack.opt.graph_gradient and attack.opt.graph_scoring)
         self.P = 0
         self._cache = None
 

@@ -32,7 +32,12 @@ import torch
 
 from . import ops
 
+import os as _os
+
 _ROPE_FILES = ("modeling_llama", "modeling_mistral", "modeling_qwen2", "modeling_gemma3")
+# Gemma-3's per-head q_norm / k_norm inside the rotary launch of the no-grad scoring forward (bma_qknorm_rope2): one pass
+# over q and k instead of two.  An A/B switch (an engine option until round 4): the engine passes it to FusedInference.
+FUSE_QK_ROPE = _os.environ.get("BMA_FUSE_QK_ROPE", "1") not in ("0", "false", "False")
 _DTYPES = (torch.bfloat16, torch.float16, torch.float32)
 
 
@@ -242,6 +247,7 @@ class FusedInference:
         self.fuse_qk_rope = fuse_qk_rope
         self._rope_norms = {}                        # id(q_norm / k_norm module) of attention blocks whose forward rotates right behind them
         self.admitted = {}
+        self.refused = {}                            # fusion -> why it was NOT admitted on this model (logged at construction)
         self._pending = {}                           # id(tensor) -> (tensor, weight, eps, gemma): a head norm deferred into the rotary launch
         self.weight_copies = weight_copies
         self.fuse_gate_up = fuse_gate_up
@@ -326,12 +332,63 @@ class FusedInference:
         kinds = sorted({k for _, k, _ in self.layers})
         # what was admitted (the source-text checks above turn a fusion off silently on a transformers upgrade or a
         # .pyc-only install: the engine logs this and bench.py prints it with the engine state)
+        self.refused = self._refusals(model, fuse_qkv, fuse_add_norm, fuse_b1_attention, norm_rope_blocks)
         self.admitted = dict(rmsnorms=len(self.norms), gated_mlps=len(self.mlps), fused_qkv_blocks=len(self.qkv),
                              transposed_copy_projections=len(self.linears), add_norm_layers=len(self.layers),
                              layer_kinds=kinds, rotary_files=[m.__name__.rsplit(".", 1)[-1] for m in self.rope_modules],
                              b1_attention_blocks=len(self.b1_attn),
                              qk_norm_in_rotary_blocks=len(self._rope_norms) // 2,
                              qk_norm_blocks_not_admitted=len(norm_rope_blocks) - len(self._rope_norms) // 2)
+
+    def _refusals(self, model, fuse_qkv, fuse_add_norm, fuse_b1_attention, norm_rope_blocks) -> dict:
+        """Which fast paths this model did NOT get, and why -- the admission checks read HuggingFace SOURCE TEXT and
+        attribute names, so a transformers upgrade or a .pyc-only install turns a fusion off without an error; this is what
+        says so (logged once at construction, printed with bench.py's engine state)."""
+        import inspect
+        out = {}
+
+        def source_of(cls):
+            try:
+                inspect.getsource(cls.forward)
+                return True
+            except (OSError, TypeError):
+                return False
+
+        stacks = [m for m in model.modules() if isinstance(getattr(m, "layers", None), torch.nn.ModuleList) and len(m.layers)
+                  and hasattr(m.layers[0], "self_attn") and hasattr(m.layers[0], "mlp")]
+        if fuse_add_norm and stacks and not self.layers:
+            cls = type(stacks[0].layers[0])
+            out["add_norm_layers"] = (f"{cls.__name__}.forward: source not available (.pyc-only install?)" if not source_of(cls)
+                                      else f"{cls.__name__}.forward is not, statement for statement, the llama / gemma3 residual structure "
+                                           "the fused layer forward restates (another transformers version or model family)")
+        attn_blocks = [m for m in model.modules() if all(hasattr(m, n) for n in ("q_proj", "k_proj", "v_proj", "o_proj")) and hasattr(m, "layer_idx")]
+        if fuse_qkv and attn_blocks and not self.qkv:
+            a = attn_blocks[0]
+            why = ("projections carry a bias" if a.q_proj.bias is not None else
+                   "the block has per-head q/k norms (dense projection outputs wanted)" if hasattr(a, "q_norm") else
+                   f"weights are {a.q_proj.weight.dtype} (16-bit only)" if a.q_proj.weight.dtype not in (torch.bfloat16, torch.float16) else
+                   "q/k/v are not plain nn.Linear modules over one input width")
+            out["fused_qkv_blocks"] = why
+        if fuse_b1_attention and self.qkv and len(self.b1_attn) < len(self.qkv):
+            a = next(m for m in self.qkv if m not in self.b1_attn)
+            cfg = getattr(a, "config", None)
+            heads = getattr(cfg, "num_attention_heads", 0)
+            kv = getattr(cfg, "num_key_value_heads", None) or heads
+            why = (f"{type(a).__name__}.forward: source not available (.pyc-only install?)" if not source_of(type(a)) else
+                   f"head width {getattr(a, 'head_dim', None)} (128 only)" if getattr(a, "head_dim", 0) != 128 else
+                   f"grouped key/value heads ({heads} on {kv})" if heads != kv else
+                   f"{type(a).__name__}.forward is not projections -> rotary -> attention function -> o_proj with nothing else touching q, k, v")
+            out["b1_attention_blocks"] = f"{len(self.qkv) - len(self.b1_attn)} of {len(self.qkv)} blocks: {why}"
+        elif fuse_b1_attention and attn_blocks and not self.qkv:
+            out["b1_attention_blocks"] = "needs the fused q/k/v product (see fused_qkv_blocks)"
+        missed = len(norm_rope_blocks) - len(self._rope_norms) // 2
+        if missed:
+            out["qk_norm_in_rotary_blocks"] = f"{missed} blocks: their modelling file's apply_rotary_pos_emb is not one this module patches"
+        files = {type(m).__module__.rsplit(".", 1)[-1] for m in attn_blocks}
+        unknown = sorted(f for f in files if f not in _ROPE_FILES and hasattr(sys.modules.get(type(attn_blocks[0]).__module__), "apply_rotary_pos_emb"))
+        if unknown:
+            out["rotary_files"] = f"{unknown}: not a modelling file whose rotary convention is known (full-head, rotate_half)"
+        return out
 
     @staticmethod
     def _act_code(act_fn):

@@ -1,7 +1,9 @@
 """Library-GEMM selection for the HuggingFace model's matmuls.
 
-The transformer GEMMs stay in rocBLAS / hipBLASLt (no hand-written GEMM on this path);
-what this module controls is WHICH library kernel serves each shape.  PyTorch's TunableOp
+The GEMMs of the candidate-scoring forward -- 82 % of a step -- stay in rocBLAS / hipBLASLt (north_star assigns
+them to the library; the batch-1 gradient pass has hand-written products of its own since rounds 3-4: csrc/gemm_nt.hip
+at <= 96 rows, csrc/gemm_mid.hip at 560-672 rows, routed in ops.linear_b1 and untouched by this module).
+What this module controls is WHICH library kernel serves each shape.  PyTorch's TunableOp
 can time every rocBLAS and hipBLASLt solution for a shape once and remember the winner;
 ``tools/tune_gemms.py`` does that offline for the attack's shapes (LLaVA-1.5-7B, sw=512,
 1/2/4/8 shards) and the result ships as ``bimodalattack_amd/tuning/<arch>.csv``.  At run

@@ -76,6 +76,21 @@ class CapturableNormalize:
         return out
 
 
+import os as _os
+
+_OFF = ("0", "false", "False")
+# A/B switches of the vision-tower fast paths (engine options until round 4; an HFAdapter instance carries its own copies,
+# which tests flip directly):
+# towers whose head width is not a multiple of 32 (SigLIP: 72): the hand-written pair at the real width, else zero-padded
+# q/k/v for the library (prefix_attention.padded_heads_attention)
+PAD_VISION_HEADS = _os.environ.get("BMA_PAD_VISION_HEADS", "1") not in _OFF
+# CLIP's QuickGELU (x * sigmoid(1.702 x): three launches forward, five backward on a launch-bound tower) as one launch each
+# way, bit-identical (bma_quick_gelu)
+FUSE_QUICK_GELU = _os.environ.get("BMA_FUSE_QUICK_GELU", "1") not in _OFF
+# the vision tower's q/k/v projections (with their biases) as one product, forward and input-gradient
+FUSE_TOWER_QKV = _os.environ.get("BMA_FUSE_TOWER_QKV", "1") not in _OFF
+
+
 class HFAdapter:
     def __init__(self, model, processor, normalize=None):
         self.model = model
@@ -108,11 +123,11 @@ class HFAdapter:
         self.shared_window: Optional[int] = None
         self.shared_ok: Optional[bool] = None
         self.ragged_ok: Optional[bool] = None
-        self.pad_vision_heads = True            # EngineOptions.pad_vision_heads, set by the attack object
+        self.pad_vision_heads = PAD_VISION_HEADS
         self._vision_cfgs = None
-        self.fuse_quick_gelu = True             # EngineOptions.fuse_quick_gelu: CLIP's MLP activation as one launch each way
+        self.fuse_quick_gelu = FUSE_QUICK_GELU   # CLIP's MLP activation as one launch each way
         self._quick_gelus = None
-        self.fuse_tower_qkv = True              # EngineOptions.fuse_tower_qkv: the tower's q/k/v projections as one product
+        self.fuse_tower_qkv = FUSE_TOWER_QKV     # the tower's q/k/v projections as one product
         self._tower_attn = None
         self._proj_norms = None
 

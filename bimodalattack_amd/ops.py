@@ -672,6 +672,14 @@ def prefix_attention(query: torch.Tensor, prefix_k: torch.Tensor, prefix_v: torc
 
 
 # ---------------------------------------------------------------------------
+# The hand-written batch-1 kernels of the gradient pass, one by one (A/B measurements: BMA_SKINNY_GEMM=0 ...).  The engine
+# has ONE option for the four (EngineOptions.own_b1_kernels); what it switches on is what this table allows.
+_OFF = ("0", "false", "False")
+OWN_KERNELS = {"skinny_gemm": _os.environ.get("BMA_SKINNY_GEMM", "1") not in _OFF,
+               "mid_gemm": _os.environ.get("BMA_MID_GEMM", "1") not in _OFF,
+               "causal_attention": _os.environ.get("BMA_CAUSAL_ATTENTION", "1") not in _OFF,
+               "b1_attention": _os.environ.get("BMA_FUSE_B1_ATTENTION", "1") not in _OFF}
+
 # rotary + causal attention of one short sequence, forward and backward (csrc/b1_attention.hip): the batch-1 gradient pass
 B1_ATTENTION_MAX_TOKENS = 80
 
@@ -734,7 +742,7 @@ class B1AttentionFn(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------
 # causal attention of one long sequence at batch 1, forward and backward (csrc/causal_attention.hip)
-CAUSAL_ATTENTION = True         # module switch (EngineOptions.causal_attention / BMA_CAUSAL_ATTENTION)
+CAUSAL_ATTENTION = True         # module switch (set by the engine: EngineOptions.own_b1_kernels and OWN_KERNELS["causal_attention"])
 CAUSAL_ATTENTION_MAX_TOKENS = 4096
 
 
@@ -861,18 +869,20 @@ def rotary_causal_attention_ok(qkv: torch.Tensor, cos: torch.Tensor, heads: int)
 
 # ---------------------------------------------------------------------------
 # skinny products of the batch-1 gradient pass on the hand-written kernel (csrc/gemm_nt.hip)
-SKINNY_GEMM = True              # module switch (EngineOptions.skinny_gemm / BMA_SKINNY_GEMM)
+SKINNY_GEMM = True              # module switch (set by the engine: EngineOptions.own_b1_kernels and OWN_KERNELS["skinny_gemm"])
 GEMM_NT_MAX_ROWS = int(_os.environ.get("BMA_GEMM_NT_MAX_ROWS", "96"))   # one 64- or 96-row tile: the shapes the kernel is built and measured for
 # Routed where the kernel measures faster than the tuned library (tools/gemm_bench.py, profiles/r4_gemm_bench.txt): every
 # product of the pass whose long side is at least 2.5x its short one -- long reductions (the library has to split K
 # itself: the input gradients through the transposed copies, down_proj: 1.3-1.5x) and wide outputs (gate/up, q/k/v, the
-# input gradient of down_proj: 1.0-1.13x); the square o_proj ties (0.98x) and stays with the library.  0 for either
-# bound routes every shape (tools, tests).
+# input gradient of down_proj: 1.0-1.13x); the square o_proj ties (0.98x) and stays with the library.
+# GEMM_NT_MIN_K_OVER_N = 0 routes EVERY shape (tools, tests); GEMM_NT_MIN_N_OVER_K = 0 switches the wide-output rule OFF
+# (only K >= MIN_K_OVER_N * N is routed then).
 GEMM_NT_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_NT_MIN_K_OVER_N", "2.5"))
 GEMM_NT_MIN_N_OVER_K = float(_os.environ.get("BMA_GEMM_NT_MIN_N_OVER_K", "2.5"))
 _GEMM_WS_BYTES = 64 << 20
 _GEMM_COUNTERS = 4096
 _GEMM_WS = {}
+_GEMM_WS_MAX_EAGER = 4
 GEMM_NT_HOOK = None             # measurement: called as hook(x, w) for every product routed to the kernel (bench.py)
 
 
@@ -890,6 +900,13 @@ def gemm_workspace(dev: torch.device):
     if ws is None:
         if capturing:
             return None
+        # eager pairs are bounded (every graph warm-up on a fresh side stream left 64 MB behind, 2 GB over the
+        # stream pool): the oldest eager pair goes when a fifth stream asks -- its memory returns to the caching
+        # allocator under the stream it was allocated on, i.e. behind that stream's own last launch; the "graphs" pair
+        # (captured launches hold its address) is never dropped
+        eager = [k for k in _GEMM_WS if k[:2] == key[:2] and k[2] != "graphs"]
+        if len(eager) >= _GEMM_WS_MAX_EAGER:
+            del _GEMM_WS[eager[0]]
         ws = (torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=dev), torch.zeros(_GEMM_COUNTERS, dtype=torch.int32, device=dev))
         _GEMM_WS[key] = ws
     return ws
@@ -963,12 +980,17 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, next_w: Optional[torch.Tensor] = N
         raise ValueError("gemm_nt wants contiguous 16-bit x (..., K) and w (N, K) of one dtype with K a multiple of 64")
     K, N = w.shape[1], w.shape[0]
     M = x.numel() // K
-    pair = gemm_workspace(dev)
-    if pair is None:
-        raise RuntimeError("bma_gemm_nt workspace requested inside a graph capture before it was allocated")
-    ws, cnt = pair
-    if lib.bma_gemm_nt_ws_bytes(M, N, K) > ws.numel() or lib.bma_gemm_nt_tiles(M, N, K) > cnt.numel():
-        raise ValueError("product beyond the fixed split-K workspace")
+    need = lib.bma_gemm_nt_ws_bytes(M, N, K)
+    if need:                                     # (an unsplit product takes no workspace: none is allocated for it)
+        pair = gemm_workspace(dev)
+        if pair is None:
+            raise RuntimeError("bma_gemm_nt workspace requested inside a graph capture before it was allocated")
+        ws, cnt = pair
+        if need > ws.numel() or lib.bma_gemm_nt_tiles(M, N, K) > cnt.numel():
+            raise ValueError("product beyond the fixed split-K workspace")
+        ws_ptr, ws_len, cnt_ptr, cnt_len = ws.data_ptr(), ws.numel(), cnt.data_ptr(), cnt.numel()
+    else:
+        ws_ptr = ws_len = cnt_ptr = cnt_len = 0
     if GEMM_NT_HOOK is not None:
         GEMM_NT_HOOK(x, w)
     y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=dev)
@@ -976,23 +998,24 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, next_w: Optional[torch.Tensor] = N
         next_w = _next_weight(w)
     if next_w is not None and next_w.dtype == w.dtype and next_w.device == w.device and next_w.dim() == 2 and next_w.is_contiguous() \
             and next_w.shape[1] % 64 == 0:
-        check("bma_gemm_nt_next", lib.bma_gemm_nt_next(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws.data_ptr(),
-                                                       ws.numel(), cnt.data_ptr(), cnt.numel(), next_w.data_ptr(), next_w.shape[1],
+        check("bma_gemm_nt_next", lib.bma_gemm_nt_next(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws_ptr,
+                                                       ws_len, cnt_ptr, cnt_len, next_w.data_ptr(), next_w.shape[1],
                                                        next_w.shape[0], next_w.shape[1], _stream(dev)))
         return y
-    check("bma_gemm_nt", lib.bma_gemm_nt(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws.data_ptr(),
-                                         ws.numel(), cnt.data_ptr(), cnt.numel(), _stream(dev)))
+    check("bma_gemm_nt", lib.bma_gemm_nt(x.data_ptr(), K, w.data_ptr(), K, y.data_ptr(), N, M, N, K, _dt(x), ws_ptr,
+                                         ws_len, cnt_ptr, cnt_len, _stream(dev)))
     return y
 
 
 # the same products at 599-644 rows (the pass with the image in the prompt) on csrc/gemm_mid.hip
-MID_GEMM = True                 # module switch (EngineOptions.mid_gemm / BMA_MID_GEMM)
+MID_GEMM = True                 # module switch (set by the engine: EngineOptions.own_b1_kernels and OWN_KERNELS["mid_gemm"])
 GEMM_MID_MIN_ROWS = int(_os.environ.get("BMA_GEMM_MID_MIN_ROWS", "560"))    # three 224-row tiles, the third at least half full
 GEMM_MID_MAX_ROWS = int(_os.environ.get("BMA_GEMM_MID_MAX_ROWS", "672"))
 # Routed where the kernel measures faster than the tuned library at 599-644 rows (tools/gemm_bench.py --mid,
 # profiles/r4_gemm_mid_bench.txt): long reductions (N = 4096 with K = 11008 / 12288 / 22016, where the library has to split
 # K itself: 1.25-1.65x) and the widest output (gate/up, N = 22016: 1.04-1.2x); q/k/v and the input gradient of down_proj
-# tie and the square o_proj loses (0.8x): those stay with the library.  0 for either bound routes every shape.
+# tie and the square o_proj loses (0.8x): those stay with the library.  MIN_K_OVER_N = 0 routes every shape; MIN_N_OVER_K = 0
+# switches the wide-output rule off.
 GEMM_MID_MIN_K_OVER_N = float(_os.environ.get("BMA_GEMM_MID_MIN_K_OVER_N", "2.5"))
 GEMM_MID_MIN_N_OVER_K = float(_os.environ.get("BMA_GEMM_MID_MIN_N_OVER_K", "4.0"))
 GEMM_MID_HOOK = None            # measurement: called as hook(x, w) for every product routed to the kernel (bench.py)
@@ -1042,10 +1065,14 @@ def gemm_mid(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 def linear_b1(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """x @ w^T for a bias-free weight: the hand-written kernels where they apply, the library otherwise."""
-    if gemm_nt_ok(x, w) and (gemm_workspace(x.device) is not None):
-        return gemm_nt(x, w)
-    if gemm_mid_ok(x, w) and (gemm_workspace(x.device) is not None):
-        return gemm_mid(x, w)
+    if gemm_nt_ok(x, w):
+        K, N = w.shape[1], w.shape[0]
+        if lib.bma_gemm_nt_ws_bytes(x.numel() // K, N, K) == 0 or gemm_workspace(x.device) is not None:
+            return gemm_nt(x, w)
+    if gemm_mid_ok(x, w):
+        K, N = w.shape[1], w.shape[0]
+        if lib.bma_gemm_mid_ws_bytes(x.numel() // K, N, K) == 0 or gemm_workspace(x.device) is not None:
+            return gemm_mid(x, w)
     return torch.nn.functional.linear(x, w)
 
 

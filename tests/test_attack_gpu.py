@@ -179,7 +179,7 @@ def test_most_base_trajectories_are_compared_to_their_last_step():
                                     # ... or launches it ahead but plans the ragged forward from the sampled ids
                                     dict(early_plan=False),
                                     # everything eager and unfused
-                                    dict(graph_prefix=False, graph_rescore=False, graph_gradient=False,
+                                    dict(graph_scoring=False, graph_gradient=False,
                                          fused_elementwise=False, gemm_tuning="off")])
 def test_restructurings_do_not_change_results(golden_dir, name, engine):
     """Full-sequence forward / full logits (the reference's call shape) and odd chunk
@@ -190,7 +190,7 @@ def test_restructurings_do_not_change_results(golden_dir, name, engine):
 
 @pytest.mark.parametrize("name", ["llava_gcg_early", "llava_pgd_gcg_early", "llava_joint_early", "gemma3_pgd",
                                   "gemma3_joint_dyn"])
-@pytest.mark.parametrize("engine", [dict(graph_rescore=False, graph_gradient=False, graph_prefix=False),
+@pytest.mark.parametrize("engine", [dict(graph_scoring=False, graph_gradient=False),
                                     dict(joint_winner_from_batch=False),
                                     dict(fuse_pgd_only=False),
                                     dict(gradient_ahead=False),
@@ -1323,8 +1323,7 @@ def test_7b_pgd_only_steps():
     x0 = image.detach().clone()
     runs = {}
     for name, opts in (("default", {}),
-                       ("library", dict(mid_gemm=False, causal_attention=False, fuse_b1_attention=False, skinny_gemm=False,
-                                        graph_gradient=False))):
+                       ("library", dict(own_b1_kernels=False, graph_gradient=False))):
         cfg = BimodalAttackConfig(num_steps=steps, search_width=8, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=False,
                                   eps=eps, alpha=alpha, images_folder=tempfile.mkdtemp())
         atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True, **opts))
@@ -1471,7 +1470,7 @@ def test_gemma3_4b_scoring_equals_reference_call_shape():
         assert int(got.argmin()) == int(want32.argmin())
 
 
-def test_text_gradient_pass_with_one_launch_attention_at_7b_width():
+def test_text_gradient_pass_with_one_launch_attention_at_7b_width(monkeypatch):
     """the text-only gradient pass at LLaVA-1.5-7B width (bf16, 65 rows, 32 heads of 128; 4
     layers here) with rotary + attention between the fused q/k/v projection and o_proj as ONE launch each way
     (bma_b1_attention) against the same pass through HuggingFace's rotary + the library's attention: same loss and token
@@ -1491,9 +1490,10 @@ def test_text_gradient_pass_with_one_launch_attention_at_7b_width():
                               images_folder=tempfile.mkdtemp())
     ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
     got = {}
+    from bimodalattack_amd import ops
     for one_launch in (True, False):
-        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True,
-                                                                                fuse_b1_attention=one_launch))
+        monkeypatch.setitem(ops.OWN_KERNELS, "b1_attention", one_launch)       # (an A/B switch of ONE of the own kernels: ops.OWN_KERNELS)
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True))
         atk._prepare_prompt(messages, target)
         assert atk.engine_state()["fusions"]["b1_attention_blocks"] == (layers if one_launch else 0)
         native.profile_enable(True)
@@ -1573,7 +1573,7 @@ def test_image_gradient_pass_forms_each_projection_once():
     assert n_qkv_shaped <= layers, seen
 
 
-def test_maskless_b1_attention_gradient_matches_masked():
+def test_maskless_b1_attention_gradient_matches_masked(monkeypatch):
     """The gradient pass of the image prompt (643 rows, LLaVA-1.5-7B width, 2 layers here) with the library
     attention asked for `is_causal` against the same pass handed HuggingFace's mask tensor: token and pixel
     gradients agree to bf16 noise (same maths, different library kernels)."""
@@ -1590,9 +1590,10 @@ def test_maskless_b1_attention_gradient_matches_masked():
                               joint_eval=True, images_folder=tempfile.mkdtemp())
     out, calls = {}, []
     orig = pa.causal_b1_attention
+    from bimodalattack_amd import attack as attack_mod
     for maskless in (True, False):
-        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, graph_gradient=False,
-                                                                                maskless_b1_attention=maskless, strict=True))
+        monkeypatch.setattr(attack_mod, "MASKLESS_B1_ATTENTION", maskless)      # (a module constant since round 5)
+        atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, graph_gradient=False, strict=True))
         atk._prepare_prompt(messages, target)
         ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
         img = image.detach().clone().requires_grad_()
@@ -1710,7 +1711,7 @@ def test_graphs_are_really_captured_with_a_list_style_normalize(reuse):
         cfg = BimodalAttackConfig(num_steps=3, search_width=16, topk=8, pgd_attack=True, gcg_attack=True, joint_eval=True,
                                   eps=64 / 255, alpha=4 / 255, seed=3, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
                                   images_folder=tempfile.mkdtemp())
-        kw = dict(graph_gradient=False, graph_prefix=False, graph_rescore=False) if eager else {}
+        kw = dict(graph_gradient=False, graph_scoring=False) if eager else {}
         kw["joint_winner_from_batch"] = False           # keep the batch-1 winner re-score (and its graph) in play
         attack = BimodalAttack(model, tok, proc, cfg, ListNormalize(),
                                EngineOptions.from_env(rng_device="cpu", grad_prefix_reuse=reuse, strict=True, **kw))
@@ -1744,7 +1745,7 @@ def test_16bit_engine_paths_agree(dtype):
     full = dict(grad_prefix_reuse=False)
     variants = [dict(full), dict(full, ragged_suffix=False), dict(full, shared_prefix_attention=False),
                 dict(full, prefix_reuse=False),
-                dict(full, fuse_qkv=False, fuse_gate_up=False, backward_weight_copies=False, graph_gradient=False),
+                dict(full, derived_weight_copies=False, graph_gradient=False),
                 dict()]
     out = []
     for eng in variants:
@@ -1843,7 +1844,7 @@ def test_gradient_pass_reusing_the_scoring_prefix_equals_the_full_pass(graphs):
                               gcg_attack=True, joint_eval=True, optim_str_init=S.TINY_OPTIM_INIT,
                               images_folder=tempfile.mkdtemp())
     atk = BimodalAttack(model, tok, proc, cfg, S.Normalize(S.CLIP_MEAN, S.CLIP_STD),
-                        EngineOptions.from_env(save_images=False, graph_gradient=graphs, graph_prefix=graphs, strict=True))
+                        EngineOptions.from_env(save_images=False, graph_gradient=graphs, graph_scoring=graphs, strict=True))
     atk._prepare_prompt("tell me a story", "Sure here is")
     assert atk._gp_enabled()
     g = torch.Generator().manual_seed(3)
@@ -1935,7 +1936,7 @@ for grouped in (False, True):
                               eps=64 / 255, alpha=4 / 255, seed=3, verbosity="ERROR", optim_str_init=S.TINY_OPTIM_INIT,
                               early_stop=False, images_folder=tempfile.mkdtemp())
     atk = BimodalAttack(model, tok, proc, cfg, S.Normalize(S.CLIP_MEAN, S.CLIP_STD),
-                        EngineOptions.from_env(rng_device="cpu", strict=True, tp_gradient=grouped, tp_graph=grouped))
+                        EngineOptions.from_env(rng_device="cpu", strict=True, tp_gradient="graph" if grouped else False))
     if grouped:
         atk.shard.enabled = True
     res = atk.run("tell me a story", "tell me a story", "Sure here is a story", image)

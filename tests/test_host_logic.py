@@ -98,6 +98,23 @@ def test_engine_options_from_env(monkeypatch):
         EngineOptions.from_env(nonsense=1)
     with pytest.raises(ValueError):
         EngineOptions.from_env(rng_device="tpu")
+    # round 5: the options are what a test or bench.py flips -- at most 30 of them; every boolean one has its BMA_<NAME>
+    import dataclasses
+    names = [f.name for f in dataclasses.fields(EngineOptions)]
+    assert len(names) <= 30 and set(EngineOptions._BOOLS) <= set(names)
+    for gone in ("skinny_gemm", "mid_gemm", "fuse_qkv", "graph_prefix", "graph_rescore", "emulate_world", "score_log", "group", "tp_graph"):
+        assert gone not in names
+    monkeypatch.setenv("BMA_OWN_B1_KERNELS", "0")
+    monkeypatch.setenv("BMA_GRAPH_SCORING", "false")
+    monkeypatch.setenv("BMA_TP_GRADIENT", "graph")
+    monkeypatch.setenv("BMA_FILTER_FIRST", "1")
+    o = EngineOptions.from_env()
+    assert (o.own_b1_kernels, o.graph_scoring, o.tp_gradient, o.filter_first) == (False, False, "graph", True)
+    assert EngineOptions.from_env(tp_gradient=True).tp_gradient is True
+    with pytest.raises(ValueError):
+        EngineOptions.from_env(tp_gradient="eager")
+    with pytest.raises(TypeError):
+        EngineOptions.from_env(_BOOLS=())
 
 
 @pytest.mark.parametrize("kind", ["opt", "llava", "gemma3"])
@@ -509,6 +526,8 @@ def test_fused_structure_detection_steps_aside_on_4_50_style_layers():
     assert f.layers == [] and f.admitted["add_norm_layers"] == 0 and f.admitted["layer_kinds"] == []
     assert f.admitted["rmsnorms"] == 5 and f.admitted["gated_mlps"] == 2 and f.admitted["transposed_copy_projections"] == 14
     assert f.admitted["rotary_files"] == [] and f.admitted["qk_norm_in_rotary_blocks"] == 0
+    # ... and the engine SAYS what it did not admit and why (logged once at construction)
+    assert "statement for statement" in f.refused["add_norm_layers"] and "DecoderLayer450" in f.refused["add_norm_layers"]
     x = torch.randn(1, 5, 8)
     want = model(x)
     with f:                                   # on the CPU the kernels step aside; the 4.50-style tuple flows through untouched
@@ -668,6 +687,7 @@ def test_qk_norm_is_deferred_only_where_the_rotary_function_is_patched(monkeypat
     monkeypatch.setattr(fused, "_ROPE_FILES", ("modeling_llama",))
     g = fused.FusedInference(model)
     assert not g._rope_norms and g.admitted["qk_norm_blocks_not_admitted"] == 2 and g.admitted["rotary_files"] == []
+    assert "2 blocks" in g.refused["qk_norm_in_rotary_blocks"] and "qk_norm_in_rotary_blocks" not in f.refused
 
 
 def test_bench_line_fits_the_drivers_window_and_is_strict_json():

@@ -20,27 +20,51 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
+# engine options of a variant; keys "module:NAME" set a module constant of bimodalattack_amd for the variant's run
+# (the A/B switches that are not engine options: ops.OWN_KERNELS entries as "ops:OWN_KERNELS.skinny_gemm")
 VARIANTS = {
     "default": {},
-    "nopad": dict(pad_vision_heads=False),
-    "nographs": dict(graph_gradient=False, graph_prefix=False, graph_rescore=False),
-    "notowerqkv": dict(fuse_tower_qkv=False),
-    "nofeatgraph": dict(graph_prefix=False),
+    "nopad": {"hf_adapter:PAD_VISION_HEADS": False},
+    "nographs": dict(graph_gradient=False, graph_scoring=False),
+    "notowerqkv": {"hf_adapter:FUSE_TOWER_QKV": False},
+    "noscoringgraphs": dict(graph_scoring=False),
     "nogradgraph": dict(graph_gradient=False),
-    "norescoregraph": dict(graph_rescore=False),
     "cpurng": dict(rng_device="cpu"),
     "noaddnorm": dict(fuse_add_norm=False),
-    "noqkrope": dict(fuse_qk_rope=False),
+    "noqkrope": {"fused:FUSE_QK_ROPE": False},
     "nofused": dict(fused_elementwise=False),
-    "noskinny": dict(skinny_gemm=False),
-    "nogateup": dict(fuse_gate_up=False, fuse_qkv=False),
-    "nobwdcopies": dict(backward_weight_copies=False),
-    "nomaskless": dict(maskless_b1_attention=False),
-    "plain": dict(pad_vision_heads=False, graph_gradient=False, graph_prefix=False, graph_rescore=False, fuse_tower_qkv=False,
-                  fuse_add_norm=False, fuse_qk_rope=False, fused_elementwise=False, skinny_gemm=False, fuse_gate_up=False,
-                  fuse_qkv=False, backward_weight_copies=False, maskless_b1_attention=False, shared_prefix_attention=False,
-                  ragged_suffix=False, gradient_ahead=False, early_plan=False, gemm_tuning="off"),
+    "noskinny": {"ops:OWN_KERNELS.skinny_gemm": False},
+    "noownkernels": dict(own_b1_kernels=False),
+    "nocopies": dict(derived_weight_copies=False),
+    "nomaskless": {"attack:MASKLESS_B1_ATTENTION": False},
+    "plain": {"hf_adapter:PAD_VISION_HEADS": False, "hf_adapter:FUSE_TOWER_QKV": False, "fused:FUSE_QK_ROPE": False,
+              "attack:MASKLESS_B1_ATTENTION": False, "graph_gradient": False, "graph_scoring": False, "fuse_add_norm": False,
+              "fused_elementwise": False, "own_b1_kernels": False, "derived_weight_copies": False, "shared_prefix_attention": False,
+              "ragged_suffix": False, "gradient_ahead": False, "early_plan": False, "gemm_tuning": "off"},
 }
+
+
+def split_variant(v: dict):
+    """(engine keyword arguments, a function that sets the variant's module constants and returns the undo function)."""
+    import importlib
+    kw = {k: val for k, val in v.items() if ":" not in k}
+    consts = {k: val for k, val in v.items() if ":" in k}
+
+    def apply():
+        undo = []
+        for key, val in consts.items():
+            mod_name, attr = key.split(":")
+            mod = importlib.import_module("bimodalattack_amd." + mod_name)
+            if "." in attr:
+                table, item = attr.split(".")
+                d = getattr(mod, table)
+                undo.append((d.__setitem__, item, d[item]))
+                d[item] = val
+            else:
+                undo.append((lambda name, old, m=mod: setattr(m, name, old), attr, getattr(mod, attr)))
+                setattr(mod, attr, val)
+        return lambda: [f(a, b) for f, a, b in undo]
+    return kw, apply
 
 
 def stats(a) -> dict:
@@ -78,10 +102,10 @@ def main() -> None:
     model, tok, proc, messages, goal, target, image0, norm = bench.build_plugins(args.workload, dev, torch.bfloat16, args.layers, share=True)
     report = {}
     for name in args.variants.split(","):
-        kw = dict(VARIANTS[name])
+        kw, apply_constants = split_variant(VARIANTS[name])
+        undo_constants = apply_constants()
         trace = None if args.no_trace else []
         score_log = []
-        kw["score_log"] = score_log
         if args.bench_schedule:
             from bimodalattack_amd.layout import dynamic_width
             K = max(1, args.steps - 4)
@@ -96,6 +120,7 @@ def main() -> None:
                                   dynamic_search=bool(wl.get("gemma")), min_search_width=min(128, args.width))
         image = None if image0 is None else image0.detach().clone()
         attack = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, trace=trace, **kw))
+        attack.score_log = score_log
         if args.probe_feats:
             orig = attack.scoring_features
             rec, arm = [], {"v": False}
@@ -165,8 +190,9 @@ def main() -> None:
             row["current_loss"] = st.get("current_loss")
             rows.append(row)
         calls = [{k: (int(v.item()) if hasattr(v, "item") else v) for k, v in c.items()} for c in score_log]
-        kw.pop("score_log", None)
+        undo_constants()
         kw.pop("width_override", None)
+        kw.update({k: v for k, v in VARIANTS[name].items() if ":" in k})
         for c in calls:
             print("   " + " ".join(f"{k}={v}" for k, v in c.items()), flush=True)
         rep = dict(options=kw, error=err, score_calls=calls, init_losses=[float(v) for v in attack.init_losses.tolist()] if hasattr(attack, "init_losses") else None,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GEMM selection for padded candidate scoring (models whose layout rules out ragged rows: Gemma-3).
 
-Padded scoring runs chunks whose candidate count is a multiple of EngineOptions.chunk_quantum (utils.plan_chunk,
+Padded scoring runs chunks whose candidate count is a multiple of attack.CHUNK_QUANTUM (utils.plan_chunk,
 attack._score_candidates), so whatever the search width -- the dynamic schedule of BASELINE configs[4] walks
 through ~385 of them -- the decoder meets one GEMM shape set per multiple up to the chunk cap.  This script
 scores 8, 16, ... candidates through the real engine under PyTorch TunableOp in TUNING mode and merges the
@@ -52,11 +52,12 @@ def main():
     model, tok, proc, messages, goal, target, image, norm = build_plugins(args.workload, dev, torch.bfloat16, 32)
     cfg = BimodalAttackConfig(num_steps=1, search_width=512, seed=1, verbosity="ERROR", pgd_attack=True, gcg_attack=True,
                               joint_eval=True, images_folder=tempfile.mkdtemp())
-    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, graph_prefix=False))
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, graph_scoring=False))
     atk._prepare_prompt(messages, target)
     ids = tok(cfg.optim_str_init, add_special_tokens=False, return_tensors="pt")["input_ids"].to(dev)
     order = segment_order("pgd", atk.hf.model_type, single=True)
-    q = atk.opt.chunk_quantum
+    from bimodalattack_amd.attack import CHUNK_QUANTUM
+    q = CHUNK_QUANTUM
 
     def score(n):
         cand = ids.repeat(n, 1)

@@ -33,7 +33,7 @@ def main():
         shutil.copyfile(dst, src)            # keep what is already tuned: only new shapes are searched
     for wl in workloads:
         for world in [int(w) for w in os.environ.get("BMA_TUNE_WORLDS", "1,2,4,8").split(",")]:
-            # rank 0's share of a `world`-GPU run, in one process (EngineOptions.emulate_world): the shapes
+            # rank 0's share of a `world`-GPU run, in one process (attack.EMULATE_WORLD, BMA_EMULATE_WORLD): the shapes
             # candidate dealing produces, not those of a smaller search width
             print(f"== tuning {wl} as rank 0 of {world}", flush=True)
             r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--steps", "1", "--warmup", "1",
