@@ -607,7 +607,7 @@ def committed_profile(name: str):
     """A committed measurement file under profiles/ (the newest round that has one), parsed; (None, None) when absent."""
     if name not in _PMC:
         hit = (None, None)
-        for tag in ("r4", "r3", "r2"):
+        for tag in ("r5", "r4", "r3", "r2"):
             path = os.path.join(REPO, "profiles", f"{tag}_{name}")
             try:
                 with open(path) as f:
@@ -624,7 +624,7 @@ def pmc_traffic(kernel: str, live_bytes: float):
     tools/kernel_bench.py -- not measured in this run): the entry of this kernel whose launch shape is within 6 % of
     this run's algorithmic bytes, scaled by its measured traffic / algorithmic ratio.  (None, None) without one."""
     pmc, src = committed_profile("pmc_traffic.json")
-    near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == kernel
+    near = [e for e in (pmc or {}).get("entries", []) if e["kernel"] == kernel and e.get("valid", e["ratio_to_algorithmic"] >= 0.97)
             and abs(e["algorithmic_bytes"] - live_bytes) <= 0.06 * e["algorithmic_bytes"]]
     if not near:
         return None, None

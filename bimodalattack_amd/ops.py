@@ -943,7 +943,11 @@ def gemm_nt_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
 # gradient pass's chain, registered by fused.FusedInference (forward: qkv -> gate/up -> down -> the next layer's qkv; backward:
 # the transposed copies in reverse).  Weights do not depend on activations, so the workgroups a split launch lets go early
 # load the first stages of the next launch's weight rows.  A hint only; empty = plain bma_gemm_nt.
-GEMM_NT_PREFETCH = _os.environ.get("BMA_GEMM_NT_PREFETCH", "1") not in ("0", "false", "False")
+# MEASURED AND SWITCHED OFF (round 5, VERDICT r4 item 3's own rule: keep only above 3 %): the pass's chain of 192 launches
+# 6.435 -> 6.347 ms at 65 rows (x1.014), 5.692 -> 5.642 at 44 (x1.009); per product x0.97-1.02 (profiles/r5_gemm_chain.txt).
+# A launch's fixed cost is not the first stages' HBM latency -- it is the split-K tail (the last arriver reads S x 48 KB
+# at one CU's L2 rate) and, for the unsplit gate/up product, 172 workgroups x ~25 GB/s of LDS-DMA per CU.
+GEMM_NT_PREFETCH = _os.environ.get("BMA_GEMM_NT_PREFETCH", "0") not in ("0", "false", "False")
 _GEMM_NT_NEXT = {}
 
 

@@ -325,13 +325,38 @@ def main():
     native.check_single_hip_runtime()
     want = [w for w in args.only.split(",") if w]
     results = {}
-    for name, (kid, make) in cases().items():
-        if want and not any(w in name for w in want):
+    all_cases = dict(cases())
+    # calibration of the PMC byte counters on a KNOWN byte count (MI355X_MICROARCH.md, HBM: "calibrate on a known byte count
+    # in your own access pattern"): a 256 MiB device-to-device copy -- reads 256 MiB, writes 256 MiB, 16 bytes per lane.
+    # tools/make_profiles.py derives the FETCH_SIZE / WRITE_SIZE factors of the pass from this case.
+    calib_src = torch.empty(128 << 20, dtype=torch.bfloat16, device=DEV).normal_()
+    calib_dst = torch.empty_like(calib_src)
+    all_cases = {"calib/copy_256MiB": ("calib", lambda: (lambda: calib_dst.copy_(calib_src))), **all_cases}
+    for name, (kid, make) in all_cases.items():
+        if want and not any(w in name for w in want) and kid != "calib":
             continue
+        # a case marker in front of every case: a float64 reduction no case launches.  tools/pmc_traffic.py cuts the counter
+        # rows at the markers, so that two cases that share a kernel symbol AND a grid (three gemm_nt shapes do) are never
+        # averaged into one "run" -- the reason two round-4 entries read fewer bytes than their weights hold
+        torch.zeros(4099, dtype=torch.float64, device=DEV).sum()
         fn = make()
         for _ in range(args.warmup):
             fn()
         torch.cuda.synchronize()
+        if kid == "calib":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / args.iters
+            nbytes = 2.0 * calib_src.numel() * 2
+            results[name] = dict(symbol="aten copy (16 B per lane)", launches=args.iters, avg_us=us, algorithmic_MB=nbytes / 1e6,
+                                 read_MB=nbytes / 2e6, write_MB=nbytes / 2e6, achieved_GBps=nbytes / (us * 1e-6) / 1e9,
+                                 frac_of_8TBps=nbytes / (us * 1e-6) / 8e12)
+            print(f"{name:40s} {us:9.1f} us  {nbytes / 1e6:9.2f} MB  {nbytes / (us * 1e-6) / 1e9:8.0f} GB/s  (PMC calibration case)", flush=True)
+            continue
         if kid is None:                       # a library GEMM: torch events on the current stream, flops not bytes
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -34,7 +34,7 @@ for w in ("gcg", "joint", "pgd", "gemma_joint"):  # the batch-1 gradient pass al
 for extra in ("bench_driver_detail.json", "bench_gcg_under_rocprof_detail.json", "bench_joint_under_rocprof_detail.json",
               "bench_pgd_under_rocprof_detail.json", "bench_gemma_joint_under_rocprof_detail.json", "bench_em8_detail.json",
               "bench_joint_em8_detail.json", "bench_opt125m_detail.json", "bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
-              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json", "gemm_bench.json", "gemm_bench.txt", "gemm_mid_bench.json", "gemm_mid_bench.txt", "kernel_bench.txt"):
+              "bench_gemma_joint.json", "bench_default.json", "bench_driver.json", "gemm_bench.json", "gemm_bench.txt", "gemm_mid_bench.json", "gemm_mid_bench.txt", "gemm_chain.json", "gemm_chain.txt", "kernel_bench.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
 for c in ("fetch", "write"):
@@ -57,8 +57,10 @@ for c in ("fetch", "write"):
 folded_path = os.path.join(src, "pmc_folded.json")
 subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), os.path.join(src, "fetch_counter_collection.csv"),
                 os.path.join(src, "write_counter_collection.csv"), folded_path], check=True, stdout=subprocess.DEVNULL)
-folded = json.load(open(folded_path))["kernels"]
+folded_all = json.load(open(folded_path))
+folded, calibration = folded_all["kernels"], folded_all.get("calibration")
 kb = json.load(open(os.path.join(src, "kernel_bench.json")))
+case_index = {name: i for i, name in enumerate(kb)}          # kernel_bench.py's case order = the order of its markers in the PMC passes
 
 # kernel_bench case -> (bench kernel name, PMC key = "<symbol><template>/threads<total threads>")
 CASES = [
@@ -91,6 +93,9 @@ CASES = [
     ("splice/c3r_rows_17152_D4096", "splice", "splice_rows_kernel<1>/threads4390912", "C3 ragged row list: 17152 rows of 8 KiB straight from the segments and the table"),
     ("gemm_nt/gate_up_dX_65x4096x22016", "gemm_nt", "gemm_nt_kernel<1, 6, 2, 4, true>/threads65536", "bma_gemm_nt 65 x 4096 x 22016 bf16 (input gradient of the fused gate/up product, 8-way split-K)"),
     ("gemm_nt/qkv_dX_65x4096x12288", "gemm_nt", "gemm_nt_kernel<1, 6, 2, 4, true>/threads65536", "bma_gemm_nt 65 x 4096 x 12288 bf16 (input gradient of the fused q/k/v product, 8-way split-K)"),
+    ("gemm_nt/gate_up_65x22016x4096", "gemm_nt", "gemm_nt_kernel", "bma_gemm_nt 65 x 22016 x 4096 bf16 (fused gate/up product: 172 slabs, unsplit)"),
+    ("gemm_nt/down_65x4096x11008", "gemm_nt", "gemm_nt_kernel", "bma_gemm_nt 65 x 4096 x 11008 bf16 (down_proj, 8-way split-K)"),
+    ("gemm_mid/down_644x4096x11008", "gemm_mid", "gemm_mid_kernel", "bma_gemm_mid 644 x 4096 x 11008 bf16 (down_proj at 644 rows; the partials' second launch not included)"),
     ("gemm_mid/gate_up_dX_644x4096x22016", "gemm_mid", "gemm_mid_kernel<1, 7, 4, 3>/threads122880", "bma_gemm_mid 644 x 4096 x 22016 bf16 (input gradient of the fused gate/up product at 644 rows: 48 tiles of 224 x 256, K split 5 ways; the partials' second launch not included)"),
     ("gemm_mid/gate_up_644x22016x4096", "gemm_mid", "gemm_mid_kernel<1, 7, 4, 3>/threads142848", "bma_gemm_mid 644 x 22016 x 4096 bf16 (fused gate/up product at 644 rows: 255 whole tiles + the last column split 8 ways)"),
     ("causal_attn/fwd_L643_H32", "causal_attn", "causal_fwd_kernel<1, 128>/threads180224", "causal attention forward, 643 tokens x 32 heads x 128 at batch 1 (3.4 GFLOP: latency-bound)"),
@@ -103,6 +108,7 @@ entries = []
 for case, kernel, key, shape in CASES:
     if case not in kb:
         continue
+    mine = f"case{case_index[case]}/"                        # only rows between THIS case's marker and the next one
     if key == "Cijk":
         # library GEMMs share one symbol family: the launch of THIS product is the one whose grid is the product's tile
         # count (macro-tile MTaxb from the kernel name, 256 threads per workgroup) -- round 2 took the launch whose
@@ -110,22 +116,29 @@ for case, kernel, key, shape in CASES:
         Mg, Ng = (int(v) for v in case.rsplit("_", 1)[1].split("x")[:2])
         cands = []
         for k in folded:
-            sym = k.split("/")[0]
+            if not k.startswith(mine):
+                continue
+            sym = k.split("/")[1]
             mt = re.search(r"_MT(\d+)x(\d+)x", sym)
-            th = re.search(r"/threads(\d+)/", k)
+            th = re.search(r"/threads(\d+)$", k)
             if "Cijk_" in sym and mt and th:
                 tiles = -(-Mg // int(mt.group(1))) * -(-Ng // int(mt.group(2)))
                 if int(th.group(1)) in (tiles * 256, tiles * 512, tiles * 128):
                     cands.append(k)
     else:
-        cands = [k for k in folded if k.rsplit("/run", 1)[0] == key] or [k for k in folded if k.split("/")[0] == key.split("/")[0]]
+        cands = [k for k in folded if k.startswith(mine) and k.split("/", 1)[1] == key] or \
+            [k for k in folded if k.startswith(mine) and k.split("/")[1].split("<")[0] == key.split("/")[0].split("<")[0]]
     # several shapes can share a symbol: take the launch whose traffic is closest to the algorithmic bytes
     algo = kb[case]["algorithmic_MB"] * 1e6
     if not cands:
         continue
     best = min(cands, key=lambda k: abs(folded[k]["hbm_bytes_per_launch"] - algo))
     v = folded[best]
-    entries.append(dict(kernel=kernel, shape=shape, pmc_key=best, algorithmic_bytes=algo, fetch_bytes_uncorrected=v["fetch_bytes_per_launch_corrected"] / 2 if v["fetch_bytes_per_launch_corrected"] else None,
+    ratio = v["hbm_bytes_per_launch"] / algo
+    # a kernel cannot move fewer bytes than its operands hold: such a row is a measurement fault (mixed cases, an operand
+    # resident in the Infinity Cache between launches, an access width the x2 does not hold for), not evidence
+    valid = ratio >= 0.97
+    entries.append(dict(kernel=kernel, shape=shape, pmc_key=best, valid=valid, algorithmic_bytes=algo, fetch_bytes_uncorrected=v["fetch_bytes_per_launch_corrected"] / 2 if v["fetch_bytes_per_launch_corrected"] else None,
                         hbm_bytes_per_launch=v["hbm_bytes_per_launch"], fetch_bytes_corrected=v["fetch_bytes_per_launch_corrected"],
                         write_bytes=v["write_bytes_per_launch"], ratio_to_algorithmic=v["hbm_bytes_per_launch"] / algo,
                         avg_us=kb[case]["avg_us"], achieved_GBps=kb[case]["achieved_GBps"],
@@ -141,6 +154,12 @@ json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate
                            "The counters sit on the L2's memory side: Infinity-Cache hits are counted, so for a library GEMM "
                            "(tiles re-read operand panels; 16-byte-per-lane buffer loads assumed for the x2) the figure is L2-miss "
                            "traffic, an upper bound on HBM bytes; without the x2 it would be fetch/2 + write",
+               calibration=calibration,
                entries=entries), open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print("calibration:", calibration)
 for e in entries:
-    print(f"{e['kernel']:11s} {e['shape'][:52]:52s} {e['avg_us']:8.1f} us {e['achieved_GBps']:7.0f} GB/s  traffic/algorithmic = {e['ratio_to_algorithmic']:.3f}")
+    print(f"{e['kernel']:11s} {e['shape'][:52]:52s} {e['avg_us']:8.1f} us {e['achieved_GBps']:7.0f} GB/s  traffic/algorithmic = {e['ratio_to_algorithmic']:.3f}"
+          + ("" if e["valid"] else "   INVALID (< 1: not evidence)"))
+bad = [e for e in entries if not e["valid"]]
+if bad:
+    print(f"WARNING: {len(bad)} entries report fewer bytes than their operands hold", file=sys.stderr)
