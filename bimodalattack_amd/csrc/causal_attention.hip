@@ -186,7 +186,7 @@ __device__ __forceinline__ bool dims_real(int dt, int g) {
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
-  constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
+  constexpr int KS = DH / 32, NT = (DR + 15) / 16, IMG = 32 * (DH + 16);   // (output tiles past the real width are never formed: 5 of 6 at DR = 72)
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (K, V, K, V) images: chunks 2t, 2t+1
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
   const int half = w >> 2, wq = w & 3;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
-  constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
+  constexpr int KS = DH / 32, NT = (DR + 15) / 16, IMG = 32 * (DH + 16);   // (output tiles past the real width are never formed: 5 of 6 at DR = 72)
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
   const int half = w >> 2, wq = w & 3;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 // ------------------------------------------------------------------------------------------------------------------------
 template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
-  constexpr int KS = DH / 32, NT = DH / 16, IMG = 32 * (DH + 16);
+  constexpr int KS = DH / 32, NT = (DR + 15) / 16, IMG = 32 * (DH + 16);   // (output tiles past the real width are never formed: 5 of 6 at DR = 72)
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (Q, dO, Q, dO) images: query chunks 2t, 2t+1
   __shared__ __attribute__((aligned(16))) float stat[2][2][64];       // per buffer and chunk: lse2 of its 32 queries, then delta
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
