@@ -62,6 +62,15 @@ __device__ __forceinline__ f32x4 pmfma(const uint4_t& a, const uint4_t& b, const
 #ifndef BMA_PA_OCC
 #define BMA_PA_OCC 2
 #endif
+// LDS fragment reads issued this many fragments AHEAD of the MFMAs that consume them.  0 = the shipped form: a pair of reads,
+// a full wait, two MFMAs -- its ISA exposes one LDS latency per fragment pair, and the SQ counters say waves spend 41 % of
+// their cycles in instruction waits with the MFMA pipe 31 % busy (profiles/r5_prefix_attn_pmc.txt).  Read-ahead was the
+// obvious cure and is NOT one (round 5, same box, us): 0 -> 286-292, 2 -> 305-310, 4 -> 307-313.  The ring costs 8-12 VGPRs
+// (168 -> 176 / 180), which takes the third wave per SIMD away (512 / 3 = 170), and three waves hide more latency than one
+// wave's own look-ahead does -- round 4's hand-counted variant (303 against 255) lost to the same arithmetic.
+#ifndef BMA_PA_PIPE
+#define BMA_PA_PIPE 0
+#endif
 constexpr int kWaves = BMA_PA_WAVES;        // waves per workgroup
 constexpr int kTiles = BMA_PA_TILES;        // 16-row query tiles per wave
 constexpr int kRowsPerWg = 16 * kTiles * kWaves;
@@ -208,15 +217,34 @@ __global__ __launch_bounds__(64 * kWaves, BMA_PA_OCC) void prefix_attn_kernel(co
     // ---- S^T = K Q^T for both query tiles: every K fragment feeds two MFMAs ------------------------
     f32x4 s[kTiles][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const uint16_t* kr = kl + (16 * kt + r) * PITCH + 8 * g;
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int t = 0; t < kTiles; ++t) s[t][kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (BMA_PA_PIPE > 0) {
+      // all 2 * KS key fragments of the chunk in flight before the first product (they are dead again before the V^T
+      // fragments of the second product are read, so the registers are shared)
+      uint4_t kf[2][KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const uint4_t kf = *reinterpret_cast<const uint4_t*>(kr + 32 * ks);
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) s[t][kt] = pmfma<DT>(kf, qf[t][ks], s[t][kt]);
+        for (int ks = 0; ks < KS; ++ks)
+          kf[kt][ks] = *reinterpret_cast<const uint4_t*>(kl + (16 * kt + r) * PITCH + 8 * g + 32 * ks);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int t = 0; t < kTiles; ++t) s[t][kt] = pmfma<DT>(kf[kt][ks], qf[t][ks], s[t][kt]);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const uint16_t* kr = kl + (16 * kt + r) * PITCH + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4_t kf = *reinterpret_cast<const uint4_t*>(kr + 32 * ks);
+#pragma unroll
+          for (int t = 0; t < kTiles; ++t) s[t][kt] = pmfma<DT>(kf, qf[t][ks], s[t][kt]);
+        }
       }
     }
     // ---- online softmax per tile; the probabilities become the B operand of the second product ----
@@ -276,16 +304,34 @@ __global__ __launch_bounds__(64 * kWaves, BMA_PA_OCC) void prefix_attn_kernel(co
     // ---- O^T += V^T P^T: every V^T fragment feeds kTiles MFMAs, accumulating in place --------------------
     const int q4 = r >> 2, p4 = r & 3;
     const uint16_t* rd = vl + (4 * g + q4) * PITCH + 4 * p4;
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) {
+    auto vt_frag = [&](int dt) {
       const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(rd + 16 * dt));
       const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
           (__attribute__((address_space(3))) short4_t*)(rd + 16 * PITCH + 16 * dt));
       const bma::uint2_t l2 = __builtin_bit_cast(bma::uint2_t, lo), h2 = __builtin_bit_cast(bma::uint2_t, hi);
       uint4_t vf;
       vf.x = l2.x; vf.y = l2.y; vf.z = h2.x; vf.w = h2.y;
+      return vf;
+    };
+    if (BMA_PA_PIPE > 0) {
+      constexpr int AHEAD = BMA_PA_PIPE < NT ? BMA_PA_PIPE : NT;
+      uint4_t ring[AHEAD > 0 ? AHEAD : 1];
 #pragma unroll
-      for (int t = 0; t < kTiles; ++t) oacc[t][dt] = pmfma<DT>(vf, pf[t], oacc[t][dt]);
+      for (int i = 0; i < AHEAD; ++i) ring[i] = vt_frag(i);
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        const uint4_t vf = ring[dt % AHEAD];
+        if (dt + AHEAD < NT) ring[dt % AHEAD] = vt_frag(dt + AHEAD);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) oacc[t][dt] = pmfma<DT>(vf, pf[t], oacc[t][dt]);
+      }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        const uint4_t vf = vt_frag(dt);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) oacc[t][dt] = pmfma<DT>(vf, pf[t], oacc[t][dt]);
+      }
     }
     // every wave left chunk c-1 (the other image pair) behind at the previous barrier: safe to overwrite it
     if (c + 1 < chunks) stash(lds + 2 * IMG * ((c + 1) & 1));
