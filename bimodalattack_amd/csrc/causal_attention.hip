@@ -402,8 +402,14 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// waves per SIMD the dk/dv kernel is compiled for at head widths <= 96: a workgroup is 8 waves = 2 per SIMD, so 4 lets two
+// workgroups share a CU where 3 (what 152 / 132 VGPRs allow) leaves the second one out.  Round 5, SigLIP's 4096 x 16 x 72
+// backward pair: 587-590 us at the default bound, 535-545 at 4 (128 VGPRs, 11 dwords spilled); CLIP's 577-token pair unchanged.
+#ifndef BMA_CA_DKV_WAVES
+#define BMA_CA_DKV_WAVES 4
+#endif
 template <int DT, int DH, int DR = DH>
-__global__ __launch_bounds__(NTHR) void causal_dkv_kernel(const CArgs a) {
+__global__ __launch_bounds__(NTHR, (DH <= 96 ? BMA_CA_DKV_WAVES : 1)) void causal_dkv_kernel(const CArgs a) {
   constexpr int KS = DH / 32, NT = (DR + 15) / 16, IMG = 32 * (DH + 16);   // (output tiles past the real width are never formed: 5 of 6 at DR = 72)
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (Q, dO, Q, dO) images: query chunks 2t, 2t+1
   __shared__ __attribute__((aligned(16))) float stat[2][2][64];       // per buffer and chunk: lse2 of its 32 queries, then delta

@@ -233,16 +233,16 @@ def cases():
             return lambda: ops.b1_attention_bwd(qkv, cos, sin, out, lse, dout, H, 128 ** -0.5)
         return lambda: ops.b1_attention(qkv, cos, sin, H, 128 ** -0.5)
 
-    def causal_attn(Lq, Lk, H, backward):
-        qkv = torch.randn((Lk, 3 * H * 128), generator=g, device=DEV).to(bf)
-        q = qkv[Lk - Lq:, :H * 128].view(Lq, H, 128)
-        k = qkv[:, H * 128:2 * H * 128].view(Lk, H, 128)
-        v = qkv[:, 2 * H * 128:].view(Lk, H, 128)
-        out, lse2 = ops.causal_attention(q, k, v, 128 ** -0.5)
-        dout = torch.randn((Lq, H, 128), generator=g, device=DEV).to(bf)
+    def causal_attn(Lq, Lk, H, backward, Dh=128, causal=True):
+        qkv = torch.randn((Lk, 3 * H * Dh), generator=g, device=DEV).to(bf)
+        q = qkv[Lk - Lq:, :H * Dh].view(Lq, H, Dh)
+        k = qkv[:, H * Dh:2 * H * Dh].view(Lk, H, Dh)
+        v = qkv[:, 2 * H * Dh:].view(Lk, H, Dh)
+        out, lse2 = ops.causal_attention(q, k, v, Dh ** -0.5, causal)
+        dout = torch.randn((Lq, H, Dh), generator=g, device=DEV).to(bf)
         if backward:
-            return lambda: ops.causal_attention_bwd(q, k, v, out, lse2, dout, 128 ** -0.5)
-        return lambda: ops.causal_attention(q, k, v, 128 ** -0.5)
+            return lambda: ops.causal_attention_bwd(q, k, v, out, lse2, dout, Dh ** -0.5, causal=causal)
+        return lambda: ops.causal_attention(q, k, v, Dh ** -0.5, causal)
 
     def gather(N, R, W):
         src = torch.randn((N, W), generator=g, device=DEV).to(bf)
@@ -303,6 +303,12 @@ def cases():
         # causal attention of the 643-token pass at batch 1 and of 44 rows behind a 599-key prefix: latency-bound (3.4 / 8.5 GFLOP)
         "causal_attn/fwd_L643_H32": ("causal_attn", lambda: causal_attn(643, 643, 32, False)),
         "causal_attn/bwd_L643_H32": ("causal_attn", lambda: causal_attn(643, 643, 32, True)),
+        # SigLIP's tower in Gemma-3: 4096 tokens x 16 heads of 72, every key visible (77 GFLOP forward, 193 backward)
+        "causal_attn/siglip_fwd_L4096_H16_D72": ("causal_attn", lambda: causal_attn(4096, 4096, 16, False, 72, False)),
+        "causal_attn/siglip_bwd_L4096_H16_D72": ("causal_attn", lambda: causal_attn(4096, 4096, 16, True, 72, False)),
+        # CLIP's tower in LLaVA: 577 tokens x 16 heads of 64
+        "causal_attn/clip_fwd_L577_H16_D64": ("causal_attn", lambda: causal_attn(577, 577, 16, False, 64, False)),
+        "causal_attn/clip_bwd_L577_H16_D64": ("causal_attn", lambda: causal_attn(577, 577, 16, True, 64, False)),
         "causal_attn/fwd_tail_L44_K643_H32": ("causal_attn", lambda: causal_attn(44, 643, 32, False)),
         "causal_attn/bwd_tail_L44_K643_H32": ("causal_attn", lambda: causal_attn(44, 643, 32, True)),
         # rotary + causal attention of the text-only gradient pass (65 rows, 32 heads of 128): latency-bound, one launch each way
