@@ -1126,3 +1126,232 @@ extern "C" int bma_swiglu_bwd(const void* gate, const void* up, const void* dy, 
                               void* dup, void* stream) {
   return bma_gated_act_bwd(gate, up, dy, n, dtype, 0, dgate, dup, stream);
 }
+
+// ---------------------------------------------------------------------------- LayerNorm (+ residual add): CLIP's pre-LN blocks
+// The vision tower of LLaVA at batch 1 (577 x 1024) is launch-bound: per encoder layer HuggingFace issues a residual add and a
+// LayerNorm twice (modeling_clip.CLIPEncoderLayer.forward), and autograd an add and a LayerNorm backward twice more.  Here:
+//   s = dt(res + h)                      (skipped without `res`: a plain LayerNorm of h)
+//   y = dt(w * (rstd * (s - mean)) + b)  mean / rstd over the row in fp32 (two passes over the registers), aten's expression
+// one launch, the row in registers throughout; (mean, rstd) are kept for the backward, which is one launch as well:
+//   dx = dt(rstd * (g - mean(g) - xhat * mean(g * xhat)))  with g = dy * w, xhat = (x - mean) * rstd,  + dsum if given
+// (the eager chain's rounding points: LayerNorm's input gradient rounded to the dtype, then the add).  Weights are constants
+// of the attack: no weight / bias gradient is formed.
+template <int DT, int NCH, bool ADD>
+__global__ __launch_bounds__(kNormThreads) void add_layernorm_kernel(const uint4_t* __restrict__ res, const uint4_t* __restrict__ h,
+                                                                     const uint4_t* __restrict__ w, const uint4_t* __restrict__ b,
+                                                                     float eps, int cpr, int D, uint4_t* __restrict__ s_out,
+                                                                     uint4_t* __restrict__ y, float* __restrict__ stats) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ float part[2][kNormThreads / 64];
+  float v[NCH][NE];
+  float sum = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      Chunk<DT>::unpack(h[row * cpr + i], v[c]);
+      if (ADD) {
+        float r[NE];
+        Chunk<DT>::unpack(res[row * cpr + i], r);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) v[c][j] = rnd<DT>(r[j] + v[c][j]);   // the sum as the eager add leaves it in the model dtype
+        s_out[row * cpr + i] = Chunk<DT>::pack(v[c]);
+      }
+#pragma unroll
+      for (int j = 0; j < NE; ++j) sum += v[c][j];
+    }
+  }
+  sum = bma::wave_sum(sum);
+  if ((tid & 63) == 0) part[0][tid >> 6] = sum;
+  __syncthreads();
+  float tot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kNormThreads / 64; ++i) tot += part[0][i];
+  const float mean = tot / static_cast<float>(D);
+  float sq = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const float d = v[c][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  sq = bma::wave_sum(sq);
+  if ((tid & 63) == 0) part[1][tid >> 6] = sq;
+  __syncthreads();
+  float tot2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kNormThreads / 64; ++i) tot2 += part[1][i];
+  const float rstd = rsqrtf(tot2 / static_cast<float>(D) + eps);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float wf[NE], bf[NE], o[NE];
+      Chunk<DT>::unpack(w[i], wf);
+      Chunk<DT>::unpack(b[i], bf);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) o[j] = wf[j] * (rstd * (v[c][j] - mean)) + bf[j];
+      y[row * cpr + i] = Chunk<DT>::pack(o);
+    }
+  }
+  if (stats && tid == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+template <int DT, int NCH>
+__global__ __launch_bounds__(kNormThreads) void add_layernorm_bwd_kernel(const uint4_t* __restrict__ x, const uint4_t* __restrict__ w,
+                                                                         const uint4_t* __restrict__ dy, const uint4_t* __restrict__ add,
+                                                                         const float* __restrict__ stats, int cpr, int D,
+                                                                         uint4_t* __restrict__ dx) {
+  constexpr int NE = Chunk<DT>::NE;
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  float xh[NCH][NE], g[NCH][NE];
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float xf[NE], wf[NE], df[NE];
+      Chunk<DT>::unpack(x[row * cpr + i], xf);
+      Chunk<DT>::unpack(w[i], wf);
+      Chunk<DT>::unpack(dy[row * cpr + i], df);
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        xh[c][j] = (xf[j] - mean) * rstd;
+        g[c][j] = df[j] * wf[j];
+        s1 += g[c][j];
+        s2 += g[c][j] * xh[c][j];
+      }
+    }
+  }
+  s1 = bma::wave_sum(s1);
+  s2 = bma::wave_sum(s2);
+  __shared__ float part[2][kNormThreads / 64];
+  if ((tid & 63) == 0) { part[0][tid >> 6] = s1; part[1][tid >> 6] = s2; }
+  __syncthreads();
+  float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kNormThreads / 64; ++i) { t1 += part[0][i]; t2 += part[1][i]; }
+  const float c1 = t1 / static_cast<float>(D), c2 = t2 / static_cast<float>(D);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = tid + c * kNormThreads;
+    if (i < cpr) {
+      float o[NE];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) o[j] = rstd * (g[c][j] - c1 - xh[c][j] * c2);
+      if (add) {
+        float af[NE];
+        Chunk<DT>::unpack(add[row * cpr + i], af);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) o[j] = af[j] + rnd<DT>(o[j]);
+      }
+      dx[row * cpr + i] = Chunk<DT>::pack(o);
+    }
+  }
+}
+
+namespace {
+template <int DT>
+int launch_add_layernorm(const void* res, const void* h, const void* w, const void* b, float eps, int64_t rows, int D, void* s_out,
+                         void* y, float* stats, hipStream_t st) {
+  constexpr int ES = bma::elem_bytes<DT>::value;
+  const int cpr = static_cast<int>(static_cast<int64_t>(D) * ES / 16);
+  const int nch = (cpr + kNormThreads - 1) / kNormThreads;
+  if (nch > kNormMaxChunks) return BMA_ELIMIT;
+  const dim3 grid(static_cast<unsigned>(rows)), block(kNormThreads);
+  const uint4_t* rp = static_cast<const uint4_t*>(res);
+  const uint4_t* hp = static_cast<const uint4_t*>(h);
+  const uint4_t* wp = static_cast<const uint4_t*>(w);
+  const uint4_t* bp = static_cast<const uint4_t*>(b);
+  uint4_t* sp = static_cast<uint4_t*>(s_out);
+  uint4_t* yp = static_cast<uint4_t*>(y);
+#define BMA_LN_GO(N)                                                                                                               \
+  do {                                                                                                                             \
+    if (res) hipLaunchKernelGGL((add_layernorm_kernel<DT, N, true>), grid, block, 0, st, rp, hp, wp, bp, eps, cpr, D, sp, yp, stats);  \
+    else hipLaunchKernelGGL((add_layernorm_kernel<DT, N, false>), grid, block, 0, st, rp, hp, wp, bp, eps, cpr, D, sp, yp, stats);     \
+  } while (0)
+  switch (nch) {
+    case 1: BMA_LN_GO(1); break;
+    case 2: BMA_LN_GO(2); break;
+    case 3: BMA_LN_GO(3); break;
+    default: BMA_LN_GO(4); break;
+  }
+#undef BMA_LN_GO
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+template <int DT>
+int launch_add_layernorm_bwd(const void* x, const void* w, const void* dy, const void* add, const float* stats, int64_t rows, int D,
+                             void* dx, hipStream_t st) {
+  constexpr int ES = bma::elem_bytes<DT>::value;
+  const int cpr = static_cast<int>(static_cast<int64_t>(D) * ES / 16);
+  const int nch = (cpr + kNormThreads - 1) / kNormThreads;
+  if (nch > kNormMaxChunks) return BMA_ELIMIT;
+  const dim3 grid(static_cast<unsigned>(rows)), block(kNormThreads);
+  const uint4_t* xp = static_cast<const uint4_t*>(x);
+  const uint4_t* wp = static_cast<const uint4_t*>(w);
+  const uint4_t* dp = static_cast<const uint4_t*>(dy);
+  const uint4_t* ap = static_cast<const uint4_t*>(add);
+  uint4_t* op = static_cast<uint4_t*>(dx);
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((add_layernorm_bwd_kernel<DT, 1>), grid, block, 0, st, xp, wp, dp, ap, stats, cpr, D, op); break;
+    case 2: hipLaunchKernelGGL((add_layernorm_bwd_kernel<DT, 2>), grid, block, 0, st, xp, wp, dp, ap, stats, cpr, D, op); break;
+    case 3: hipLaunchKernelGGL((add_layernorm_bwd_kernel<DT, 3>), grid, block, 0, st, xp, wp, dp, ap, stats, cpr, D, op); break;
+    default: hipLaunchKernelGGL((add_layernorm_bwd_kernel<DT, 4>), grid, block, 0, st, xp, wp, dp, ap, stats, cpr, D, op); break;
+  }
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+}  // namespace
+
+extern "C" int bma_add_layernorm(const void* residual, const void* h, const void* weight, const void* bias, float eps, int64_t rows,
+                                 int D, int dtype, void* sum_out, void* out, float* stats, void* stream) {
+  if (rows < 0 || D <= 0 || rows > 0x7fffffffLL) return BMA_EINVAL;
+  if (rows == 0) return BMA_OK;
+  if (!h || !weight || !bias || !out || (residual && !sum_out)) return BMA_EINVAL;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((static_cast<int64_t>(D) * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(weight) |
+       reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(sum_out) | reinterpret_cast<uintptr_t>(out)) % 16 ||
+      reinterpret_cast<uintptr_t>(stats) % 4)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BMA_F32: return launch_add_layernorm<BMA_F32>(residual, h, weight, bias, eps, rows, D, sum_out, out, stats, st);
+    case BMA_BF16: return launch_add_layernorm<BMA_BF16>(residual, h, weight, bias, eps, rows, D, sum_out, out, stats, st);
+    case BMA_F16: return launch_add_layernorm<BMA_F16>(residual, h, weight, bias, eps, rows, D, sum_out, out, stats, st);
+    default: return BMA_EDTYPE;
+  }
+}
+
+extern "C" int bma_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dsum, const float* stats,
+                                     int64_t rows, int D, int dtype, void* dx, void* stream) {
+  if (rows < 0 || D <= 0 || rows > 0x7fffffffLL) return BMA_EINVAL;
+  if (rows == 0) return BMA_OK;
+  if (!x || !weight || !dy || !stats || !dx) return BMA_EINVAL;
+  const int es = dtype == BMA_F32 ? 4 : 2;
+  if ((static_cast<int64_t>(D) * es) % 16) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(dy) |
+       reinterpret_cast<uintptr_t>(dsum) | reinterpret_cast<uintptr_t>(dx)) % 16 || reinterpret_cast<uintptr_t>(stats) % 4)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case BMA_F32: return launch_add_layernorm_bwd<BMA_F32>(x, weight, dy, dsum, stats, rows, D, dx, st);
+    case BMA_BF16: return launch_add_layernorm_bwd<BMA_BF16>(x, weight, dy, dsum, stats, rows, D, dx, st);
+    case BMA_F16: return launch_add_layernorm_bwd<BMA_F16>(x, weight, dy, dsum, stats, rows, D, dx, st);
+    default: return BMA_EDTYPE;
+  }
+}

@@ -89,6 +89,38 @@ PAD_VISION_HEADS = _os.environ.get("BMA_PAD_VISION_HEADS", "1") not in _OFF
 FUSE_QUICK_GELU = _os.environ.get("BMA_FUSE_QUICK_GELU", "1") not in _OFF
 # the vision tower's q/k/v projections (with their biases) as one product, forward and input-gradient
 FUSE_TOWER_QKV = _os.environ.get("BMA_FUSE_TOWER_QKV", "1") not in _OFF
+# CLIP's pre-LN encoder layers: each residual add fused into the LayerNorm that follows it (also across the layer boundary),
+# forward and backward -- four 5-us launches per layer and pass fewer on a launch-bound tower (bma_add_layernorm)
+FUSE_TOWER_LAYERNORM = _os.environ.get("BMA_FUSE_TOWER_LAYERNORM", "1") not in _OFF
+
+# modeling_clip.CLIPEncoderLayer.forward, statement for statement (every line that touches `self.`, `residual` or returns)
+_CLIP_LAYER_BODY = ["self,", "residual = hidden_states", "hidden_states = self.layer_norm1(hidden_states)",
+                    "hidden_states, _ = self.self_attn(", "hidden_states = residual + hidden_states", "residual = hidden_states",
+                    "hidden_states = self.layer_norm2(hidden_states)", "hidden_states = self.mlp(hidden_states)",
+                    "hidden_states = residual + hidden_states", "return hidden_states"]
+
+
+def _clip_layer_ok(layer) -> bool:
+    """Is this encoder layer's forward, statement for statement, the pre-LN block the fused forward restates (read from its
+    source), with plain affine nn.LayerNorm norms?"""
+    try:
+        src = inspect.getsource(type(layer).forward)
+    except (OSError, TypeError):
+        return False
+    lines = []
+    for ln in src.splitlines():
+        t = ln.strip()
+        if not t or t.startswith("#") or t.startswith("def "):
+            continue
+        if "self." in t or t == "self," or t.startswith("residual") or t.startswith("return") or "residual +" in t:
+            lines.append(t)
+    if lines != _CLIP_LAYER_BODY:
+        return False
+    for n in ("layer_norm1", "layer_norm2"):
+        m = getattr(layer, n, None)
+        if type(m) is not torch.nn.LayerNorm or m.weight is None or m.bias is None or len(m.normalized_shape) != 1:
+            return False
+    return hasattr(layer, "self_attn") and hasattr(layer, "mlp")
 
 
 class HFAdapter:
@@ -130,6 +162,8 @@ class HFAdapter:
         self.fuse_tower_qkv = FUSE_TOWER_QKV     # the tower's q/k/v projections as one product
         self._tower_attn = None
         self._proj_norms = None
+        self.fuse_tower_layernorm = FUSE_TOWER_LAYERNORM
+        self._tower_layers = None
 
     # ------------------------------------------------------------ vision
     def vision_configs(self) -> list:
@@ -193,6 +227,62 @@ class HFAdapter:
                         found.append(m)
             self._tower_attn = found
         return self._tower_attn if self.fuse_tower_qkv else []
+
+    def tower_layers(self) -> list:
+        """[(layer, the encoder layer behind it or None)] of the CLIP vision tower whose blocks the fused add + LayerNorm forward
+        restates (`_clip_layer_ok`); [] on the CPU or with the switch off."""
+        if self._tower_layers is None:
+            found = []
+            if self.device.type == "cuda":
+                for parent in self.model.modules():
+                    layers = getattr(parent, "layers", None)
+                    if not isinstance(layers, torch.nn.ModuleList) or len(layers) == 0:
+                        continue
+                    if not all(type(l).__module__.rsplit(".", 1)[-1] == "modeling_clip" and type(l).__name__ == "CLIPEncoderLayer"
+                               and _clip_layer_ok(l) for l in layers):
+                        continue
+                    for i, l in enumerate(layers):
+                        found.append((l, layers[i + 1] if i + 1 < len(layers) else None))
+            self._tower_layers = found
+        return self._tower_layers if self.fuse_tower_layernorm else []
+
+    def _tower_layer_forward(self, layer, nxt, stash):
+        """CLIPEncoderLayer.forward with each residual add fused into the LayerNorm behind it -- the layer's own layer_norm2, and
+        across the layer boundary the NEXT layer's layer_norm1, whose result is handed over through `stash` and picked up when
+        that layer is called on the very tensor this one returned.  Same statements, same rounding points (the sum in the model
+        dtype, the norm from it)."""
+        from . import ops
+
+        def ln(norm, x):
+            if not ops.layernorm_ok(x, norm.weight, norm.bias):
+                return norm(x)
+            if torch.is_grad_enabled() and x.requires_grad:
+                return ops.LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+            return ops.add_layernorm(None, x, norm.weight, norm.bias, norm.eps)[1]
+
+        def add_ln(residual, h, norm):
+            if not (h.shape == residual.shape and h.dtype == residual.dtype and h.is_contiguous() and residual.is_contiguous()
+                    and ops.layernorm_ok(h, norm.weight, norm.bias)):
+                s = residual + h
+                return s, norm(s)
+            if torch.is_grad_enabled() and (residual.requires_grad or h.requires_grad):
+                return ops.AddLayerNormFn.apply(residual, h, norm.weight, norm.bias, norm.eps)
+            s, y, _ = ops.add_layernorm(residual, h, norm.weight, norm.bias, norm.eps)
+            return s, y
+
+        def forward(hidden_states, attention_mask=None, **kwargs):
+            hit = stash.pop(id(layer), None)
+            residual = hidden_states
+            h = hit[1] if (hit is not None and hit[0] is hidden_states) else ln(layer.layer_norm1, hidden_states)
+            h, _ = layer.self_attn(hidden_states=h, attention_mask=attention_mask, **kwargs)
+            residual, h = add_ln(residual, h, layer.layer_norm2)
+            h = layer.mlp(h)
+            if nxt is None:
+                return residual + h
+            out, normed = add_ln(residual, h, nxt.layer_norm1)
+            stash[id(nxt)] = (out, normed)
+            return out
+        return forward
 
     def _tower_qkv_forwards(self, attn):
         """q_proj, k_proj and v_proj of one tower attention block as ONE product against the concatenated weight (and
@@ -264,6 +354,8 @@ class HFAdapter:
         # hipGraph on this stack, returned NaN rows (attack.image_features).  A contiguous input keeps it a one-block-
         # per-row reduction.  (Only where the engine's fused context has not already replaced the norm's forward.)
         proj_norms = [m for m in self.projector_norms() if "forward" not in m.__dict__]
+        layers = self.tower_layers()
+        stash = {}                                  # id(next layer) -> (sum, its layer_norm1 of it): lives for this one tower forward
         try:
             for m in mods:
                 m.forward = forward
@@ -271,8 +363,13 @@ class HFAdapter:
                 a.q_proj.forward, a.k_proj.forward, a.v_proj.forward = self._tower_qkv_forwards(a)
             for m in proj_norms:
                 m.__dict__["forward"] = (lambda x, _f=type(m).forward.__get__(m): _f(x.contiguous()))
+            for l, nxt in layers:
+                l.__dict__["forward"] = self._tower_layer_forward(l, nxt, stash)
             yield
         finally:
+            stash.clear()
+            for l, _ in layers:
+                l.__dict__.pop("forward", None)
             for m in mods:
                 m.__dict__.pop("forward", None)
             for a in attns:

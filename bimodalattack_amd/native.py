@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 109
+ABI_VERSION = 110
 
 
 class BmaSegment(Structure):
@@ -62,6 +62,9 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p]),
     "bma_add_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_int, c_void_p,
                                     c_void_p]),
+    "bma_add_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    "bma_add_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "bma_rope2": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
                           c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
                           c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),

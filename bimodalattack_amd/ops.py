@@ -327,6 +327,87 @@ class AddRMSNormFn(torch.autograd.Function):
         return dx, dx, None, None, None
 
 
+# ---------------------------------------------------------------------------
+# LayerNorm (+ the residual add in front of it) of a pre-LN vision-tower block, one launch each way (csrc/fused_elementwise.hip)
+def layernorm_ok(x: torch.Tensor, weight, bias) -> bool:
+    """Rows bma_add_layernorm takes: a contiguous GPU tensor in one of the three dtypes whose rows are 16-byte multiples of at
+    most 16 KiB, with contiguous (D,) weight and bias of its dtype."""
+    if not (torch.is_tensor(weight) and torch.is_tensor(bias)):
+        return False
+    D = x.shape[-1]
+    rb = D * x.element_size()
+    return bool(x.is_cuda and x.dtype in _DT and x.is_contiguous() and rb % 16 == 0 and rb <= 16384
+                and weight.shape == (D,) and bias.shape == (D,) and weight.dtype == x.dtype and bias.dtype == x.dtype
+                and weight.is_contiguous() and bias.is_contiguous())
+
+
+def add_layernorm(residual: Optional[torch.Tensor], h: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float,
+                  want_stats: bool = False):
+    """(sum, y, stats): sum = dt(residual + h) (None without a residual), y = LayerNorm(sum or h; weight, bias, eps), stats (rows, 2)
+    fp32 = (mean, rstd) per row when asked for (the backward's input).  One launch (include/bma.h: bma_add_layernorm)."""
+    dev = _need_gpu(h, weight, bias)
+    if not layernorm_ok(h, weight, bias) or (residual is not None and (residual.shape != h.shape or residual.dtype != h.dtype
+                                                                         or not residual.is_contiguous() or residual.device != dev)):
+        raise ValueError("add_layernorm wants contiguous residual / h of one shape and dtype, rows of 16-byte multiples <= 16 KiB")
+    D = h.shape[-1]
+    rows = h.numel() // D
+    s_out = torch.empty_like(h) if residual is not None else None
+    y = torch.empty_like(h)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=dev) if want_stats else None
+    check("bma_add_layernorm", lib.bma_add_layernorm(
+        residual.data_ptr() if residual is not None else None, h.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), rows, D,
+        _dt(h), s_out.data_ptr() if s_out is not None else None, y.data_ptr(), stats.data_ptr() if stats is not None else None,
+        _stream(dev)))
+    return s_out, y, stats
+
+
+def _layernorm_bwd(x, w, stats, d_y, d_sum):
+    d_y = d_y.contiguous()
+    d_sum = None if d_sum is None else d_sum.contiguous()
+    dx = torch.empty_like(x)
+    D = x.shape[-1]
+    check("bma_add_layernorm_bwd", lib.bma_add_layernorm_bwd(
+        x.data_ptr(), w.data_ptr(), d_y.data_ptr(), d_sum.data_ptr() if d_sum is not None else None, stats.data_ptr(),
+        x.numel() // D, D, _dt(x), dx.data_ptr(), _stream(x.device)))
+    return dx
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """(residual, h) -> (residual + h, LayerNorm(residual + h)) under autograd, with the gradient arriving at the sum through the
+    residual stream folded into the norm's backward launch.  Weight and bias are constants of the attack (the engine only ever
+    asks for gradients w.r.t. inputs)."""
+
+    @staticmethod
+    def forward(ctx, residual, h, weight, bias, eps):
+        s_out, y, stats = add_layernorm(residual.contiguous(), h.contiguous(), weight, bias, eps, want_stats=True)
+        ctx.save_for_backward(s_out, weight, stats)
+        return s_out, y
+
+    @staticmethod
+    def backward(ctx, d_sum, d_y):
+        x, w, stats = ctx.saved_tensors
+        if d_y is None:
+            return d_sum, d_sum, None, None, None
+        dx = _layernorm_bwd(x, w, stats, d_y, d_sum)
+        return dx, dx, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm(h) under autograd through the same kernels (no residual in front: the first block of the tower)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, eps):
+        hc = h.contiguous()
+        _, y, stats = add_layernorm(None, hc, weight, bias, eps, want_stats=True)
+        ctx.save_for_backward(hc, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, w, stats = ctx.saved_tensors
+        return _layernorm_bwd(x, w, stats, d_y, None), None, None, None
+
+
 ACT_SILU, ACT_GELU_TANH = 0, 1
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 109 /* 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 110 /* 0.1.10: bma_add_layernorm(+_bwd) (CLIP's residual add + LayerNorm pairs in one launch each way); 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -175,6 +175,21 @@ int bma_add_rmsnorm(const void* residual, const void* h, const void* pre_weight,
                     void* sum_out, void* out, void* stream);
 int bma_add_rmsnorm_bwd(const void* x, const void* weight, const void* dy, const void* dsum, float eps,
                         int64_t rows, int D, int dtype, int gemma_style, void* dx, void* stream);
+
+/* bma_add_layernorm / bma_add_layernorm_bwd: the residual add and the LayerNorm behind it of a pre-LN vision-tower block in ONE
+ *   launch each way (a1 with PGD on, :970-979: `get_image_features` runs CLIP's 24 encoder layers at batch 1, 577 x 1024, where
+ *   HuggingFace's modeling_clip.CLIPEncoderLayer.forward issues an add and a LayerNorm twice per layer and autograd an add and a
+ *   LayerNorm backward twice more -- all launch-bound).  Forward: sum_out = dt(residual + h), out = dt(weight * (rstd * (sum -
+ *   mean)) + bias) with mean / rstd of the row in fp32 (aten's expression and rounding points); residual == NULL: a plain
+ *   LayerNorm of h (sum_out unused).  stats [rows][2] fp32 receives (mean, rstd) for the backward (may be NULL).  Backward:
+ *   dx = dt(rstd * (g - mean(g) - xhat * mean(g * xhat))) with g = dy * weight, xhat = (x - mean) * rstd, x the SUM the forward
+ *   normalised; + dsum when given (the gradient arriving through the residual stream; rounding as the eager chain: the norm's
+ *   gradient rounded to dtype, then the add).  Weight and bias are constants: no gradient for them.  Rows of D elements,
+ *   D * es a multiple of 16 and at most 16 KiB; f32 / bf16 / f16. */
+int bma_add_layernorm(const void* residual, const void* h, const void* weight, const void* bias, float eps, int64_t rows, int D,
+                      int dtype, void* sum_out, void* out, float* stats, void* stream);
+int bma_add_layernorm_bwd(const void* x, const void* weight, const void* dy, const void* dsum, const float* stats, int64_t rows,
+                          int D, int dtype, void* dx, void* stream);
 int bma_swiglu(const void* gate, const void* up, int64_t n, int dtype, void* out, void* stream);
 /* bma_gated_act: out = dt(dt(act(gate)) * up); act 0 = SiLU (== bma_swiglu), 1 = GELU-tanh as
  *   aten evaluates gelu(x, approximate="tanh") (Gemma's gated MLP). */

@@ -890,8 +890,10 @@ def test_tower_qkv_as_one_product_matches_the_three():
     sh = Shell()
     sh.model, sh.device = tower, torch.device(DEV)
     sh.fuse_quick_gelu = sh.fuse_tower_qkv = True
-    sh._quick_gelus = sh._tower_attn = sh._proj_norms = None
-    for name in ("quick_gelu_modules", "tower_attention_modules", "projector_norms", "_tower_qkv_forwards", "_fused_activations"):
+    sh.fuse_tower_layernorm = False                 # (its own test below)
+    sh._quick_gelus = sh._tower_attn = sh._proj_norms = sh._tower_layers = None
+    for name in ("quick_gelu_modules", "tower_attention_modules", "projector_norms", "_tower_qkv_forwards", "_fused_activations",
+                 "tower_layers", "_tower_layer_forward"):
         setattr(sh, name, getattr(HFAdapter, name).__get__(sh))
     assert len(sh.tower_attention_modules()) == 3 and len(sh.quick_gelu_modules()) == 3
 
@@ -913,3 +915,120 @@ def test_tower_qkv_as_one_product_matches_the_three():
     o2, _ = run(False)
     o3, _ = run(True)
     assert float((o2 - o3).abs().max()) <= 3e-2 * float(o2.abs().max()) and float((o2 - o0).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_add_layernorm_forward_and_backward(dtype):
+    """bma_add_layernorm / _bwd (round 5: CLIP's residual add + LayerNorm pairs, one launch each way) against float64 on the
+    same operands -- the sum exactly the eager add's, the norm within one rounding of the dtype (plus the fp32 statistics'
+    own error), the gradient within two -- and against the eager chain aten runs (add, F.layer_norm, autograd): equal up to
+    one unit in the last place on a sliver of the elements (aten's Welford mean / variance differ from the two-pass ones in
+    the last fp32 bits).  CLIP's 577 x 1024, a short row, four chunks per lane, one row; with and without the residual."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(31)
+    eps_dt = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 2.0 ** -23}[dtype]
+    for rows, D in ((577, 1024), (3, 8 if dtype != torch.float32 else 4), (5, 8192 if dtype != torch.float32 else 4096), (1, 1152)):
+        r = torch.randn((rows, D), generator=g, device=DEV).to(dtype)
+        h = (torch.randn((rows, D), generator=g, device=DEV) * 0.7 + 0.3).to(dtype)
+        w = (1.0 + 0.2 * torch.randn(D, generator=g, device=DEV)).to(dtype)
+        b = (0.1 * torch.randn(D, generator=g, device=DEV)).to(dtype)
+        dy = torch.randn((rows, D), generator=g, device=DEV).to(dtype)
+        ds = torch.randn((rows, D), generator=g, device=DEV).to(dtype)
+        eps = 1e-5
+        for with_res in (True, False):
+            ra, ha = r.clone().requires_grad_(), h.clone().requires_grad_()
+            if with_res:
+                s_k, y_k = ops.AddLayerNormFn.apply(ra, ha, w, b, eps)
+                gr_k, gh_k = torch.autograd.grad([s_k, y_k], [ra, ha], [ds, dy])
+            else:
+                y_k = ops.LayerNormFn.apply(ha, w, b, eps)
+                (gh_k,) = torch.autograd.grad(y_k, ha, dy)
+            # eager chain, the model dtype
+            rb, hb = r.clone().requires_grad_(), h.clone().requires_grad_()
+            s_e = rb + hb if with_res else hb
+            y_e = torch.nn.functional.layer_norm(s_e, (D,), w, b, eps)
+            if with_res:
+                gr_e, gh_e = torch.autograd.grad([s_e, y_e], [rb, hb], [ds, dy])
+                assert torch.equal(s_k.detach(), s_e.detach())                     # the sum: the eager add's bits
+                assert torch.equal(gr_k, gh_k)                                       # one gradient for both inputs
+            else:
+                (gh_e,) = torch.autograd.grad(y_e, hb, dy)
+            # float64 on the same (rounded) sum
+            sd = s_e.detach().double().requires_grad_()
+            yd = torch.nn.functional.layer_norm(sd, (D,), w.double(), b.double(), eps)
+            (gd,) = torch.autograd.grad(yd, sd, dy.double())
+            if with_res:
+                gd = gd + ds.double()
+            scale_y, scale_g = float(yd.abs().max()), float(gd.abs().max())
+            assert float((y_k.detach().double() - yd.detach()).abs().max()) <= 1.1 * eps_dt * scale_y + 1e-6 * scale_y, (rows, D, with_res)
+            assert float((gh_k.double() - gd).abs().max()) <= 2.2 * eps_dt * scale_g + 1e-5 * scale_g, (rows, D, with_res)
+            # against aten: the same function, statistics summed in another order
+            ne_y = float((y_k.detach() != y_e.detach()).float().mean())
+            assert ne_y <= (0.02 if dtype != torch.float32 else 1.0), ne_y
+            assert float((y_k.detach().double() - y_e.detach().double()).abs().max()) <= 1.1 * eps_dt * scale_y + 1e-6 * scale_y
+            assert float((gh_k.double() - gh_e.double()).abs().max()) <= 2.2 * eps_dt * scale_g + 1e-5 * scale_g
+            # no-grad form: the same bits as under autograd
+            with torch.no_grad():
+                s_n, y_n, _ = ops.add_layernorm(r if with_res else None, h, w, b, eps)
+            assert torch.equal(y_n, y_k.detach()) and (not with_res or torch.equal(s_n, s_k.detach()))
+    assert not ops.layernorm_ok(torch.zeros((2, 12), device=DEV, dtype=torch.bfloat16), torch.zeros(12, device=DEV, dtype=torch.bfloat16),
+                                torch.zeros(12, device=DEV, dtype=torch.bfloat16))        # 24-byte rows
+
+
+def test_tower_layers_with_add_and_layernorm_fused():
+    """A CLIP-L-shaped vision tower (1024 wide, 577 tokens, 3 layers) in bf16 with each residual add fused into the LayerNorm
+    behind it -- inside a layer and across the layer boundary, forward and backward (hf_adapter._tower_layer_forward) -- against
+    the untouched modules: hidden states of every layer and the pixel gradient within bf16 noise, the launches really on the
+    kernel (2 per layer and direction, counted), the patches gone afterwards."""
+    import contextlib
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.hf_adapter import HFAdapter, _clip_layer_ok
+    torch.manual_seed(0)
+    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16,
+                           image_size=336, patch_size=14, hidden_act="quick_gelu")
+    tower = CLIPVisionModel(cfg).to(DEV, torch.bfloat16).eval()
+    for p_ in tower.parameters():
+        p_.requires_grad_(False)
+
+    class Shell:
+        pass
+    sh = Shell()
+    sh.model, sh.device = tower, torch.device(DEV)
+    sh.fuse_quick_gelu = sh.fuse_tower_qkv = False
+    sh.fuse_tower_layernorm = True
+    sh._quick_gelus = sh._tower_attn = sh._proj_norms = sh._tower_layers = None
+    for name in ("quick_gelu_modules", "tower_attention_modules", "projector_norms", "_tower_qkv_forwards", "_fused_activations",
+                 "tower_layers", "_tower_layer_forward"):
+        setattr(sh, name, getattr(HFAdapter, name).__get__(sh))
+    layers = [m for m in tower.modules() if type(m).__name__ == "CLIPEncoderLayer"]
+    assert len(sh.tower_layers()) == 3 and all(_clip_layer_ok(l) for l in layers)
+    calls = {"fwd": 0, "bwd": 0}
+    keep_f, keep_b = ops.add_layernorm, ops._layernorm_bwd
+    ops.add_layernorm = lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), keep_f(*a, **k))[1]
+    ops._layernorm_bwd = lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), keep_b(*a, **k))[1]
+
+    def run(fused):
+        px = torch.randn((1, 3, 336, 336), generator=torch.Generator(device=DEV).manual_seed(1), device=DEV).to(torch.bfloat16).requires_grad_()
+        ctx = sh._fused_activations() if fused else contextlib.nullcontext()
+        with ctx:
+            out = tower(pixel_values=px, output_hidden_states=True)
+        hs = [t.detach().float() for t in out.hidden_states]
+        (g,) = torch.autograd.grad(out.hidden_states[-2].float().pow(2).sum(), px)
+        return hs, g.float()
+    try:
+        h0, g0 = run(False)
+        assert calls == {"fwd": 0, "bwd": 0}
+        h1, g1 = run(True)
+    finally:
+        ops.add_layernorm, ops._layernorm_bwd = keep_f, keep_b
+    # forward: layer_norm1 of layer 0 alone, then (add + layer_norm2) and (add + next layer_norm1) per layer, the last layer's
+    # second add in aten; backward: everything that feeds hidden_states[-2] -- the last layer does not
+    assert calls["fwd"] == 1 + 2 * 3 - 1 and calls["bwd"] == 1 + 2 * 2, calls
+    assert all("forward" not in l.__dict__ for l in layers)
+    assert len(h0) == len(h1) == 4
+    for a, b in zip(h0, h1):
+        assert float((a - b).abs().max()) <= 3e-2 * float(a.abs().max())
+    assert float((g0 - g1).abs().max()) <= 5e-2 * float(g0.abs().max())
+    big = g0.abs() > 0.1 * g0.abs().max()
+    assert float((torch.sign(g1[big]) == torch.sign(g0[big])).float().mean()) > 0.98
