@@ -93,7 +93,7 @@ FUSE_TOWER_QKV = _os.environ.get("BMA_FUSE_TOWER_QKV", "1") not in _OFF
 # forward and backward -- four 5-us launches per layer and pass fewer on a launch-bound tower (bma_add_layernorm)
 FUSE_TOWER_LAYERNORM = _os.environ.get("BMA_FUSE_TOWER_LAYERNORM", "1") not in _OFF
 
-# modeling_clip.CLIPEncoderLayer.forward, statement for statement (every line that touches `self.`, `residual` or returns)
+# modeling_clip.CLIPEncoderLayer.forward (and modeling_siglip.SiglipEncoderLayer.forward), statement for statement (every line that touches `self.`, `residual` or returns)
 _CLIP_LAYER_BODY = ["self,", "residual = hidden_states", "hidden_states = self.layer_norm1(hidden_states)",
                     "hidden_states, _ = self.self_attn(", "hidden_states = residual + hidden_states", "residual = hidden_states",
                     "hidden_states = self.layer_norm2(hidden_states)", "hidden_states = self.mlp(hidden_states)",
@@ -110,7 +110,7 @@ def _clip_layer_ok(layer) -> bool:
     lines = []
     for ln in src.splitlines():
         t = ln.strip()
-        if not t or t.startswith("#") or t.startswith("def "):
+        if not t or t.startswith("#") or t.startswith("def ") or t.startswith("@"):
             continue
         if "self." in t or t == "self," or t.startswith("residual") or t.startswith("return") or "residual +" in t:
             lines.append(t)
@@ -238,7 +238,9 @@ class HFAdapter:
                     layers = getattr(parent, "layers", None)
                     if not isinstance(layers, torch.nn.ModuleList) or len(layers) == 0:
                         continue
-                    if not all(type(l).__module__.rsplit(".", 1)[-1] == "modeling_clip" and type(l).__name__ == "CLIPEncoderLayer"
+                    # (SigLIP's encoder layer -- Gemma-3's tower -- is the same block, statement for statement)
+                    if not all((type(l).__module__.rsplit(".", 1)[-1], type(l).__name__) in
+                               (("modeling_clip", "CLIPEncoderLayer"), ("modeling_siglip", "SiglipEncoderLayer"))
                                and _clip_layer_ok(l) for l in layers):
                         continue
                     for i, l in enumerate(layers):

@@ -7,6 +7,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")      # no exhaustive search for the patch-embedding convolution
 import torch  # noqa: E402
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 from bimodalattack_amd import synthetic as S  # noqa: E402
