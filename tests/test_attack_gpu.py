@@ -580,7 +580,7 @@ def test_weights_changed_between_runs_are_picked_up():
 
 
 # ------------------------------------------------------------------ sharded engine, 2 ranks on one GPU
-def _sharded_worker(rank, world, port, name, out, backend="gloo", cfg_over=None):
+def _sharded_worker(rank, world, port, name, out, backend="gloo", cfg_over=None, engine=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if backend == "nccl":                                                 # RCCL: one GPU per rank
@@ -593,7 +593,7 @@ def _sharded_worker(rank, world, port, name, out, backend="gloo", cfg_over=None)
     try:
         if backend != "nccl":
             torch.cuda.set_device(0)
-        m, res, trace, tmp = run_case(name, cfg_over)
+        m, res, trace, tmp = run_case(name, cfg_over, **(engine or {}))
         out.put((rank, res.losses, res.strings, [st["n_scored"] for st in trace],
                  [st["losses"][0].tolist() for st in trace if st["losses"]]))
     finally:
@@ -637,15 +637,18 @@ def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
 MANY_RANKS = 4
 
 
-@pytest.mark.parametrize("name", ["llava_joint_dyn", "gemma3_joint_dyn", "llava_gcg"])
-def test_sharded_engine_more_ranks_than_candidates(name):
+@pytest.mark.parametrize("name,engine", [("llava_joint_dyn", {}), ("gemma3_joint_dyn", {}), ("llava_gcg", {}),
+                                         # ... and with the filter run BEFORE scoring on every rank (the reference's order): the
+                                         # partition is then made over the survivors, not over the sampled candidates
+                                         ("llava_joint_dyn", {"filter_first": True}), ("llava_gcg", {"filter_first": True})])
+def test_sharded_engine_more_ranks_than_candidates(name, engine):
     """BASELINE configs[3]/[4]'s tail in miniature: a dynamic width that decays to fewer candidates than there are ranks
     (12, 10, 8, 6, 4, 2 over 4 ranks; the retokenisation filter thins it further): every rank returns the single-process
     run -- strings, losses, candidates scored per step, every candidate's loss."""
     import socket
     import torch.multiprocessing as mp
     over = dict(num_steps=6, search_width=12, dynamic_search=True, min_search_width=2, early_stop=False)
-    m, res1, trace1, _ = run_case(name, over)
+    m, res1, trace1, _ = run_case(name, over)          # (the single process runs the default policy: same winners either way)
     widths = [st["sampled"].shape[0] for st in trace1]
     assert widths == [12, 10, 8, 6, 4, 2] and min(st["n_scored"] for st in trace1) <= 2
     s = socket.socket()
@@ -654,7 +657,7 @@ def test_sharded_engine_more_ranks_than_candidates(name):
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, MANY_RANKS, port, name, out, "gloo", over)) for r in range(MANY_RANKS)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, MANY_RANKS, port, name, out, "gloo", over, engine)) for r in range(MANY_RANKS)]
     for p in procs:
         p.start()
     got = [out.get(timeout=600) for _ in procs]
@@ -767,6 +770,28 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
         assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) + 3
     assert not d["engine"]["fallbacks"]
     assert d["roofline"]["bound"] in ("mfma", "hbm") and d["value"] > 0
+
+
+def test_bench_prints_the_first_leg_when_the_tensor_parallel_leg_does_not_return():
+    """bench.py's multi-GPU A/B must never cost the run its line: with the tensor-parallel leg's time limit set to a
+    millisecond (as if a collective never returned) the watchdog prints the FIRST leg's complete line -- n_gpus 2, the
+    replicated pass's figures, `rccl.tp_note` saying what happened -- and every rank leaves with status 0."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMA_DIST_BACKEND="gloo", BMA_TP_LEG_LIMIT_S="0.001")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2",
+                        "--warmup", "1", "--profile-steps", "1", "--search-width", "64", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["finite"] is True and d["value"] > 0
+    rc = d["rccl"]
+    assert rc["chosen"] == "off" and rc["tp_on_ms"] is None and rc["tp_off_ms"] == pytest.approx(d["ms_per_step"], rel=1e-3)
+    assert "did not finish" in rc["tp_note"]
 
 
 # ------------------------------------------------------------------ BASELINE-size parity of the scoring path
