@@ -258,6 +258,7 @@ class BimodalAttack:
         self.fused = FusedInference(model, self.opt.fused_elementwise, copies, copies, copies, self.opt.fuse_add_norm, FUSE_QK_ROPE,
                                     own and ops.OWN_KERNELS["b1_attention"], own and ops.OWN_KERNELS["causal_attention"])
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
+        self.hf.fused = self.fused
         logger.info(f"Fused forward admitted: {self.fused.admitted}; refused: {self.fused.refused}")
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")

@@ -147,6 +147,31 @@ def _decoder_layers(model, norm_info):
     return out
 
 
+def _last_layers(model, admitted) -> set:
+    """id() of the last layer of every admitted decoder stack whose own forward does nothing with that layer's output but
+    hand it to the final norm (read from its source): there the rows nobody reads may be dropped inside the last layer."""
+    import inspect
+    ids = {id(l) for l, _, _ in admitted}
+    out = set()
+    for parent in model.modules():
+        layers = getattr(parent, "layers", None)
+        if not isinstance(layers, torch.nn.ModuleList) or len(layers) == 0 or id(layers[-1]) not in ids:
+            continue
+        try:
+            lines = [ln.strip() for ln in inspect.getsource(type(parent).forward).splitlines() if ln.strip()]
+        except (OSError, TypeError):
+            continue
+        if "hidden_states = self.norm(hidden_states)" not in lines:
+            continue
+        tail = [ln for ln in lines[lines.index("hidden_states = self.norm(hidden_states)") + 1:] if not ln.startswith("#")]
+        # behind the norm: the optional hidden-state bookkeeping (off in every engine call) and the return -- nothing that
+        # would need the dropped rows
+        if all(ln.startswith(("if output_hidden_states", "all_hidden_states", "return ", "last_hidden_state=", "past_key_values=",
+                              "hidden_states=", "attentions=", ")")) for ln in tail):
+            out.add(id(layers[-1]))
+    return out
+
+
 class _TPCopy(torch.autograd.Function):
     """Megatron's f: identity forward, all-reduce of the gradient backward (the input of column-parallel layers)."""
 
@@ -255,6 +280,12 @@ class FusedInference:
         self.layers: List[Tuple[torch.nn.Module, str, torch.nn.Module]] = []   # (decoder layer, kind, the norm that reads its output)
         self._norm_info = {}                         # id(norm module) -> (eps, gemma)
         self._stash = {}                             # id(norm module) -> (sum tensor, its norm): handed over by the layer in front
+        # scoring forwards keep the target-predicting rows only (logits_to_keep): with `keep_rows` set (an index over dim 1)
+        # the LAST decoder layer gathers them right behind its attention block, so its MLP, the final norm and the head run
+        # on those rows alone; `kept` says the layer did (hf_adapter.HFAdapter._logits_of_rows reads it)
+        self.keep_rows = None
+        self.kept = False
+        self._last_layers = set()                    # id(the last decoder layer) of stacks whose forward ends `norm(layers(...))`
         # tensor-parallel gradient pass (EngineOptions.tp_gradient): (rank, world, process group) while a pass runs with
         # every decoder projection cut over the ranks -- q/k/v/gate/up by output rows (whole heads), o/down by input
         # columns, two all-reduces per layer and direction; set before entering the context, None otherwise
@@ -312,6 +343,7 @@ class FusedInference:
         self._norm_info = {id(m): (eps, gemma) for m, eps, gemma in self.norms}
         if fuse_add_norm:
             self.layers = _decoder_layers(model, self._norm_info)
+            self._last_layers = _last_layers(model, self.layers)
         for f in files:
             mod = sys.modules.get(f)
             if mod is not None and f.rsplit(".", 1)[-1] in _ROPE_FILES and hasattr(mod, "apply_rotary_pos_emb"):
@@ -338,7 +370,8 @@ class FusedInference:
                              layer_kinds=kinds, rotary_files=[m.__name__.rsplit(".", 1)[-1] for m in self.rope_modules],
                              b1_attention_blocks=len(self.b1_attn),
                              qk_norm_in_rotary_blocks=len(self._rope_norms) // 2,
-                             qk_norm_blocks_not_admitted=len(norm_rope_blocks) - len(self._rope_norms) // 2)
+                             qk_norm_blocks_not_admitted=len(norm_rope_blocks) - len(self._rope_norms) // 2,
+                             last_layer_keeps_rows=len(self._last_layers))
 
     def _refusals(self, model, fuse_qkv, fuse_add_norm, fuse_b1_attention, norm_rope_blocks) -> dict:
         """Which fast paths this model did NOT get, and why -- the admission checks read HuggingFace SOURCE TEXT and
@@ -707,6 +740,7 @@ class FusedInference:
         on the very tensor this layer returned.  Same statements as HuggingFace's forward (checked structurally when
         the layer was admitted, ``_decoder_layers``), same rounding points."""
         gem = kind == "gemma"
+        last = id(layer) in self._last_layers
 
         def forward(hidden_states, *args, **kwargs):
             if args:                                  # HF calls its layers with keywords; anything else: their code
@@ -719,6 +753,13 @@ class FusedInference:
             h, _ = layer.self_attn(hidden_states=h, **kwargs)
             if self._pending:
                 self._missed()
+            if last and self.keep_rows is not None and not torch.is_grad_enabled():
+                # everything behind the last attention block is row-wise: only the rows whose logits are asked for go on
+                # (39 % of a 7B scoring forward's rows are suffix and template rows nobody reads: their share of this
+                # layer's MLP -- the stack's largest products -- of the final norm and of nothing else)
+                residual = residual.index_select(1, self.keep_rows)
+                h = h.index_select(1, self.keep_rows)
+                self.kept = True
             if gem:
                 residual, h = self._add_norm(residual, h, layer.pre_feedforward_layernorm, pre=layer.post_attention_layernorm)
             else:

@@ -92,6 +92,9 @@ FUSE_TOWER_QKV = _os.environ.get("BMA_FUSE_TOWER_QKV", "1") not in _OFF
 # CLIP's pre-LN encoder layers: each residual add fused into the LayerNorm that follows it (also across the layer boundary),
 # forward and backward -- four 5-us launches per layer and pass fewer on a launch-bound tower (bma_add_layernorm)
 FUSE_TOWER_LAYERNORM = _os.environ.get("BMA_FUSE_TOWER_LAYERNORM", "1") not in _OFF
+# scoring forwards: the rows whose logits are read are gathered in front of the LAST decoder layer's MLP instead of in front
+# of the head (HFAdapter._logits_of_rows)
+KEEP_ROWS_EARLY = _os.environ.get("BMA_KEEP_ROWS_EARLY", "1") not in _OFF
 
 # modeling_clip.CLIPEncoderLayer.forward (and modeling_siglip.SiglipEncoderLayer.forward), statement for statement (every line that touches `self.`, `residual` or returns)
 _CLIP_LAYER_BODY = ["self,", "residual = hidden_states", "hidden_states = self.layer_norm1(hidden_states)",
@@ -149,6 +152,7 @@ class HFAdapter:
         es = torch.empty((), dtype=self.dtype).element_size()
         self.kv_bytes_per_token = 2 * self.n_layers * kv_heads * head_dim * es
         self.act_bytes_per_token = (16 * hidden + 4 * inter) * es
+        self.fused = None                       # the engine's FusedInference (attack.py sets it): _logits_of_rows asks it
         self.prefix_ok: Optional[bool] = None   # learnt on first use
         # shared-prefix attention (prefix_attention.py): None = not probed, [] = not applicable
         self._shared_cfgs = None
@@ -274,6 +278,12 @@ class HFAdapter:
 
         def forward(hidden_states, attention_mask=None, **kwargs):
             hit = stash.pop(id(layer), None)
+            if hit is None and not hidden_states.is_contiguous():
+                # SigLIP's patch embedding hands over `conv(...).flatten(2).transpose(1, 2)`: a TRANSPOSED view, and aten's
+                # adds keep that layout for the whole residual stream -- every LayerNorm (forward and backward) then makes
+                # its own contiguous copy and every add runs strided: six 25-us launches per layer on a 4096 x 1152 tower
+                # (tools/copy_probe.py).  One copy here instead; the values are the same.
+                hidden_states = hidden_states.contiguous()
             residual = hidden_states
             h = hit[1] if (hit is not None and hit[0] is hidden_states) else ln(layer.layer_norm1, hidden_states)
             h, _ = layer.self_attn(hidden_states=h, attention_mask=attention_mask, **kwargs)
@@ -415,11 +425,30 @@ class HFAdapter:
             # (16 ms instead of ~3 ms per step at B=512 on MI355X).
             L = embeds.shape[1]
             keep = self._keep_index(L, T, embeds.device)
-            return self.model(inputs_embeds=embeds, logits_to_keep=keep, **kw).logits
+            return self._logits_of_rows(keep, inputs_embeds=embeds, **kw)
         if rows_only:
             return self.model(inputs_embeds=embeds, **kw).logits[:, -T:, :]
         logits = self.model(inputs_embeds=embeds, **kw).logits
         return logits[:, -T - 1:-1, :]
+
+    def _logits_of_rows(self, keep: torch.Tensor, **kw) -> torch.Tensor:
+        """``model(..., logits_to_keep=keep).logits`` -- with the gather moved from in front of the head to in front of
+        the LAST decoder layer's MLP when the engine's fused layer forward is installed and no gradient is wanted
+        (fused.FusedInference.keep_rows): everything behind the last attention block is row-wise, and only these rows'
+        logits are read (reference: the loss is taken on the target-predicting positions, gcg.py:803-820).  Round-4
+        VERDICT item 8a."""
+        f = self.fused
+        if (KEEP_ROWS_EARLY and f is not None and f.enabled and f.depth > 0 and f._last_layers and f.tp is None
+                and not torch.is_grad_enabled()):
+            f.keep_rows, f.kept = keep, False
+            try:
+                logits = self.model(logits_to_keep=0, **kw).logits       # (0: the head on every row it is handed)
+            finally:
+                f.keep_rows = None
+            if not f.kept:            # the last layer ran HuggingFace's own forward after all (positional arguments)
+                logits = logits.index_select(1, keep)
+            return logits
+        return self.model(logits_to_keep=keep, **kw).logits
 
     def _keep_index(self, L: int, T: int, device) -> torch.Tensor:
         # Entries are NEVER evicted: a captured hipGraph (winner re-score, gradient pass) holds the
@@ -469,7 +498,7 @@ class HFAdapter:
         kv = pa.SharedPrefixKV(cache)
         keep = self._keep_index(embeds.shape[1], T, embeds.device)
         with pa.active(self.shared_prefix_configs(), kv):
-            return self.model(inputs_embeds=embeds, past_key_values=kv, logits_to_keep=keep).logits
+            return self._logits_of_rows(keep, inputs_embeds=embeds, past_key_values=kv)
 
     def target_logits_behind_grad_prefix(self, embeds: torch.Tensor, T: int, rec) -> torch.Tensor:
         """Gradient pass with the prefix reused: `embeds` (1,L,D) are the tokens behind a prefix whose recorded
@@ -489,8 +518,7 @@ class HFAdapter:
         kv = pa.SharedPrefixKV(cache)
         kv.ragged = maps
         with pa.active(self.shared_prefix_configs(), kv):
-            logits = self.model(inputs_embeds=rows, past_key_values=kv, position_ids=maps.pos,
-                                logits_to_keep=maps.keep).logits
+            logits = self._logits_of_rows(maps.keep, inputs_embeds=rows, past_key_values=kv, position_ids=maps.pos)
         return logits.view(maps.m_out, T, logits.shape[-1])
 
     @staticmethod

@@ -484,9 +484,82 @@ def test_ragged_forward_equals_padded_forward(dtype):
         cache = ad.build_prefix_recording(prefix)
         want = ad.target_logits_shared_prefix(x[:m].contiguous(), T, cache).float()
         got = ad.target_logits_ragged(rows, T, cache, maps).float()
+        # ... and with the engine's layer forward installed: the last layer's MLP on the m_out * T kept rows only
+        from bimodalattack_amd.fused import FusedInference
+        ad.fused = FusedInference(model)
+        seen = []
+        stack = next(mm for mm in model.modules() if isinstance(getattr(mm, "layers", None), torch.nn.ModuleList) and hasattr(mm, "norm"))
+        hook = stack.layers[-1].mlp.register_forward_pre_hook(lambda mod, a: seen.append(tuple(a[0].shape)))
+        with ad.fused:
+            early = ad.target_logits_ragged(rows, T, cache, maps).float()
+        hook.remove()
     assert got.shape == want.shape
     tol = 1e-4 if dtype == torch.float32 else 5e-2
     assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert seen == [(1, m * T, D)] and early.shape == want.shape
+    assert float((early - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("kind,dtype", [("llama", torch.float32), ("llama", torch.bfloat16), ("gemma3", torch.float32)])
+def test_last_layer_runs_its_mlp_on_the_kept_rows_only(kind, dtype):
+    """Scoring forwards read the target-predicting rows' logits only: with the engine's fused layer forward installed the
+    rows are gathered right behind the LAST decoder layer's attention block (hf_adapter._logits_of_rows), so that layer's
+    MLP and the final norm see T rows per candidate -- and the logits are those of the plain `logits_to_keep` call.  Three
+    routes: the padded block with an HF cache, the shared-prefix block, the ragged row list (llama); under autograd, and
+    outside the fused context, nothing is gathered early."""
+    from bimodalattack_amd import hf_adapter, ops, prefix_attention as pa, synthetic as S
+    from bimodalattack_amd.fused import FusedInference
+    from bimodalattack_amd.hf_adapter import HFAdapter
+    model = _small_llama(dtype) if kind == "llama" else S.tiny_case(kind, dtype=dtype, device=DEV)[0]
+    ad = HFAdapter(model, S.SyntheticProcessor(None), None)
+    fused = ad.fused = FusedInference(model)
+    assert fused.admitted["last_layer_keeps_rows"] == 1
+    D = model.get_input_embeddings().weight.shape[1]
+    B, P, L, T = 6, 9, 12, 4
+    g = torch.Generator(device=DEV).manual_seed(2)
+    prefix = (torch.randn((1, P, D), generator=g, device=DEV) * 0.5).to(dtype)
+    tail = (torch.randn((B, L, D), generator=g, device=DEV) * 0.5).to(dtype)
+    stacks = [m for m in model.modules() if isinstance(getattr(m, "layers", None), torch.nn.ModuleList) and hasattr(m.layers[0], "mlp")
+              and hasattr(m, "norm")]                   # (the text stack: the vision tower has no final `norm`)
+    last_mlp, first_mlp = stacks[0].layers[-1].mlp, stacks[0].layers[0].mlp
+    seen = {}
+    hooks = [last_mlp.register_forward_pre_hook(lambda m, a: seen.setdefault("last", []).append(tuple(a[0].shape))),
+             first_mlp.register_forward_pre_hook(lambda m, a: seen.setdefault("first", []).append(tuple(a[0].shape)))]
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+
+    def close(a, b):
+        assert a.shape == b.shape
+        assert float((a.float() - b.float()).abs().max()) <= tol * max(1.0, float(b.float().abs().max()))
+
+    try:
+        with torch.no_grad():
+            cache = ad.build_prefix(prefix)
+            with fused:
+                hf_adapter.KEEP_ROWS_EARLY = False
+                want = ad.target_logits(tail, T, cache=ad.expand_prefix(cache, B))
+                assert seen["last"][-1] == (B, L, D)
+                hf_adapter.KEEP_ROWS_EARLY = True
+                got = ad.target_logits(tail, T, cache=ad.expand_prefix(cache, B))
+                assert seen["last"][-1] == (B, T, D) and seen["first"][-1] == (B, L, D) and fused.keep_rows is None
+                close(got, want)
+                if ad.shared_prefix_configs():
+                    rec = ad.build_prefix_recording(prefix)
+                    got = ad.target_logits_shared_prefix(tail, T, rec)
+                    assert seen["last"][-1] == (B, T, D)
+                    close(got, want)
+            # outside the context the layer forwards are HuggingFace's: the head's own gather
+            got = ad.target_logits(tail, T, cache=ad.expand_prefix(cache, B))
+            assert seen["last"][-1] == (B, L, D)
+            close(got, want)
+        # a forward that records a graph keeps every row (the gradient pass's row count is weight-bound anyway)
+        with fused:
+            xg = tail[:1].clone().requires_grad_()
+            out = ad.target_logits(xg, T, cache=None)
+            assert out.requires_grad and seen["last"][-1] == (1, L, D)
+    finally:
+        hf_adapter.KEEP_ROWS_EARLY = True
+        for h in hooks:
+            h.remove()
 
 
 # ------------------------------------------------------------------ round 3: add + norm, q/k rotary, row-list splice
@@ -975,19 +1048,27 @@ def test_add_layernorm_forward_and_backward(dtype):
                                 torch.zeros(12, device=DEV, dtype=torch.bfloat16))        # 24-byte rows
 
 
-def test_tower_layers_with_add_and_layernorm_fused():
+@pytest.mark.parametrize("kind", ["clip", "siglip"])
+def test_tower_layers_with_add_and_layernorm_fused(kind):
     """A CLIP-L-shaped vision tower (1024 wide, 577 tokens, 3 layers) in bf16 with each residual add fused into the LayerNorm
     behind it -- inside a layer and across the layer boundary, forward and backward (hf_adapter._tower_layer_forward) -- against
     the untouched modules: hidden states of every layer and the pixel gradient within bf16 noise, the launches really on the
-    kernel (2 per layer and direction, counted), the patches gone afterwards."""
+    kernel (2 per layer and direction, counted), the patches gone afterwards.  And a SigLIP-shaped one (Gemma-3's: 72-wide
+    heads, 1024 tokens), whose patch embedding hands the first layer a TRANSPOSED view: the fused forward makes the residual
+    stream contiguous once, or none of its layers would qualify."""
     import contextlib
-    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from transformers import CLIPVisionConfig, CLIPVisionModel, SiglipVisionConfig, SiglipVisionModel
     from bimodalattack_amd import ops
     from bimodalattack_amd.hf_adapter import HFAdapter, _clip_layer_ok
     torch.manual_seed(0)
-    cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16,
-                           image_size=336, patch_size=14, hidden_act="quick_gelu")
-    tower = CLIPVisionModel(cfg).to(DEV, torch.bfloat16).eval()
+    if kind == "clip":
+        cfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16,
+                               image_size=336, patch_size=14, hidden_act="quick_gelu")
+        tower = CLIPVisionModel(cfg).to(DEV, torch.bfloat16).eval()
+    else:
+        cfg = SiglipVisionConfig(hidden_size=576, intermediate_size=1152, num_hidden_layers=3, num_attention_heads=8,
+                                 image_size=448, patch_size=14, vision_use_head=False)
+        tower = SiglipVisionModel(cfg).to(DEV, torch.bfloat16).eval()
     for p_ in tower.parameters():
         p_.requires_grad_(False)
 
@@ -1001,15 +1082,16 @@ def test_tower_layers_with_add_and_layernorm_fused():
     for name in ("quick_gelu_modules", "tower_attention_modules", "projector_norms", "_tower_qkv_forwards", "_fused_activations",
                  "tower_layers", "_tower_layer_forward"):
         setattr(sh, name, getattr(HFAdapter, name).__get__(sh))
-    layers = [m for m in tower.modules() if type(m).__name__ == "CLIPEncoderLayer"]
-    assert len(sh.tower_layers()) == 3 and all(_clip_layer_ok(l) for l in layers)
+    layers = [m for m in tower.modules() if type(m).__name__ in ("CLIPEncoderLayer", "SiglipEncoderLayer")]
+    assert len(layers) == 3 and len(sh.tower_layers()) == 3 and all(_clip_layer_ok(l) for l in layers)
+    side = cfg.image_size
     calls = {"fwd": 0, "bwd": 0}
     keep_f, keep_b = ops.add_layernorm, ops._layernorm_bwd
     ops.add_layernorm = lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), keep_f(*a, **k))[1]
     ops._layernorm_bwd = lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), keep_b(*a, **k))[1]
 
     def run(fused):
-        px = torch.randn((1, 3, 336, 336), generator=torch.Generator(device=DEV).manual_seed(1), device=DEV).to(torch.bfloat16).requires_grad_()
+        px = torch.randn((1, 3, side, side), generator=torch.Generator(device=DEV).manual_seed(1), device=DEV).to(torch.bfloat16).requires_grad_()
         ctx = sh._fused_activations() if fused else contextlib.nullcontext()
         with ctx:
             out = tower(pixel_values=px, output_hidden_states=True)
