@@ -19,8 +19,11 @@
 // No atomics: every output element has one owner, results are bitwise reproducible.
 //
 // Queries are the LAST Lq positions of the Lk keys (P = Lk - Lq keys of prefix in front): query i sees keys 0 .. P + i.
-// H query heads = H key/value heads of 128; q/k/v through (row, head) strides (views of a fused projection), o / dO /
-// dq / dk / dv [rows][H][128] contiguous.
+// H query heads over H / rep key/value heads (rep = 1: LLaVA, the towers; rep = 2: Gemma-3's decoder) of 64, 72, 128 or 256;
+// q/k/v through (row, head) strides (views of a fused projection), o / dO / dq [rows][H][D] and dk / dv [rows][H / rep][D]
+// contiguous.  At 256-wide heads (Gemma-3's decoder, ~320 rows: the library's four launches take 119 us per layer, all
+// latency) a chunk is two 16-byte pieces per thread and the dk/dv launch splits the OUTPUT dims between its two wave halves
+// instead of the chunks (each accumulator pair then fits the register file without spilling).
 #include <type_traits>
 
 #include "bma_common.h"
@@ -45,8 +48,10 @@ struct CArgs {
   uint16_t *out, *dq, *dk, *dv;
   float *lse2, *delta;            // [H][Lq]
   int64_t q_rs, q_hs, k_rs, k_hs, v_rs, v_hs;
-  int64_t d_rs;                   // row stride of dq / dk / dv (elements)
+  int64_t d_rs;                   // row stride of dq (elements)
+  int64_t dkv_rs;                 // row stride of dk / dv
   int Lq, Lk, H, P;
+  int rep;                        // query heads per key/value head (grouped-query attention); H counts QUERY heads
   float scale, scale_log2e;
 };
 
@@ -77,23 +82,33 @@ __device__ __forceinline__ float rows_sum(float x) {
 }
 
 // ---- a 32-row chunk of a [rows][heads][DH] tensor: L2 -> registers -> LDS image [32][PITCH] ----------------------------
+template <int DR>
 struct Chunk {
-  uint4_t reg;
+  static constexpr int N = (32 * (DR / 8) + NTHR - 1) / NTHR;    // 16-byte pieces per thread: 1, or 2 at 256-wide heads
+  uint4_t reg[N];
 };
 // (DR: the head's REAL width in memory, DH: the width of its LDS image and of the products -- DR = 72, SigLIP's heads, rides
 // in 96-wide images whose last 24 columns are zero: zero dims add nothing to q.k and give zero outputs, which are not stored)
 template <int DH, int DR>
-__device__ __forceinline__ void fetch_chunk(Chunk& ch, const uint16_t* base, int64_t rs, int row0, int rows, int tid) {
-  if (32 * (DR / 8) < NTHR && tid >= 32 * (DR / 8)) return;
-  int row = row0 + tid / (DR / 8);
-  const int piece = tid % (DR / 8);
-  row = row < rows ? row : rows - 1;                            // rows past the end repeat the last one (masked by the caller)
-  ch.reg = *reinterpret_cast<const uint4_t*>(base + static_cast<int64_t>(row) * rs + 8 * piece);
+__device__ __forceinline__ void fetch_chunk(Chunk<DR>& ch, const uint16_t* base, int64_t rs, int row0, int rows, int tid) {
+#pragma unroll
+  for (int j = 0; j < Chunk<DR>::N; ++j) {
+    const int i = tid + j * NTHR;
+    if ((32 * (DR / 8)) % NTHR != 0 && i >= 32 * (DR / 8)) return;
+    int row = row0 + i / (DR / 8);
+    const int piece = i % (DR / 8);
+    row = row < rows ? row : rows - 1;                          // rows past the end repeat the last one (masked by the caller)
+    ch.reg[j] = *reinterpret_cast<const uint4_t*>(base + static_cast<int64_t>(row) * rs + 8 * piece);
+  }
 }
 template <int DH, int DR>
-__device__ __forceinline__ void stash_chunk(const Chunk& ch, uint16_t* img, int tid) {
-  if (32 * (DR / 8) < NTHR && tid >= 32 * (DR / 8)) return;
-  *reinterpret_cast<uint4_t*>(img + (tid / (DR / 8)) * (DH + 16) + 8 * (tid % (DR / 8))) = ch.reg;
+__device__ __forceinline__ void stash_chunk(const Chunk<DR>& ch, uint16_t* img, int tid) {
+#pragma unroll
+  for (int j = 0; j < Chunk<DR>::N; ++j) {
+    const int i = tid + j * NTHR;
+    if ((32 * (DR / 8)) % NTHR != 0 && i >= 32 * (DR / 8)) return;
+    *reinterpret_cast<uint4_t*>(img + (i / (DR / 8)) * (DH + 16) + 8 * (i % (DR / 8))) = ch.reg[j];
+  }
 }
 // the columns DR .. DH-1 of `n_img` chunk images, once, before the first stash (a stash never touches them)
 template <int DH, int DR>
@@ -158,11 +173,12 @@ __device__ __forceinline__ void landed(const uint4_t (&f)[KS]) {
 // the odd 32-row chunks of the other side -- a trip of the loop stages TWO chunks (one barrier) and each wave's chain of
 // dependent products and softmax steps is half as long as the sequence; the halves' partial results meet in LDS at the end.
 // (One wave per 16 rows over all chunks: 1.07 us per chunk, 25 us forward and 58 us backward at 643 tokens.)
+template <int DR>
 struct Pair {
-  Chunk x0, y0, x1, y1;                                          // (K, V) or (Q, dO) images of chunks 2t and 2t+1
+  Chunk<DR> x0, y0, x1, y1;                                      // (K, V) or (Q, dO) images of chunks 2t and 2t+1
 };
 template <int DH, int DR>
-__device__ __forceinline__ void fetch_pair(Pair& p, const uint16_t* xb, int64_t x_rs, const uint16_t* yb, int64_t y_rs, int t,
+__device__ __forceinline__ void fetch_pair(Pair<DR>& p, const uint16_t* xb, int64_t x_rs, const uint16_t* yb, int64_t y_rs, int t,
                                            int rows, int tid) {
   fetch_chunk<DH, DR>(p.x0, xb, x_rs, 64 * t, rows, tid);
   fetch_chunk<DH, DR>(p.y0, yb, y_rs, 64 * t, rows, tid);
@@ -170,7 +186,7 @@ __device__ __forceinline__ void fetch_pair(Pair& p, const uint16_t* xb, int64_t 
   fetch_chunk<DH, DR>(p.y1, yb, y_rs, 64 * t + 32, rows, tid);
 }
 template <int DH, int DR>
-__device__ __forceinline__ void stash_pair(const Pair& p, uint16_t* buf, int tid) {
+__device__ __forceinline__ void stash_pair(const Pair<DR>& p, uint16_t* buf, int tid) {
   constexpr int IMG = 32 * (DH + 16);
   stash_chunk<DH, DR>(p.x0, buf, tid);
   stash_chunk<DH, DR>(p.y0, buf + IMG, tid);
@@ -200,14 +216,14 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   float mrun = NEG, lsum = 0.0f;
-  const uint16_t* kb = a.k + static_cast<int64_t>(h) * a.k_hs;
-  const uint16_t* vb = a.v + static_cast<int64_t>(h) * a.v_hs;
+  const uint16_t* kb = a.k + static_cast<int64_t>(h / a.rep) * a.k_hs;     // (grouped queries: `rep` query heads read one k/v head)
+  const uint16_t* vb = a.v + static_cast<int64_t>(h / a.rep) * a.v_hs;
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
   int chunks = (a.P + last + 1 + 31) >> 5;                         // keys 0 .. P + last
   chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;   // (not causal: P is past every key)
   const int trips = (chunks + 1) >> 1;
-  Pair pr;
+  Pair<DR> pr;
   fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
   zero_pad_columns<DH, DR>(lds, 8, tid);
   stash_pair<DH, DR>(pr, lds, tid);
@@ -333,14 +349,14 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
   f32x4 dqacc[NT];
 #pragma unroll
   for (int dt = 0; dt < NT; ++dt) dqacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  const uint16_t* kb = a.k + static_cast<int64_t>(h) * a.k_hs;
-  const uint16_t* vb = a.v + static_cast<int64_t>(h) * a.v_hs;
+  const uint16_t* kb = a.k + static_cast<int64_t>(h / a.rep) * a.k_hs;     // (grouped queries: `rep` query heads read one k/v head)
+  const uint16_t* vb = a.v + static_cast<int64_t>(h / a.rep) * a.v_hs;
   int last = 64 * qb + 63;
   last = last < a.Lq ? last : a.Lq - 1;
   int chunks = (a.P + last + 1 + 31) >> 5;
   chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;
   const int trips = (chunks + 1) >> 1;
-  Pair pr;
+  Pair<DR> pr;
   fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
   zero_pad_columns<DH, DR>(lds, 8, tid);
   stash_pair<DH, DR>(pr, lds, tid);
@@ -411,108 +427,136 @@ __global__ __launch_bounds__(NTHR) void causal_dq_kernel(const CArgs a) {
 template <int DT, int DH, int DR = DH>
 __global__ __launch_bounds__(NTHR, (DH <= 96 ? BMA_CA_DKV_WAVES : 1)) void causal_dkv_kernel(const CArgs a) {
   constexpr int KS = DH / 32, NT = (DR + 15) / 16, IMG = 32 * (DH + 16);   // (output tiles past the real width are never formed: 5 of 6 at DR = 72)
+  // Up to 128-wide heads the two wave halves take the even and the odd query chunks and own ALL output dims (their sums meet in
+  // LDS at the end).  At 256 two full accumulator pairs are 128 registers on top of 64 of key/value fragments: the halves
+  // split the OUTPUT dims instead -- both walk every chunk (S and dP computed twice, at a size where the launch is latency)
+  // and each stores its own half of dk / dv.
+  constexpr bool SPLIT_D = DH > 128;
+  constexpr int NTW = SPLIT_D ? NT / 2 : NT;                          // output tiles a wave owns
+  static_assert(!SPLIT_D || (NT % 2 == 0 && DR == DH), "the dims split wants an even tile count and no padded columns");
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (Q, dO, Q, dO) images: query chunks 2t, 2t+1
   __shared__ __attribute__((aligned(16))) float stat[2][2][64];       // per buffer and chunk: lse2 of its 32 queries, then delta
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
   const int half = w >> 2, wk = w & 3;
-  const int h = blockIdx.x % a.H, kblk = blockIdx.x / a.H;
+  const int Hkv = a.H / a.rep;
+  const int h = blockIdx.x % Hkv, kblk = blockIdx.x / Hkv;        // h: the key/value head; its `rep` query heads follow each other
   const int key0 = 64 * kblk + 16 * wk;                           // first key of this wave
   const int key = key0 + r;                                       // this lane's key (a column of S)
+  const int dt0 = SPLIT_D ? half * NTW : 0;
   uint4_t kf[KS], vf[KS];
   load_row_frags<KS, DR>(kf, a.k + static_cast<int64_t>(h) * a.k_hs, a.k_rs, key < a.Lk ? key : a.Lk - 1, g);
   load_row_frags<KS, DR>(vf, a.v + static_cast<int64_t>(h) * a.v_hs, a.v_rs, key < a.Lk ? key : a.Lk - 1, g);
-  f32x4 dkacc[NT], dvacc[NT];
+  f32x4 dkacc[NTW], dvacc[NTW];
 #pragma unroll
-  for (int dt = 0; dt < NT; ++dt) {
+  for (int dt = 0; dt < NTW; ++dt) {
     dkacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     dvacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   }
-  const uint16_t* qbase = a.q + static_cast<int64_t>(h) * a.q_hs;
-  const uint16_t* dobase = a.d_o + static_cast<int64_t>(h) * DR;
   const int64_t do_rs = static_cast<int64_t>(a.H) * DR;
-  // queries that see at least one key of this block: i >= 64*kblk - P; chunk pairs t0 .. t1-1 of 64 queries
+  // queries that see at least one key of this block: i >= 64*kblk - P; chunk pairs t0 .. t1-1 of 64 queries, once per query
+  // head of the group: `it` runs over (query head of the group, chunk pair)
   int q0 = 64 * kblk - a.P;
   q0 = q0 > 0 ? q0 : 0;
   const int t0 = q0 >> 6, t1 = (a.Lq + 63) >> 6;
+  const int nt = t1 - t0, its = nt * a.rep;
   const int c1 = (a.Lq + 31) >> 5;
-  Pair pr;
+  Pair<DR> pr;
   float st = 0.0f;
-  auto fetch = [&](int t) {
-    fetch_pair<DH, DR>(pr, qbase, a.q_rs, dobase, do_rs, t, a.Lq, tid);
+  auto fetch = [&](int it) {
+    const int hq = h * a.rep + it / nt, t = t0 + it % nt;
+    fetch_pair<DH, DR>(pr, a.q + static_cast<int64_t>(hq) * a.q_hs, a.q_rs, a.d_o + static_cast<int64_t>(hq) * DR, do_rs, t, a.Lq, tid);
     if (tid < 128) {                                               // lse2 and delta of the pair's 64 queries
       int qi = 64 * t + 32 * (tid >> 6) + (tid & 31);
       qi = qi < a.Lq ? qi : a.Lq - 1;
-      st = ((tid & 32) ? a.delta : a.lse2)[static_cast<int64_t>(h) * a.Lq + qi];
+      st = ((tid & 32) ? a.delta : a.lse2)[static_cast<int64_t>(hq) * a.Lq + qi];
     }
   };
   auto stash = [&](int buf) {
     stash_pair<DH, DR>(pr, lds + 4 * IMG * buf, tid);
     if (tid < 128) stat[buf][tid >> 6][tid & 63] = st;
   };
-  fetch(t0);
+  if (its > 0) fetch(0);
   zero_pad_columns<DH, DR>(lds, 8, tid);
-  stash(0);
+  if (its > 0) stash(0);
   landed(kf);
   landed(vf);
   __syncthreads();
-  for (int t = t0; t < t1; ++t) {
-    const int buf = (t - t0) & 1;
-    const uint16_t* ql = lds + 4 * IMG * buf + 2 * IMG * half;
-    const uint16_t* dl = ql + IMG;
-    if (t + 1 < t1) fetch(t + 1);
-    const int c = 2 * t + half;
-    if (c < c1 && 32 * c + 31 + a.P >= key0) {                     // (a chunk whose queries all sit in front of this wave's keys adds nothing)
-      f32x4 s[2], dp[2];
+  for (int it = 0; it < its; ++it) {
+    const int buf = it & 1, t = t0 + it % nt;
+    if (it + 1 < its) fetch(it + 1);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        s[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        dp[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int cc = 0; cc < (SPLIT_D ? 2 : 1); ++cc) {
+      const int hc = SPLIT_D ? cc : half;                          // which chunk of the pair this wave works on now
+      const uint16_t* ql = lds + 4 * IMG * buf + 2 * IMG * hc;
+      const uint16_t* dl = ql + IMG;
+      const int c = 2 * t + hc;
+      if (c < c1 && 32 * c + 31 + a.P >= key0) {                   // (a chunk whose queries all sit in front of this wave's keys adds nothing)
+        f32x4 s[2], dp[2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s[qt] = cmfma<DT>(row_frag<DH>(ql, qt, ks, r, g), kf[ks], s[qt]);
-          dp[qt] = cmfma<DT>(row_frag<DH>(dl, qt, ks, r, g), vf[ks], dp[qt]);
+        for (int qt = 0; qt < 2; ++qt) {
+          s[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          dp[qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s[qt] = cmfma<DT>(row_frag<DH>(ql, qt, ks, r, g), kf[ks], s[qt]);
+            dp[qt] = cmfma<DT>(row_frag<DH>(dl, qt, ks, r, g), vf[ks], dp[qt]);
+          }
         }
-      }
-      float pe[2][4], de[2][4];
-      // masked: the chunk reaches past Lq, or some of its queries do not see some key of this wave
-      const bool edge = 32 * c + 32 > a.Lq || key0 + 15 > a.P + 32 * c;
+        float pe[2][4], de[2][4];
+        // masked: the chunk reaches past Lq, or some of its queries do not see some key of this wave
+        const bool edge = 32 * c + 32 > a.Lq || key0 + 15 > a.P + 32 * c;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[buf][half][16 * qt + 4 * g]);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[buf][half][32 + 16 * qt + 4 * g]);
+        for (int qt = 0; qt < 2; ++qt) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[buf][hc][16 * qt + 4 * g]);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[buf][hc][32 + 16 * qt + 4 * g]);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int qi = 32 * c + 16 * qt + 4 * g + rr;
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][rr], a.scale_log2e, -l4[rr]));
-          if (edge && (qi >= a.Lq || key > a.P + qi)) p = 0.0f;
-          pe[qt][rr] = p;
-          de[qt][rr] = p * (dp[qt][rr] - d4[rr]) * a.scale;
+          for (int rr = 0; rr < 4; ++rr) {
+            const int qi = 32 * c + 16 * qt + 4 * g + rr;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][rr], a.scale_log2e, -l4[rr]));
+            if (edge && (qi >= a.Lq || key > a.P + qi)) p = 0.0f;
+            pe[qt][rr] = p;
+            de[qt][rr] = p * (dp[qt][rr] - d4[rr]) * a.scale;
+          }
         }
-      }
-      const uint4_t pf = pack_acc<DT>(pe), dsf = pack_acc<DT>(de);
+        const uint4_t pf = pack_acc<DT>(pe), dsf = pack_acc<DT>(de);
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt) {
-        dvacc[dt] = cmfma<DT>(tr_frag<DH>(dl, dt, r, g), pf, dvacc[dt]);
-        dkacc[dt] = cmfma<DT>(tr_frag<DH>(ql, dt, r, g), dsf, dkacc[dt]);
+        for (int dt = 0; dt < NTW; ++dt) {
+          dvacc[dt] = cmfma<DT>(tr_frag<DH>(dl, dt0 + dt, r, g), pf, dvacc[dt]);
+          dkacc[dt] = cmfma<DT>(tr_frag<DH>(ql, dt0 + dt, r, g), dsf, dkacc[dt]);
+        }
       }
     }
-    if (t + 1 < t1) stash(buf ^ 1);
+    if (it + 1 < its) stash(buf ^ 1);
     __syncthreads();
+  }
+  uint16_t* kp = a.dk + static_cast<int64_t>(key) * a.dkv_rs + h * DR + 4 * g;
+  uint16_t* vp = a.dv + static_cast<int64_t>(key) * a.dkv_rs + h * DR + 4 * g;
+  if (SPLIT_D) {
+    if (key >= a.Lk) return;
+#pragma unroll
+    for (int dt = 0; dt < NTW; ++dt) {
+      bma::uint2_t ow;
+      ow.x = bma::pack16<DT>(dkacc[dt][0], dkacc[dt][1]);
+      ow.y = bma::pack16<DT>(dkacc[dt][2], dkacc[dt][3]);
+      *reinterpret_cast<bma::uint2_t*>(kp + 16 * (dt0 + dt)) = ow;
+      ow.x = bma::pack16<DT>(dvacc[dt][0], dvacc[dt][1]);
+      ow.y = bma::pack16<DT>(dvacc[dt][2], dvacc[dt][3]);
+      *reinterpret_cast<bma::uint2_t*>(vp + 16 * (dt0 + dt)) = ow;
+    }
+    return;
   }
   float* xch = reinterpret_cast<float*>(lds) + (wk * 64 + lane) * (8 * NT);
   if (half == 1) {
 #pragma unroll
-    for (int dt = 0; dt < NT; ++dt) {
+    for (int dt = 0; dt < NTW; ++dt) {
       *reinterpret_cast<f32x4*>(xch + 8 * dt) = dkacc[dt];
       *reinterpret_cast<f32x4*>(xch + 8 * dt + 4) = dvacc[dt];
     }
   }
   __syncthreads();
   if (half == 1 || key >= a.Lk) return;
-  uint16_t* kp = a.dk + static_cast<int64_t>(key) * a.d_rs + h * DR + 4 * g;
-  uint16_t* vp = a.dv + static_cast<int64_t>(key) * a.d_rs + h * DR + 4 * g;
 #pragma unroll
-  for (int dt = 0; dt < NT; ++dt) {
+  for (int dt = 0; dt < NTW; ++dt) {
     if (!dims_real<DR>(dt, g)) continue;
     const f32x4 k2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt), v2 = *reinterpret_cast<const f32x4*>(xch + 8 * dt + 4);
     bma::uint2_t ow;
@@ -525,12 +569,12 @@ __global__ __launch_bounds__(NTHR, (DH <= 96 ? BMA_CA_DKV_WAVES : 1)) void causa
   }
 }
 
-int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
+int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_t Lk, int H, int Hkv, int Dh, int dtype,
                  const int64_t* strides, int n_strides) {
-  if (Lq < 0 || Lk < Lq || H <= 0) return BMA_EINVAL;
+  if (Lq < 0 || Lk < Lq || H <= 0 || Hkv <= 0 || H % Hkv) return BMA_EINVAL;
   if (!q || !k || !v) return BMA_EINVAL;
   if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
-  if ((Dh != 64 && Dh != 72 && Dh != 128) || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
+  if ((Dh != 64 && Dh != 72 && Dh != 128 && Dh != 256) || Lk > (1 << 20) || static_cast<int64_t>(H) * ((Lk + 63) / 64) > 0x7fffffffLL) return BMA_ELIMIT;
   for (int i = 0; i < n_strides; ++i)
     if (strides[i] % 8) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) % 16) return BMA_EALIGN;
@@ -541,11 +585,18 @@ int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_
 
 constexpr int kAllVisible = 1 << 28;      // CArgs::P when the attention is not causal: past every key
 
-extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
-                                    const void* v, int64_t v_rs, int64_t v_hs, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
-                                    int causal, float scale, void* out, float* lse2, void* stream) {
+// the head widths the kernels are built for: (width in memory) -> (DH, DR)
+#define BMA_CAUSAL_WIDTHS(X, DT_)        \
+  if (Dh == 128) X(DT_, 128, 128);       \
+  else if (Dh == 256) X(DT_, 256, 256);  \
+  else if (Dh == 72) X(DT_, 96, 72);     \
+  else X(DT_, 64, 64)
+
+extern "C" int bma_causal_attention_gqa(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
+                                        const void* v, int64_t v_rs, int64_t v_hs, int64_t Lq, int64_t Lk, int H, int Hkv, int Dh,
+                                        int dtype, int causal, float scale, void* out, float* lse2, void* stream) {
   const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
-  const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
+  const int rc = check_common(q, k, v, Lq, Lk, H, Hkv, Dh, dtype, strides, 6);
   if (rc != BMA_OK) return rc;
   if (Lq == 0) return BMA_OK;
   if (!out || !lse2 || reinterpret_cast<uintptr_t>(out) % 16 || reinterpret_cast<uintptr_t>(lse2) % 4) return out && lse2 ? BMA_EALIGN : BMA_EINVAL;
@@ -553,17 +604,67 @@ extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
   a.out = static_cast<uint16_t*>(out); a.lse2 = lse2;
   a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs;
-  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = causal ? static_cast<int>(Lk - Lq) : kAllVisible;
+  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.rep = H / Hkv; a.P = causal ? static_cast<int>(Lk - Lq) : kAllVisible;
   a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(H * ((Lq + 63) / 64)));
-  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) + 2.0 * static_cast<double>(Lk)) * H * Dh);
-  if (dtype == BMA_BF16 && Dh == 128) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 128>), grid, dim3(NTHR), 0, st, a);
-  else if (dtype == BMA_BF16 && Dh == 72) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 96, 72>), grid, dim3(NTHR), 0, st, a);
-  else if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 64>), grid, dim3(NTHR), 0, st, a);
-  else if (Dh == 128) hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 128>), grid, dim3(NTHR), 0, st, a);
-  else if (Dh == 72) hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 96, 72>), grid, dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 64>), grid, dim3(NTHR), 0, st, a);
+  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) * H + 2.0 * static_cast<double>(Lk) * Hkv) * Dh);
+#define BMA_CAUSAL_FWD(DT_, DH_, DR_) hipLaunchKernelGGL((causal_fwd_kernel<DT_, DH_, DR_>), grid, dim3(NTHR), 0, st, a)
+  if (dtype == BMA_BF16) { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_FWD, BMA_BF16); }
+  else { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_FWD, BMA_F16); }
+#undef BMA_CAUSAL_FWD
+  BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
+  BMA_LAUNCH_CHECK();
+  return BMA_OK;
+}
+
+extern "C" int bma_causal_attention(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
+                                    const void* v, int64_t v_rs, int64_t v_hs, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
+                                    int causal, float scale, void* out, float* lse2, void* stream) {
+  return bma_causal_attention_gqa(q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, v_hs, Lq, Lk, H, H, Dh, dtype, causal, scale, out, lse2, stream);
+}
+
+extern "C" int bma_causal_attention_bwd_gqa(const void* q, int64_t q_rs, int64_t q_hs, const void* k, int64_t k_rs, int64_t k_hs,
+                                            const void* v, int64_t v_rs, int64_t v_hs, const void* out, const float* lse2,
+                                            const void* d_out, int64_t Lq, int64_t Lk, int H, int Hkv, int Dh, int dtype, int causal,
+                                            float scale, void* dq, void* dk, void* dv, int64_t dq_row_stride,
+                                            int64_t dkv_row_stride, float* delta, void* stream) {
+  const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
+  const int rc = check_common(q, k, v, Lq, Lk, H, Hkv, Dh, dtype, strides, 6);
+  if (rc != BMA_OK) return rc;
+  if (!out || !lse2 || !d_out || !dq || !dk || !dv || !delta) return BMA_EINVAL;
+  if (dq_row_stride < static_cast<int64_t>(H) * Dh || dkv_row_stride < static_cast<int64_t>(Hkv) * Dh) return BMA_EINVAL;
+  if (dq_row_stride % 8 || dkv_row_stride % 8) return BMA_EALIGN;
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(dq) |
+       reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 ||
+      (reinterpret_cast<uintptr_t>(lse2) | reinterpret_cast<uintptr_t>(delta)) % 4)
+    return BMA_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (Lq == 0) {                                                  // no query: the keys' gradients are zero
+    if (Lk > 0) {
+      if (hipMemset2DAsync(dk, static_cast<size_t>(dkv_row_stride) * 2, 0, static_cast<size_t>(Hkv) * Dh * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
+      if (hipMemset2DAsync(dv, static_cast<size_t>(dkv_row_stride) * 2, 0, static_cast<size_t>(Hkv) * Dh * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
+    }
+    return BMA_OK;
+  }
+  CArgs a = {};
+  a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
+  a.o = static_cast<const uint16_t*>(out); a.d_o = static_cast<const uint16_t*>(d_out);
+  a.dq = static_cast<uint16_t*>(dq); a.dk = static_cast<uint16_t*>(dk); a.dv = static_cast<uint16_t*>(dv);
+  a.lse2 = const_cast<float*>(lse2); a.delta = delta;
+  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs; a.d_rs = dq_row_stride; a.dkv_rs = dkv_row_stride;
+  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.rep = H / Hkv; a.P = causal ? static_cast<int>(Lk - Lq) : kAllVisible;
+  a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+  const dim3 gq(static_cast<unsigned>(H * ((Lq + 63) / 64))), gk(static_cast<unsigned>(Hkv * ((Lk + 63) / 64)));
+  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (4.0 * static_cast<double>(Lq) * H + 4.0 * static_cast<double>(Lk) * Hkv) * Dh);
+#define BMA_CAUSAL_BWD(DT_, DH_, DR_)                                                                                          \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL((causal_dq_kernel<DT_, DH_, DR_>), gq, dim3(NTHR), 0, st, a); /* writes delta for the next launch */   \
+    hipLaunchKernelGGL((causal_dkv_kernel<DT_, DH_, DR_>), gk, dim3(NTHR), 0, st, a);                                          \
+  } while (0)
+  if (dtype == BMA_BF16) { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_BWD, BMA_BF16); }
+  else { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_BWD, BMA_F16); }
+#undef BMA_CAUSAL_BWD
   BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;
@@ -574,47 +675,6 @@ extern "C" int bma_causal_attention_bwd(const void* q, int64_t q_rs, int64_t q_h
                                         const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype, int causal,
                                         float scale, void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta,
                                         void* stream) {
-  const int64_t strides[] = {q_rs, q_hs, k_rs, k_hs, v_rs, v_hs};
-  const int rc = check_common(q, k, v, Lq, Lk, H, Dh, dtype, strides, 6);
-  if (rc != BMA_OK) return rc;
-  if (!out || !lse2 || !d_out || !dq || !dk || !dv || !delta) return BMA_EINVAL;
-  if (d_row_stride < static_cast<int64_t>(H) * Dh) return BMA_EINVAL;
-  if (d_row_stride % 8) return BMA_EALIGN;
-  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(dq) |
-       reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 ||
-      (reinterpret_cast<uintptr_t>(lse2) | reinterpret_cast<uintptr_t>(delta)) % 4)
-    return BMA_EALIGN;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (Lq == 0) {                                                  // no query: the keys' gradients are zero
-    if (Lk > 0) {
-      if (hipMemset2DAsync(dk, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * Dh * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
-      if (hipMemset2DAsync(dv, static_cast<size_t>(d_row_stride) * 2, 0, static_cast<size_t>(H) * Dh * 2, static_cast<size_t>(Lk), st) != hipSuccess) return BMA_ELAUNCH;
-    }
-    return BMA_OK;
-  }
-  CArgs a = {};
-  a.q = static_cast<const uint16_t*>(q); a.k = static_cast<const uint16_t*>(k); a.v = static_cast<const uint16_t*>(v);
-  a.o = static_cast<const uint16_t*>(out); a.d_o = static_cast<const uint16_t*>(d_out);
-  a.dq = static_cast<uint16_t*>(dq); a.dk = static_cast<uint16_t*>(dk); a.dv = static_cast<uint16_t*>(dv);
-  a.lse2 = const_cast<float*>(lse2); a.delta = delta;
-  a.q_rs = q_rs; a.q_hs = q_hs; a.k_rs = k_rs; a.k_hs = k_hs; a.v_rs = v_rs; a.v_hs = v_hs; a.d_rs = d_row_stride;
-  a.Lq = static_cast<int>(Lq); a.Lk = static_cast<int>(Lk); a.H = H; a.P = causal ? static_cast<int>(Lk - Lq) : kAllVisible;
-  a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
-  const dim3 gq(static_cast<unsigned>(H * ((Lq + 63) / 64))), gk(static_cast<unsigned>(H * ((Lk + 63) / 64)));
-  BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (4.0 * static_cast<double>(Lq) + 4.0 * static_cast<double>(Lk)) * H * Dh);
-#define BMA_CAUSAL_BWD(DT_, DH_, DR_)                                                                                          \
-  do {                                                                                                                         \
-    hipLaunchKernelGGL((causal_dq_kernel<DT_, DH_, DR_>), gq, dim3(NTHR), 0, st, a); /* writes delta for the next launch */   \
-    hipLaunchKernelGGL((causal_dkv_kernel<DT_, DH_, DR_>), gk, dim3(NTHR), 0, st, a);                                          \
-  } while (0)
-  if (dtype == BMA_BF16 && Dh == 128) BMA_CAUSAL_BWD(BMA_BF16, 128, 128);
-  else if (dtype == BMA_BF16 && Dh == 72) BMA_CAUSAL_BWD(BMA_BF16, 96, 72);
-  else if (dtype == BMA_BF16) BMA_CAUSAL_BWD(BMA_BF16, 64, 64);
-  else if (Dh == 128) BMA_CAUSAL_BWD(BMA_F16, 128, 128);
-  else if (Dh == 72) BMA_CAUSAL_BWD(BMA_F16, 96, 72);
-  else BMA_CAUSAL_BWD(BMA_F16, 64, 64);
-#undef BMA_CAUSAL_BWD
-  BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
-  BMA_LAUNCH_CHECK();
-  return BMA_OK;
+  return bma_causal_attention_bwd_gqa(q, q_rs, q_hs, k, k_rs, k_hs, v, v_rs, v_hs, out, lse2, d_out, Lq, Lk, H, H, Dh, dtype, causal, scale,
+                                      dq, dk, dv, d_row_stride, d_row_stride, delta, stream);
 }

@@ -833,12 +833,14 @@ def _rows_heads(t: torch.Tensor):
 
 
 def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
-    """q (Lq, H, Dh), k / v (Lk, H, Dh) views with Dh 64, 72 (SigLIP; computed in 96-wide LDS images) or 128, 16-bit, last
-    dim contiguous, strides multiples of 8, the same heads on both sides, Lq <= Lk (causal: the queries are the last Lq
-    positions)."""
+    """q (Lq, H, Dh), k / v (Lk, Hkv, Dh) views with Dh 64, 72 (SigLIP; computed in 96-wide LDS images), 128 or 256 (Gemma-3's
+    decoder), 16-bit, last dim contiguous, strides multiples of 8, H a multiple of Hkv (grouped queries: heads h*rep ..
+    share key/value head h), Lq <= Lk (causal: the queries are the last Lq positions)."""
     if not (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype):
         return False
-    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[1:] != k.shape[1:] or q.shape[2] not in (64, 72, 128):
+    if q.dim() != 3 or k.dim() != 3 or v.shape != k.shape or q.shape[2] != k.shape[2] or q.shape[2] not in (64, 72, 128, 256):
+        return False
+    if k.shape[1] < 1 or q.shape[1] % k.shape[1]:
         return False
     if not (0 < q.shape[0] <= k.shape[0] <= CAUSAL_ATTENTION_MAX_TOKENS):
         return False
@@ -849,44 +851,45 @@ def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bo
 
 
 def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, causal: bool = True):
-    """(out (Lq, H, Dh) contiguous, lse2 (H, Lq) fp32) through bma_causal_attention (include/bma.h); ``causal=False``: every
-    query sees every key (a vision tower)."""
+    """(out (Lq, H, Dh) contiguous, lse2 (H, Lq) fp32) through bma_causal_attention_gqa (include/bma.h); ``causal=False``:
+    every query sees every key (a vision tower)."""
     dev = _need_gpu(q, k, v)
     if not causal_attention_ok(q, k, v):
-        raise ValueError("causal_attention wants 16-bit (L, H, 64 | 72 | 128) views with a contiguous last dim, Lq <= Lk")
+        raise ValueError("causal_attention wants 16-bit (L, H, 64 | 72 | 128 | 256) views with a contiguous last dim, Lq <= Lk, "
+                         "H a multiple of the key/value heads")
     Lq, H, Dh = q.shape
-    Lk = k.shape[0]
+    Lk, Hkv = k.shape[0], k.shape[1]
     out = torch.empty((Lq, H, Dh), dtype=q.dtype, device=dev)
     lse2 = torch.empty((H, Lq), dtype=torch.float32, device=dev)
-    check("bma_causal_attention", lib.bma_causal_attention(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
-                                                           *_rows_heads(v), Lq, Lk, H, Dh, _dt(q), 1 if causal else 0, float(scale),
-                                                           out.data_ptr(), lse2.data_ptr(), _stream(dev)))
+    check("bma_causal_attention_gqa", lib.bma_causal_attention_gqa(
+        q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(), *_rows_heads(v), Lq, Lk, H, Hkv, Dh, _dt(q),
+        1 if causal else 0, float(scale), out.data_ptr(), lse2.data_ptr(), _stream(dev)))
     return out, lse2
 
 
 def causal_attention_bwd(q, k, v, out, lse2, d_out, scale: float, into=None, causal: bool = True):
-    """(dq (Lq, H, Dh), dk, dv (Lk, H, Dh)) through bma_causal_attention_bwd: fresh contiguous tensors, or -- `into` a
-    (Lk, 3, H, Dh) buffer with Lq == Lk -- views of it, the three written straight into the gradient of a fused q/k/v
-    projection."""
+    """(dq (Lq, H, Dh), dk, dv (Lk, Hkv, Dh)) through bma_causal_attention_bwd_gqa: fresh contiguous tensors, or -- `into` a
+    (Lk, 3, H, Dh) buffer with Lq == Lk and Hkv == H -- views of it, the three written straight into the gradient of a fused
+    q/k/v projection."""
     dev = _need_gpu(q, k, v)
     Lq, H, Dh = q.shape
-    Lk = k.shape[0]
+    Lk, Hkv = k.shape[0], k.shape[1]
     d_out = d_out.contiguous()
     if into is None:
         dq = torch.empty((Lq, H, Dh), dtype=q.dtype, device=dev)
-        dk = torch.empty((Lk, H, Dh), dtype=q.dtype, device=dev)
-        dv = torch.empty((Lk, H, Dh), dtype=q.dtype, device=dev)
-        d_rs = H * Dh
+        dk = torch.empty((Lk, Hkv, Dh), dtype=q.dtype, device=dev)
+        dv = torch.empty((Lk, Hkv, Dh), dtype=q.dtype, device=dev)
+        dq_rs, dkv_rs = H * Dh, Hkv * Dh
     else:
-        if Lq != Lk or into.shape != (Lk, 3, H, Dh) or not into.is_contiguous() or into.dtype != q.dtype:
-            raise ValueError("`into` must be a contiguous (L, 3, H, Dh) buffer of the operands' type with Lq == Lk")
+        if Lq != Lk or Hkv != H or into.shape != (Lk, 3, H, Dh) or not into.is_contiguous() or into.dtype != q.dtype:
+            raise ValueError("`into` must be a contiguous (L, 3, H, Dh) buffer of the operands' type with Lq == Lk and Hkv == H")
         dq, dk, dv = into[:, 0], into[:, 1], into[:, 2]
-        d_rs = 3 * H * Dh
+        dq_rs = dkv_rs = 3 * H * Dh
     delta = torch.empty((H, Lq), dtype=torch.float32, device=dev)
-    check("bma_causal_attention_bwd", lib.bma_causal_attention_bwd(q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(),
-                                                                   *_rows_heads(v), out.data_ptr(), lse2.data_ptr(), d_out.data_ptr(), Lq,
-                                                                   Lk, H, Dh, _dt(q), 1 if causal else 0, float(scale), dq.data_ptr(),
-                                                                   dk.data_ptr(), dv.data_ptr(), d_rs, delta.data_ptr(), _stream(dev)))
+    check("bma_causal_attention_bwd_gqa", lib.bma_causal_attention_bwd_gqa(
+        q.data_ptr(), *_rows_heads(q), k.data_ptr(), *_rows_heads(k), v.data_ptr(), *_rows_heads(v), out.data_ptr(), lse2.data_ptr(),
+        d_out.data_ptr(), Lq, Lk, H, Hkv, Dh, _dt(q), 1 if causal else 0, float(scale), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+        dq_rs, dkv_rs, delta.data_ptr(), _stream(dev)))
     return dq, dk, dv
 
 

@@ -400,13 +400,21 @@ def causal_b1_attention(module, query, key, value, attention_mask=None, dropout:
     return out.transpose(1, 2).contiguous(), None
 
 
+# 256-wide and grouped-query heads on the hand-written pair (round 5; BMA_OWN_WIDE_HEADS=0: the library's flash kernels behind
+# repeated copies of k / v, as before)
+OWN_WIDE_HEADS = os.environ.get("BMA_OWN_WIDE_HEADS", "1") not in ("0", "false", "False")
+
+
 def _own_causal(query, key, value, scale: float, dropout: float, causal: bool = True):
     """(1, Lq, H, Dh) through the hand-written attention pair (csrc/causal_attention.hip: forward 18 us and backward 53 us
     at 643 tokens x 32 heads x 128, where the library's pair and its helper launches take ~150), or None when the call is not
-    its shape: batch 1, the same 64- or 128-wide heads on both sides, 16-bit, no dropout; causal with the queries as the
+    its shape: batch 1, heads of 64, 72, 128 or 256 (grouped queries included: Gemma-3's decoder, 8 heads over 4 of 256 -- no
+    repeated copies of k / v, the group's sum inside the backward launch), 16-bit, no dropout; causal with the queries as the
     last Lq of the Lk key positions, or every key visible (a vision tower)."""
     from . import ops
-    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] != key.shape[1] or query.shape[3] not in (64, 72, 128):
+    if not ops.CAUSAL_ATTENTION or dropout or query.shape[0] != 1 or query.shape[1] % key.shape[1] \
+            or query.shape[3] not in ((64, 72, 128, 256) if OWN_WIDE_HEADS else (64, 72, 128)) \
+            or (query.shape[1] != key.shape[1] and not OWN_WIDE_HEADS):
         return None
     # (squeeze, not [0]: the backward of an index is a zero fill plus a copy per operand, of a squeeze nothing)
     q3, k3, v3 = query.squeeze(0).transpose(0, 1), key.squeeze(0).transpose(0, 1), value.squeeze(0).transpose(0, 1)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 110 /* 0.1.10: bma_add_layernorm(+_bwd) (CLIP's residual add + LayerNorm pairs in one launch each way); 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 111 /* 0.1.11: bma_causal_attention_gqa(+_bwd_gqa) (grouped-query heads, 256-wide heads: Gemma-3's decoder at batch 1); 0.1.10: bma_add_layernorm(+_bwd) (CLIP's residual add + LayerNorm pairs in one launch each way); 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -311,7 +311,7 @@ int bma_gemm_nt_next(const void* x, int64_t ldx, const void* w, int64_t ldw, voi
  *   gradient pass with the image in the prompt (a1, :953-1028 with PGD on: 599-644 tokens per layer) and for the rows
  *   behind a reused prefix (joint mode: 44 new tokens against 643 keys).  The Lq queries are the LAST Lq positions of the
  *   Lk keys: query i attends to keys 0 .. (Lk - Lq) + i.  q [Lq][H][Dh], k / v [Lk][H][Dh] through (row, head) strides in
- *   elements (multiples of 8; views of a fused projection are fine), H query heads = H key/value heads, Dh = 64 or 128, bf16 /
+ *   elements (multiples of 8; views of a fused projection are fine), H query heads = H key/value heads, Dh = 64, 72, 128 or 256, bf16 /
  *   f16, rotary already applied.  causal = 0: every query sees every key (a vision tower's attention: CLIP's 577 tokens x 16
  *   heads of 64).  Forward: out [Lq][H][Dh] contiguous and lse2 [H][Lq] fp32 = log2 of the softmax
  *   denominator in units of the scaled scores (an opaque token for the backward).  Backward: dq [Lq][H][Dh], dk / dv
@@ -327,6 +327,20 @@ int bma_causal_attention_bwd(const void* q, int64_t q_row_stride, int64_t q_head
                              const float* lse2, const void* d_out, int64_t Lq, int64_t Lk, int H, int Dh, int dtype,
                              int causal, float scale, void* dq, void* dk, void* dv, int64_t d_row_stride, float* delta,
                              void* stream);
+/* ... with grouped-query heads: H query heads read Hkv key/value heads (H a multiple of Hkv; query heads h*rep .. h*rep+rep-1
+ *   share key/value head h, HuggingFace's repeat_kv order) -- k / v [Lk][Hkv][Dh], dk / dv [Lk][Hkv][Dh] with their own row
+ *   stride, summed over the group inside the launch (no repeated copies of k / v, no reduction afterwards) -- and head widths
+ *   64, 72, 128 or 256 (Gemma-3's decoder in the gradient pass, reference :953-1028 on a Gemma-3 model: ~320 tokens x 8 heads
+ *   over 4 of 256).  Hkv == H is bma_causal_attention / _bwd. */
+int bma_causal_attention_gqa(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
+                             int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, int64_t Lq,
+                             int64_t Lk, int H, int Hkv, int Dh, int dtype, int causal, float scale, void* out, float* lse2,
+                             void* stream);
+int bma_causal_attention_bwd_gqa(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
+                                 int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride,
+                                 const void* out, const float* lse2, const void* d_out, int64_t Lq, int64_t Lk, int H, int Hkv,
+                                 int Dh, int dtype, int causal, float scale, void* dq, void* dk, void* dv,
+                                 int64_t dq_row_stride, int64_t dkv_row_stride, float* delta, void* stream);
 
 /* bma_gemm_mid: y[M][N] = x[M][K] . w[N][K]^T for the products of the batch-1 gradient pass when the image is part of the
  *   prompt (a1, :953-1028 with PGD on: 576 image rows + the text = 599-644 rows; the same shapes occur in the prefix

@@ -630,12 +630,87 @@ def test_causal_attention_forward_and_backward_match_float64(dtype):
         assert float((lse2.double() - ref_lse2.detach()).abs().max()) <= 1e-3
     # what it does not take
     q32 = torch.zeros((10, 2, 32), device=DEV, dtype=dtype)
-    assert not ops.causal_attention_ok(q32, q32, q32)                         # head widths 64, 72 and 128 only
+    assert not ops.causal_attention_ok(q32, q32, q32)                         # head widths 64, 72, 128 and 256 only
     q3 = torch.zeros((10, 2, 128), device=DEV, dtype=dtype)
     assert not ops.causal_attention_ok(q3, q3[:5], q3[:5])                       # more queries than keys
-    assert not ops.causal_attention_ok(q3, torch.zeros((10, 1, 128), device=DEV, dtype=dtype), torch.zeros((10, 1, 128), device=DEV, dtype=dtype))
+    k3 = torch.zeros((10, 3, 128), device=DEV, dtype=dtype)
+    assert not ops.causal_attention_ok(q3, k3, k3)                              # 2 query heads over 3 key/value heads
     assert not ops.causal_attention_ok(q3.float(), q3.float(), q3.float())
     assert not ops.causal_attention_ok(torch.zeros((10, 2, 256), device=DEV, dtype=dtype)[:, :, ::2], q3, q3)      # last dim not contiguous
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_causal_attention_grouped_queries_and_256_wide_heads(dtype):
+    """The same three kernels with H query heads over Hkv key/value heads (HuggingFace's repeat_kv order: heads h*rep ..
+    share key/value head h; dk / dv summed over the group INSIDE the launch) and at 256-wide heads (two 16-byte pieces per
+    thread and chunk, the dk/dv launch splitting the output dims between its wave halves): Gemma-3's decoder in the gradient
+    pass -- ~320 tokens x 8 heads over 4 of 256 -- lengths on and off the block and chunk sizes, a prefix in front, one
+    key/value head for all, every key visible, grouped 64-, 72- and 128-wide heads; against float64 on the same 16-bit
+    operands (k / v repeated, autograd doing the group's sum), and the gradients against the library's pair on repeated
+    copies.  Bit-equal over repeated launches."""
+    from bimodalattack_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(23)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for H, Hkv, Lq, Lk, Dh, causal in ((8, 4, 320, 320, 256, True), (8, 8, 643, 643, 256, True), (4, 1, 77, 77, 256, True),
+                                       (8, 4, 44, 300, 256, True), (2, 2, 1, 1, 256, True), (4, 2, 65, 65, 256, False),
+                                       (6, 2, 33, 64 + 33, 256, True), (8, 2, 200, 200, 128, True), (32, 8, 44, 643, 128, True),
+                                       (4, 2, 130, 130, 64, False), (6, 3, 100, 100, 72, True), (8, 4, 1100, 1100, 256, True)):
+        rep = H // Hkv
+        q = torch.randn((Lq, H * Dh), generator=g, device=DEV).to(dtype).view(Lq, H, Dh)
+        kv = torch.randn((Lk, 2 * Hkv * Dh), generator=g, device=DEV).to(dtype)
+        k, v = kv[:, :Hkv * Dh].view(Lk, Hkv, Dh), kv[:, Hkv * Dh:].view(Lk, Hkv, Dh)
+        assert ops.causal_attention_ok(q, k, v)
+        scale = Dh ** -0.5
+        qd, kd, vd = (t.detach().double().requires_grad_() for t in (q, k, v))
+        o_ref = _causal_reference(qd, kd.repeat_interleave(rep, dim=1), vd.repeat_interleave(rep, dim=1), scale, causal)
+        do = torch.randn((Lq, H, Dh), generator=g, device=DEV).to(dtype)
+        gq, gk, gv = torch.autograd.grad(o_ref, (qd, kd, vd), do.double())
+        out, lse2 = ops.causal_attention(q, k, v, scale, causal)
+        dq, dk, dv = ops.causal_attention_bwd(q, k, v, out, lse2, do, scale, causal=causal)
+        assert dq.shape == (Lq, H, Dh) and dk.shape == dv.shape == (Lk, Hkv, Dh)
+        rel = lambda a_, b_: float((a_.double() - b_).abs().max() / b_.abs().max().clamp_min(1e-2))      # noqa: E731
+        case = (H, Hkv, Lq, Lk, Dh, causal)
+        assert rel(out, o_ref.detach()) <= 3 * eps, (case, rel(out, o_ref.detach()))
+        for name, mine, want in (("dq", dq, gq), ("dk", dk, gk), ("dv", dv, gv)):
+            # (the group's sum is taken in fp32 before the one rounding: no worse than a single head's)
+            assert rel(mine, want) <= 6 * eps, (name, case, rel(mine, want))
+        if Lq == Lk and Lq > 1:
+            ql, kl, vl = (t.detach().clone().requires_grad_() for t in (q, k, v))
+            ol = torch.nn.functional.scaled_dot_product_attention(
+                ql.transpose(0, 1)[None], kl.repeat_interleave(rep, dim=1).transpose(0, 1)[None],
+                vl.repeat_interleave(rep, dim=1).transpose(0, 1)[None], is_causal=causal, scale=scale)[0].transpose(0, 1)
+            lq, lk_, lv = torch.autograd.grad(ol, (ql, kl, vl), do)
+            for name, mine, theirs, want in (("dq", dq, lq, gq), ("dk", dk, lk_, gk), ("dv", dv, lv, gv)):
+                assert rel(mine, want) <= 1.5 * rel(theirs, want) + eps, (name, case, rel(mine, want), rel(theirs, want))
+        out2, lse2b = ops.causal_attention(q, k, v, scale, causal)
+        again = ops.causal_attention_bwd(q, k, v, out, lse2, do, scale, causal=causal)
+        assert torch.equal(out, out2) and torch.equal(lse2, lse2b) and all(torch.equal(a_, b_) for a_, b_ in zip(again, (dq, dk, dv)))
+    # through the decoder's attention-interface function, as Gemma-3's attention block calls it: (1, H, S, 256) against
+    # (1, Hkv, S, 256), under autograd; the library route (repeated k / v, flash kernels) as the yardstick
+    from bimodalattack_amd import prefix_attention as pa
+    H, Hkv, S, Dh = 8, 4, 323, 256
+    q4 = torch.randn((1, S, H, Dh), generator=g, device=DEV).to(dtype).requires_grad_()
+    k4 = torch.randn((1, S, Hkv, Dh), generator=g, device=DEV).to(dtype).requires_grad_()
+    v4 = torch.randn((1, S, Hkv, Dh), generator=g, device=DEV).to(dtype).requires_grad_()
+    do = torch.randn((1, S, H, Dh), generator=g, device=DEV).to(dtype)
+    calls = []
+    keep = ops.causal_attention
+    ops.causal_attention = lambda q_, *a_, **k_: (calls.append(tuple(q_.shape)), keep(q_, *a_, **k_))[1]
+    try:
+        out, _ = pa.causal_b1_attention(None, q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2), scaling=Dh ** -0.5)
+        g_own = torch.autograd.grad(out, (q4, k4, v4), do)
+    finally:
+        ops.causal_attention = keep
+    assert calls == [(S, H, Dh)] and out.shape == (1, S, H, Dh)
+    try:
+        pa.OWN_WIDE_HEADS = False
+        out_l, _ = pa.causal_b1_attention(None, q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2), scaling=Dh ** -0.5)
+        g_lib = torch.autograd.grad(out_l, (q4, k4, v4), do)
+    finally:
+        pa.OWN_WIDE_HEADS = True
+    assert float((out.float() - out_l.float()).abs().max()) <= 4 * eps * float(out_l.float().abs().max())
+    for a_, b_ in zip(g_own, g_lib):
+        assert a_.shape == b_.shape and float((a_.float() - b_.float()).abs().max()) <= 8 * eps * float(b_.float().abs().max())
 
 
 def test_causal_attention_under_autograd_in_a_graph_and_through_the_interface():
