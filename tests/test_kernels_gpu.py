@@ -740,8 +740,9 @@ def test_causal_attention_under_autograd_in_a_graph_and_through_the_interface():
         ops.CAUSAL_ATTENTION = True
     assert float((out.float() - out_l.float()).abs().max()) <= 2 ** -6 * float(out_l.float().abs().max())
     assert float((g_own.float() - g_lib.float()).abs().max()) <= 2 ** -5 * float(g_lib.float().abs().max())
-    # refusals: grouped heads, 32-wide heads, dropout
-    assert pa._own_causal(q, k[:, :8], v[:, :8], 0.1, 0.0) is None
+    # refusals: query heads that do not divide over the key/value heads (grouped heads are taken since round 5), 32-wide heads, dropout
+    assert pa._own_causal(q, k[:, :5], v[:, :5], 0.1, 0.0) is None
+    assert pa._own_causal(q, k[:, :8], v[:, :8], 0.1, 0.0) is not None
     assert pa._own_causal(q[..., :32], k[..., :32], v[..., :32], 0.1, 0.0) is None
     assert pa._own_causal(q, k, v, 0.1, 0.1) is None
     # the tail behind a prefix with history: gradients reach the prefix keys/values and the new rows alike
