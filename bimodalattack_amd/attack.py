@@ -79,6 +79,9 @@ CHUNK_QUANTUM = max(1, int(os.environ.get("BMA_CHUNK_QUANTUM", "8")))
 # GEMM tuning aid (tools/tune_gemms.py): in a single process, score only what rank 0 of an N-rank run would score, with
 # that run's row budget -- the exact GEMM shapes of the multi-GPU run.  Results of the attack are meaningless with it.
 EMULATE_WORLD = int(os.environ.get("BMA_EMULATE_WORLD", "0") or 0)
+# debugging aid: host clock stamps at the loop's hand-over points (BimodalAttack.host_stamps; tools/host_stamps.py folds them) --
+# where the host spends a step matters once the forward is short (W = 8: 24 ms of GPU work per step)
+HOST_STAMPS = os.environ.get("BMA_HOST_STAMPS", "0") not in ("0", "false", "False", "")
 SHARED_PREFIX_MIN_TOKENS = 1     # shortest prefix worth the shared-prefix attention route
 
 TEMPLATE_PGD = "USER: <image>\n{{ messages[0]['content'][0]['text'] }} \nASSISTANT: "
@@ -248,6 +251,7 @@ class BimodalAttack:
         self._rb: Optional[Tensor] = None          # pinned block of the step's packed read-back (_read_later)
         self._stage: dict = {}                     # pinned staging buffer of the ragged index maps (one upload per step)
         self.graphs_captured: List[str] = []       # hipGraphs in use, by what they replay
+        self.host_stamps: Optional[list] = [] if HOST_STAMPS else None     # (label, host clock) pairs, in order
         self.fallbacks: Dict[str, str] = {}        # fast path -> why it was abandoned for the slower one
         own = bool(self.opt.own_b1_kernels)               # the hand-written batch-1 kernels: one option, four process-wide switches
         ops.SKINNY_GEMM = own and ops.OWN_KERNELS["skinny_gemm"]
@@ -572,6 +576,10 @@ class BimodalAttack:
         np.put_along_axis(fake, pos, -1 - rank, axis=1)
         return fake, par
 
+    def _stamp(self, label: str) -> None:
+        if self.host_stamps is not None:
+            self.host_stamps.append((label, time.perf_counter()))
+
     def candidate_sampling(self, step: int, optim_ids: Tensor, g_tok: Optional[Tensor], image: Optional[Tensor] = None):
         """mask -> top-k -> random position/rank -> scatter (:130-163).  Returns every sampled
         candidate and a FilterJob: the retokenisation filter (:166-186) runs on the host while
@@ -792,8 +800,10 @@ class BimodalAttack:
         # the same predicate the attention function evaluates on the tensors: the library route needs the padded-block
         # maps (BMA_FUSED_RAGGED_ATTENTION=0, fp32 models, head sizes the kernel does not take), the kernel route not
         fused = fused_ragged_route(self.model.dtype, hf.head_dim, hf.heads, hf.kv_heads, L)
+        self._stamp("dealt")
         plan = ragged_plan(host_ids, host_parent, L, self.T, P, n_rows, dedup=False, padded_maps=not fused,
                            inverse=inverse)
+        self._stamp("planned")
         if plan is None:
             return None
         mu = int(plan["m"])           # distinct candidates, in the plan's order: duplicates are computed once
@@ -818,6 +828,7 @@ class BimodalAttack:
             maps.ids = torch.cat([real[0], real[1]], dim=0)
             if maps.ids.shape != (mu + 1, int(plan["n_opt"])):
                 raise RuntimeError("ragged scoring: gathered ids do not match the plan")
+            self._stamp("maps_up")
             return forward(maps, mu + 1)
         maps = RaggedMaps(plan, dev, ids=ids, stage=self._stage)
         return forward(maps, mu + 1)
@@ -1225,6 +1236,7 @@ class BimodalAttack:
             for i in range(cfg.num_steps):
                 if hook is not None:
                     hook(i)
+                self._stamp("step")
                 n_done = i + 1
                 st: Optional[dict] = {} if trace is not None else None
                 if st is not None:
@@ -1300,8 +1312,10 @@ class BimodalAttack:
                     # (the sampling kernels' own ~0.3 ms of GPU time are booked with the scoring phase: event pairs
                     # around them, recorded while the gradient graph was still running, read 3-18 ms too long)
                     flying = (span, time.perf_counter() - t_s, pgd_span)
+                    self._stamp("sampled")
                     if early is not None and self._parent_host is not None:
                         virtual = self._virtual_ids(early, self._parent_host)
+                    self._stamp("virtual")
                 else:
                     t0 = self._sync()
                     sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok,
@@ -1336,7 +1350,9 @@ class BimodalAttack:
                         """Apply the retokenisation filter, computed on the host while the GPU
                         scored, to the losses: the reference's filtered vector, in order.  `defer_hit`: the
                         early-stop verdict is handed back as a device tensor instead of being read here."""
+                        self._stamp("enqueued")
                         keep = job.result()
+                        self._stamp("filtered")
                         if getattr(job, "enabled", False):
                             self._keep_rates.append(len(keep) / max(1, loss_all.shape[0]))
                         if len(keep) == loss_all.shape[0]:
@@ -1384,7 +1400,9 @@ class BimodalAttack:
                             with torch.enable_grad():
                                 g_next = self.compute_gradient(winner, img)
                             queued = (g_next, None, sp.stop())
+                        self._stamp("queued_next")
                         host = read()
+                        self._stamp("read")
                         if rng_before is not None and host[2] != 0.0:
                             self._rng_state(rng_before)
                             self._early = None
