@@ -26,6 +26,18 @@ def _dt(t: torch.Tensor) -> int:
         raise TypeError(f"unsupported dtype {t.dtype}; the kernels take float32, bfloat16, float16") from None
 
 
+_ARCH_CHECKED = set()          # device indices whose architecture has been looked at
+
+
+def check_arch(arch_name: str) -> None:
+    """The library is built for gfx950 and only for it: MFMA 16x16x32, ds_read_b64_tr_b16, LDS-DMA loads, 160 KB of LDS --
+    and `bma_gemm_nt`'s split-K hand-off relies on gfx950's cache behaviour for write-through (sc1) stores and loads, which
+    the HIP memory model does not promise elsewhere.  Anything else is refused, loudly, at the first launch."""
+    if not str(arch_name).split(":")[0] == "gfx950":
+        raise RuntimeError(f"bimodalattack_amd: the HIP kernels are built and validated for gfx950 (MI355X) only; this device "
+                           f"reports '{arch_name}'.  There is no fallback path.")
+
+
 def _need_gpu(*ts: torch.Tensor) -> torch.device:
     dev = ts[0].device
     for t in ts:
@@ -34,6 +46,9 @@ def _need_gpu(*ts: torch.Tensor) -> torch.device:
                 "bimodalattack_amd kernels run on an AMD GPU only (tensor on %s); there is no CPU path" % t.device)
         if t.device != dev:
             raise RuntimeError("tensors on different devices")
+    if dev.index not in _ARCH_CHECKED:
+        check_arch(getattr(torch.cuda.get_device_properties(dev), "gcnArchName", "unknown"))
+        _ARCH_CHECKED.add(dev.index)
     return dev
 
 

@@ -772,3 +772,14 @@ def test_virtual_ids_plan_what_the_real_candidates_need():
         assert (p_fake <= p_real).all() and (p_fake == pos.min(1)).all()
         plan = ragged_plan(uniq, par, L=n_opt + 6, T=3, P=11, dedup=False, padded_maps=False, inverse=inv)
         assert plan is not None and (plan["cand"] == uniq).all() and (plan["p"] <= p_real[first]).all()
+
+
+def test_kernels_refuse_any_architecture_but_gfx950():
+    """The library is gfx950-only by construction (and `bma_gemm_nt`'s unfenced split-K hand-off by validation): the first
+    launch on a device looks at its architecture name and refuses anything else."""
+    from bimodalattack_amd import ops
+    ops.check_arch("gfx950:sramecc+:xnack-")
+    ops.check_arch("gfx950")
+    for other in ("gfx942:sramecc+:xnack-", "gfx90a", "gfx1100", "unknown", ""):
+        with pytest.raises(RuntimeError, match="gfx950"):
+            ops.check_arch(other)
