@@ -948,6 +948,48 @@ def rccl_info(torch, dist, device, world: int, keep: dict) -> dict:
 TP_LEG_LIMIT_S = float(os.environ.get("BMA_TP_LEG_LIMIT_S", "150"))
 
 
+class _LineGuard:
+    """Several GPUs: a child of rank 0, started before anything touches the GPU, that HOLDS the first leg's finished line
+    while the tensor-parallel leg runs and prints it if rank 0 goes away without saying it is done -- a fault inside a
+    collective, or the launcher's SIGTERM after another rank died: exits no Python `except` or watchdog thread sees.  It
+    reads a pipe to its end: a held line followed by the DONE mark (or nothing at all) prints nothing."""
+    DONE = "\0DONE"
+    CODE = ("import sys\n"
+            "data = sys.stdin.read()\n"
+            "if data and not data.rstrip('\\n').endswith('\\0DONE'):\n"
+            "    line = data.split('\\n', 1)[0]\n"
+            "    if line.strip():\n"
+            "        sys.stdout.write(line + '\\n')\n"
+            "        sys.stdout.flush()\n")
+
+    def __init__(self):
+        import subprocess
+        self.p = subprocess.Popen([sys.executable, "-c", self.CODE], stdin=subprocess.PIPE, text=True)
+
+    def hold(self, line: str) -> None:
+        try:
+            self.p.stdin.write(line + "\n")
+            self.p.stdin.flush()
+        except Exception:
+            pass
+
+    def release(self) -> None:
+        """Rank 0 prints its own line from here on: the held one must not appear."""
+        if self.p is None:
+            return
+        try:
+            self.p.stdin.write(self.DONE + "\n")
+            self.p.stdin.flush()
+            self.p.stdin.close()
+            self.p.wait(10)
+        except Exception:
+            pass
+        self.p = None
+
+
+_GUARD = None            # rank 0 of a multi-GPU run only
+
+
 def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
     """Several GPUs: the SAME timed block a second time (same seed, same steps, same model object) with the batch-1
     gradient pass TENSOR-PARALLEL over the ranks (EngineOptions.tp_gradient, as one hipGraph with its RCCL all-reduces
@@ -972,9 +1014,19 @@ def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
         if rank == 0:
             rc["tp_note"] = f"tensor-parallel leg did not finish within {TP_LEG_LIMIT_S:.0f} s; the replicated leg stands"
             out["cpu_baseline"] = None
+            if _GUARD is not None:
+                _GUARD.release()
             print(json.dumps(build_line(out, None), allow_nan=False), flush=True)
         os._exit(0)          # (every rank: the launcher must not turn a measured first leg into a failed run)
 
+    if rank == 0 and _GUARD is not None:
+        held = dict(out, cpu_baseline=None)
+        held["rccl"] = dict(rc, tp_note="the process ended inside the tensor-parallel leg (a fault, or the launcher's signal after "
+                                        "another rank died); the replicated leg stands")
+        _GUARD.hold(json.dumps(build_line(held, None), allow_nan=False))
+    if os.environ.get("BMA_BENCH_TP_CRASH") and rank == 0:        # test hook: rank 0 dies as a faulting collective would
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)
     threading.Thread(target=watchdog, daemon=True).start()
     try:
         log("tensor-parallel gradient pass: the same timed block again (A/B against the replicated pass)")
@@ -1042,6 +1094,10 @@ def main() -> None:
         sys.stdout.flush()
         return
 
+    global _GUARD
+    if world > 1 and rank == 0 and os.environ.get("BMA_BENCH_TP_AB", "1") not in ("0", "false", "False"):
+        _GUARD = _LineGuard()                   # (a plain child process, started while this one has not touched the GPU)
+
     import torch
     import torch.distributed as dist
 
@@ -1106,9 +1162,7 @@ def main() -> None:
                                    "sample": f"failed: {type(e).__name__}: {e}"}
     else:
         out["cpu_baseline"] = None
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    status = 0
     if rank == 0:
         detail = args.detail or os.path.join(REPO, "gpurun_out", "bench_detail.json")
         try:
@@ -1120,10 +1174,27 @@ def main() -> None:
             log(f"detail file not written: {e}")
             detail = None
         line = build_line(out, None if detail is None else os.path.relpath(detail, REPO))
+        if _GUARD is not None:
+            _GUARD.release()
         print(json.dumps(line, allow_nan=False), flush=True)
         if not line["finite"]:
             log("NON-FINITE loss inside the timed steps of the headline workload: the number above is not a measurement")
-            sys.exit(3)
+            status = 3
+    if world > 1:
+        # the line is out: a teardown that hangs or raises (ranks that left the tensor-parallel leg by different doors) must
+        # not turn it into a failed run
+        import threading
+        timer = threading.Timer(60.0, lambda: os._exit(status))
+        timer.daemon = True
+        timer.start()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:
+            log(f"process group teardown: {type(e).__name__}: {e}")
+        timer.cancel()
+    if status:
+        sys.exit(status)
 
 
 if __name__ == "__main__":

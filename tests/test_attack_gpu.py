@@ -794,6 +794,26 @@ def test_bench_prints_the_first_leg_when_the_tensor_parallel_leg_does_not_return
     assert "did not finish" in rc["tp_note"]
 
 
+def test_bench_line_survives_rank_0_dying_inside_the_tensor_parallel_leg():
+    """... and when rank 0 is KILLED inside that leg (what a faulting collective does -- no Python handler runs), the child
+    process that held the first leg's line prints it: one line on stdout, complete, saying what happened; the launcher's
+    exit status is the crash's."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMA_DIST_BACKEND="gloo", BMA_BENCH_TP_CRASH="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2",
+                        "--warmup", "1", "--profile-steps", "1", "--search-width", "64", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["finite"] is True and d["value"] > 0 and d["rccl"]["chosen"] == "off"
+    assert "process ended inside the tensor-parallel leg" in d["rccl"]["tp_note"]
+
+
 # ------------------------------------------------------------------ BASELINE-size parity of the scoring path
 def _reference_call_shape_losses(model, atk, cand, order, feats, chunk=8):
     """What the reference computes for these candidates (:1112-1225, :1278-1310): emb(ids) + repeated

@@ -783,3 +783,31 @@ def test_kernels_refuse_any_architecture_but_gfx950():
     for other in ("gfx942:sramecc+:xnack-", "gfx90a", "gfx1100", "unknown", ""):
         with pytest.raises(RuntimeError, match="gfx950"):
             ops.check_arch(other)
+
+
+def test_bench_line_guard_prints_the_held_line_only_when_its_parent_dies():
+    """bench.py on several GPUs: a child of rank 0 holds the first leg's line while the tensor-parallel leg runs.  Parent
+    killed (as by a faulting collective, or the launcher's signal): the held line comes out, once.  Parent says DONE (it prints
+    its own line): nothing.  Nothing ever held (the first leg itself failed): nothing."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, signal\n"
+        f"sys.path.insert(0, {repo!r})\n"
+        "import bench\n"
+        "g = bench._LineGuard()\n"
+        "mode = sys.argv[1]\n"
+        "if mode != 'none':\n"
+        "    g.hold('{\"held\": 1}')\n"
+        "if mode == 'release':\n"
+        "    g.release(); print('{\"own\": 1}', flush=True)\n"
+        "elif mode == 'die':\n"
+        "    os.kill(os.getpid(), signal.SIGKILL)\n")
+    got = {}
+    for mode in ("die", "release", "none"):
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=120)
+        got[mode] = (r.returncode, r.stdout)
+    assert got["die"] == (-9, '{"held": 1}\n')
+    assert got["release"] == (0, '{"own": 1}\n')
+    assert got["none"] == (0, "")
