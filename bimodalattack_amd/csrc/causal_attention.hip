@@ -24,6 +24,7 @@
 // contiguous.  At 256-wide heads (Gemma-3's decoder, ~320 rows: the library's four launches take 119 us per layer, all
 // latency) a chunk is two 16-byte pieces per thread and the dk/dv launch splits the OUTPUT dims between its two wave halves
 // instead of the chunks (each accumulator pair then fits the register file without spilling).
+#include <cstdlib>
 #include <type_traits>
 
 #include "bma_common.h"
@@ -200,25 +201,44 @@ __device__ __forceinline__ bool dims_real(int dt, int g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-template <int DT, int DH, int DR = DH>
-__global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
+// TQ: 16-query tiles per wave.  1 is the latency shape (643 tokens: as many workgroups as possible, the shortest chain per
+// wave); 2 makes every K fragment (ds_read_b128) and V^T fragment (ds_read_b64_tr_b16) read from LDS feed TWO MFMAs -- the
+// throughput shape for a tower of thousands of tokens (SigLIP: 4096 x 16 x 72), where the one-tile kernel spends more issue
+// slots on LDS reads than on products (16 reads per 11 MFMAs per chunk at 96-wide images; 16 per 22 with two tiles).
+// Measured at SigLIP's 4096 x 16 x 72 (round 5, one box): one tile per wave 212 us; two tiles at the registers the compiler
+// wants (146: one workgroup per CU) 210; two tiles compiled for four waves per SIMD (128 VGPRs, 9 dwords spilled: two workgroups
+// per CU) 194.  With one tile the loop is bound by the latency of a chunk pair's trip L2 -> registers -> LDS (one pair in
+// flight per workgroup, two rounds of workgroups); with two tiles and two workgroups per CU it reaches the issue limit of the
+// softmax's VALU work, which at 72-wide heads outweighs the products 1.6 : 1.
+#ifndef BMA_CA_FWD_TQ2_WAVES
+#define BMA_CA_FWD_TQ2_WAVES 4      // waves per SIMD the two-tile forward is compiled for
+#endif
+template <int DT, int DH, int DR = DH, int TQ = 1>
+__global__ __launch_bounds__(NTHR, (TQ == 2 ? BMA_CA_FWD_TQ2_WAVES : 1)) void causal_fwd_kernel(const CArgs a) {
   constexpr int KS = DH / 32, NT = (DR + 15) / 16, IMG = 32 * (DH + 16);   // (output tiles past the real width are never formed: 5 of 6 at DR = 72)
+  constexpr int RWG = 64 * TQ;                                        // query rows of a workgroup
   __shared__ __attribute__((aligned(16))) uint16_t lds[8 * IMG];      // two buffers of (K, V, K, V) images: chunks 2t, 2t+1
+  static_assert(4 * 64 * TQ * (4 + 4 * NT) * 4 <= 8 * IMG * 2, "the halves' exchange must fit the chunk images");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
   const int half = w >> 2, wq = w & 3;
   const int h = blockIdx.x % a.H, qb = blockIdx.x / a.H;
-  const int row0 = 64 * qb + 16 * wq;                             // first query of this wave
-  const int qrow = row0 + r;                                      // this lane's query
+  const int row0 = RWG * qb + 16 * TQ * wq;                           // first query of this wave
   const float NEG = -__builtin_inff();
-  uint4_t qf[KS];
-  load_row_frags<KS, DR>(qf, a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qrow < a.Lq ? qrow : a.Lq - 1, g);
-  f32x4 oacc[NT];
+  uint4_t qf[TQ][KS];
+  f32x4 oacc[TQ][NT];
+  float mrun[TQ], lsum[TQ];
 #pragma unroll
-  for (int dt = 0; dt < NT; ++dt) oacc[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  float mrun = NEG, lsum = 0.0f;
+  for (int t = 0; t < TQ; ++t) {
+    const int qrow = row0 + 16 * t + r;                               // this lane's query of tile t
+    load_row_frags<KS, DR>(qf[t], a.q + static_cast<int64_t>(h) * a.q_hs, a.q_rs, qrow < a.Lq ? qrow : a.Lq - 1, g);
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) oacc[t][dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    mrun[t] = NEG;
+    lsum[t] = 0.0f;
+  }
   const uint16_t* kb = a.k + static_cast<int64_t>(h / a.rep) * a.k_hs;     // (grouped queries: `rep` query heads read one k/v head)
   const uint16_t* vb = a.v + static_cast<int64_t>(h / a.rep) * a.v_hs;
-  int last = 64 * qb + 63;
+  int last = RWG * qb + RWG - 1;
   last = last < a.Lq ? last : a.Lq - 1;
   int chunks = (a.P + last + 1 + 31) >> 5;                         // keys 0 .. P + last
   chunks = chunks < ((a.Lk + 31) >> 5) ? chunks : (a.Lk + 31) >> 5;   // (not causal: P is past every key)
@@ -227,91 +247,133 @@ __global__ __launch_bounds__(NTHR) void causal_fwd_kernel(const CArgs a) {
   fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, 0, a.Lk, tid);
   zero_pad_columns<DH, DR>(lds, 8, tid);
   stash_pair<DH, DR>(pr, lds, tid);
-  landed(qf);
+#pragma unroll
+  for (int t = 0; t < TQ; ++t) landed(qf[t]);
   __syncthreads();
-  for (int t = 0; t < trips; ++t) {
-    const uint16_t* kl = lds + 4 * IMG * (t & 1) + 2 * IMG * half;
+  for (int tr = 0; tr < trips; ++tr) {
+    const uint16_t* kl = lds + 4 * IMG * (tr & 1) + 2 * IMG * half;
     const uint16_t* vl = kl + IMG;
-    if (t + 1 < trips) fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, t + 1, a.Lk, tid);
-    const int c = 2 * t + half;
+    if (tr + 1 < trips) fetch_pair<DH, DR>(pr, kb, a.k_rs, vb, a.v_rs, tr + 1, a.Lk, tid);
+    const int c = 2 * tr + half;
     if (c < chunks) {
-      f32x4 s[2];
+      f32x4 s[TQ][2];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        s[kt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[kt] = cmfma<DT>(row_frag<DH>(kl, kt, ks, r, g), qf[ks], s[kt]);
+      for (int t = 0; t < TQ; ++t) {
+        s[t][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        s[t][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       }
-      float e[2][4];
-      const bool edge = 32 * c + 31 > a.P + row0 || 32 * c + 31 >= a.Lk;   // wave-uniform: some key of the chunk is masked for some query
-      float cmax = NEG;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          float v = s[kt][rr];
-          if (edge && (32 * c + 16 * kt + 4 * g + rr > a.P + qrow || 32 * c + 16 * kt + 4 * g + rr >= a.Lk)) v = NEG;
-          e[kt][rr] = v;
-          cmax = vmax(cmax, v);
+        for (int ks = 0; ks < KS; ++ks) {
+          const uint4_t kf = row_frag<DH>(kl, kt, ks, r, g);           // one read, TQ products
+#pragma unroll
+          for (int t = 0; t < TQ; ++t) s[t][kt] = cmfma<DT>(kf, qf[t][ks], s[t][kt]);
         }
-      cmax = rows_max(cmax);
-      // (a wave whose 16 queries see none of this chunk's keys -- only in the block's last chunks -- keeps its state)
-      if (__builtin_amdgcn_ballot_w64(cmax > NEG) != 0) {
-        const float mnew = vmax(mrun, cmax);
-        const float msafe = mnew > NEG ? mnew : 0.0f;               // a query that has seen no key yet: exponents of -inf, no NaN
-        const float alpha = __builtin_amdgcn_exp2f((mrun - msafe) * a.scale_log2e);
-        const float mneg = -msafe * a.scale_log2e;
-        float rs = 0.0f;
+      uint4_t pf[TQ];
+      bool live[TQ];
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) {
+        const int trow0 = row0 + 16 * t, qrow = trow0 + r;
+        float e[2][4];
+        const bool edge = 32 * c + 31 > a.P + trow0 || 32 * c + 31 >= a.Lk;   // wave-uniform: some key of the chunk is masked for some query
+        float cmax = NEG;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            e[kt][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kt][rr], a.scale_log2e, mneg));
-            rs += e[kt][rr];
+            float v = s[t][kt][rr];
+            if (edge && (32 * c + 16 * kt + 4 * g + rr > a.P + qrow || 32 * c + 16 * kt + 4 * g + rr >= a.Lk)) v = NEG;
+            e[kt][rr] = v;
+            cmax = vmax(cmax, v);
           }
-        lsum = lsum * alpha + rs;
-        mrun = mnew;
-        const uint4_t pf = pack_acc<DT>(e);
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        cmax = rows_max(cmax);
+        // (a tile whose 16 queries see none of this chunk's keys -- only in the block's last chunks -- keeps its state)
+        live[t] = __builtin_amdgcn_ballot_w64(cmax > NEG) != 0;
+        pf[t] = uint4_t{0u, 0u, 0u, 0u};
+        if (live[t]) {
+          const float mnew = vmax(mrun[t], cmax);
+          const float msafe = mnew > NEG ? mnew : 0.0f;               // a query that has seen no key yet: exponents of -inf, no NaN
+          const float alpha = __builtin_amdgcn_exp2f((mrun[t] - msafe) * a.scale_log2e);
+          const float mneg = -msafe * a.scale_log2e;
+          float rs = 0.0f;
 #pragma unroll
-          for (int dt = 0; dt < NT; ++dt) {
-            oacc[dt][0] *= alpha; oacc[dt][1] *= alpha; oacc[dt][2] *= alpha; oacc[dt][3] *= alpha;
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              e[kt][rr] = __builtin_amdgcn_exp2f(__builtin_fmaf(e[kt][rr], a.scale_log2e, mneg));
+              rs += e[kt][rr];
+            }
+          lsum[t] = lsum[t] * alpha + rs;
+          mrun[t] = mnew;
+          pf[t] = pack_acc<DT>(e);
+          if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int dt = 0; dt < NT; ++dt) {
+              oacc[t][dt][0] *= alpha; oacc[t][dt][1] *= alpha; oacc[t][dt][2] *= alpha; oacc[t][dt][3] *= alpha;
+            }
           }
         }
+      }
+      if (TQ == 1) {
+        if (live[0]) {
 #pragma unroll
-        for (int dt = 0; dt < NT; ++dt) oacc[dt] = cmfma<DT>(tr_frag<DH>(vl, dt, r, g), pf, oacc[dt]);
+          for (int dt = 0; dt < NT; ++dt) oacc[0][dt] = cmfma<DT>(tr_frag<DH>(vl, dt, r, g), pf[0], oacc[0][dt]);
+        }
+      } else {
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) any = any || live[t];
+        if (any) {                                                       // (a dead tile's P is zero: its products add nothing)
+#pragma unroll
+          for (int dt = 0; dt < NT; ++dt) {
+            const uint4_t vf = tr_frag<DH>(vl, dt, r, g);               // one read, TQ products
+#pragma unroll
+            for (int t = 0; t < TQ; ++t) oacc[t][dt] = cmfma<DT>(vf, pf[t], oacc[t][dt]);
+          }
+        }
       }
     }
-    if (t + 1 < trips) stash_pair<DH, DR>(pr, lds + 4 * IMG * ((t + 1) & 1), tid);
+    if (tr + 1 < trips) stash_pair<DH, DR>(pr, lds + 4 * IMG * ((tr + 1) & 1), tid);
     __syncthreads();
   }
   // ---- the odd-chunk half hands (m, l, o) over through LDS; the even half merges and stores -------------------------------
-  float* xch = reinterpret_cast<float*>(lds) + (wq * 64 + lane) * (4 + 4 * NT);     // 16-byte aligned rows: m, l, -, -, o[32]
-  const float lfull = rows_sum(lsum);
-  if (half == 1) {
-    xch[0] = mrun;
-    xch[1] = lfull;
 #pragma unroll
-    for (int dt = 0; dt < NT; ++dt) *reinterpret_cast<f32x4*>(xch + 4 + 4 * dt) = oacc[dt];
+  for (int t = 0; t < TQ; ++t) {
+    float* xch = reinterpret_cast<float*>(lds) + ((wq * 64 + lane) * TQ + t) * (4 + 4 * NT);     // 16-byte aligned rows: m, l, -, -, o[..]
+    const float lfull = rows_sum(lsum[t]);
+    lsum[t] = lfull;
+    if (half == 1) {
+      xch[0] = mrun[t];
+      xch[1] = lfull;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) *reinterpret_cast<f32x4*>(xch + 4 + 4 * dt) = oacc[t][dt];
+    }
   }
   __syncthreads();
-  if (half == 1 || qrow >= a.Lq) return;
-  const float m2 = xch[0], l2 = xch[1];
-  const float m = vmax(mrun, m2);                                   // finite: chunk 0 belongs to this half and shows key 0
-  const float a1 = __builtin_amdgcn_exp2f((mrun - m) * a.scale_log2e), a2 = __builtin_amdgcn_exp2f((m2 - m) * a.scale_log2e);
-  const float l = lfull * a1 + l2 * a2;
-  const float inv = 1.0f / l;
-  if (g == 0) a.lse2[static_cast<int64_t>(h) * a.Lq + qrow] = m * a.scale_log2e + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
-  uint16_t* op = a.out + (static_cast<int64_t>(qrow) * a.H + h) * DR + 4 * g;
-  const float c1 = a1 * inv, c2 = a2 * inv;
+  if (half == 1) return;
 #pragma unroll
-  for (int dt = 0; dt < NT; ++dt) {
-    if (!dims_real<DR>(dt, g)) continue;
-    const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 + 4 * dt);
-    bma::uint2_t ow;
-    ow.x = bma::pack16<DT>(oacc[dt][0] * c1 + o2[0] * c2, oacc[dt][1] * c1 + o2[1] * c2);
-    ow.y = bma::pack16<DT>(oacc[dt][2] * c1 + o2[2] * c2, oacc[dt][3] * c1 + o2[3] * c2);
-    *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
+  for (int t = 0; t < TQ; ++t) {
+    const int qrow = row0 + 16 * t + r;
+    if (qrow >= a.Lq) continue;
+    const float* xch = reinterpret_cast<const float*>(lds) + ((wq * 64 + lane) * TQ + t) * (4 + 4 * NT);
+    const float m2 = xch[0], l2 = xch[1];
+    const float m = vmax(mrun[t], m2);                                // finite: chunk 0 belongs to this half and shows key 0
+    const float a1 = __builtin_amdgcn_exp2f((mrun[t] - m) * a.scale_log2e), a2 = __builtin_amdgcn_exp2f((m2 - m) * a.scale_log2e);
+    const float l = lsum[t] * a1 + l2 * a2;
+    const float inv = 1.0f / l;
+    if (g == 0) a.lse2[static_cast<int64_t>(h) * a.Lq + qrow] = m * a.scale_log2e + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
+    uint16_t* op = a.out + (static_cast<int64_t>(qrow) * a.H + h) * DR + 4 * g;
+    const float c1 = a1 * inv, c2 = a2 * inv;
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      if (!dims_real<DR>(dt, g)) continue;
+      const f32x4 o2 = *reinterpret_cast<const f32x4*>(xch + 4 + 4 * dt);
+      bma::uint2_t ow;
+      ow.x = bma::pack16<DT>(oacc[t][dt][0] * c1 + o2[0] * c2, oacc[t][dt][1] * c1 + o2[1] * c2);
+      ow.y = bma::pack16<DT>(oacc[t][dt][2] * c1 + o2[2] * c2, oacc[t][dt][3] * c1 + o2[3] * c2);
+      *reinterpret_cast<bma::uint2_t*>(op + 16 * dt) = ow;
+    }
   }
 }
 
@@ -609,10 +671,21 @@ extern "C" int bma_causal_attention_gqa(const void* q, int64_t q_rs, int64_t q_h
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>(H * ((Lq + 63) / 64)));
   BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) * H + 2.0 * static_cast<double>(Lk) * Hkv) * Dh);
+  // a 72-wide tower of thousands of tokens is throughput, not latency: two query tiles per wave (128 rows per workgroup)
+  static const int64_t tq2_min = [] {
+    const char* e = getenv("BMA_CA_FWD_TQ2_MIN");
+    return e ? static_cast<int64_t>(atoll(e)) : static_cast<int64_t>(1024);
+  }();
+  if (Dh == 72 && tq2_min > 0 && Lq >= tq2_min) {
+    const dim3 grid2(static_cast<unsigned>(H * ((Lq + 127) / 128)));
+    if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 96, 72, 2>), grid2, dim3(NTHR), 0, st, a);
+    else hipLaunchKernelGGL((causal_fwd_kernel<BMA_F16, 96, 72, 2>), grid2, dim3(NTHR), 0, st, a);
+  } else {
 #define BMA_CAUSAL_FWD(DT_, DH_, DR_) hipLaunchKernelGGL((causal_fwd_kernel<DT_, DH_, DR_>), grid, dim3(NTHR), 0, st, a)
-  if (dtype == BMA_BF16) { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_FWD, BMA_BF16); }
-  else { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_FWD, BMA_F16); }
+    if (dtype == BMA_BF16) { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_FWD, BMA_BF16); }
+    else { BMA_CAUSAL_WIDTHS(BMA_CAUSAL_FWD, BMA_F16); }
 #undef BMA_CAUSAL_FWD
+  }
   BMA_PROF_END(BMA_K_CAUSAL_ATTN, st);
   BMA_LAUNCH_CHECK();
   return BMA_OK;

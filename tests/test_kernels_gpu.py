@@ -511,9 +511,11 @@ def test_tower_attention_64_wide_heads_every_key_visible(dtype):
     from bimodalattack_amd import ops
     g = torch.Generator(device=DEV).manual_seed(14)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # (72-wide heads of 1024 tokens and more run the two-tiles-per-wave forward: 128 rows per workgroup -- lengths on and off
+    # that block, causal and not)
     for H, L, Dh, causal in ((16, 577, 64, False), (2, 64, 64, False), (2, 33, 64, False), (2, 130, 128, False), (4, 100, 64, True),
                              (2, 1, 64, False), (16, 4096, 72, False), (2, 100, 72, False), (3, 65, 72, False), (2, 33, 72, True),
-                             (2, 1, 72, False), (1, 700, 72, True)):
+                             (2, 1, 72, False), (1, 700, 72, True), (2, 1024, 72, True), (3, 1100, 72, False), (1, 1217, 72, True)):
         qkv = torch.randn((L, 3 * H * Dh), generator=g, device=DEV).to(dtype)
         q, k, v = (qkv[:, i * H * Dh:(i + 1) * H * Dh].view(L, H, Dh) for i in range(3))
         assert ops.causal_attention_ok(q, k, v)
