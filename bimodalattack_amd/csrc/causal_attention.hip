@@ -24,7 +24,6 @@
 // contiguous.  At 256-wide heads (Gemma-3's decoder, ~320 rows: the library's four launches take 119 us per layer, all
 // latency) a chunk is two 16-byte pieces per thread and the dk/dv launch splits the OUTPUT dims between its two wave halves
 // instead of the chunks (each accumulator pair then fits the register file without spilling).
-#include <cstdlib>
 #include <type_traits>
 
 #include "bma_common.h"
@@ -647,6 +646,14 @@ int check_common(const void* q, const void* k, const void* v, int64_t Lq, int64_
 
 constexpr int kAllVisible = 1 << 28;      // CArgs::P when the attention is not causal: past every key
 
+// experiment knob (bma_causal_attention_set_plan): 72-wide heads with at least this many queries take the two-tiles-per-wave
+// forward; 0 = never
+static int64_t g_fwd_two_tiles_min_rows = 1024;
+
+extern "C" void bma_causal_attention_set_plan(int64_t fwd_two_tiles_min_rows) {
+  g_fwd_two_tiles_min_rows = fwd_two_tiles_min_rows;
+}
+
 // the head widths the kernels are built for: (width in memory) -> (DH, DR)
 #define BMA_CAUSAL_WIDTHS(X, DT_)        \
   if (Dh == 128) X(DT_, 128, 128);       \
@@ -672,10 +679,7 @@ extern "C" int bma_causal_attention_gqa(const void* q, int64_t q_rs, int64_t q_h
   const dim3 grid(static_cast<unsigned>(H * ((Lq + 63) / 64)));
   BMA_PROF_BEGIN(BMA_K_CAUSAL_ATTN, st, 2.0 * (2.0 * static_cast<double>(Lq) * H + 2.0 * static_cast<double>(Lk) * Hkv) * Dh);
   // a 72-wide tower of thousands of tokens is throughput, not latency: two query tiles per wave (128 rows per workgroup)
-  static const int64_t tq2_min = [] {
-    const char* e = getenv("BMA_CA_FWD_TQ2_MIN");
-    return e ? static_cast<int64_t>(atoll(e)) : static_cast<int64_t>(1024);
-  }();
+  const int64_t tq2_min = g_fwd_two_tiles_min_rows;
   if (Dh == 72 && tq2_min > 0 && Lq >= tq2_min) {
     const dim3 grid2(static_cast<unsigned>(H * ((Lq + 127) / 128)));
     if (dtype == BMA_BF16) hipLaunchKernelGGL((causal_fwd_kernel<BMA_BF16, 96, 72, 2>), grid2, dim3(NTHR), 0, st, a);

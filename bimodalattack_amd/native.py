@@ -112,6 +112,7 @@ PROTOTYPES = {
     "bma_causal_attention_bwd": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                          c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),
+    "bma_causal_attention_set_plan": (None, [c_int64]),
     "bma_causal_attention_gqa": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                          c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bma_causal_attention_bwd_gqa": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,

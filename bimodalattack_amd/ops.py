@@ -847,6 +847,10 @@ def _rows_heads(t: torch.Tensor):
     return t.stride(0), t.stride(1)
 
 
+if _os.environ.get("BMA_CA_FWD_TQ2_MIN") is not None:        # experiment knob: the library itself reads no environment
+    lib.bma_causal_attention_set_plan(int(_os.environ["BMA_CA_FWD_TQ2_MIN"]))
+
+
 def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:
     """q (Lq, H, Dh), k / v (Lk, Hkv, Dh) views with Dh 64, 72 (SigLIP; computed in 96-wide LDS images), 128 or 256 (Gemma-3's
     decoder), 16-bit, last dim contiguous, strides multiples of 8, H a multiple of Hkv (grouped queries: heads h*rep ..

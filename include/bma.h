@@ -332,6 +332,10 @@ int bma_causal_attention_bwd(const void* q, int64_t q_row_stride, int64_t q_head
  *   stride, summed over the group inside the launch (no repeated copies of k / v, no reduction afterwards) -- and head widths
  *   64, 72, 128 or 256 (Gemma-3's decoder in the gradient pass, reference :953-1028 on a Gemma-3 model: ~320 tokens x 8 heads
  *   over 4 of 256).  Hkv == H is bma_causal_attention / _bwd. */
+/* experiment knob: 72-wide heads (SigLIP) with at least this many queries run the forward with two 16-query tiles per wave
+ *   (128 rows per workgroup: every K / V^T fragment read from LDS feeds two MFMAs); 0 = never; default 1024.  Results are
+ *   the same attention either way (the accumulation order over keys does not change). */
+void bma_causal_attention_set_plan(int64_t fwd_two_tiles_min_rows);
 int bma_causal_attention_gqa(const void* q, int64_t q_row_stride, int64_t q_head_stride, const void* k, int64_t k_row_stride,
                              int64_t k_head_stride, const void* v, int64_t v_row_stride, int64_t v_head_stride, int64_t Lq,
                              int64_t Lk, int H, int Hkv, int Dh, int dtype, int causal, float scale, void* out, float* lse2,
