@@ -523,28 +523,44 @@ __global__ __launch_bounds__(NTHR, (DH <= 96 ? BMA_CA_DKV_WAVES : 1)) void causa
   const int c1 = (a.Lq + 31) >> 5;
   Pair<DR> pr;
   float st = 0.0f;
-  auto fetch = [&](int it) {
-    const int hq = h * a.rep + it / nt, t = t0 + it % nt;
-    fetch_pair<DH, DR>(pr, a.q + static_cast<int64_t>(hq) * a.q_hs, a.q_rs, a.d_o + static_cast<int64_t>(hq) * DR, do_rs, t, a.Lq, tid);
+  // the pair to fetch next: chunk pair `ft` of the query head whose bases are fq / fdo / flse / fdelta -- they move on to the
+  // group's next head when the pairs of one are through (once per head: the loop itself carries no address arithmetic
+  // beyond what the one-head kernel had)
+  int ft = t0;
+  const uint16_t* fq = a.q + static_cast<int64_t>(h * a.rep) * a.q_hs;
+  const uint16_t* fdo = a.d_o + static_cast<int64_t>(h * a.rep) * DR;
+  const float* flse = a.lse2 + static_cast<int64_t>(h * a.rep) * a.Lq;
+  const float* fdelta = a.delta + static_cast<int64_t>(h * a.rep) * a.Lq;
+  auto fetch = [&]() {
+    fetch_pair<DH, DR>(pr, fq, a.q_rs, fdo, do_rs, ft, a.Lq, tid);
     if (tid < 128) {                                               // lse2 and delta of the pair's 64 queries
-      int qi = 64 * t + 32 * (tid >> 6) + (tid & 31);
+      int qi = 64 * ft + 32 * (tid >> 6) + (tid & 31);
       qi = qi < a.Lq ? qi : a.Lq - 1;
-      st = ((tid & 32) ? a.delta : a.lse2)[static_cast<int64_t>(hq) * a.Lq + qi];
+      st = ((tid & 32) ? fdelta : flse)[qi];
+    }
+    if (++ft == t1) {
+      ft = t0;
+      fq += a.q_hs;
+      fdo += DR;
+      flse += a.Lq;
+      fdelta += a.Lq;
     }
   };
   auto stash = [&](int buf) {
     stash_pair<DH, DR>(pr, lds + 4 * IMG * buf, tid);
     if (tid < 128) stat[buf][tid >> 6][tid & 63] = st;
   };
-  if (its > 0) fetch(0);
+  if (its > 0) fetch();
   zero_pad_columns<DH, DR>(lds, 8, tid);
   if (its > 0) stash(0);
   landed(kf);
   landed(vf);
   __syncthreads();
+  int t = t0 - 1;
   for (int it = 0; it < its; ++it) {
-    const int buf = it & 1, t = t0 + it % nt;
-    if (it + 1 < its) fetch(it + 1);
+    const int buf = it & 1;
+    if (++t == t1) t = t0;
+    if (it + 1 < its) fetch();
 #pragma unroll
     for (int cc = 0; cc < (SPLIT_D ? 2 : 1); ++cc) {
       const int hc = SPLIT_D ? cc : half;                          // which chunk of the pair this wave works on now
