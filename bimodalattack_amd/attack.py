@@ -1655,6 +1655,7 @@ class _GradPrefix:
         if self.g1 is not None:
             with torch.no_grad():
                 self.image.copy_(image)
+            ops.note_graph_replay(self.image.device)
             self.g1.replay()
         else:
             self.image = image.detach().clone().requires_grad_()
@@ -1702,6 +1703,7 @@ class _GradPrefix:
             self.a.graphs_captured.append("grad_tail_tokens")
         with torch.no_grad():
             self.ids3.copy_(optim_ids)
+        ops.note_graph_replay(self.ids3.device)
         self.g3.replay()
         return self.out3
 
@@ -1715,6 +1717,7 @@ class _GradPrefix:
         if self.g2 is not None:
             with torch.no_grad():
                 self.ids.copy_(optim_ids)
+            ops.note_graph_replay(self.ids.device)
             self.g2.replay()
             return self.out
         self.ids = optim_ids
@@ -1772,6 +1775,7 @@ class _GradientGraph:
             self.ids.copy_(optim_ids)
             if self.image is not None:
                 self.image.copy_(image)
+        ops.note_graph_replay(self.ids.device)
         self.graph.replay()
         return self.out
 
@@ -1797,6 +1801,7 @@ class _ReplayGraph:
         with torch.no_grad():
             for dst, src in zip(self.inputs, inputs):
                 dst.copy_(src)
+        ops.note_graph_replay(self.inputs[0].device)
         self.graph.replay()
         return self.out
 

@@ -1015,6 +1015,21 @@ def gemm_workspace(dev: torch.device):
     return ws
 
 
+_GRAPH_REPLAY_STREAM = {}      # device index -> the stream handle captured graphs have been replayed from
+
+
+def note_graph_replay(dev: torch.device) -> None:
+    """Every captured graph of a device shares ONE split-K workspace and ticket array (``gemm_workspace``): their replays
+    must be ordered on one stream, or two graphs would race on partial sums and tickets.  The engine replays from the
+    stream current at the call; this makes a second stream an error instead of a silent race."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    handle = torch.cuda.current_stream(dev).cuda_stream
+    first = _GRAPH_REPLAY_STREAM.setdefault(idx, handle)
+    if first != handle:
+        raise RuntimeError("bimodalattack_amd: captured graphs of one device must be replayed from one stream (they share the "
+                           f"split-K workspace); first replay came from stream {first:#x}, this one from {handle:#x}")
+
+
 def gemm_workspace_for_graphs(dev: torch.device):
     """Allocate the pair captured launches use (call outside any capture)."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()

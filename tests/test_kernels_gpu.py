@@ -972,6 +972,17 @@ def test_gemm_nt_under_autograd_and_in_a_graph(monkeypatch):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ops.gemm_nt(xs, w)) and torch.equal(out2, ops.gemm_nt(out, wt))
+    # ... and the engine's captured graphs, which all share that one pair, say so when a second stream replays one
+    keep = dict(ops._GRAPH_REPLAY_STREAM)
+    try:
+        ops._GRAPH_REPLAY_STREAM.clear()
+        ops.note_graph_replay(torch.device(DEV))
+        ops.note_graph_replay(torch.device(DEV))
+        with torch.cuda.stream(side), pytest.raises(RuntimeError, match="one stream"):
+            ops.note_graph_replay(torch.device(DEV))
+    finally:
+        ops._GRAPH_REPLAY_STREAM.clear()
+        ops._GRAPH_REPLAY_STREAM.update(keep)
 
 
 @pytest.mark.gpu
