@@ -1096,7 +1096,11 @@ def main() -> None:
 
     global _GUARD
     if world > 1 and rank == 0 and os.environ.get("BMA_BENCH_TP_AB", "1") not in ("0", "false", "False"):
-        _GUARD = _LineGuard()                   # (a plain child process, started while this one has not touched the GPU)
+        try:
+            _GUARD = _LineGuard()               # (a plain child process, started while this one has not touched the GPU)
+        except Exception as e:                  # no guard, no harm: the watchdog and the early print still stand
+            log(f"line guard not started: {type(e).__name__}: {e}")
+            _GUARD = None
 
     import torch
     import torch.distributed as dist
