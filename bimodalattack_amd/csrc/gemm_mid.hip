@@ -35,6 +35,11 @@
 // Algorithmic bytes per launch: (M*K + N*K + M*N) * es; FLOPs 2*M*N*K.
 
 #include <type_traits>
+#ifdef BMA_MID_STAMPS
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 
 #include "bma_common.h"
 #include "bma_profile.h"
@@ -51,13 +56,13 @@ constexpr int kBK = 64;           // k per ring unit: 128-byte rows
 constexpr int kRowB = kBK * 2;    // bytes per LDS row (16-bit types only)
 constexpr int kLds = 160 * 1024;
 constexpr int kNA = 2;            // ring slots of x
-// Timing experiments only (the loop with its MFMAs or its DMA compiled out): build with -DBMA_MID_DEBUG and
-// bma_gemm_mid_set_plan's flags bits 2-4 switch them on -- WRONG results.  The shipped library has no such switch.
-#ifdef BMA_MID_DEBUG
-constexpr bool kDbg = true;
-#else
-constexpr bool kDbg = false;
+constexpr int kStampN = 128;      // diagnostic builds: stamps per wave
+// Timing experiments only (-DBMA_MID_ABLATE=<bits>, WRONG results; tools/mid_ablate.sh): 1 = no DMA pieces inside the loop,
+// 2 = no fragment reads inside the loop, 4 = no MFMAs, 8 = no s_setprio around the MFMAs
+#ifndef BMA_MID_ABLATE
+#define BMA_MID_ABLATE 0
 #endif
+constexpr int kAblate = BMA_MID_ABLATE;
 
 struct MidArgs {
   const char* x;
@@ -69,7 +74,9 @@ struct MidArgs {
   int t_full;              // tiles [0, t_full) run over all of K; the others are split S ways
   int S;
   int xcd;                 // 1: remap workgroup ids so that an XCD owns a contiguous run of tiles
-  int dbg;                 // BMA_MID_DEBUG builds only (flags >> 2): bit 0 = no DMA after the prologue, bit 1 = no MFMA, bit 2 = every workgroup reads the same w rows
+  unsigned long long* stamps;   // diagnostic builds only (-DBMA_MID_STAMPS): clock stamps of workgroups 0, 100 and 200
+  int prio;                // experiments with the arbitration between a SIMD's two waves (flags bits 4-5), see the k loop
+  int stagger;             // workgroup v walks its units of K from unit (v * stagger) % units on, wrapping round
 };
 
 template <int DT>
@@ -79,22 +86,50 @@ __device__ __forceinline__ f32x4 mfma16(const uint4_t& a, const uint4_t& b, cons
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
+// one LDS-DMA piece: 64 lanes x 16 B from descriptor base + per-lane offset + scalar offset to lds_dst + lane * 16.  (A device
+// function of its own: inside the kernel TEMPLATE the host pass drops the whole instantiation -- stub included -- over this builtin.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   static_assert(N >= 0 && N <= 63, "vmcnt is six bits");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// MF / NF: 16-row fragments of x / of w per wave (tile = 32 MF rows of x by 64 NF rows of w); NB: ring slots of w
-template <int DT, int MF, int NF, int NB>
+// MF / NF: 16-row fragments of x / of w per wave (tile = 32 MF rows of x by 64 NF rows of w)
+// LOOP: 0 = every wave runs the whole k step on its own (fragments read one sub-step ahead, one barrier per unit);
+//       1 = the two row halves alternate load and MFMA phases between barriers (rounds 4-5; kept for A/B, flags bit 1)
+template <int DT, int MF, int NF, int LOOP>
 __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
+  constexpr int NB = 3;                                          // ring slots of w
   constexpr int BM = 32 * MF, BN = 64 * NF;
   constexpr int ASZ = BM * kRowB, BSZ = BN * kRowB;              // bytes of a unit of x / of w
-  constexpr int CA = MF, CB = 2 * NF;                            // 1-KiB pieces (8 rows x 128 B) per wave of the issuing half
-  constexpr int CMAX = CA > CB ? CA : CB;
+  constexpr int PA = BM / 8, PB = BN / 8;                        // 1-KiB pieces (8 rows x 128 B) per unit
+  constexpr int CA = (PA + kNW - 1) / kNW, CB = PB / kNW;        // pieces per wave and unit: x 4 (waves 4-7: 3), w 4 or 3
+  constexpr int H0 = (MF + 1) / 2, H1 = MF - H0;                 // row fragments of the two halves of a k step
+  static_assert(PB % kNW == 0 && CA <= 4 && CB >= 2 && CB <= 4, "piece schedule");
   static_assert(kNA * ASZ + NB * BSZ <= kLds, "rings beyond the LDS");
-  static_assert(NB >= 3 && NB <= 4 && CB * (NB - 2) <= 63, "w ring");
+#ifdef BMA_MID_STAMPS
+  // diagnostic build (tools/mid_stamps.py): 8 KiB behind the rings take kStampN clock stamps per wave, written by lane 0 with
+  // ds_write (counted by lgkmcnt, so the DMA's vmcnt arithmetic is untouched) and copied out when the workgroup is done
+  static_assert(kNA * ASZ + NB * BSZ + 8192 <= kLds, "no room for stamps");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + NB * BSZ + 8192];
+  unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(lds + kNA * ASZ + NB * BSZ);
+  int stamp_i = 0;
+#define BMA_MID_STAMP()                                                                                         \
+  do {                                                                                                          \
+    if (stamp_on) {                                                                                             \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
+      if ((threadIdx.x & 63) == 0 && stamp_i < kStampN) stamp_base[(threadIdx.x >> 6) * kStampN + stamp_i] = t_; \
+      ++stamp_i;                                                                                                \
+    }                                                                                                           \
+  } while (0)
+#else
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + NB * BSZ];
+#define BMA_MID_STAMP() do {} while (0)
+#endif
   unsigned char* const lds_b = lds + kNA * ASZ;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -131,41 +166,39 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   const int m_tile = tile % a.m_tiles, n_tile = tile / a.m_tiles;
   const int m0 = m_tile * BM, n0 = n_tile * BN;
 
-  // ---- DMA pieces: the upper row half issues x (piece p = rows 8p..8p+7 of the tile, dealt to wave p % 4), the lower w ----
+  // ---- DMA pieces: piece p of an operand = rows 8p..8p+7 of the tile, dealt to wave p % 8: every wave issues for both ----
+  // `buffer_load_dwordx4 ... offen lds`: the descriptor holds the tile's first row, the per-lane offset (row in the tile x
+  // leading dimension + swizzled chunk) never changes, the unit of K is the scalar offset -- no address arithmetic per piece.
   const int prow = lane >> 3;                                    // row inside the piece == (tile row & 7)
   const int pchunk = (lane & 7) ^ prow;                          // source chunk that lands at LDS position lane & 7
-  const char* src[CMAX];
-  if (wr == 0) {
+  int vox[CA], vow[CB];
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      int m = m0 + (wc + 4 * i) * 8 + prow;
-      m = m < a.M ? m : a.M - 1;                                 // rows past M repeat the last one (never stored)
-      src[i] = a.x + (static_cast<int64_t>(m) * a.ldx) * 2 + pchunk * 16;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      int n = ((kDbg && (a.dbg & 4)) ? 0 : n0) + (wc + 4 * i) * 8 + prow;
-      n = n < a.N ? n : a.N - 1;
-      src[i] = a.w + (static_cast<int64_t>(n) * a.ldw) * 2 + pchunk * 16;
-    }
+  for (int i = 0; i < CA; ++i) {
+    int m = m0 + (wave + kNW * i) * 8 + prow;
+    m = m < a.M ? m : a.M - 1;                                   // rows past M repeat the last one (never stored)
+    vox[i] = static_cast<int>((m - m0) * a.ldx * 2) + pchunk * 16;
   }
-  auto issue_a = [&](int u, int slot) {                          // wave-uniform destination; the DMA adds lane*16
-    unsigned char* base = lds + slot * ASZ + wc * 1024;
-    const int64_t ko = static_cast<int64_t>(u) * kRowB;
 #pragma unroll
-    for (int i = 0; i < CA; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
-                                       (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
-  };
-  auto issue_b = [&](int u, int slot) {
-    unsigned char* base = lds_b + slot * BSZ + wc * 1024;
-    const int64_t ko = static_cast<int64_t>(u) * kRowB;
-#pragma unroll
-    for (int i = 0; i < CB; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + ko),
-                                       (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
-  };
+  for (int i = 0; i < CB; ++i) {
+    int n = n0 + (wave + kNW * i) * 8 + prow;
+    n = n < a.N ? n : a.N - 1;
+    vow[i] = static_cast<int>((n - n0) * a.ldw * 2) + pchunk * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(a.x) + static_cast<int64_t>(m0) * a.ldx * 2, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(a.w) + static_cast<int64_t>(n0) * a.ldw * 2, 0, 0x7fffffff, 0x00020000);
+  // piece i of this wave, unit u -> ring slot; wave-uniform destination, the DMA adds lane*16
+#define BMA_MID_X(i_, u_, slot_)                                                                                         \
+  do {                                                                                                                   \
+    if ((i_) < CA && (kNW * (i_) + kNW <= PA || wave + kNW * (i_) < PA) && !(in_loop && (kAblate & 1)))                                              \
+      dma16(rx, lds + (slot_) * ASZ + (wave + kNW * (i_)) * 1024, vox[(i_) < CA ? (i_) : 0], (u_) * kRowB);                    \
+  } while (0)
+#define BMA_MID_W(i_, u_, slot_)                                                                                         \
+  do {                                                                                                                   \
+    if ((i_) < CB && !(in_loop && (kAblate & 1)))                                                                        \
+      dma16(rw, lds_b + (slot_) * BSZ + (wave + kNW * (i_)) * 1024, vow[(i_) < CB ? (i_) : 0], (u_) * kRowB);                  \
+  } while (0)
 
   f32x4 acc[NF][MF];
 #pragma unroll
@@ -179,103 +212,206 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   const int foff1 = frow * kRowB + ((4 + fg) ^ (frow & 7)) * 16;      // kk = 1
   const int offa = (wr * MF) * 2048, offb = (wc * NF) * 2048;
 
-  uint4_t wf[2][NF], xf[2][MF];
-  auto read_frags = [&](int sa, int sb) {
-    const unsigned char* pa = lds + sa * ASZ + offa;
-    const unsigned char* pb = lds_b + sb * BSZ + offb;
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-      wf[0][j] = *reinterpret_cast<const uint4_t*>(pb + j * 2048 + foff0);
-      wf[1][j] = *reinterpret_cast<const uint4_t*>(pb + j * 2048 + foff1);
-    }
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-      xf[0][i] = *reinterpret_cast<const uint4_t*>(pa + i * 2048 + foff0);
-      xf[1][i] = *reinterpret_cast<const uint4_t*>(pa + i * 2048 + foff1);
-    }
-  };
-  auto compute = [&]() {
-    if (kDbg && (a.dbg & 2)) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(wf[kk][j]));
-#pragma unroll
-        for (int i = 0; i < MF; ++i) asm volatile("" ::"v"(xf[kk][i]));
-      }
-      return;
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[j][i] = mfma16<DT>(wf[kk][j], xf[kk][i], acc[j][i]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
   const int n_units = u1 - u0;
-  if (wr == 0) {
-    // ---- upper row half: issues x.  Unit u+1 goes out in the memory phase of unit u and is waited for behind the MFMAs ----
-    issue_a(u0, 0);
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    int sa = 0, sb = 0;
-    for (int k = 0; k < n_units; ++k) {
-      read_frags(sa, sb);
-      if (k + 1 < n_units && !(kDbg && (a.dbg & 1))) issue_a(u0 + k + 1, sa ^ 1);   // slot of unit k-1: both halves read it a barrier ago
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // fragments in registers: slots may be refilled behind the barrier
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      compute();
-      wait_vm<0>();                                              // x of unit k+1 landed
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      sa ^= 1;
-      sb = sb + 1 == NB ? 0 : sb + 1;
-    }
-    __builtin_amdgcn_s_barrier();                                // sits out the lower half's last phase
-  } else {
-    // ---- lower row half, one phase behind: issues w.  Unit u+NB-1 goes out in the memory phase of unit u --------------------
-#pragma unroll
-    for (int s_ = 0; s_ < NB - 1; ++s_)
-      if (s_ < n_units) issue_b(u0 + s_, s_);
+  bool in_loop = false;
+  // Staggered start (Tensile's StaggerU), per XCD: measured null to negative here (profiles/r6_gemm_mid_stagger.txt); kept as a
+  // sweep knob (flags bits 8-15), off by default.
+  const int start = a.stagger ? static_cast<int>((static_cast<unsigned>(blockIdx.x & 7) * static_cast<unsigned>(a.stagger)) % static_cast<unsigned>(n_units)) : 0;
+  auto unit = [&](int k) {
+    int t = k + start;
+    t = t >= n_units ? t - n_units : t;
+    return u0 + t;
+  };
+  if constexpr (LOOP == 0) {
+    // ---- every wave on its own: MFMAs of sub-step s while the fragments of sub-step s+1 travel LDS -> registers ------------
+    // A unit of K is four sub-steps: (k 0..31, row fragments [0,H0)), (k 0..31, [H0,MF)), (k 32..63, [0,H0)), (k 32..63, [H0,MF)).
+    // ONE barrier per unit, B_k, behind sub-step 2: in front of it every read of unit k has landed in registers (the
+    // fragments of sub-step 3 were asked for a sub-step earlier) and this wave's pieces of unit k+1 have landed in the LDS,
+    // so behind it (a) unit k's slots are free: x of unit k+2 goes out in sub-step 3, w of unit k+2 -- into the slot unit
+    // k-1 left at B_{k-1} -- went out in sub-steps 0 and 1; (b) sub-step 3 reads the first fragments of unit k+1.
+    // vmcnt at B_k: issue order is w(k+1) [unit k-1], x(k+1) [unit k-1, sub-step 3], w(k+2) [unit k]: all but the CB
+    // youngest.  No phase alternation, no priority flips: the two waves of a SIMD keep its MFMA pipe fed between them.
+    uint4_t wf0[NF], wf1[NF], xfA[H0], xfB[H0];
+#define BMA_MID_RDF(dst_, base_, n_, i0_, foff_)                                                    \
+  if (!(kAblate & 2) || !in_loop) _Pragma("unroll") for (int i = 0; i < (n_); ++i)                  \
+    dst_[i] = *reinterpret_cast<const uint4_t*>((base_) + ((i0_) + i) * 2048 + (foff_))
+#define BMA_MID_MM(wf_, xf_, i0_, n_)                                                               \
+  _Pragma("unroll") for (int i = 0; i < (n_); ++i)                                                  \
+    _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                  \
+      if (kAblate & 4) asm volatile("" ::"v"(wf_[j]), "v"(xf_[i]));                                 \
+      else acc[j][(i0_) + i] = mfma16<DT>(wf_[j], xf_[i], acc[j][(i0_) + i])
     {
-      const int behind = (n_units < NB - 1 ? n_units : NB - 1) - 1;
-      if (behind >= 2 && NB > 3) wait_vm<CB * 2>();
-      else if (behind >= 1) wait_vm<CB>();
-      else wait_vm<0>();
+      const int ua = unit(0);
+      BMA_MID_X(0, ua, 0); BMA_MID_X(1, ua, 0); BMA_MID_X(2, ua, 0); BMA_MID_X(3, ua, 0);
+      BMA_MID_W(0, ua, 0); BMA_MID_W(1, ua, 0); BMA_MID_W(2, ua, 0); BMA_MID_W(3, ua, 0);
+    }
+    if (n_units > 1) {
+      const int ub = unit(1);
+      BMA_MID_W(0, ub, 1); BMA_MID_W(1, ub, 1); BMA_MID_W(2, ub, 1); BMA_MID_W(3, ub, 1);
+      BMA_MID_X(0, ub, 1); BMA_MID_X(1, ub, 1); BMA_MID_X(2, ub, 1); BMA_MID_X(3, ub, 1);
+      if (wave + kNW * 3 < PA) wait_vm<CB + 4>();                // (waves 0-3 issue four x pieces, waves 4-7 three)
+      else wait_vm<CB + 3>();
+    } else {
+      wait_vm<0>();
     }
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();
+    BMA_MID_RDF(wf0, lds_b + offb, NF, 0, foff0);
+    BMA_MID_RDF(xfA, lds + offa, H0, 0, foff0);
     int sa = 0, sb = 0;
-    for (int k = 0; k < n_units; ++k) {
-      read_frags(sa, sb);
-      if (k + NB - 1 < n_units && !(kDbg && (a.dbg & 1))) {                 // into the slot of unit k-1
-        int ns = sb + NB - 1;
-        ns = ns >= NB ? ns - NB : ns;
-        issue_b(u0 + k + NB - 1, ns);
-      }
-      {                                                          // w of unit k+1 landed: the units issued behind it may stay in flight
-        const int behind = n_units - 2 - k;                      // min(behind, NB-2)
-        if (kDbg && (a.dbg & 1)) wait_vm<0>();
-        else if (behind >= NB - 2) wait_vm<CB * (NB - 2)>();
-        else if (NB > 3 && behind == 1) wait_vm<CB>();
-        else wait_vm<0>();
-      }
+    in_loop = true;
+    // The two waves of a SIMD (w and w + 4) share its MFMA pipe; the older one wins every tie and reaches B_k ~750 cycles
+    // ahead of the younger (tools/mid_stamps.py).  prio 1: the younger half one level up for good; prio 2: the younger half up
+    // for the first half of a unit, the older for the second.
+    if (a.prio == 1 && wr == 1) __builtin_amdgcn_s_setprio(1);
+    auto one_unit = [&](const bool more1, const bool more2, const int k) __attribute__((always_inline)) {
+      const int u2 = more2 ? unit(k + 2) : u0;
+      const int sb1 = sb + 1 == NB ? 0 : sb + 1;                 // w slot of unit k+1
+      const int sw = sb == 0 ? NB - 1 : sb - 1;                  // w slot of unit k-1 == of unit k+2
+      const unsigned char* pa = lds + sa * ASZ + offa;
+      const unsigned char* pb = lds_b + sb * BSZ + offb;
+      // sub-step 0
+      if (a.prio == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+      BMA_MID_RDF(xfB, pa, H1, H0, foff0);
+      BMA_MID_RDF(wf1, pb, NF, 0, foff1);
+      if (more2) { BMA_MID_W(0, u2, sw); BMA_MID_W(1, u2, sw); }
+      BMA_MID_MM(wf0, xfA, 0, H0);
+      // sub-step 1
+      BMA_MID_RDF(xfA, pa, H0, 0, foff1);
+      if (more2) { BMA_MID_W(2, u2, sw); BMA_MID_W(3, u2, sw); }
+      BMA_MID_MM(wf0, xfB, H0, H1);
+      // sub-step 2, then B_k
+      if (a.prio == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+      BMA_MID_RDF(xfB, pa, H1, H0, foff1);
+      BMA_MID_MM(wf1, xfA, 0, H0);
+#ifdef BMA_MID_STAMPS
+      const bool stamp_on = a.stamps && k >= 16 && k < 16 + kStampN / 4 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      BMA_MID_STAMP();                                           // sub-steps 0-2 issued
+      if (more2) wait_vm<CB>();
+      else wait_vm<0>();
+      BMA_MID_STAMP();                                           // pieces of unit k+1 landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      BMA_MID_STAMP();                                           // every fragment read landed (and the MFMAs that wait for them issued)
       __builtin_amdgcn_s_barrier();
-      compute();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      BMA_MID_STAMP();                                           // through B_k
+      // sub-step 3
+      if (more2) { BMA_MID_X(0, u2, sa); BMA_MID_X(1, u2, sa); BMA_MID_X(2, u2, sa); BMA_MID_X(3, u2, sa); }
+      if (more1) {
+        BMA_MID_RDF(wf0, lds_b + sb1 * BSZ + offb, NF, 0, foff0);
+        BMA_MID_RDF(xfA, lds + (sa ^ 1) * ASZ + offa, H0, 0, foff0);
+      }
+      BMA_MID_MM(wf1, xfB, H0, H1);
       sa ^= 1;
-      sb = sb + 1 == NB ? 0 : sb + 1;
-    }
-  }
+      sb = sb1;
+    };
+    int k = 0;
+    for (; k + 2 < n_units; ++k) one_unit(true, true, k);        // the steady state carries no tail conditions
+    for (; k < n_units; ++k) one_unit(k + 1 < n_units, false, k);
+#undef BMA_MID_RDF
+#undef BMA_MID_MM
+  } else {
+  uint4_t wf[NF], xf[H0];
+  const unsigned char* pa = lds + offa;
+  const unsigned char* pb = lds_b + offb;
+  // One PHASE = the fragments of half a k step LDS -> registers, this wave's share of the DMA pieces, every read landed,
+  // barrier, the MFMAs on registers only, barrier.  The lower row half runs one barrier behind the upper one.
+#define BMA_MID_RD_W(foff_)                                                                         \
+  if (!(kAblate & 2) || k == 0) _Pragma("unroll") for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const uint4_t*>(pb + j * 2048 + (foff_))
+#define BMA_MID_RD_X(i0_, n_, foff_)                                                                \
+  if (!(kAblate & 2) || k == 0) _Pragma("unroll") for (int i = 0; i < (n_); ++i) xf[i] = *reinterpret_cast<const uint4_t*>(pa + ((i0_) + i) * 2048 + (foff_))
+#define BMA_MID_GO(i0_, n_)                                                                         \
+  do {                                                                                              \
+    BMA_MID_STAMP(); /* reads and pieces issued */                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    BMA_MID_STAMP(); /* reads landed */                                                             \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    BMA_MID_STAMP(); /* through the first barrier */                                                \
+    if (!(kAblate & 8)) __builtin_amdgcn_s_setprio(1);                                              \
+    _Pragma("unroll") for (int i = 0; i < (n_); ++i)                                                \
+      _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
+        if (kAblate & 4) asm volatile("" ::"v"(wf[j]), "v"(xf[i]));                                 \
+        else acc[j][(i0_) + i] = mfma16<DT>(wf[j], xf[i], acc[j][(i0_) + i]);                       \
+    if (!(kAblate & 8)) __builtin_amdgcn_s_setprio(0);                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    BMA_MID_STAMP(); /* MFMAs issued */                                                             \
+    __builtin_amdgcn_s_barrier();                                                                   \
+    BMA_MID_STAMP(); /* through the second barrier = the next phase starts */                       \
+  } while (0)
 
-  // ---- split tiles: the partial leaves in register order; bma_gemm_mid's second launch sums the splits ---------------------
+  // ---- prologue: x and w of unit 0 land, w of unit 1 stays in flight ------------------------------------------------------
+  {
+    const int ua = unit(0);
+    BMA_MID_X(0, ua, 0); BMA_MID_X(1, ua, 0); BMA_MID_X(2, ua, 0); BMA_MID_X(3, ua, 0);
+    BMA_MID_W(0, ua, 0); BMA_MID_W(1, ua, 0); BMA_MID_W(2, ua, 0); BMA_MID_W(3, ua, 0);
+  }
+  if (n_units > 1) {
+    const int ub = unit(1);
+    BMA_MID_W(0, ub, 1); BMA_MID_W(1, ub, 1); BMA_MID_W(2, ub, 1); BMA_MID_W(3, ub, 1);
+    wait_vm<CB>();
+  } else {
+    wait_vm<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();                     // the lower half: one barrier behind from here on
+
+  int sa = 0, sb = 0;
+  in_loop = true;
+  for (int k = 0; k < n_units; ++k) {
+#ifdef BMA_MID_STAMPS
+    const bool stamp_on = a.stamps && k >= 16 && k < 16 + kStampN / 20 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200);
+#endif
+    const bool more_x = k + 1 < n_units, more_w = k + 2 < n_units;
+    const int ux = more_x ? unit(k + 1) : u0, uw = more_w ? unit(k + 2) : u0;
+    const int sx = sa ^ 1;                                       // slot of x unit k-1: its last read retired before the
+    const int sw = sb == 0 ? NB - 1 : sb - 1;                    // barrier in front of this phase (w: slot of unit k-1, too)
+    pa = lds + sa * ASZ + offa;
+    pb = lds_b + sb * BSZ + offb;
+    // phase 0: k 0..31, row fragments [0, H0)
+    BMA_MID_RD_W(foff0);
+    BMA_MID_RD_X(0, H0, foff0);
+    if (more_x) { BMA_MID_X(0, ux, sx); BMA_MID_X(1, ux, sx); }
+    BMA_MID_GO(0, H0);
+    // phase 1: k 0..31, row fragments [H0, MF)
+    BMA_MID_RD_X(H0, H1, foff0);
+    if (more_x) { BMA_MID_X(2, ux, sx); BMA_MID_X(3, ux, sx); }
+    BMA_MID_GO(H0, H1);
+    // phase 2: k 32..63, row fragments [0, H0)
+    BMA_MID_RD_W(foff1);
+    BMA_MID_RD_X(0, H0, foff1);
+    if (more_w) { BMA_MID_W(0, uw, sw); BMA_MID_W(1, uw, sw); }
+    BMA_MID_GO(0, H0);
+    // phase 3: k 32..63, row fragments [H0, MF); x of unit k+1 and w of unit k+1 land (w of unit k+2 stays in flight:
+    // it was issued behind them), read from the next phase on -- one barrier later for either half
+    BMA_MID_RD_X(H0, H1, foff1);
+    if (more_w) {
+      BMA_MID_W(2, uw, sw); BMA_MID_W(3, uw, sw);
+      wait_vm<CB>();
+    } else {
+      wait_vm<0>();
+    }
+    BMA_MID_GO(H0, H1);
+    sa ^= 1;
+    sb = sb + 1 == NB ? 0 : sb + 1;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();                     // sits out the lower half's last phase
+  }
+#ifdef BMA_MID_STAMPS
+  if (a.stamps && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200)) {
+    __syncthreads();
+    for (int i = tid; i < kNW * kStampN; i += kNW * 64) a.stamps[(blockIdx.x / 100) * kNW * kStampN + i] = stamp_base[i];
+  }
+#endif
+#undef BMA_MID_X
+#undef BMA_MID_W
+#undef BMA_MID_RD_W
+#undef BMA_MID_RD_X
+#undef BMA_MID_GO
+#undef BMA_MID_STAMP
+
+// ---- split tiles: the partial leaves in register order; bma_gemm_mid's second launch sums the splits ---------------------
   if (split >= 0) {
     f32x4* out = reinterpret_cast<f32x4*>(a.ws) +
                  ((static_cast<int64_t>(tile - a.t_full) * a.S + split) * kNW + wave) * (NF * MF * 64) + lane;
@@ -347,7 +483,7 @@ constexpr int kCUs = 256;
 constexpr int kMaxSplit = 8;
 constexpr int kMF = 7;
 struct MidPlan {
-  int mf, nf, m_tiles, n_tiles, t_full, S, xcd, dbg;
+  int mf, nf, m_tiles, n_tiles, t_full, S, xcd, stagger, loop, prio;
 };
 
 int g_nf = 0, g_S = 0, g_tail = -1, g_flags = -1;   // tuning override (bma_gemm_mid_set_plan): 0 / -1 = the planner's choice
@@ -392,7 +528,10 @@ bool make_plan(int M, int N, int K, MidPlan& p) {
   p.t_full = S == 1 ? T : (tail > 0 ? T - tail * p.m_tiles : 0);
   const int flags = g_flags >= 0 ? g_flags : 1;
   p.xcd = flags & 1;
-  p.dbg = kDbg ? (flags >> 2) & 7 : 0;
+  p.prio = (flags >> 4) & 3;
+  p.loop = (flags >> 1) & 1;                                     // A/B: the alternating-phase loop of rounds 4-5
+  const int sg = (flags >> 8) & 0xff;                            // sweeps: 255 = walk K in step, 1..254 = that stride
+  p.stagger = sg == 0 || sg == 255 ? 0 : sg;
   return true;
 }
 
@@ -426,6 +565,7 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   if (!x || !w || !y) return BMA_EINVAL;
   if (dtype != BMA_BF16 && dtype != BMA_F16) return BMA_EDTYPE;
   if (K % kBK) return BMA_ELIMIT;
+  if ((ldx > ldw ? ldx : ldw) * 2 * 256 + static_cast<int64_t>(K) * 2 >= (int64_t{1} << 31)) return BMA_ELIMIT;   // (32-bit offsets inside a tile)
   if ((ldx * 2) % 16 || (ldw * 2) % 16 || (ldy * 2) % 8) return BMA_EALIGN;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16 || reinterpret_cast<uintptr_t>(y) % 8 ||
       reinterpret_cast<uintptr_t>(ws) % 16)
@@ -439,20 +579,46 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   a.y = static_cast<char*>(y);
   a.ws = static_cast<float*>(ws);
   a.ldx = ldx; a.ldw = ldw; a.ldy = ldy;
-  a.M = M; a.N = N; a.K = K; a.S = p.S; a.t_full = p.t_full; a.m_tiles = p.m_tiles; a.n_tiles = p.n_tiles; a.xcd = p.xcd; a.dbg = p.dbg;
+  a.M = M; a.N = N; a.K = K; a.S = p.S; a.t_full = p.t_full; a.m_tiles = p.m_tiles; a.n_tiles = p.n_tiles; a.xcd = p.xcd; a.stagger = p.stagger; a.prio = p.prio;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  a.stamps = nullptr;
+#ifdef BMA_MID_STAMPS
+  // diagnostic build: BMA_MID_STAMPS_FILE=<file> gets kStampN x u64 per wave of workgroups 0, 100, 200 of every launch
+  const char* dump = getenv("BMA_MID_STAMPS_FILE");
+  if (dump && *dump) {
+    (void)hipMalloc(reinterpret_cast<void**>(&a.stamps), 3 * kNW * kStampN * 8);
+    (void)hipMemsetAsync(a.stamps, 0, 3 * kNW * kStampN * 8, st);
+  }
+#endif
   const int n_split_tiles = p.m_tiles * p.n_tiles - p.t_full;
   const dim3 grid(static_cast<unsigned>(p.t_full + n_split_tiles * p.S)), block(kNW * 64), rblock(256);
   BMA_PROF_BEGIN(BMA_K_GEMM_MID, st, 2.0 * (static_cast<double>(M) * K + static_cast<double>(N) * K + static_cast<double>(M) * N));
 #define BMA_MID_GO(DT_)                                                                           \
   do {                                                                                            \
-    if (p.nf == 3) hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 3, 4>), grid, block, 0, st, a);   \
-    else hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 4, 3>), grid, block, 0, st, a);             \
+    if (p.loop == 0) {                                                                            \
+      if (p.nf == 3) hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 3, 0>), grid, block, 0, st, a); \
+      else hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 4, 0>), grid, block, 0, st, a);           \
+    } else {                                                                                      \
+      if (p.nf == 3) hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 3, 1>), grid, block, 0, st, a); \
+      else hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 4, 1>), grid, block, 0, st, a);           \
+    }                                                                                             \
   } while (0)
   if (dtype == BMA_BF16) BMA_MID_GO(BMA_BF16);
   else BMA_MID_GO(BMA_F16);
 #undef BMA_MID_GO
   BMA_LAUNCH_CHECK();
+#ifdef BMA_MID_STAMPS
+  if (a.stamps) {
+    std::vector<unsigned long long> host(3 * kNW * kStampN);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(host.data(), a.stamps, host.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(a.stamps);
+    if (FILE* f = fopen(dump, "wb")) {
+      fwrite(host.data(), 8, host.size(), f);
+      fclose(f);
+    }
+  }
+#endif
   if (p.S > 1) {
     const int64_t n4 = static_cast<int64_t>(n_split_tiles) * kNW * p.mf * p.nf * 64;
     const dim3 rgrid(static_cast<unsigned>((n4 + 255) / 256));

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Where a wave of bma_gemm_mid spends a unit of K (a -DBMA_MID_STAMPS build of the library; cdna_hip_programming.md 7,
+"In-kernel stamps").
+
+    make -C bimodalattack_amd/csrc OUTDIR=$PWD/bimodalattack_amd/lib_diag EXTRA=-DBMA_MID_STAMPS
+    python tools/mid_stamps.py [--rows 644] [--n 22016] [--k 4096] [--flags 1|3]
+
+flags 1 (the shipped loop: every wave on its own, one barrier B_k per unit): four stamps per unit -- sub-steps 0-2 issued /
+this wave's DMA pieces of unit k+1 landed (vmcnt) / every fragment read landed (lgkmcnt 0) / through B_k.  Printed per wave,
+averaged over 30 units of the middle of the loop of workgroups 0, 100 and 200, in shader cycles: the unit, then
+[issue of sub-step 3 + 0-2 of the next unit | vmcnt wait | lgkmcnt wait | barrier].
+flags 3 (the alternating-phase loop of rounds 4-5): five stamps per phase, four phases per unit -- issue / read wait /
+barrier 1 / MFMAs / barrier 2.  The stamps themselves cost ~100 cycles each.
+"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+os.environ.setdefault("BMA_LIB", os.path.join(REPO, "bimodalattack_amd", "lib_diag", "libbma_hip.so"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bimodalattack_amd import ops  # noqa: E402
+from bimodalattack_amd.native import lib  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=644)
+    ap.add_argument("--n", type=int, default=22016)
+    ap.add_argument("--k", type=int, default=4096)
+    ap.add_argument("--flags", type=int, default=1)
+    ap.add_argument("--out", default="/tmp/mid_stamps.bin")
+    args = ap.parse_args()
+    ops.GEMM_MID_MIN_K_OVER_N = 0.0
+    ops.gemm_workspace(DEV)
+    lib.bma_gemm_mid_set_plan(0, 0, -1, args.flags)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn((args.rows, args.k), generator=g, device=DEV).to(torch.bfloat16)
+    ws = [(torch.randn((args.n, args.k), generator=g, device=DEV) * 0.02).to(torch.bfloat16) for _ in range(4)]
+    for w in ws:                                                     # warm: clocks, code
+        for _ in range(20):
+            ops.gemm_mid(x, w)
+    torch.cuda.synchronize()
+    os.environ["BMA_MID_STAMPS_FILE"] = args.out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.gemm_mid(x, ws[0])
+    os.environ["BMA_MID_STAMPS_FILE"] = ""
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        ops.gemm_mid(x, ws[1])
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"M={args.rows} N={args.n} K={args.k} flags={args.flags}: {1e2 * e0.elapsed_time(e1):.1f} us per launch (stamped build, stamps off in these)")
+    a = np.fromfile(args.out, dtype=np.uint64).astype(np.int64).reshape(3, 8, 128)
+    if args.flags & 2:
+        names, per_unit, units = ["issue", "read wait", "barrier 1", "MFMAs", "barrier 2"], 20, 6
+    else:
+        names, per_unit, units = ["issue", "vmcnt", "lgkmcnt", "barrier"], 4, 30
+    ns = len(names)
+    for wg in range(3):
+        if a[wg].max() == 0:
+            continue
+        print(f"workgroup {wg * 100}:")
+        for wave in range(8):
+            flat = a[wg, wave, :per_unit * units]
+            d = np.diff(flat)                                        # interval j ends at stamp j+1
+            groups = per_unit // ns
+            per = {n: [[] for _ in range(groups)] for n in names}
+            for j, dt in enumerate(d):
+                end = (j + 1) % ns
+                ph = ((j + 1) // ns) % groups
+                per[names[end]][ph].append(dt)
+            unit = (flat[per_unit * (units - 1)] - flat[0]) / (units - 1.0)
+            cells = [" ".join(f"{np.mean(per[n][ph]):5.0f}" for n in names) for ph in range(groups)]
+            print(f"  wave {wave}: unit {unit:6.0f} cyc | " + " | ".join(cells))
+        print("           per group: " + " / ".join(names))
+
+
+if __name__ == "__main__":
+    main()
