@@ -988,6 +988,7 @@ class _LineGuard:
 
 
 _GUARD = None            # rank 0 of a multi-GPU run only
+TP_HUNG_STATUS = 4       # exit status of every rank when the tensor-parallel leg's watchdog fires
 
 
 def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
@@ -1017,7 +1018,10 @@ def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
             if _GUARD is not None:
                 _GUARD.release()
             print(json.dumps(build_line(out, None), allow_nan=False), flush=True)
-        os._exit(0)          # (every rank: the launcher must not turn a measured first leg into a failed run)
+        # Every rank leaves with TP_HUNG_STATUS, never 0: a collective that did not return is a deadlock, and a launcher or CI
+        # must see one.  The first leg's line is already on stdout: "status 4 + a JSON line" reads as "the
+        # replicated leg is valid, the tensor-parallel leg hung" (DESIGN.md 8).
+        os._exit(TP_HUNG_STATUS)
 
     if rank == 0 and _GUARD is not None:
         held = dict(out, cpu_baseline=None)

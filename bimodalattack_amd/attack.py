@@ -1196,6 +1196,7 @@ class BimodalAttack:
         self.filter_first_steps: List[int] = []    # steps that ran the retokenisation filter BEFORE scoring (filter policy)
         self._keep_rates: List[float] = []     # survivor rate of the filter, step by step
         self._warned_nonfinite = False
+        ops.set_graph_owner(id(self))            # (captured graphs replayed from here on are this attack's: ops.note_graph_replay)
         self._prepare_prompt(messages, target)
         buffer = self.init_buffer(image)
         optim_ids = buffer.get_best_ids()

@@ -179,11 +179,35 @@ class EngineOptions:
               "own_b1_kernels", "grad_prefix_reuse", "fuse_add_norm", "joint_winner_from_batch", "shared_prefix_attention",
               "ragged_suffix", "fuse_pgd_only", "gradient_ahead", "early_plan", "filter_first", "warm_gemms", "strict", "save_images")
 
+    # Names round 5's consolidation retired (42 options -> 27): an A/B script that still exports one would silently measure
+    # the default -- from_env says so once per name.  Value: what replaces it.
+    _RETIRED_ENV = {
+        "BMA_GRAPH_RESCORE": "BMA_GRAPH_SCORING", "BMA_GRAPH_PREFIX": "BMA_GRAPH_SCORING", "BMA_SCORE_GRAPHS": "BMA_GRAPH_SCORING",
+        "BMA_BACKWARD_WEIGHT_COPIES": "BMA_DERIVED_WEIGHT_COPIES", "BMA_FUSE_QKV": "BMA_DERIVED_WEIGHT_COPIES",
+        "BMA_FUSE_GATE_UP": "BMA_DERIVED_WEIGHT_COPIES", "BMA_FUSE_TOWER_QKV": "BMA_DERIVED_WEIGHT_COPIES",
+        "BMA_FUSE_QK_ROPE": "BMA_FUSE_ADD_NORM", "BMA_FUSE_QUICK_GELU": "BMA_FUSED_ELEMENTWISE", "BMA_PAD_VISION_HEADS": None,
+        "BMA_TP_GRAPH": "BMA_TP_GRADIENT=graph", "BMA_SHARED_PREFIX_MIN_TOKENS": None, "BMA_CHUNK_QUANTUM": None,
+    }
+    _RETIRED_KW = {"group": "the default process group is used when torch.distributed is initialised (dist.CandidateSharder)",
+                   "score_log": "set `attack.score_log = []` on the BimodalAttack object (tools/nan_bisect.py)",
+                   "emulate_world": "the BMA_EMULATE_WORLD environment variable", "tp_graph": "tp_gradient='graph'",
+                   "graph_rescore": "graph_scoring", "graph_prefix": "graph_scoring", "backward_weight_copies": "derived_weight_copies",
+                   "fuse_qkv": "derived_weight_copies", "fuse_gate_up": "derived_weight_copies", "skinny_gemm": "own_b1_kernels",
+                   "mid_gemm": "own_b1_kernels", "causal_attention": "own_b1_kernels"}
+    _warned_retired = set()
+
     @classmethod
     def from_env(cls, **overrides) -> "EngineOptions":
         opts = cls()
         env = os.environ
         off = ("0", "false", "False")
+        for name, instead in cls._RETIRED_ENV.items():
+            if name in env and name not in cls._warned_retired:
+                cls._warned_retired.add(name)
+                import logging
+                logging.getLogger("gcg").warning(
+                    f"{name} is set but no longer read (engine options were consolidated in round 5): "
+                    + (f"use {instead}" if instead else "it has no replacement"))
         for name in cls._BOOLS:
             key = "BMA_" + name.upper()
             if key in env:
@@ -199,6 +223,8 @@ class EngineOptions:
         for k, v in overrides.items():
             if v is None:
                 continue
+            if k in cls._RETIRED_KW:
+                raise TypeError(f"engine option {k!r} was retired in round 5: {cls._RETIRED_KW[k]}")
             if k.startswith("_") or not hasattr(opts, k):
                 raise TypeError(f"unknown engine option {k!r}")
             setattr(opts, k, v)

@@ -74,6 +74,7 @@ struct MidArgs {
   int t_full;              // tiles [0, t_full) run over all of K; the others are split S ways
   int S;
   int xcd;                 // 1: remap workgroup ids so that an XCD owns a contiguous run of tiles
+  int stamp_units;              // diagnostic builds: 0 = only the loop's start / end stamps (the clock), 1 = per-unit stamps too
   unsigned long long* stamps;   // diagnostic builds only (-DBMA_MID_STAMPS): clock stamps of workgroups 0, 100 and 200
   int prio;                // experiments with the arbitration between a SIMD's two waves (flags bits 4-5), see the k loop
   int stagger;             // workgroup v walks its units of K from unit (v * stagger) % units on, wrapping round
@@ -118,6 +119,8 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + NB * BSZ + 8192];
   unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(lds + kNA * ASZ + NB * BSZ);
   int stamp_i = 0;
+  const int stamp_wg = blockIdx.x == gridDim.x - 1 ? 3 : (blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : (blockIdx.x == 200 ? 2 : -1)));
+  if (a.stamps && stamp_wg >= 0 && (threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 122] = __builtin_amdgcn_s_memrealtime();   // kernel entry
 #define BMA_MID_STAMP()                                                                                         \
   do {                                                                                                          \
     if (stamp_on) {                                                                                             \
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       BMA_MID_RDF(xfB, pa, H1, H0, foff1);
       BMA_MID_MM(wf1, xfA, 0, H0);
 #ifdef BMA_MID_STAMPS
-      const bool stamp_on = a.stamps && k >= 16 && k < 16 + kStampN / 4 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200);
+      const bool stamp_on = a.stamps && a.stamp_units && k >= 16 && k < 16 + 120 / 4 && stamp_wg >= 0;
       __builtin_amdgcn_sched_barrier(0);
 #endif
       BMA_MID_STAMP();                                           // sub-steps 0-2 issued
@@ -306,9 +309,21 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       sa ^= 1;
       sb = sb1;
     };
+#ifdef BMA_MID_STAMPS
+    if (a.stamps && lane == 0) {                                 // the clock the loop runs at: cycles against the 100 MHz counter
+      stamp_base[wave * kStampN + 124] = __builtin_amdgcn_s_memtime();
+      stamp_base[wave * kStampN + 125] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     int k = 0;
     for (; k + 2 < n_units; ++k) one_unit(true, true, k);        // the steady state carries no tail conditions
     for (; k < n_units; ++k) one_unit(k + 1 < n_units, false, k);
+#ifdef BMA_MID_STAMPS
+    if (a.stamps && lane == 0) {
+      stamp_base[wave * kStampN + 126] = __builtin_amdgcn_s_memtime();
+      stamp_base[wave * kStampN + 127] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 #undef BMA_MID_RDF
 #undef BMA_MID_MM
   } else {
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   in_loop = true;
   for (int k = 0; k < n_units; ++k) {
 #ifdef BMA_MID_STAMPS
-    const bool stamp_on = a.stamps && k >= 16 && k < 16 + kStampN / 20 && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200);
+    const bool stamp_on = a.stamps && k >= 16 && k < 16 + kStampN / 20 && stamp_wg >= 0;
 #endif
     const bool more_x = k + 1 < n_units, more_w = k + 2 < n_units;
     const int ux = more_x ? unit(k + 1) : u0, uw = more_w ? unit(k + 2) : u0;
@@ -398,12 +413,6 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();                     // sits out the lower half's last phase
   }
-#ifdef BMA_MID_STAMPS
-  if (a.stamps && (blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 200)) {
-    __syncthreads();
-    for (int i = tid; i < kNW * kStampN; i += kNW * 64) a.stamps[(blockIdx.x / 100) * kNW * kStampN + i] = stamp_base[i];
-  }
-#endif
 #undef BMA_MID_X
 #undef BMA_MID_W
 #undef BMA_MID_RD_W
@@ -419,6 +428,14 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     for (int j = 0; j < NF; ++j)
 #pragma unroll
       for (int i = 0; i < MF; ++i) out[(j * MF + i) * 64] = acc[j][i];
+#ifdef BMA_MID_STAMPS
+  if (a.stamps && stamp_wg >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the epilogue's stores have left
+    if ((threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 123] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    for (int i = tid; i < kNW * kStampN; i += kNW * 64) a.stamps[stamp_wg * kNW * kStampN + i] = stamp_base[i];
+  }
+#endif
     return;
   }
 
@@ -445,6 +462,14 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       }
     }
   }
+#ifdef BMA_MID_STAMPS
+  if (a.stamps && stamp_wg >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the epilogue's stores have left
+    if ((threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 123] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    for (int i = tid; i < kNW * kStampN; i += kNW * 64) a.stamps[stamp_wg * kNW * kStampN + i] = stamp_base[i];
+  }
+#endif
 }
 
 // second launch of a split product: one thread per float4 of a split tile, the S partials summed in split order
@@ -582,12 +607,14 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   a.M = M; a.N = N; a.K = K; a.S = p.S; a.t_full = p.t_full; a.m_tiles = p.m_tiles; a.n_tiles = p.n_tiles; a.xcd = p.xcd; a.stagger = p.stagger; a.prio = p.prio;
   hipStream_t st = static_cast<hipStream_t>(stream);
   a.stamps = nullptr;
+  a.stamp_units = 0;
 #ifdef BMA_MID_STAMPS
   // diagnostic build: BMA_MID_STAMPS_FILE=<file> gets kStampN x u64 per wave of workgroups 0, 100, 200 of every launch
   const char* dump = getenv("BMA_MID_STAMPS_FILE");
+  a.stamp_units = getenv("BMA_MID_STAMPS_UNITS") ? atoi(getenv("BMA_MID_STAMPS_UNITS")) : 1;
   if (dump && *dump) {
-    (void)hipMalloc(reinterpret_cast<void**>(&a.stamps), 3 * kNW * kStampN * 8);
-    (void)hipMemsetAsync(a.stamps, 0, 3 * kNW * kStampN * 8, st);
+    (void)hipMalloc(reinterpret_cast<void**>(&a.stamps), 4 * kNW * kStampN * 8);
+    (void)hipMemsetAsync(a.stamps, 0, 4 * kNW * kStampN * 8, st);
   }
 #endif
   const int n_split_tiles = p.m_tiles * p.n_tiles - p.t_full;
@@ -609,7 +636,7 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   BMA_LAUNCH_CHECK();
 #ifdef BMA_MID_STAMPS
   if (a.stamps) {
-    std::vector<unsigned long long> host(3 * kNW * kStampN);
+    std::vector<unsigned long long> host(4 * kNW * kStampN);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(host.data(), a.stamps, host.size() * 8, hipMemcpyDeviceToHost);
     (void)hipFree(a.stamps);

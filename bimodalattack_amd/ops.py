@@ -1004,30 +1004,54 @@ def gemm_workspace(dev: torch.device):
         if capturing:
             return None
         # eager pairs are bounded (every graph warm-up on a fresh side stream left 64 MB behind, 2 GB over the
-        # stream pool): the oldest eager pair goes when a fifth stream asks -- its memory returns to the caching
-        # allocator under the stream it was allocated on, i.e. behind that stream's own last launch; the "graphs" pair
-        # (captured launches hold its address) is never dropped
+        # stream pool): the LEAST RECENTLY USED eager pair goes when a fifth stream asks (by insertion order the
+        # main stream's pair -- the one every eager call uses -- went first and was reallocated again and again) -- its
+        # memory returns to the caching allocator under the stream it was allocated on, i.e. behind that stream's own last
+        # launch; the "graphs" pair (captured launches hold its address) is never dropped
         eager = [k for k in _GEMM_WS if k[:2] == key[:2] and k[2] != "graphs"]
         if len(eager) >= _GEMM_WS_MAX_EAGER:
             del _GEMM_WS[eager[0]]
         ws = (torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=dev), torch.zeros(_GEMM_COUNTERS, dtype=torch.int32, device=dev))
         _GEMM_WS[key] = ws
+    elif not capturing:
+        _GEMM_WS[key] = _GEMM_WS.pop(key)        # a hit moves the pair to the young end (dicts keep insertion order)
     return ws
 
 
-_GRAPH_REPLAY_STREAM = {}      # device index -> the stream handle captured graphs have been replayed from
+_GRAPH_REPLAY_STREAM = {}      # device index -> (stream handle captured graphs are being replayed from, owner token)
+_GRAPH_OWNER = [None]          # the attack whose run() started last (BimodalAttack.run sets it): default owner of a replay
 
 
-def note_graph_replay(dev: torch.device) -> None:
+def set_graph_owner(token) -> None:
+    """Called by the engine when an attack's run starts: replays from here on belong to it (see note_graph_replay)."""
+    _GRAPH_OWNER[0] = token
+
+
+def note_graph_replay(dev: torch.device, owner=None) -> None:
     """Every captured graph of a device shares ONE split-K workspace and ticket array (``gemm_workspace``): their replays
     must be ordered on one stream, or two graphs would race on partial sums and tickets.  The engine replays from the
-    stream current at the call; this makes a second stream an error instead of a silent race."""
+    stream current at the call; this makes a second stream an error instead of a silent race.  The pin belongs
+    to an `owner` (the attack object whose graphs are being replayed): a LATER owner -- the next attack of the process, a
+    test -- may legitimately replay its own graphs under another stream once the previous owner is done, and takes the
+    pin over (the first replay stream used to be pinned for the whole process); two streams within one owner
+    are the race."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     handle = torch.cuda.current_stream(dev).cuda_stream
-    first = _GRAPH_REPLAY_STREAM.setdefault(idx, handle)
-    if first != handle:
+    owner = _GRAPH_OWNER[0] if owner is None else owner
+    first = _GRAPH_REPLAY_STREAM.get(idx)
+    if first is None or (owner is not None and first[1] != owner):
+        _GRAPH_REPLAY_STREAM[idx] = (handle, owner)
+        return
+    if first[0] != handle:
         raise RuntimeError("bimodalattack_amd: captured graphs of one device must be replayed from one stream (they share the "
-                           f"split-K workspace); first replay came from stream {first:#x}, this one from {handle:#x}")
+                           f"split-K workspace); first replay came from stream {first[0]:#x}, this one from {handle:#x}")
+
+
+def release_graph_replay(dev: torch.device, owner) -> None:
+    """The owner's graphs are gone (its attack finished): the next replay on this device may come from any stream."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if _GRAPH_REPLAY_STREAM.get(idx, (None, None))[1] == owner:
+        _GRAPH_REPLAY_STREAM.pop(idx, None)
 
 
 def gemm_workspace_for_graphs(dev: torch.device):

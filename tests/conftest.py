@@ -12,6 +12,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
+AUDIT_LINES = []     # what tests/test_attack_gpu.py's audits of `check_against_golden` found, printed again at the very end
 
 
 def pytest_configure(config):
@@ -37,3 +38,10 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The golden-comparison audit (how many reference trajectories were compared to their LAST step on this device) at the
+    end of the report, where the tail of a driver's log keeps it."""
+    for line in AUDIT_LINES:
+        terminalreporter.write_line("golden audit: " + line)

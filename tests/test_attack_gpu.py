@@ -138,6 +138,14 @@ def check_against_golden(golden_dir, name, m, res, trace, tmp, png=True):
 
 # how each base trajectory ended on THIS device: None = compared to its last step, i = the escape hatch opened at step i
 # (a near-tied candidate won and every later step went unchecked); audited by the test behind the parametrised one
+def _audit_line(line: str) -> None:
+    """The audit's outcome where a log tail keeps it: as a warning (pytest's summary) and in conftest's terminal summary."""
+    import warnings
+    import conftest
+    conftest.AUDIT_LINES.append(line)
+    warnings.warn("golden audit: " + line, UserWarning, stacklevel=2)
+
+
 _DIVERGED_AT = {}
 _ALL_RUNS = []          # (case, diverged_at, steps) of EVERY check_against_golden call of the session (the last test of the file audits it)
 
@@ -156,8 +164,10 @@ def test_most_base_trajectories_are_compared_to_their_last_step():
     if len(_DIVERGED_AT) < len(META["cases"]):
         pytest.skip("the base trajectories were not all run in this session")
     ended_early = {k: v for k, v in _DIVERGED_AT.items() if v is not None}
-    print(f"trajectories compared to their last step: {len(_DIVERGED_AT) - len(ended_early)} of {len(_DIVERGED_AT)}; "
-          f"diverged (near-tied winner) at: {ended_early}")
+    line = (f"trajectories compared to their last step: {len(_DIVERGED_AT) - len(ended_early)} of {len(_DIVERGED_AT)}; "
+            f"diverged (near-tied winner) at: {ended_early}")
+    print(line)
+    _audit_line(line)                                  # (the driver's log tail must carry this)
     assert len(_DIVERGED_AT) - len(ended_early) >= min(10, len(_DIVERGED_AT)), ended_early
 
 
@@ -775,7 +785,9 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
 def test_bench_prints_the_first_leg_when_the_tensor_parallel_leg_does_not_return():
     """bench.py's multi-GPU A/B must never cost the run its line: with the tensor-parallel leg's time limit set to a
     millisecond (as if a collective never returned) the watchdog prints the FIRST leg's complete line -- n_gpus 2, the
-    replicated pass's figures, `rccl.tp_note` saying what happened -- and every rank leaves with status 0."""
+    replicated pass's figures, `rccl.tp_note` saying what happened -- and every rank leaves with bench.TP_HUNG_STATUS (4),
+    never 0: a hung collective is a deadlock the launcher must see; "status 4 + one JSON line" = the replicated
+    leg is valid, the tensor-parallel leg hung."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -786,7 +798,7 @@ def test_bench_prints_the_first_leg_when_the_tensor_parallel_leg_does_not_return
                         "--warmup", "1", "--profile-steps", "1", "--search-width", "64", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert len(lines) == 1 and r.returncode != 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["finite"] is True and d["value"] > 0
     rc = d["rccl"]
@@ -2100,7 +2112,9 @@ def test_zz_every_golden_comparison_of_the_session_is_audited():
     by_case = {}
     for n, d, _ in early:
         by_case.setdefault(n, []).append(d)
-    print(f"golden comparisons: {len(_ALL_RUNS)}, to the last step: {len(_ALL_RUNS) - len(early)}; steps compared {compared} of {steps}; "
-          f"ended at a near-tied winner: {by_case}")
+    line = (f"golden comparisons: {len(_ALL_RUNS)}, to the last step: {len(_ALL_RUNS) - len(early)}; steps compared {compared} of {steps}; "
+            f"ended at a near-tied winner: {by_case}")
+    print(line)
+    _audit_line(line)
     assert len(early) <= 0.2 * len(_ALL_RUNS), by_case
     assert compared >= 0.85 * steps

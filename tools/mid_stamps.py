@@ -47,8 +47,32 @@ def main():
         for _ in range(20):
             ops.gemm_mid(x, w)
     torch.cuda.synchronize()
-    os.environ["BMA_MID_STAMPS_FILE"] = args.out
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # first the loop's own clock: only a start and an end stamp per wave (cycles against the 100 MHz counter), after a warm-up
+    # long enough for the chip to settle at the clock it holds under this load
+    for _ in range(400):
+        ops.gemm_mid(x, ws[_ % 4])
+    os.environ["BMA_MID_STAMPS_FILE"] = args.out
+    os.environ["BMA_MID_STAMPS_UNITS"] = "0"
+    ops.gemm_mid(x, ws[0])
+    torch.cuda.synchronize()
+    full = np.fromfile(args.out, dtype=np.uint64).astype(np.int64).reshape(4, 8, 128)
+    c = full[:3, :, 124:]
+    ok = c[:, :, 3] > c[:, :, 1]
+    cyc, ticks = (c[:, :, 2] - c[:, :, 0])[ok], (c[:, :, 3] - c[:, :, 1])[ok]
+    if len(cyc):
+        print(f"the k loop of workgroups 0 / 100 / 200: {np.median(cyc):.0f} shader cycles in {np.median(ticks) / 100.0:.1f} us = "
+              f"{np.median(cyc / (ticks * 10.0)):.2f} GHz in-kernel clock (no per-unit stamps in this launch)")
+    # the 100 MHz counter at kernel entry [122], loop start [125], loop end [127], after the epilogue's stores [123]
+    t_first = min(int(full[g_, w_, 122]) for g_ in range(4) for w_ in range(8) if full[g_, w_, 122] > 0)
+    for g_, name in enumerate(("workgroup 0", "workgroup 100", "workgroup 200", "the LAST workgroup (a second-round split piece when the grid overflows)")):
+        e = full[g_, :, 122], full[g_, :, 125], full[g_, :, 127], full[g_, :, 123]
+        if e[0].max() == 0:
+            continue
+        print(f"  {name}: enters at {(np.median(e[0]) - t_first) / 100.0:6.1f} us; prologue {np.median(e[1] - e[0]) / 100.0:5.1f} us, "
+              f"k loop {np.median(e[2] - e[1]) / 100.0:5.1f} us, epilogue {np.median(e[3] - e[2]) / 100.0:5.1f} us; leaves at "
+              f"{(np.median(e[3]) - t_first) / 100.0:6.1f} us")
+    os.environ["BMA_MID_STAMPS_UNITS"] = "1"
     ops.gemm_mid(x, ws[0])
     os.environ["BMA_MID_STAMPS_FILE"] = ""
     torch.cuda.synchronize()
@@ -58,7 +82,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     print(f"M={args.rows} N={args.n} K={args.k} flags={args.flags}: {1e2 * e0.elapsed_time(e1):.1f} us per launch (stamped build, stamps off in these)")
-    a = np.fromfile(args.out, dtype=np.uint64).astype(np.int64).reshape(3, 8, 128)
+    a = np.fromfile(args.out, dtype=np.uint64).astype(np.int64).reshape(4, 8, 128)[:3]
     if args.flags & 2:
         names, per_unit, units = ["issue", "read wait", "barrier 1", "MFMAs", "barrier 2"], 20, 6
     else:

@@ -52,7 +52,7 @@ def main():
     env = dict(os.environ, PYTORCH_TUNABLEOP_ENABLED="1", PYTORCH_TUNABLEOP_TUNING="1", PYTORCH_TUNABLEOP_FILENAME=results,
                PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=args.ms, PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS="5",
                PYTORCH_TUNABLEOP_ROTATING_BUFFER_SIZE=str(args.rotate_mb),
-               BMA_GRAPH_GRADIENT="0", BMA_GRAPH_PREFIX="0", BMA_GRAPH_RESCORE="0", BMA_GEMM_TUNING="off", MIOPEN_FIND_MODE="FAST",
+               BMA_GRAPH_GRADIENT="0", BMA_GRAPH_SCORING="0", BMA_GEMM_TUNING="off", MIOPEN_FIND_MODE="FAST",
                BMA_SKINNY_GEMM="0")          # every product through the library, so that every shape gets an entry
     for wl in [w for w in args.workloads.split(",") if w]:
         print(f"== tuning the batch-1 products of {wl} (rotating buffer {args.rotate_mb} MB)", flush=True)
