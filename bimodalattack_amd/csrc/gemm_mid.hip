@@ -11,18 +11,19 @@
 //   * tiles of 224 rows (MF = 7 fragments of 16 per row half: 644 rows = three row tiles, 96 % full) by 64*NF columns,
 //     NF = 3 or 4; one workgroup per CU (the operand rings fill the LDS), 8 waves as 2 (row halves) x 4 (column
 //     quarters), two per SIMD, each with a 112 x 16 NF accumulator tile;
-//   * both operands go L2 -> LDS by `global_load_lds_dwordx4` in 1-KiB pieces of 8 rows x 128 B (whole cache lines: with
-//     64-byte rows a CU took in 19 B/clk, half of what it does with full lines), per operand its own ring of K = 64
-//     units: two slots for x (L2-resident: every column tile re-reads it), three or four for w (HBM);
+//   * both operands go L2 -> LDS by `buffer_load_dwordx4 ... offen lds` in 1-KiB pieces of 8 rows x 128 B (whole cache
+//     lines), per operand its own ring of K = 64 units: two slots for x (L2-resident: every column tile re-reads it),
+//     three for w (HBM).  The descriptor holds the tile's first row, the per-lane offset never changes, the unit of K is
+//     the scalar offset: a piece costs its wave one M0 write and the load (round 6; `global_load_lds` with 64-bit per-lane
+//     addresses before that: k loop 2720 -> 2430 cycles per unit);
 //   * LDS image: 128-byte rows, the 16-byte chunk c of row r stored at position c ^ (r & 7) -- applied to the DMA's SOURCE
-//     address and to the fragment read -- so every `ds_read_b128` of an MFMA fragment is conflict-free (as gemm_nt.hip);
-//   * the k loop runs in PHASES separated by workgroup barriers: a wave alternates a memory phase (fragments of unit u
-//     LDS -> registers, its DMA pieces of a later unit, the counted `s_waitcnt vmcnt` that lands the next one) with a
-//     compute phase (2 MF NF MFMAs, registers only); the two row halves run one phase apart, so on every SIMD one wave
-//     issues MFMAs while the other sits in its loads -- an LDS-DMA piece holds its wave's issue for 60-100 cycles
-//     (MI355X_MICROARCH.md, price list), which at one wave per SIMD came straight out of the MFMA time.  The upper half
-//     issues every x piece, the lower half every w piece: a unit of x is issued two phases, a unit of w three or five
-//     phases before its first read;
+//     offset and to the fragment read -- so every `ds_read_b128` of an MFMA fragment is conflict-free (SQ_LDS_BANK_CONFLICT 0);
+//   * the k loop (round 6): every wave runs the whole unit on its own -- four sub-steps of 16 / 12 MFMAs, the fragments
+//     of sub-step s+1 travelling LDS -> registers while sub-step s multiplies -- with ONE workgroup barrier per unit; the
+//     two waves of a SIMD keep its MFMA pipe fed between them.  (Rounds 4-5 alternated a load phase and an MFMA phase
+//     between the row halves, two barriers per phase; round 6 first cut those phases four times finer.  All three
+//     schedules ran the same product in the same time -- what they shared was the cost of a DMA piece and the chip's
+//     clock under LDS reads: DESIGN.md 5d.)
 //   * workgroup ids are remapped so that an XCD owns a contiguous run of (column tile, row tile) pairs, row tile
 //     fastest: the three row tiles that read the same weight rows and the ~10 column tiles that read the same
 //     activation rows share the XCD's L2, and the weight leaves HBM once;
@@ -33,6 +34,10 @@
 //     reproducible.
 //
 // Algorithmic bytes per launch: (M*K + N*K + M*N) * es; FLOPs 2*M*N*K.
+//
+// Diagnostic builds (never shipped): -DBMA_MID_STAMPS (tools/mid_stamps.py: s_memtime / s_memrealtime stamps of workgroups
+// 0, 100, 200 and the last one, kept in 8 KiB of LDS behind the rings and copied out at the end) and -DBMA_MID_ABLATE=<bits>
+// (tools/mid_ablate.sh: the loop without its DMA pieces / fragment reads / MFMAs -- WRONG results, timing only).
 
 #include <type_traits>
 #ifdef BMA_MID_STAMPS
@@ -56,11 +61,12 @@ constexpr int kBK = 64;           // k per ring unit: 128-byte rows
 constexpr int kRowB = kBK * 2;    // bytes per LDS row (16-bit types only)
 constexpr int kLds = 160 * 1024;
 constexpr int kNA = 2;            // ring slots of x
-constexpr int kStampN = 128;      // diagnostic builds: stamps per wave
-// Timing experiments only (-DBMA_MID_ABLATE=<bits>, WRONG results; tools/mid_ablate.sh): 1 = no DMA pieces inside the loop,
-// 2 = no fragment reads inside the loop, 4 = no MFMAs, 8 = no s_setprio around the MFMAs
+constexpr int kNB = 3;            // ring slots of w
+#ifdef BMA_MID_STAMPS
+constexpr int kStampN = 128;      // stamps per wave
+#endif
 #ifndef BMA_MID_ABLATE
-#define BMA_MID_ABLATE 0
+#define BMA_MID_ABLATE 0          // 1 = no DMA pieces inside the loop, 2 = no fragment reads inside the loop, 4 = no MFMAs
 #endif
 constexpr int kAblate = BMA_MID_ABLATE;
 
@@ -74,10 +80,8 @@ struct MidArgs {
   int t_full;              // tiles [0, t_full) run over all of K; the others are split S ways
   int S;
   int xcd;                 // 1: remap workgroup ids so that an XCD owns a contiguous run of tiles
-  int stamp_units;              // diagnostic builds: 0 = only the loop's start / end stamps (the clock), 1 = per-unit stamps too
-  unsigned long long* stamps;   // diagnostic builds only (-DBMA_MID_STAMPS): clock stamps of workgroups 0, 100 and 200
-  int prio;                // experiments with the arbitration between a SIMD's two waves (flags bits 4-5), see the k loop
-  int stagger;             // workgroup v walks its units of K from unit (v * stagger) % units on, wrapping round
+  int stamp_units;         // diagnostic builds: 0 = only the loop's start / end stamps (the clock), 1 = per-unit stamps too
+  unsigned long long* stamps;
 };
 
 template <int DT>
@@ -100,38 +104,44 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // MF / NF: 16-row fragments of x / of w per wave (tile = 32 MF rows of x by 64 NF rows of w)
-// LOOP: 0 = every wave runs the whole k step on its own (fragments read one sub-step ahead, one barrier per unit);
-//       1 = the two row halves alternate load and MFMA phases between barriers (rounds 4-5; kept for A/B, flags bit 1)
-template <int DT, int MF, int NF, int LOOP>
+template <int DT, int MF, int NF>
 __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
-  constexpr int NB = 3;                                          // ring slots of w
   constexpr int BM = 32 * MF, BN = 64 * NF;
   constexpr int ASZ = BM * kRowB, BSZ = BN * kRowB;              // bytes of a unit of x / of w
   constexpr int PA = BM / 8, PB = BN / 8;                        // 1-KiB pieces (8 rows x 128 B) per unit
   constexpr int CA = (PA + kNW - 1) / kNW, CB = PB / kNW;        // pieces per wave and unit: x 4 (waves 4-7: 3), w 4 or 3
   constexpr int H0 = (MF + 1) / 2, H1 = MF - H0;                 // row fragments of the two halves of a k step
-  static_assert(PB % kNW == 0 && CA <= 4 && CB >= 2 && CB <= 4, "piece schedule");
-  static_assert(kNA * ASZ + NB * BSZ <= kLds, "rings beyond the LDS");
+  static_assert(PB % kNW == 0 && CA == 4 && CB >= 2 && CB <= 4, "piece schedule");
+  static_assert(kNA * ASZ + kNB * BSZ <= kLds, "rings beyond the LDS");
 #ifdef BMA_MID_STAMPS
-  // diagnostic build (tools/mid_stamps.py): 8 KiB behind the rings take kStampN clock stamps per wave, written by lane 0 with
-  // ds_write (counted by lgkmcnt, so the DMA's vmcnt arithmetic is untouched) and copied out when the workgroup is done
-  static_assert(kNA * ASZ + NB * BSZ + 8192 <= kLds, "no room for stamps");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + NB * BSZ + 8192];
-  unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(lds + kNA * ASZ + NB * BSZ);
+  static_assert(kNA * ASZ + kNB * BSZ + 8192 <= kLds, "no room for stamps");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + kNB * BSZ + 8192];
+  unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(lds + kNA * ASZ + kNB * BSZ);
   int stamp_i = 0;
   const int stamp_wg = blockIdx.x == gridDim.x - 1 ? 3 : (blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : (blockIdx.x == 200 ? 2 : -1)));
   if (a.stamps && stamp_wg >= 0 && (threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 122] = __builtin_amdgcn_s_memrealtime();   // kernel entry
+  // lane 0 writes with ds_write (counted by lgkmcnt, so the DMA's vmcnt arithmetic is untouched)
 #define BMA_MID_STAMP()                                                                                         \
   do {                                                                                                          \
     if (stamp_on) {                                                                                             \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
-      if ((threadIdx.x & 63) == 0 && stamp_i < kStampN) stamp_base[(threadIdx.x >> 6) * kStampN + stamp_i] = t_; \
+      if ((threadIdx.x & 63) == 0 && stamp_i < 120) stamp_base[(threadIdx.x >> 6) * kStampN + stamp_i] = t_;    \
       ++stamp_i;                                                                                                \
     }                                                                                                           \
   } while (0)
+#define BMA_MID_COPY_STAMPS()                                                                                   \
+  do {                                                                                                          \
+    if (a.stamps && stamp_wg >= 0) {                                                                            \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the stores have left */                              \
+      if ((threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 123] = __builtin_amdgcn_s_memrealtime(); \
+      __syncthreads();                                                                                          \
+      for (int i_ = threadIdx.x; i_ < kNW * kStampN; i_ += kNW * 64) a.stamps[stamp_wg * kNW * kStampN + i_] = stamp_base[i_]; \
+    }                                                                                                           \
+  } while (0)
 #else
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + NB * BSZ];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kNA * ASZ + kNB * BSZ];
 #define BMA_MID_STAMP() do {} while (0)
+#define BMA_MID_COPY_STAMPS() do {} while (0)
 #endif
   unsigned char* const lds_b = lds + kNA * ASZ;
 
@@ -170,8 +180,6 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   const int m0 = m_tile * BM, n0 = n_tile * BN;
 
   // ---- DMA pieces: piece p of an operand = rows 8p..8p+7 of the tile, dealt to wave p % 8: every wave issues for both ----
-  // `buffer_load_dwordx4 ... offen lds`: the descriptor holds the tile's first row, the per-lane offset (row in the tile x
-  // leading dimension + swizzled chunk) never changes, the unit of K is the scalar offset -- no address arithmetic per piece.
   const int prow = lane >> 3;                                    // row inside the piece == (tile row & 7)
   const int pchunk = (lane & 7) ^ prow;                          // source chunk that lands at LDS position lane & 7
   int vox[CA], vow[CB];
@@ -191,16 +199,18 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       const_cast<char*>(a.x) + static_cast<int64_t>(m0) * a.ldx * 2, 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(a.w) + static_cast<int64_t>(n0) * a.ldw * 2, 0, 0x7fffffff, 0x00020000);
-  // piece i of this wave, unit u -> ring slot; wave-uniform destination, the DMA adds lane*16
-#define BMA_MID_X(i_, u_, slot_)                                                                                         \
-  do {                                                                                                                   \
-    if ((i_) < CA && (kNW * (i_) + kNW <= PA || wave + kNW * (i_) < PA) && !(in_loop && (kAblate & 1)))                                              \
-      dma16(rx, lds + (slot_) * ASZ + (wave + kNW * (i_)) * 1024, vox[(i_) < CA ? (i_) : 0], (u_) * kRowB);                    \
+  bool in_loop = false;
+  // piece i of this wave, unit u -> ring slot; wave-uniform destination, the DMA adds lane*16 (the last x piece exists for
+  // waves 0-3 only: 28 pieces over 8 waves)
+#define BMA_MID_X(i_, u_, slot_)                                                                                \
+  do {                                                                                                          \
+    if ((kNW * (i_) + kNW <= PA || wave + kNW * (i_) < PA) && !(in_loop && (kAblate & 1)))                      \
+      dma16(rx, lds + (slot_) * ASZ + (wave + kNW * (i_)) * 1024, vox[i_], (u_) * kRowB);                       \
   } while (0)
-#define BMA_MID_W(i_, u_, slot_)                                                                                         \
-  do {                                                                                                                   \
-    if ((i_) < CB && !(in_loop && (kAblate & 1)))                                                                        \
-      dma16(rw, lds_b + (slot_) * BSZ + (wave + kNW * (i_)) * 1024, vow[(i_) < CB ? (i_) : 0], (u_) * kRowB);                  \
+#define BMA_MID_W(i_, u_, slot_)                                                                                \
+  do {                                                                                                          \
+    if ((i_) < CB && !(in_loop && (kAblate & 1)))                                                               \
+      dma16(rw, lds_b + (slot_) * BSZ + (wave + kNW * (i_)) * 1024, vow[(i_) < CB ? (i_) : 0], (u_) * kRowB);   \
   } while (0)
 
   f32x4 acc[NF][MF];
@@ -214,26 +224,20 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
   const int foff0 = frow * kRowB + ((fg) ^ (frow & 7)) * 16;          // kk = 0
   const int foff1 = frow * kRowB + ((4 + fg) ^ (frow & 7)) * 16;      // kk = 1
   const int offa = (wr * MF) * 2048, offb = (wc * NF) * 2048;
-
   const int n_units = u1 - u0;
-  bool in_loop = false;
-  // Staggered start (Tensile's StaggerU), per XCD: measured null to negative here (profiles/r6_gemm_mid_stagger.txt); kept as a
-  // sweep knob (flags bits 8-15), off by default.
-  const int start = a.stagger ? static_cast<int>((static_cast<unsigned>(blockIdx.x & 7) * static_cast<unsigned>(a.stagger)) % static_cast<unsigned>(n_units)) : 0;
-  auto unit = [&](int k) {
-    int t = k + start;
-    t = t >= n_units ? t - n_units : t;
-    return u0 + t;
-  };
-  if constexpr (LOOP == 0) {
-    // ---- every wave on its own: MFMAs of sub-step s while the fragments of sub-step s+1 travel LDS -> registers ------------
-    // A unit of K is four sub-steps: (k 0..31, row fragments [0,H0)), (k 0..31, [H0,MF)), (k 32..63, [0,H0)), (k 32..63, [H0,MF)).
-    // ONE barrier per unit, B_k, behind sub-step 2: in front of it every read of unit k has landed in registers (the
-    // fragments of sub-step 3 were asked for a sub-step earlier) and this wave's pieces of unit k+1 have landed in the LDS,
-    // so behind it (a) unit k's slots are free: x of unit k+2 goes out in sub-step 3, w of unit k+2 -- into the slot unit
-    // k-1 left at B_{k-1} -- went out in sub-steps 0 and 1; (b) sub-step 3 reads the first fragments of unit k+1.
-    // vmcnt at B_k: issue order is w(k+1) [unit k-1], x(k+1) [unit k-1, sub-step 3], w(k+2) [unit k]: all but the CB
-    // youngest.  No phase alternation, no priority flips: the two waves of a SIMD keep its MFMA pipe fed between them.
+
+  // ---- the k loop: every wave on its own, MFMAs of sub-step s while the fragments of sub-step s+1 travel LDS -> registers ----
+  // A unit of K is four sub-steps: (k 0..31, row fragments [0,H0)), (k 0..31, [H0,MF)), (k 32..63, [0,H0)), (k 32..63, [H0,MF)).
+  // ONE barrier per unit, B_k, behind sub-step 2: in front of it every read of unit k has landed in registers (the
+  // fragments of sub-step 3 were asked for a sub-step earlier) and this wave's pieces of unit k+1 have landed in the LDS,
+  // so behind it (a) unit k's slots are free: x of unit k+2 goes out in sub-step 3, w of unit k+2 -- into the slot unit
+  // k-1 left at B_{k-1} -- went out in sub-steps 0 and 1; (b) sub-step 3 reads the first fragments of unit k+1.
+  // vmcnt at B_k: issue order is w(k+1) [unit k-1], x(k+1) [unit k-1, sub-step 3], w(k+2) [unit k]: all but the CB
+  // youngest.  Measured (tools/mid_stamps.py, profiles/r6_gemm_mid_stamps.txt): a unit takes 2430 cycles against the 1792
+  // its 2 x 56 MFMAs occupy the SIMD's pipe -- the same 74 % the library's 256 x 256 kernel reaches on a 17k-row product;
+  // vmcnt and lgkmcnt waits are nil; the older wave of a SIMD reaches B_k ~700 cycles before the younger whichever half is
+  // given priority or the DMA issue (the younger one's finish IS the unit).
+  {
     uint4_t wf0[NF], wf1[NF], xfA[H0], xfB[H0];
 #define BMA_MID_RDF(dst_, base_, n_, i0_, foff_)                                                    \
   if (!(kAblate & 2) || !in_loop) _Pragma("unroll") for (int i = 0; i < (n_); ++i)                  \
@@ -243,15 +247,12 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                  \
       if (kAblate & 4) asm volatile("" ::"v"(wf_[j]), "v"(xf_[i]));                                 \
       else acc[j][(i0_) + i] = mfma16<DT>(wf_[j], xf_[i], acc[j][(i0_) + i])
-    {
-      const int ua = unit(0);
-      BMA_MID_X(0, ua, 0); BMA_MID_X(1, ua, 0); BMA_MID_X(2, ua, 0); BMA_MID_X(3, ua, 0);
-      BMA_MID_W(0, ua, 0); BMA_MID_W(1, ua, 0); BMA_MID_W(2, ua, 0); BMA_MID_W(3, ua, 0);
-    }
+    // prologue: x and w of unit 0 land; w and x of unit 1 stay in flight
+    BMA_MID_X(0, u0, 0); BMA_MID_X(1, u0, 0); BMA_MID_X(2, u0, 0); BMA_MID_X(3, u0, 0);
+    BMA_MID_W(0, u0, 0); BMA_MID_W(1, u0, 0); BMA_MID_W(2, u0, 0); BMA_MID_W(3, u0, 0);
     if (n_units > 1) {
-      const int ub = unit(1);
-      BMA_MID_W(0, ub, 1); BMA_MID_W(1, ub, 1); BMA_MID_W(2, ub, 1); BMA_MID_W(3, ub, 1);
-      BMA_MID_X(0, ub, 1); BMA_MID_X(1, ub, 1); BMA_MID_X(2, ub, 1); BMA_MID_X(3, ub, 1);
+      BMA_MID_W(0, u0 + 1, 1); BMA_MID_W(1, u0 + 1, 1); BMA_MID_W(2, u0 + 1, 1); BMA_MID_W(3, u0 + 1, 1);
+      BMA_MID_X(0, u0 + 1, 1); BMA_MID_X(1, u0 + 1, 1); BMA_MID_X(2, u0 + 1, 1); BMA_MID_X(3, u0 + 1, 1);
       if (wave + kNW * 3 < PA) wait_vm<CB + 4>();                // (waves 0-3 issue four x pieces, waves 4-7 three)
       else wait_vm<CB + 3>();
     } else {
@@ -262,18 +263,13 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     BMA_MID_RDF(xfA, lds + offa, H0, 0, foff0);
     int sa = 0, sb = 0;
     in_loop = true;
-    // The two waves of a SIMD (w and w + 4) share its MFMA pipe; the older one wins every tie and reaches B_k ~750 cycles
-    // ahead of the younger (tools/mid_stamps.py).  prio 1: the younger half one level up for good; prio 2: the younger half up
-    // for the first half of a unit, the older for the second.
-    if (a.prio == 1 && wr == 1) __builtin_amdgcn_s_setprio(1);
     auto one_unit = [&](const bool more1, const bool more2, const int k) __attribute__((always_inline)) {
-      const int u2 = more2 ? unit(k + 2) : u0;
-      const int sb1 = sb + 1 == NB ? 0 : sb + 1;                 // w slot of unit k+1
-      const int sw = sb == 0 ? NB - 1 : sb - 1;                  // w slot of unit k-1 == of unit k+2
+      const int u2 = u0 + k + 2;
+      const int sb1 = sb + 1 == kNB ? 0 : sb + 1;                // w slot of unit k+1
+      const int sw = sb == 0 ? kNB - 1 : sb - 1;                 // w slot of unit k-1 == of unit k+2
       const unsigned char* pa = lds + sa * ASZ + offa;
       const unsigned char* pb = lds_b + sb * BSZ + offb;
       // sub-step 0
-      if (a.prio == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
       BMA_MID_RDF(xfB, pa, H1, H0, foff0);
       BMA_MID_RDF(wf1, pb, NF, 0, foff1);
       if (more2) { BMA_MID_W(0, u2, sw); BMA_MID_W(1, u2, sw); }
@@ -283,7 +279,6 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       if (more2) { BMA_MID_W(2, u2, sw); BMA_MID_W(3, u2, sw); }
       BMA_MID_MM(wf0, xfB, H0, H1);
       // sub-step 2, then B_k
-      if (a.prio == 2) { if (wr == 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
       BMA_MID_RDF(xfB, pa, H1, H0, foff1);
       BMA_MID_MM(wf1, xfA, 0, H0);
 #ifdef BMA_MID_STAMPS
@@ -296,7 +291,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       BMA_MID_STAMP();                                           // pieces of unit k+1 landed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      BMA_MID_STAMP();                                           // every fragment read landed (and the MFMAs that wait for them issued)
+      BMA_MID_STAMP();                                           // every fragment read landed
       __builtin_amdgcn_s_barrier();
       BMA_MID_STAMP();                                           // through B_k
       // sub-step 3
@@ -326,101 +321,16 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
 #endif
 #undef BMA_MID_RDF
 #undef BMA_MID_MM
-  } else {
-  uint4_t wf[NF], xf[H0];
-  const unsigned char* pa = lds + offa;
-  const unsigned char* pb = lds_b + offb;
-  // One PHASE = the fragments of half a k step LDS -> registers, this wave's share of the DMA pieces, every read landed,
-  // barrier, the MFMAs on registers only, barrier.  The lower row half runs one barrier behind the upper one.
-#define BMA_MID_RD_W(foff_)                                                                         \
-  if (!(kAblate & 2) || k == 0) _Pragma("unroll") for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const uint4_t*>(pb + j * 2048 + (foff_))
-#define BMA_MID_RD_X(i0_, n_, foff_)                                                                \
-  if (!(kAblate & 2) || k == 0) _Pragma("unroll") for (int i = 0; i < (n_); ++i) xf[i] = *reinterpret_cast<const uint4_t*>(pa + ((i0_) + i) * 2048 + (foff_))
-#define BMA_MID_GO(i0_, n_)                                                                         \
-  do {                                                                                              \
-    BMA_MID_STAMP(); /* reads and pieces issued */                                                  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    BMA_MID_STAMP(); /* reads landed */                                                             \
-    __builtin_amdgcn_s_barrier();                                                                   \
-    BMA_MID_STAMP(); /* through the first barrier */                                                \
-    if (!(kAblate & 8)) __builtin_amdgcn_s_setprio(1);                                              \
-    _Pragma("unroll") for (int i = 0; i < (n_); ++i)                                                \
-      _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
-        if (kAblate & 4) asm volatile("" ::"v"(wf[j]), "v"(xf[i]));                                 \
-        else acc[j][(i0_) + i] = mfma16<DT>(wf[j], xf[i], acc[j][(i0_) + i]);                       \
-    if (!(kAblate & 8)) __builtin_amdgcn_s_setprio(0);                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                              \
-    BMA_MID_STAMP(); /* MFMAs issued */                                                             \
-    __builtin_amdgcn_s_barrier();                                                                   \
-    BMA_MID_STAMP(); /* through the second barrier = the next phase starts */                       \
-  } while (0)
-
-  // ---- prologue: x and w of unit 0 land, w of unit 1 stays in flight ------------------------------------------------------
-  {
-    const int ua = unit(0);
-    BMA_MID_X(0, ua, 0); BMA_MID_X(1, ua, 0); BMA_MID_X(2, ua, 0); BMA_MID_X(3, ua, 0);
-    BMA_MID_W(0, ua, 0); BMA_MID_W(1, ua, 0); BMA_MID_W(2, ua, 0); BMA_MID_W(3, ua, 0);
-  }
-  if (n_units > 1) {
-    const int ub = unit(1);
-    BMA_MID_W(0, ub, 1); BMA_MID_W(1, ub, 1); BMA_MID_W(2, ub, 1); BMA_MID_W(3, ub, 1);
-    wait_vm<CB>();
-  } else {
-    wait_vm<0>();
-  }
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();                     // the lower half: one barrier behind from here on
-
-  int sa = 0, sb = 0;
-  in_loop = true;
-  for (int k = 0; k < n_units; ++k) {
-#ifdef BMA_MID_STAMPS
-    const bool stamp_on = a.stamps && k >= 16 && k < 16 + kStampN / 20 && stamp_wg >= 0;
-#endif
-    const bool more_x = k + 1 < n_units, more_w = k + 2 < n_units;
-    const int ux = more_x ? unit(k + 1) : u0, uw = more_w ? unit(k + 2) : u0;
-    const int sx = sa ^ 1;                                       // slot of x unit k-1: its last read retired before the
-    const int sw = sb == 0 ? NB - 1 : sb - 1;                    // barrier in front of this phase (w: slot of unit k-1, too)
-    pa = lds + sa * ASZ + offa;
-    pb = lds_b + sb * BSZ + offb;
-    // phase 0: k 0..31, row fragments [0, H0)
-    BMA_MID_RD_W(foff0);
-    BMA_MID_RD_X(0, H0, foff0);
-    if (more_x) { BMA_MID_X(0, ux, sx); BMA_MID_X(1, ux, sx); }
-    BMA_MID_GO(0, H0);
-    // phase 1: k 0..31, row fragments [H0, MF)
-    BMA_MID_RD_X(H0, H1, foff0);
-    if (more_x) { BMA_MID_X(2, ux, sx); BMA_MID_X(3, ux, sx); }
-    BMA_MID_GO(H0, H1);
-    // phase 2: k 32..63, row fragments [0, H0)
-    BMA_MID_RD_W(foff1);
-    BMA_MID_RD_X(0, H0, foff1);
-    if (more_w) { BMA_MID_W(0, uw, sw); BMA_MID_W(1, uw, sw); }
-    BMA_MID_GO(0, H0);
-    // phase 3: k 32..63, row fragments [H0, MF); x of unit k+1 and w of unit k+1 land (w of unit k+2 stays in flight:
-    // it was issued behind them), read from the next phase on -- one barrier later for either half
-    BMA_MID_RD_X(H0, H1, foff1);
-    if (more_w) {
-      BMA_MID_W(2, uw, sw); BMA_MID_W(3, uw, sw);
-      wait_vm<CB>();
-    } else {
-      wait_vm<0>();
-    }
-    BMA_MID_GO(H0, H1);
-    sa ^= 1;
-    sb = sb + 1 == NB ? 0 : sb + 1;
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();                     // sits out the lower half's last phase
   }
 #undef BMA_MID_X
 #undef BMA_MID_W
-#undef BMA_MID_RD_W
-#undef BMA_MID_RD_X
-#undef BMA_MID_GO
 #undef BMA_MID_STAMP
 
-// ---- split tiles: the partial leaves in register order; bma_gemm_mid's second launch sums the splits ---------------------
+  // ---- split tiles: the partial leaves in register order; bma_gemm_mid's second launch sums the splits ---------------------
+  // (Round 6 built the alternative -- the S workgroups of a tile reduce-scattering it among themselves inside the one launch,
+  // sc1 stores, a ticket per tile, bit-equal to this form -- and measured it 5-8 us SLOWER per split product: one workgroup
+  // per CU has eight waves to push 224 KB write-through and pull 224 KB back behind a wait for the slowest piece, while the
+  // second launch streams the same bytes from every CU at full occupancy: profiles/r6_gemm_mid_fused_reduce_ab.txt.)
   if (split >= 0) {
     f32x4* out = reinterpret_cast<f32x4*>(a.ws) +
                  ((static_cast<int64_t>(tile - a.t_full) * a.S + split) * kNW + wave) * (NF * MF * 64) + lane;
@@ -428,14 +338,7 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
     for (int j = 0; j < NF; ++j)
 #pragma unroll
       for (int i = 0; i < MF; ++i) out[(j * MF + i) * 64] = acc[j][i];
-#ifdef BMA_MID_STAMPS
-  if (a.stamps && stamp_wg >= 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the epilogue's stores have left
-    if ((threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 123] = __builtin_amdgcn_s_memrealtime();
-    __syncthreads();
-    for (int i = tid; i < kNW * kStampN; i += kNW * 64) a.stamps[stamp_wg * kNW * kStampN + i] = stamp_base[i];
-  }
-#endif
+    BMA_MID_COPY_STAMPS();
     return;
   }
 
@@ -462,15 +365,9 @@ __global__ __launch_bounds__(kNW * 64) void gemm_mid_kernel(MidArgs a) {
       }
     }
   }
-#ifdef BMA_MID_STAMPS
-  if (a.stamps && stamp_wg >= 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the epilogue's stores have left
-    if ((threadIdx.x & 63) == 0) stamp_base[(threadIdx.x >> 6) * kStampN + 123] = __builtin_amdgcn_s_memrealtime();
-    __syncthreads();
-    for (int i = tid; i < kNW * kStampN; i += kNW * 64) a.stamps[stamp_wg * kNW * kStampN + i] = stamp_base[i];
-  }
-#endif
+  BMA_MID_COPY_STAMPS();
 }
+#undef BMA_MID_COPY_STAMPS
 
 // second launch of a split product: one thread per float4 of a split tile, the S partials summed in split order
 template <int DT>
@@ -508,15 +405,13 @@ constexpr int kCUs = 256;
 constexpr int kMaxSplit = 8;
 constexpr int kMF = 7;
 struct MidPlan {
-  int mf, nf, m_tiles, n_tiles, t_full, S, xcd, stagger, loop, prio;
+  int mf, nf, m_tiles, n_tiles, t_full, S, xcd;
 };
 
 int g_nf = 0, g_S = 0, g_tail = -1, g_flags = -1;   // tuning override (bma_gemm_mid_set_plan): 0 / -1 = the planner's choice
 
 // The decomposition, by tile count (measured on the seven products of a LLaVA-7B layer at 644 rows, tools/gemm_bench.py
-// --mid --sweep; profiles/r4_gemm_mid_sweep.txt).  With every CU pulling operands the kernel runs at what L2 delivers into
-// the LDS (~8.5 TB/s chip-wide, measured with the MFMAs compiled out and every line an L2 hit), so the plan that moves the
-// fewest bytes in ONE round of 256 workgroups wins:
+// --mid --sweep; profiles/r4_gemm_mid_sweep.txt): the plan that moves the fewest bytes in ONE round of 256 workgroups wins:
 //   * few tiles (N = 4096: 48 of 224 x 256): K split floor(256 / tiles) ways for every tile;
 //   * up to one round of the wide tile: unsplit, 192-wide tiles when those still fit one round (N = 12288: 192 workgroups
 //     against 144; N = 11008: 174 against 129), the 256-wide tile otherwise;
@@ -553,10 +448,6 @@ bool make_plan(int M, int N, int K, MidPlan& p) {
   p.t_full = S == 1 ? T : (tail > 0 ? T - tail * p.m_tiles : 0);
   const int flags = g_flags >= 0 ? g_flags : 1;
   p.xcd = flags & 1;
-  p.prio = (flags >> 4) & 3;
-  p.loop = (flags >> 1) & 1;                                     // A/B: the alternating-phase loop of rounds 4-5
-  const int sg = (flags >> 8) & 0xff;                            // sweeps: 255 = walk K in step, 1..254 = that stride
-  p.stagger = sg == 0 || sg == 255 ? 0 : sg;
   return true;
 }
 
@@ -604,12 +495,12 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   a.y = static_cast<char*>(y);
   a.ws = static_cast<float*>(ws);
   a.ldx = ldx; a.ldw = ldw; a.ldy = ldy;
-  a.M = M; a.N = N; a.K = K; a.S = p.S; a.t_full = p.t_full; a.m_tiles = p.m_tiles; a.n_tiles = p.n_tiles; a.xcd = p.xcd; a.stagger = p.stagger; a.prio = p.prio;
+  a.M = M; a.N = N; a.K = K; a.S = p.S; a.t_full = p.t_full; a.m_tiles = p.m_tiles; a.n_tiles = p.n_tiles; a.xcd = p.xcd;
   hipStream_t st = static_cast<hipStream_t>(stream);
   a.stamps = nullptr;
   a.stamp_units = 0;
 #ifdef BMA_MID_STAMPS
-  // diagnostic build: BMA_MID_STAMPS_FILE=<file> gets kStampN x u64 per wave of workgroups 0, 100, 200 of every launch
+  // BMA_MID_STAMPS_FILE=<file> gets kStampN x u64 per wave of workgroups 0, 100, 200 and the last one of every launch
   const char* dump = getenv("BMA_MID_STAMPS_FILE");
   a.stamp_units = getenv("BMA_MID_STAMPS_UNITS") ? atoi(getenv("BMA_MID_STAMPS_UNITS")) : 1;
   if (dump && *dump) {
@@ -620,15 +511,10 @@ extern "C" int bma_gemm_mid(const void* x, int64_t ldx, const void* w, int64_t l
   const int n_split_tiles = p.m_tiles * p.n_tiles - p.t_full;
   const dim3 grid(static_cast<unsigned>(p.t_full + n_split_tiles * p.S)), block(kNW * 64), rblock(256);
   BMA_PROF_BEGIN(BMA_K_GEMM_MID, st, 2.0 * (static_cast<double>(M) * K + static_cast<double>(N) * K + static_cast<double>(M) * N));
-#define BMA_MID_GO(DT_)                                                                           \
-  do {                                                                                            \
-    if (p.loop == 0) {                                                                            \
-      if (p.nf == 3) hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 3, 0>), grid, block, 0, st, a); \
-      else hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 4, 0>), grid, block, 0, st, a);           \
-    } else {                                                                                      \
-      if (p.nf == 3) hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 3, 1>), grid, block, 0, st, a); \
-      else hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 4, 1>), grid, block, 0, st, a);           \
-    }                                                                                             \
+#define BMA_MID_GO(DT_)                                                                         \
+  do {                                                                                          \
+    if (p.nf == 3) hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 3>), grid, block, 0, st, a);   \
+    else hipLaunchKernelGGL((gemm_mid_kernel<DT_, kMF, 4>), grid, block, 0, st, a);             \
   } while (0)
   if (dtype == BMA_BF16) BMA_MID_GO(BMA_BF16);
   else BMA_MID_GO(BMA_F16);

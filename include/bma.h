@@ -349,7 +349,8 @@ int bma_causal_attention_bwd_gqa(const void* q, int64_t q_row_stride, int64_t q_
 /* bma_gemm_mid: y[M][N] = x[M][K] . w[N][K]^T for the products of the batch-1 gradient pass when the image is part of the
  *   prompt (a1, :953-1028 with PGD on: 576 image rows + the text = 599-644 rows; the same shapes occur in the prefix
  *   pass of joint candidate scoring, :605-612).  Operands, accumulation, rounding and leading dimensions as for
- *   bma_gemm_nt; K a multiple of 64; any M (row tiles of 224), any N.  Tiles of 224 x {192, 256} on one workgroup per CU;
+ *   bma_gemm_nt; K a multiple of 64; any M (row tiles of 224), any N; a tile's operands within 2 GiB (256 rows x the larger
+ *   leading dimension + K, in bytes: BMA_ELIMIT beyond).  Tiles of 224 x {192, 256} on one workgroup per CU;
  *   the tile width and a split of K -- of every tile, or of the last columns of tiles only -- are chosen so that the
  *   grid fits the 256 CUs (bma_gemm_mid_plan reports them).  Split tiles pass their fp32 partials through `ws`
  *   (bma_gemm_mid_ws_bytes(M,N,K) bytes, 16-byte aligned; may be NULL when that is 0) and a second launch on the same
@@ -357,7 +358,7 @@ int bma_causal_attention_bwd_gqa(const void* q, int64_t q_row_stride, int64_t q_
  * bma_gemm_mid_plan: out8 = {16-row x fragments per wave, row-tile count, 16-row w fragments per wave, column-tile
  *   count, K splits, XCD-contiguous tile order (0/1), workgroups, tiles that run unsplit}.  bma_gemm_mid_set_plan:
  *   measurement only -- pins w fragments per wave / splits / columns of tiles that are split (0, 0, -1 = the planner's
- *   choice; 0 columns = every tile) and the flags (bit 0 XCD order; -1 = default) for every later call in the process;
+ *   choice; 0 columns = every tile) and the flags (bit 0 XCD order; -1 = default; other bits ignored) for every later call in the process;
  *   results never depend on it. */
 size_t bma_gemm_mid_ws_bytes(int M, int N, int K);
 int bma_gemm_mid_plan(int M, int N, int K, int* out8);

@@ -58,10 +58,6 @@ def main():
                     "weight prefetch of bma_gemm_nt_next; per-product figures of the same-shape chains as well")
     ap.add_argument("--mid", action="store_true", help="bma_gemm_mid at a few hundred rows (default --rows 644,599 --layers 16) "
                     "instead of bma_gemm_nt; with --sweep also pinned tile widths / K splits / split tail columns")
-    ap.add_argument("--stagger", default=None, help="with --mid: comma list of staggered-start strides to time (255 = every "
-                    "workgroup walks K from unit 0; bma_gemm_mid_set_plan flags bits 8-15)")
-    ap.add_argument("--flags", default=None, help="with --mid: comma list of bma_gemm_mid_set_plan flag words to time one after "
-                    "the other (bit 0 XCD-contiguous tile order, bit 1 the alternating-phase loop of rounds 4-5)")
     args = ap.parse_args()
     if args.mid:
         return main_mid(args)
@@ -211,18 +207,6 @@ def main_mid(args):
             print(f"{name:11s} M={M:3d} N={N:5d} K={K:5d}: library {l:7.1f} us ({flops / l / 1e6:6.0f} TF/s)   bma_gemm_mid {o:7.1f} us "
                   f"({flops / o / 1e6:6.0f} TF/s = {flops / o / 1e6 / 2500:4.2f} of MFMA peak; tiles 224x{64 * pl[2]} x{pl[3] * pl[1]}, "
                   f"{pl[4]} splits, {pl[6]} workgroups; L2->LDS {l2_bytes / o / 1e6:4.1f} TB/s)   x{l / o:4.2f}{'' if routed else '   (not routed)'}", flush=True)
-            if args.flags:
-                for fl in [int(t) for t in args.flags.split(",")]:
-                    lib.bma_gemm_mid_set_plan(0, 0, -1, fl)
-                    tt = statistics.median(graph_time(own_fn, len(ws)) for _ in range(5))
-                    print(f"      flags {fl:3d}: {tt:7.1f} us ({flops / tt / 1e6:6.0f} TF/s = {flops / tt / 1e6 / 2500:4.2f})", flush=True)
-                lib.bma_gemm_mid_set_plan(0, 0, -1, -1)
-            if args.stagger:
-                for sg in [int(t) for t in args.stagger.split(",")]:
-                    lib.bma_gemm_mid_set_plan(0, 0, -1, 1 | (sg << 8))
-                    tt = statistics.median(graph_time(own_fn, len(ws)) for _ in range(3))
-                    print(f"      staggered start, stride {sg:3d}: {tt:7.1f} us ({flops / tt / 1e6:6.0f} TF/s = {flops / tt / 1e6 / 2500:4.2f})", flush=True)
-                lib.bma_gemm_mid_set_plan(0, 0, -1, -1)
             if args.sweep:
                 for nf, S_, tail in ((3, 1, 0), (4, 1, 0), (3, 3, 0), (4, 3, 0), (4, 4, 0), (4, 5, 0), (4, 6, 0), (4, 8, 1), (4, 4, 1), (4, 8, 2)):
                     lib.bma_gemm_mid_set_plan(nf, S_, tail, -1)

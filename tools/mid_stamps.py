@@ -3,14 +3,14 @@
 "In-kernel stamps").
 
     make -C bimodalattack_amd/csrc OUTDIR=$PWD/bimodalattack_amd/lib_diag EXTRA=-DBMA_MID_STAMPS
-    python tools/mid_stamps.py [--rows 644] [--n 22016] [--k 4096] [--flags 1|3]
+    python tools/mid_stamps.py [--rows 644] [--n 22016] [--k 4096]
 
-flags 1 (the shipped loop: every wave on its own, one barrier B_k per unit): four stamps per unit -- sub-steps 0-2 issued /
-this wave's DMA pieces of unit k+1 landed (vmcnt) / every fragment read landed (lgkmcnt 0) / through B_k.  Printed per wave,
-averaged over 30 units of the middle of the loop of workgroups 0, 100 and 200, in shader cycles: the unit, then
-[issue of sub-step 3 + 0-2 of the next unit | vmcnt wait | lgkmcnt wait | barrier].
-flags 3 (the alternating-phase loop of rounds 4-5): five stamps per phase, four phases per unit -- issue / read wait /
-barrier 1 / MFMAs / barrier 2.  The stamps themselves cost ~100 cycles each.
+First the loop's own clock and the launch's anatomy (one launch with a start and an end stamp per wave only): shader cycles
+against the 100 MHz counter over the k loop; when each of workgroups 0 / 100 / 200 and the LAST one (a second-round split
+piece when the grid overflows the chip) entered, how long its prologue, k loop and epilogue took, when it left.  Then four
+stamps per unit -- sub-steps 0-2 issued / this wave's DMA pieces of unit k+1 landed (vmcnt) / every fragment read landed
+(lgkmcnt 0) / through B_k -- printed per wave, averaged over 30 units of the middle of the loop, in shader cycles: the unit,
+then [issue of sub-step 3 + 0-2 of the next unit | vmcnt wait | lgkmcnt wait | barrier].  A stamp costs ~100 cycles.
 """
 import argparse
 import os
@@ -83,10 +83,7 @@ def main():
     torch.cuda.synchronize()
     print(f"M={args.rows} N={args.n} K={args.k} flags={args.flags}: {1e2 * e0.elapsed_time(e1):.1f} us per launch (stamped build, stamps off in these)")
     a = np.fromfile(args.out, dtype=np.uint64).astype(np.int64).reshape(4, 8, 128)[:3]
-    if args.flags & 2:
-        names, per_unit, units = ["issue", "read wait", "barrier 1", "MFMAs", "barrier 2"], 20, 6
-    else:
-        names, per_unit, units = ["issue", "vmcnt", "lgkmcnt", "barrier"], 4, 30
+    names, per_unit, units = ["issue", "vmcnt", "lgkmcnt", "barrier"], 4, 30
     ns = len(names)
     for wg in range(3):
         if a[wg].max() == 0:
