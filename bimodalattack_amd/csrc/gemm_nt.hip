@@ -244,6 +244,11 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
   }
 
   // ---- split-K: publish the partial, the last arriver of a tile sums them in split order ---------------------------
+  // (Round 6 built the alternative VERDICT r5 asked for -- a REDUCE-SCATTER among the tile's S resident workgroups, everybody
+  // waiting on the tile's ticket and then summing every S-th fragment -- bit-equal to this form, and measured it 4-13 us SLOWER
+  // on every split product of the pass (profiles/r6_gemm_nt_reduce_scatter_ab.txt: qkv dX 35.7 against 27.5 us at 65 rows):
+  // waiting costs every workgroup an agent-scope poll that has to go past its XCD's L2 -- ~2 us a round trip under load -- where
+  // the last arriver pays one ticket add; reading 1/S of the tile each does not win that back.  Reverted.)
   if (a.S > 1) {
     f32x4* wsv = reinterpret_cast<f32x4*>(a.ws);
     const int64_t per = static_cast<int64_t>(kNW) * NTW * MT * 64;        // float4 per (tile, split)
@@ -274,47 +279,44 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
     if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();                                            // (also: every wave is done with the stage ring)
     int* flag = reinterpret_cast<int*>(lds);
-    if (tid == 0) {
-      const int ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int last = ticket == a.S - 1;
-      if (last) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-      *flag = last;
-    }
-    __syncthreads();
-    if (*flag == 0) {
-      if (a.nw) prefetch_next(a, blockIdx.x, gridDim.x);
-      return;
-    }
-    if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // Every partial -- this workgroup's own too -- is read back in split order, by sc1 loads (buffer_load_dwordx4 ... sc1:
-    // past this CU's L1, which may hold stale lines of the workspace from an earlier launch) INSTEAD of an agent-scope
-    // acquire in front of plain loads: valid because every byte was stored sc1, every storing wave drained before its
-    // workgroup's barrier and ticket add, the reducer learnt it is last from the value its own add returned, and its
-    // other waves load behind the barrier above (MI355X_MICROARCH.md, visibility: the hand-off table's third row);
-    // one workgroup per CU (the ring fills the LDS).  All loads of a split are independent (a per-element "own registers
-    // or load" select would serialise them behind one wait each).  What remains of the tail -- ~6 us -- is a latency
-    // chain (ticket round trip, barrier, read rounds, stores) and the arrival skew: issuing four splits' loads together,
-    // and leaving out the x tiles without a real row, were each measured in round 4 and moved nothing.
-    typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(a.ws) + (static_cast<int64_t>(tile) * a.S * per + static_cast<int64_t>(wave) * NTW * MT * 64) * 16, 0,
         static_cast<int>(a.S * per * 16), 0x00020000);
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < a.S; ++s) {
-      f32x4 v[NTW][MT];
-      const int so = static_cast<int>(static_cast<int64_t>(s) * per * 16);
+    {
+      if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = ticket == a.S - 1;
+        if (last) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        *flag = last;
+      }
+      __syncthreads();
+      if (*flag == 0) {
+        if (a.nw) prefetch_next(a, blockIdx.x, gridDim.x);
+        return;
+      }
+      if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // The last arriver reads every partial -- its own too -- back in split order, by sc1 loads (buffer_load_dwordx4 ... sc1:
+      // past this CU's L1, which may hold stale lines of the workspace from an earlier launch) INSTEAD of an agent-scope
+      // acquire in front of plain loads: valid because every byte was stored sc1, every storing wave drained before its
+      // workgroup's barrier and ticket add, the reducer learnt it is last from the value its own add returned, and its
+      // other waves load behind the barrier above (MI355X_MICROARCH.md, visibility: the hand-off table's third row).
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          v[j][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16 + (j * MT + m) * 1024, so, 16));
+        for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      for (int s = 0; s < a.S; ++s) {
+        f32x4 v[NTW][MT];
+        const int so = static_cast<int>(static_cast<int64_t>(s) * per * 16);
 #pragma unroll
-      for (int j = 0; j < NTW; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[j][m] += v[j][m];
+          for (int m = 0; m < MT; ++m)
+            v[j][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16 + (j * MT + m) * 1024, so, 16));
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[j][m] += v[j][m];
+      }
     }
   }
 
@@ -346,15 +348,17 @@ __global__ __launch_bounds__(kNW * 64) void gemm_nt_kernel(GemmArgs a) {
 
 constexpr int kMaxSplit = 16;
 
-// compute units of the device the process runs on (256 on an MI355X; asked once -- the planner fills whole rounds of them)
+// compute units of the device CURRENT on the calling thread (256 on an MI355X; the planner fills whole rounds of them), asked
+// once per device id (one function-local static served every device and thread -- a partitioned node's 32-CU
+// devices would have been planned for 256).  Plain ints written once with the same value: a race here is harmless.
 int cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
-  return n;
+  static int cached[64] = {0};
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < 64 && cached[dev]) return cached[dev];
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  if (dev >= 0 && dev < 64) cached[dev] = v;
+  return v;
 }
 
 struct Plan {

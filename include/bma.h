@@ -289,7 +289,8 @@ int bma_allgather_f32(const float* local, int64_t n_local, float* out, int rank,
  *   default; bit 3: the split-K hand-off with an agent-scope release / acquire fence pair on top of the write-through
  *   stores -- the form the HIP memory model asks for, ~2 us per split launch slower; the default relies on gfx942 /
  *   gfx950 cache behaviour) for every later call in the process; results never depend on it.  Process-global and not
- *   synchronised: not to be called while another thread sizes or launches a product.
+ *   synchronised: not to be called while another thread sizes or launches a product -- nor once hipGraphs that hold
+ *   bma_gemm_nt_next launches exist (they baked the next launch's plan in at capture time).
  * bma_gemm_nt_next: bma_gemm_nt that also knows the NEXT product of the caller's chain -- its weight next_w [next_N][next_ldw]
  *   (next_K columns used), applied to the same M rows (the gradient pass walks qkv -> gate/up -> down -> the next layer's
  *   qkv, and the transposed copies in reverse, bimodal_attack.py:1003, :1016-1025; weights do not depend on activations).
