@@ -1242,7 +1242,8 @@ class BimodalAttack:
                 st: Optional[dict] = {} if trace is not None else None
                 if st is not None:
                     trace.append(st)
-                    st.update(optim_ids_in=optim_ids.cpu().numpy(), n_grad=0, grad_tok=[], grad_img=[], losses=[])
+                    st.update(optim_ids_in=optim_ids.cpu().numpy(), n_grad=0, grad_tok=[], grad_img=[], losses=[],
+                              collectives=self.shard.n_collectives)     # (data-path collectives issued so far: tests)
 
                 # ---- phase A: gradients --------------------------------------------------
                 def note(g):
@@ -1549,6 +1550,8 @@ class BimodalAttack:
                 t_total.append(grad_time + samp_time + pgd_time + loss_time)
             if hook is not None:
                 hook(n_done)
+            if trace:
+                trace[-1]["collectives_end"] = self.shard.n_collectives
         finally:
             if writer is not None:
                 writer.close()

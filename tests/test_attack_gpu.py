@@ -639,6 +639,58 @@ def test_sharded_engine_two_ranks_equal_single(golden_dir, name):
     assert got[0][1] == got[1][1] and got[0][2] == got[1][2]          # ranks agree bit for bit
 
 
+def _collectives_worker(rank, world, port, name, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        m, res, trace, tmp = run_case(name)
+        out.put((rank, [st["collectives"] for st in trace] + [trace[-1]["collectives_end"]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,per_step", [
+    # GCG-only: rank 0's sampled ids in one broadcast + one gather of the losses (the early-stop hits ride in it) + the NEXT
+    # step's random draws, made ahead of the gradient pass (early_plan: not behind the last step of the schedule)
+    ("llava_gcg", [3, 3, 3, 2]), ("llava_gcg_early", [3, 3, 3, 3, 3]),
+    # joint: ids + PGD image in ONE packed broadcast, the gather, the early draws
+    ("llava_joint", [3, 3, 2]), ("llava_joint_early", [3, 3, 3]),
+    # Gemma-3 (suffix in front of the image: padded blocks, nothing is planned ahead): the two and nothing else
+    ("gemma3_joint", [2, 2, 2]),
+    # PGD+GCG, candidates scored without the image: the image goes out on its own in front of the second gradient pass (which
+    # caches what it derives from the image by tensor identity), then the ids, then the gather
+    ("llava_pgd_gcg", [3, 3, 3]),
+    # PGD-only: the image, nothing to gather
+    ("llava_pgd", [1, 1, 1, 1]),
+])
+def test_sharded_engine_issues_exactly_its_collectives_per_step(name, per_step):
+    """at world 2 (gloo, both ranks on the one GPU) every mode issues EXACTLY the data-path collectives
+    DESIGN.md 8 lists -- two per step (one packed broadcast of rank 0's state, one all-gather of the losses) plus the early
+    draws' broadcast where the engine plans ahead -- counted by dist.CandidateSharder.n_collectives at every step's start;
+    one more in front of the loop (the initial suffix's loss).  A collective that crept into the step loop would scale with
+    the 8-GPU run's 600 steps; this holds the count."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_collectives_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, counts in got:
+        assert counts[0] == 1, (rank, counts)                              # the initial suffix's loss gather (image broadcast for PGD-only)
+        assert [b - a for a, b in zip(counts[:-1], counts[1:])] == per_step, (rank, counts)
+
+
 # Ranks of the many-rank rehearsal.  The driver's node has 8; a GPU box of this pool lets at most 6 processes use its one
 # card at a time and the test runner is one of them, so the rehearsal runs 4 ranks on a width that decays BELOW 4: the
 # same code paths as 8 ranks on a width decayed to 8 and thinned by the filter (VERDICT r4 item 2b) -- `per` = 1, empty
@@ -1495,6 +1547,41 @@ def test_gemma3_4b_joint_steps_finite(width):
         eager = atk.image_features(final)
     assert bool(torch.isfinite(replayed.float()).all()) and torch.equal(replayed, eager)
     assert len(set(atk.n_scored)) > 1                      # the width did change from step to step
+
+
+def test_gemma3_4b_joint_first_40_steps_of_the_600_step_schedule_hold_their_pace():
+    """BASELINE configs[4] changes its search width ~385 times over its 600 steps (reference :919-923) --
+    new GEMM row counts, new ragged grids, the library's first-sight cost of an unseen shape.  The first 40 CONSECUTIVE steps
+    of the real schedule (widths 512 -> 478, a new width every step or two), timed by the host clock at the engine's step
+    hook (one packed read-back per step: consecutive hooks are a step apart): no step from the third on may take more than
+    1.3 x the median (the widths themselves differ by 7 %), every loss finite, nothing fell back.  The whole 600 steps are in
+    profiles/r6_full_gemma600.json (tools/full_length.py): ms = 64.7 + 1.687 x width, no step over 1.15 x that line."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_plugins
+    from bimodalattack_amd import BimodalAttackConfig
+    from bimodalattack_amd.attack import BimodalAttack
+    from bimodalattack_amd.config import EngineOptions
+    from bimodalattack_amd.layout import dynamic_width
+
+    dev = torch.device(DEV)
+    model, tok, proc, messages, goal, target, image, norm = build_plugins("gemma_joint", dev, torch.bfloat16, 34)
+    steps = 40
+    sched = lambda i: dynamic_width(i, 512, 600, 128, True)             # noqa: E731  (the 600-step run's own widths)
+    stamps = []
+    cfg = BimodalAttackConfig(num_steps=steps, search_width=512, topk=256, seed=1, verbosity="ERROR", pgd_attack=True,
+                              gcg_attack=True, joint_eval=True, eps=64 / 255, alpha=4 / 255, dynamic_search=True,
+                              min_search_width=128, images_folder=tempfile.mkdtemp())
+    atk = BimodalAttack(model, tok, proc, cfg, norm, EngineOptions.from_env(save_images=False, strict=True, width_override=sched,
+                                                                            step_hook=lambda i: stamps.append(time.perf_counter())))
+    res = atk.run(messages, goal, target, image.detach().clone())
+    assert len(res.losses) == steps and all(np.isfinite(res.losses)) and not atk.fallbacks
+    ms = [1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:])]
+    assert len(ms) == steps and len(set(atk.n_scored)) >= 15           # (the width did change: 512 ... 478 less what the filter took)
+    med = float(np.median(ms[2:]))
+    worst = max(range(2, steps), key=lambda i: ms[i])
+    assert ms[worst] <= 1.3 * med, (worst, ms[worst], med, [round(v, 1) for v in ms])
 
 
 def test_gemma3_4b_scoring_equals_reference_call_shape():
