@@ -569,6 +569,8 @@ def build_line(out: dict, detail_file=None) -> dict:
         if isinstance(line["rccl"].get("tp_fallbacks"), dict):
             line["rccl"]["tp_fallbacks"] = {k: str(v)[:100] for k, v in line["rccl"]["tp_fallbacks"].items()}
         line["rccl"]["devices"] = len(rc.get("device_names") or [])
+    if out.get("scaling_table"):
+        line["scaling_table"] = out["scaling_table"]
     eng = out.get("engine") or {}
     line["engine"] = {"fallbacks": eng.get("fallbacks"), "graphs": len(eng.get("graphs_captured") or []),
                       "tuned_gemms": eng.get("tuned_gemms"), "collectives": eng.get("collectives")}
@@ -1060,6 +1062,30 @@ def tp_ab(args, out: dict, device, world: int, rank: int) -> None:
         done.set()
 
 
+def scaling_table(dist, out: dict, solo, world: int) -> dict:
+    """north_star's table for THIS N, from this run alone: steps/s and candidate forwards/s on N GPUs, the same job on ONE of
+    these GPUs (the run's own N = 1 leg: every rank ran it by itself, rank 0's is quoted, all are listed), the efficiency
+    value_N / (N x value_1), and every rank's dominant-kernel roofline fraction.  (The driver computes its own efficiency
+    from separate N = 1 / 2 / 4 / 8 runs; this one needs no post-processing and no second box.)  Every rank calls it."""
+    r = out.get("roofline") or {}
+    mine = dict(frac=r.get("frac"), solo=None if not solo or "error" in solo else solo.get("candidate_forwards_per_sec"))
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, mine)
+    t = dict(n_gpus=world, attack_steps_per_sec=out.get("attack_steps_per_sec"), candidate_forwards_per_sec=out.get("value"),
+             ms_per_step=out.get("ms_per_step"), own_n1_leg=solo,
+             own_n1_leg_candidate_forwards_per_sec_per_rank=[p_["solo"] for p_ in per_rank],
+             efficiency_vs_own_n1=None,
+             dominant_kernel=dict(kernel=str(r.get("kernel"))[:90], bound=r.get("bound"), unit=r.get("unit"), peak=r.get("peak"),
+                                  frac_per_rank=[p_["frac"] for p_ in per_rank]),
+             gradient_pass=(out.get("config") or {}).get("gradient_pass", "replicated on every rank"))
+    if solo and "error" not in solo and solo.get("candidate_forwards_per_sec") and out.get("value"):
+        if solo["candidate_forwards_per_sec"] > 0:
+            t["efficiency_vs_own_n1"] = out["value"] / (world * solo["candidate_forwards_per_sec"])
+        elif solo.get("attack_steps_per_sec"):
+            t["efficiency_vs_own_n1"] = out["attack_steps_per_sec"] / (world * solo["attack_steps_per_sec"])
+    return t
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1128,11 +1154,25 @@ def main() -> None:
     native.check_single_hip_runtime()
 
     n_prof = max(0, args.profile_steps)
+    solo = None
+    if world > 1 and os.environ.get("BMA_BENCH_N1_LEG", "1") not in ("0", "false", "False"):
+        # The run's OWN one-GPU leg: every rank runs the whole job by itself (EngineOptions.shard=False: no collectives), a few
+        # steps, before the sharded legs -- what `scaling_table.efficiency_vs_own_n1` divides by (same box, same build, same clock
+        # state as the N-GPU legs; the driver's separate N = 1 run is another box hours apart).
+        try:
+            s1, _ = measure(args, args.workload, min(args.steps, 5), 2, 0, device, 1, 0, primary=True,
+                            engine_kw=dict(shard=False, tp_gradient=False))
+            solo = dict(ms_per_step=s1["ms_per_step"], candidate_forwards_per_sec=s1["value"], attack_steps_per_sec=s1["attack_steps_per_sec"],
+                        steps=s1["steps"], finite=s1["finite"])
+        except Exception as e:
+            solo = dict(error=f"{type(e).__name__}: {e}"[:200])
+            torch.cuda.synchronize(device)
     out, keep = measure(args, args.workload, args.steps, args.warmup, n_prof, device, world, rank, primary=True,
                         engine_kw=dict(tp_gradient=False) if world > 1 else None)
     if world > 1:
         out["rccl"] = rccl_info(torch, dist, device, world, keep)
         tp_ab(args, out, device, world, rank)
+        out["scaling_table"] = scaling_table(dist, out, solo, world)
 
     # ---- the other single-GPU BASELINE configurations, on the same models, under `workloads` ----------
     if args.extra_workloads is None:

@@ -209,6 +209,14 @@ class _PngWriter:
             raise self.err
 
 
+def _transformers_version() -> str:
+    try:
+        import transformers
+        return f"transformers {transformers.__version__}"
+    except Exception:
+        return "transformers ?"
+
+
 class BimodalAttack:
     def __init__(self, model, tokenizer, processor, config: BimodalAttackConfig, normalize=None,
                  options: Optional[EngineOptions] = None):
@@ -224,7 +232,7 @@ class BimodalAttack:
         self.not_allowed_ids = None if config.allow_non_ascii else get_nonascii_toks(tokenizer, device=model.device)
         self.mask_bits = ops.build_mask_bits(self.not_allowed_ids, self.embedding_layer.num_embeddings, model.device)
         self.stop_flag = False
-        self.shard = CandidateSharder()
+        self.shard = CandidateSharder(enabled=self.opt.shard)
         self.emulate_world = EMULATE_WORLD             # (tools: rank 0's share of an N-rank run in one process)
         self.score_log: Optional[list] = None          # debugging aid (tools/nan_bisect.py): one dict per scoring call when set to a list
         self._chunk_cap: Optional[int] = None      # what an OOM taught us; kept across steps
@@ -264,6 +272,16 @@ class BimodalAttack:
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
         self.hf.fused = self.fused
         logger.info(f"Fused forward admitted: {self.fused.admitted}; refused: {self.fused.refused}")
+        # A fast path refused because the installed transformers' SOURCE no longer reads like what it was checked against (or is
+        # not available) costs speed silently -- results are unchanged, strict=False keeps running: say so once, at WARNING
+        # (VERDICT r5 item 14).  Refusals the model's own architecture explains (a bias, grouped heads, fp32) stay at INFO.
+        drift = {k: v for k, v in self.fused.refused.items()
+                 if any(t in str(v) for t in ("source not available", "statement for statement", "with nothing else touching",
+                                              "not one this module patches", "not a modelling file"))}
+        if drift:
+            logger.warning(f"bimodalattack_amd: {len(drift)} fast path(s) NOT admitted on this model because the installed transformers "
+                           f"({_transformers_version()}) does not read like the versions they were checked against -- the attack runs "
+                           f"on the slower HuggingFace route for them, results unchanged: {drift}")
         if hasattr(model.config, "model_type"):
             logger.info(f"Model type: {model.config.model_type}")
         if model.dtype in (torch.float32, torch.float64):

@@ -158,6 +158,9 @@ class EngineOptions:
     warm_gemms: bool = True
     # Candidates per forward chunk; None = size analytically from free HBM.
     chunk: Optional[int] = None
+    # Several ranks (torch.distributed initialised): None = shard the candidates over them; False = every rank runs the whole
+    # job on its own, no collectives (bench.py's own one-GPU leg inside an N-GPU run: what N GPUs are measured against).
+    shard: Optional[bool] = None
     # Measurement only: the candidate count of loop step i (bench.py samples the dynamic-width schedule of a 600-step run,
     # reference :919-923, at evenly spaced points of a handful of timed steps).  None: the reference's schedule.
     width_override: object = None

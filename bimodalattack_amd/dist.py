@@ -31,8 +31,9 @@ import torch.distributed as dist
 
 
 class CandidateSharder:
-    def __init__(self, group=None):
-        self.enabled = dist.is_available() and dist.is_initialized()
+    def __init__(self, group=None, enabled: Optional[bool] = None):
+        """`enabled=False`: a sharder of one (world 1, rank 0, no collectives) whatever torch.distributed says."""
+        self.enabled = dist.is_available() and dist.is_initialized() and enabled is not False
         self.group = group
         if self.enabled:
             self.world = dist.get_world_size(group)

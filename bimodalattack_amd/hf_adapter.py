@@ -97,27 +97,56 @@ FUSE_TOWER_LAYERNORM = _os.environ.get("BMA_FUSE_TOWER_LAYERNORM", "1") not in _
 KEEP_ROWS_EARLY = _os.environ.get("BMA_KEEP_ROWS_EARLY", "1") not in _OFF
 
 # modeling_clip.CLIPEncoderLayer.forward (and modeling_siglip.SiglipEncoderLayer.forward), statement for statement (every line that touches `self.`, `residual` or returns)
-_CLIP_LAYER_BODY = ["self,", "residual = hidden_states", "hidden_states = self.layer_norm1(hidden_states)",
-                    "hidden_states, _ = self.self_attn(", "hidden_states = residual + hidden_states", "residual = hidden_states",
-                    "hidden_states = self.layer_norm2(hidden_states)", "hidden_states = self.mlp(hidden_states)",
-                    "hidden_states = residual + hidden_states", "return hidden_states"]
+# The pre-LN encoder block the fused tower forward restates (CLIPEncoderLayer / SiglipEncoderLayer.forward of the transformers
+# this was written against), as source: admitted layers must parse to the SAME tree -- every statement, the keyword list of
+# the attention call included -- under the signature (self, hidden_states, attention_mask, **kwargs).
+_CLIP_LAYER_SOURCE = """
+def forward(self, hidden_states, attention_mask, **kwargs):
+    residual = hidden_states
+    hidden_states = self.layer_norm1(hidden_states)
+    hidden_states, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, **kwargs)
+    hidden_states = residual + hidden_states
+    residual = hidden_states
+    hidden_states = self.layer_norm2(hidden_states)
+    hidden_states = self.mlp(hidden_states)
+    hidden_states = residual + hidden_states
+    return hidden_states
+"""
+
+
+def _forward_shape(src: str):
+    """(argument names incl. *args / **kwargs markers, ast.dump of every body statement without the docstring) of the one
+    function definition in `src`; None when it does not parse to one."""
+    import ast
+    import textwrap
+    try:
+        tree = ast.parse(textwrap.dedent(src))
+    except SyntaxError:
+        return None
+    if len(tree.body) != 1 or not isinstance(tree.body[0], ast.FunctionDef):
+        return None
+    fn = tree.body[0]
+    a = fn.args
+    names = [x.arg for x in a.posonlyargs + a.args] + (["*" + a.vararg.arg] if a.vararg else []) + \
+            [x.arg for x in a.kwonlyargs] + (["**" + a.kwarg.arg] if a.kwarg else [])
+    body = fn.body
+    if body and isinstance(body[0], ast.Expr) and isinstance(getattr(body[0], "value", None), ast.Constant) and isinstance(body[0].value.value, str):
+        body = body[1:]
+    return names, [ast.dump(st) for st in body]
+
+
+_CLIP_LAYER_SHAPE = _forward_shape(_CLIP_LAYER_SOURCE)
 
 
 def _clip_layer_ok(layer) -> bool:
-    """Is this encoder layer's forward, statement for statement, the pre-LN block the fused forward restates (read from its
-    source), with plain affine nn.LayerNorm norms?"""
+    """Is this encoder layer's forward, statement for statement AND argument for argument, the pre-LN block the fused forward
+    restates -- compared as syntax trees (a line filter let another keyword of the attention call through, and the
+    restated forward would have dropped it silently) -- with plain affine nn.LayerNorm norms?"""
     try:
         src = inspect.getsource(type(layer).forward)
     except (OSError, TypeError):
         return False
-    lines = []
-    for ln in src.splitlines():
-        t = ln.strip()
-        if not t or t.startswith("#") or t.startswith("def ") or t.startswith("@"):
-            continue
-        if "self." in t or t == "self," or t.startswith("residual") or t.startswith("return") or "residual +" in t:
-            lines.append(t)
-    if lines != _CLIP_LAYER_BODY:
+    if _forward_shape(src) != _CLIP_LAYER_SHAPE:
         return False
     for n in ("layer_norm1", "layer_norm2"):
         m = getattr(layer, n, None)

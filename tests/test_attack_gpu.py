@@ -832,6 +832,16 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
         assert d["engine"]["collectives"] == 1 + 2 * (1 + 2 + 1) + 3
     assert not d["engine"]["fallbacks"]
     assert d["roofline"]["bound"] in ("mfma", "hbm") and d["value"] > 0
+    # north_star's table for this N without post-processing: steps/s and candidates/s on N GPUs, the run's
+    # OWN one-GPU leg (every rank ran the whole job by itself, no collectives), the efficiency against it, the dominant
+    # kernel's roofline fraction on every rank
+    t = d["scaling_table"]
+    assert t["n_gpus"] == 2 and t["candidate_forwards_per_sec"] == pytest.approx(d["value"]) and t["attack_steps_per_sec"] > 0
+    n1 = t["own_n1_leg"]
+    assert n1["finite"] is True and n1["candidate_forwards_per_sec"] > 0 and n1["steps"] == 2
+    assert len(t["own_n1_leg_candidate_forwards_per_sec_per_rank"]) == 2 and all(v > 0 for v in t["own_n1_leg_candidate_forwards_per_sec_per_rank"])
+    assert t["efficiency_vs_own_n1"] == pytest.approx(d["value"] / (2 * n1["candidate_forwards_per_sec"]), rel=1e-3)
+    assert len(t["dominant_kernel"]["frac_per_rank"]) == 2 and all(f is not None and f > 0 for f in t["dominant_kernel"]["frac_per_rank"])
 
 
 def test_bench_prints_the_first_leg_when_the_tensor_parallel_leg_does_not_return():

@@ -452,6 +452,46 @@ def test_image_features_across_transformers_return_types():
         assert hf.emb_scale == 1.0 and hf.has_logits_to_keep and hf.projector_norms() == []
 
 
+def test_tower_layer_admission_compares_syntax_trees():
+    """the vision tower's fused add + LayerNorm forward is admitted by comparing the encoder layer's forward as a
+    SYNTAX TREE -- signature (self, hidden_states, attention_mask, **kwargs) and every statement, the attention call's keyword
+    list included -- not by filtering lines: the installed CLIP / SigLIP layers pass; the same block with one more keyword in
+    the attention call, another signature or a statement more is refused (the restated forward would drop it silently)."""
+    import torch
+    from transformers import CLIPVisionConfig, SiglipVisionConfig
+    from transformers.models.clip.modeling_clip import CLIPEncoderLayer
+    from transformers.models.siglip.modeling_siglip import SiglipEncoderLayer
+    from bimodalattack_amd.hf_adapter import _clip_layer_ok, _forward_shape, _CLIP_LAYER_SHAPE
+    kw = dict(hidden_size=32, intermediate_size=64, num_attention_heads=2, num_hidden_layers=1)
+    assert _clip_layer_ok(CLIPEncoderLayer(CLIPVisionConfig(**kw))) and _clip_layer_ok(SiglipEncoderLayer(SiglipVisionConfig(**kw)))
+    good = """
+def forward(self, hidden_states: "T", attention_mask: "T", **kwargs) -> "T":
+    \"\"\"a docstring and annotations do not matter\"\"\"
+    residual = hidden_states
+
+    hidden_states = self.layer_norm1(hidden_states)
+    hidden_states, _ = self.self_attn(
+        hidden_states=hidden_states,
+        attention_mask=attention_mask,
+        **kwargs,
+    )
+    hidden_states = residual + hidden_states
+    residual = hidden_states
+    hidden_states = self.layer_norm2(hidden_states)
+    hidden_states = self.mlp(hidden_states)
+    hidden_states = residual + hidden_states
+    return hidden_states
+"""
+    assert _forward_shape(good) == _CLIP_LAYER_SHAPE
+    for old, new_ in (("attention_mask=attention_mask,", "attention_mask=attention_mask, causal_attention_mask=None,"),   # one more keyword
+                      ("**kwargs) ->", "output_attentions=False, **kwargs) ->"),                                            # another signature
+                      ("    return hidden_states", "    hidden_states = hidden_states * 1.0\n    return hidden_states"),  # a statement more
+                      ("self.layer_norm2(hidden_states)", "self.layer_norm2(residual)")):                                   # another operand
+        bad = good.replace(old, new_)
+        assert bad != good and _forward_shape(bad) != _CLIP_LAYER_SHAPE, old
+    assert _forward_shape("x = (") is None and _forward_shape("a = 1\nb = 2") is None
+
+
 def test_fused_structure_detection_steps_aside_on_4_50_style_layers():
     """transformers 4.50.2's decoder layers return a TUPLE and unpack ``hidden_states, self_attn_weights = self.self_attn(``;
     the fused layer forward restates 5.x's statements and returns a tensor, so on such a layer it must NOT be installed
