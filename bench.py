@@ -609,7 +609,7 @@ def committed_profile(name: str):
     """A committed measurement file under profiles/ (the newest round that has one), parsed; (None, None) when absent."""
     if name not in _PMC:
         hit = (None, None)
-        for tag in ("r5", "r4", "r3", "r2"):
+        for tag in ("r6", "r5", "r4"):
             path = os.path.join(REPO, "profiles", f"{tag}_{name}")
             try:
                 with open(path) as f:
@@ -831,7 +831,7 @@ def measure(args, workload: str, steps: int, warmup: int, n_prof: int, device, w
                             note="dominant kernel of the step by summed device time; achieved = 2*M*N*K / HIP-event time around "
                                  "the library call on torch's current stream, over the profiled steps that follow the timed "
                                  "region; the rocprofv3 kernel-trace line of the same launch shape is in "
-                                 "profiles/r3_bench_*_kernel_by_grid.txt; peak = 2.5 PFLOP/s dense bf16; traffic = HBM bytes "
+                                 "profiles/r6_bench_*_kernel_by_grid.txt; peak = 2.5 PFLOP/s dense bf16; traffic = HBM bytes "
                                  "of this launch shape from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)")
         elif top.startswith("grad:"):
             r = grad_profile["gemms"][int(top[5:])]

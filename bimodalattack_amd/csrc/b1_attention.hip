@@ -5,7 +5,7 @@
 // prompt; every decoder layer's attention there is 32 heads of a 65 x 65 causal problem -- a few MFLOP -- which the
 // HuggingFace code reaches through six launches forward (three reshapes folded away, rotary, attention) and, under
 // autograd, through the library's attention backward, a counter fill, the rotary backward and a concatenation: 46 us of
-// launch-bound kernels per layer, 1.5 ms of the 10.6 ms pass (profiles/r3_gradient_pass_gcg_by_grid.txt).  Here the
+// launch-bound kernels per layer, 1.5 ms of the 10.6 ms pass (profiles/archive/r3_gradient_pass_gcg_by_grid.txt).  Here the
 // fused q/k/v projection output goes in as it is and the attention output comes out in the layout o_proj reads; the
 // backward takes d(out) and returns d(qkv) in the projection's own layout.
 //

@@ -4,7 +4,7 @@
 // inside the HuggingFace model every RMSNorm, rotary embedding and SwiGLU gate is a
 // chain of 5-8 eager elementwise launches that re-read and re-write the whole activation
 // (B*L x D, 184 MB at B=512, L=44, D=4096): ~40 % of the scoring phase on MI355X
-// (profiles/r1_bench_gcg_kernel_stats.csv).  These three kernels do each chain in ONE
+// (profiles/archive/r1_bench_gcg_kernel_stats.csv).  These three kernels do each chain in ONE
 // pass over HBM.  They reproduce the eager chain's ROUNDING POINTS (every intermediate the
 // eager code materialises in the model dtype is rounded to the model dtype here too), so
 // SwiGLU and RoPE are bit-identical to the eager modules and RMSNorm differs only through

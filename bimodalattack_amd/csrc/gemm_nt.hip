@@ -23,7 +23,7 @@
 //     whichever workgroup arrives last -- then resets the ticket for the next launch.
 //
 // Measured against the tuned library kernels, each shape over 32 different weights from one hipGraph (tools/
-// gemm_bench.py; profiles/r3_gemm_bench.txt): it wins where the library has to split K itself -- the input-gradient
+// gemm_bench.py; profiles/archive/r3_gemm_bench.txt): it wins where the library has to split K itself -- the input-gradient
 // products through the transposed copies, N = 4096 with K = 12288 / 22016: 1.09-1.27x at 65 rows -- ties on down_proj
 // and loses 7-27 % on the wide forward products (whose 172 / 96 / 86 slabs do not fill 256 CUs in whole rounds),
 // so ops.gemm_nt_ok routes only K >= 3N to it.  What was tried on top and measured WORSE or no better: a stream-K

@@ -311,7 +311,7 @@ class HFAdapter:
                 # SigLIP's patch embedding hands over `conv(...).flatten(2).transpose(1, 2)`: a TRANSPOSED view, and aten's
                 # adds keep that layout for the whole residual stream -- every LayerNorm (forward and backward) then makes
                 # its own contiguous copy and every add runs strided: six 25-us launches per layer on a 4096 x 1152 tower
-                # (tools/copy_probe.py).  One copy here instead; the values are the same.
+                # (tools/copy_probe.py of round 5 (git history)).  One copy here instead; the values are the same.
                 hidden_states = hidden_states.contiguous()
             residual = hidden_states
             h = hit[1] if (hit is not None and hit[0] is hidden_states) else ln(layer.layer_norm1, hidden_states)
