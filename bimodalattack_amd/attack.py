@@ -1433,12 +1433,17 @@ class BimodalAttack:
                     t_read = None           # when the host had this step's outcome (gradient_ahead: the stream is still busy then)
                     ids_host = None
                     parent = optim_ids if cfg.gcg_attack else None      # what the candidates were sampled from
-                    if fuse_pgd and i + 1 < cfg.num_steps:
-                        # the forward of the NEXT gradient pass scores the image just updated
+                    if fuse_pgd:
+                        # the forward of the NEXT gradient pass scores the image just updated.  Behind the LAST step there is
+                        # no next pass: the same (captured) pass still scores the final image -- its backward is wasted, 28 ms at
+                        # configs[1]'s size, where the eager scoring forward it replaces met the library with first-sight shapes
+                        # and took 195 ms, once per attack (profiles/r6_full_pgd100.json) -- and its time is scoring time
                         with torch.enable_grad():
                             pending = (*grad_pass(record=False), None)
-                        prefetch_s = pending[1]
+                        prefetch_s = pending[1] if i + 1 < cfg.num_steps else 0.0
                         full = pending[0][2].reshape(1)
+                        if i + 1 >= cfg.num_steps:
+                            pending = None
                         if self.opt.loss_in_model_dtype:
                             full = full.to(self.model.dtype)
                         current_loss = full.item()

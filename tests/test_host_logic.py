@@ -740,7 +740,7 @@ def test_bench_line_fits_the_drivers_window_and_is_strict_json():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, repo)
     import bench
-    full = json.load(open(os.path.join(repo, "profiles", "r3_bench_driver.json")))
+    full = json.load(open(os.path.join(repo, "profiles", "archive", "r3_bench_driver.json")))
     full["finite"] = True
     full["workloads"]["joint"]["finite"] = True
     full["workloads"]["gemma_joint"]["final_loss"] = float("nan")
@@ -751,6 +751,13 @@ def test_bench_line_fits_the_drivers_window_and_is_strict_json():
                         # the multi-GPU A/B of the tensor-parallel gradient pass (bench.tp_ab)
                         tp_off_ms=37.91, tp_on_ms=31.25, chosen="on", tp_graph=True, tp_note="n" * 400,
                         tp_fallbacks={"graph_gradient_tp": "RuntimeError: " + "e" * 300})
+    # north_star's table for this N, as bench.scaling_table builds it on 8 ranks (round 6)
+    full["scaling_table"] = dict(n_gpus=8, attack_steps_per_sec=26.7, candidate_forwards_per_sec=13615.0, ms_per_step=37.46,
+                                 own_n1_leg=dict(ms_per_step=180.7, candidate_forwards_per_sec=2826.0, attack_steps_per_sec=5.53, steps=5, finite=True),
+                                 own_n1_leg_candidate_forwards_per_sec_per_rank=[2826.0 + i for i in range(8)], efficiency_vs_own_n1=0.6022,
+                                 dominant_kernel=dict(kernel="hipBLASLt/rocBLAS GEMM gate_up_proj M=2176 N=22016 K=4096 (decoder gate_up_proj, bf16)",
+                                                      bound="mfma", unit="TFLOP/s", peak=2500.0, frac_per_rank=[0.5312 + 0.001 * i for i in range(8)]),
+                                 gradient_pass="replicated on every rank")
     for blow in (0, 1):
         if blow:
             full["roofline"]["note"] = "prose " * 2000
@@ -776,6 +783,9 @@ def test_bench_line_fits_the_drivers_window_and_is_strict_json():
             assert back["rccl"]["world"] == 8 and back["rccl"]["devices"] == 8 and "what" not in back["rccl"]
             assert (back["rccl"]["tp_off_ms"], back["rccl"]["tp_on_ms"], back["rccl"]["chosen"]) == (37.91, 31.25, "on")
             assert back["rccl"]["tp_graph"] is True and len(back["rccl"]["tp_note"]) <= 160
+            t = back["scaling_table"]
+            assert t["n_gpus"] == 8 and len(t["dominant_kernel"]["frac_per_rank"]) == 8 and t["efficiency_vs_own_n1"] == pytest.approx(0.6022, rel=1e-3)
+            assert t["own_n1_leg"]["candidate_forwards_per_sec"] == pytest.approx(2826.0)
     assert bench._strict({"a": [float("inf"), 1.0, {"b": float("nan")}]}) == {"a": [None, 1.0, {"b": None}]}
 
 
