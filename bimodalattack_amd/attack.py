@@ -1444,6 +1444,7 @@ class BimodalAttack:
                         full = pending[0][2].reshape(1)
                         if i + 1 >= cfg.num_steps:
                             pending = None
+                            t_grad.pop()                  # (booked as scoring time: the result keeps one gradient time per step)
                         if self.opt.loss_in_model_dtype:
                             full = full.to(self.model.dtype)
                         current_loss = full.item()
