@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "bma_common.h"
+#include "bma_lds.h"
 #include "bma_profile.h"
 
 namespace {
@@ -357,14 +358,324 @@ __global__ __launch_bounds__(64 * kWaves, BMA_PA_OCC) void prefix_attn_kernel(co
   }
 }
 
+// =====================================================================================================================
+// prefix_attn32_kernel (round 6): the same product for 128-wide heads, rebuilt around what the SQ
+// counters of the kernel above said (profiles/r5_prefix_attn_pmc.txt: MFMA pipe 31 % busy, 41 % of the wave cycles in
+// instruction waits, ~190 vector-class instructions per 32 keys and wave):
+//
+//   products    v_mfma_f32_32x32x16: S^T[64 keys][32 queries] = K Q^T in 16 instructions per 64-key chunk, O^T[128][32] +=
+//               V^T P^T in 16 -- half the MFMA count of the 16x16x32 form for the same LDS bytes per flop (a wave owns
+//               32 rows either way), and a query's 64 scores sit in TWO lanes (l, l ^ 32): the row maximum is 31 v_max +
+//               one v_permlane32_swap instead of 2 x (7 v_max + two swap levels)
+//   P operand   the exponentiated S^T accumulator, packed pairwise, IS the B operand of the second product: registers
+//               8s..8s+7 of key tile kt are k-step (kt, s), whose slot 8h + j is key 32kt + 16s + 8(j>>2) + 4h + (j&3)
+//               (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"); the V^T fragments are
+//               read in that same key order (two ds_read_b64_tr_b16 per fragment: keys +4h..+4h+3 and +8+4h..), so
+//               nothing moves between lanes
+//   staging     64 keys per chunk, K and V images of 64 x 256 B, two slots; a chunk travels L2 -> LDS by LDS-DMA
+//               (buffer_load_dwordx4 ... lds, 1 KiB = 4 key rows per wave instruction; rows past the prefix read as
+//               zeros through the descriptor's bounds check, no clamping) while the chunk before it is multiplied:
+//               no staging registers, no ds_write; one barrier per chunk
+//   LDS images  16-byte pieces permuted on the DMA's SOURCE side: K piece c of row r at position c ^ (r & 15) (ds_read_b128
+//               of 16 rows x one piece per lane group: 16 distinct positions), V piece c at c ^ ((r & 3) << 2) (a
+//               transposing read takes 4 rows x 64 B per half wave: four distinct 64-byte quarters); both conflict-free
+//               by the bank rule of MI355X_MICROARCH.md (checked with a script before the first run)
+//   LDS reads   inline asm with hand-counted lgkmcnt (bma_lds.h: the compiler cannot tell a read from the DMA's writes
+//               and would drain the ring in front of each): groups of four, a group in flight while the one before it
+//               is multiplied; the first V^T groups are requested before the softmax
+//   epilogue    v_permlane32_swap pairs the two half-waves' 8-byte column groups into 16-byte stores (guide T21)
+//
+// Per launch the same 4*N*P*Dh*H flops; K/V pulled through L2 -> LDS once per 32*NW rows.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+using bma::u32x2;
+using bma::u32x4;
+using bma::tr_read;
+using bma::row_read;
+using bma::wait_rows;
+
 template <int DT>
-int launch(const PArgs& a, int Dh, hipStream_t st) {
-  const int hx = a.H % 8 == 0 ? a.H / 8 : 0;
-  // with the XCD mapping the grid is padded so that every (b & 7, j % hx) pair has row_blocks entries
+__device__ __forceinline__ f32x16 pmfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+  if (DT == BMA_BF16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait4x2(u32x2 (&f)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N));
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// both halves of a lane pair (l, l ^ 32) get max / sum of the pair
+__device__ __forceinline__ float pair_max(float x) {
+  u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return vmax(__uint_as_float(b.x), __uint_as_float(b.y));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  u32x2 b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+template <int DT, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PArgs a) {
+  constexpr int DH = 128;
+  constexpr int KS = DH / 16;          // k-steps of the QK product
+  constexpr int OT = DH / 32;          // 32-dim tiles of the output
+  constexpr int ROWB = 2 * DH;         // bytes of an LDS row
+  constexpr int IMGB = 64 * ROWB;      // one 64-key image
+  constexpr int SLOTB = 2 * IMGB;      // K image + V image
+  constexpr int PPW = 16 / NW;         // 1-KiB pieces per wave, image and chunk
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLOTB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qc = lane & 31, hi = lane >> 5;
+  int h, rb;
+  {
+    const int b = blockIdx.x;
+    if (a.H % 8 == 0) {
+      const int hx = a.H / 8;
+      const int j = b >> 3;
+      h = (b & 7) * hx + j % hx;
+      rb = j / hx;
+    } else {
+      h = b % a.H;
+      rb = b / a.H;
+    }
+  }
+  if (rb >= a.row_blocks) return;
+  const int hk = h / (a.H / a.Hk);
+  const int row0 = rb * (32 * NW) + 32 * wave;            // first row of this wave
+  const float NEG = -__builtin_inff();
+
+  // ---- the chunk stream: descriptors over this head's prefix rows, per-lane offsets computed once -----------------
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.pk + static_cast<int64_t>(hk) * a.pk_hs), 0,
+      static_cast<int>((static_cast<int64_t>(a.P - 1) * a.pk_rs + DH) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(a.pv + static_cast<int64_t>(hk) * a.pv_hs), 0,
+      static_cast<int>((static_cast<int64_t>(a.P - 1) * a.pv_rs + DH) * 2), 0x00020000);
+  const int krb = static_cast<int>(a.pk_rs) * 2, vrb = static_cast<int>(a.pv_rs) * 2;      // bytes per key row
+  const int lrow = 4 * wave + (lane >> 4), pos = lane & 15;     // piece j of this wave: key rows 4*NW*j + lrow
+  const int kvo = lrow * krb + 16 * (pos ^ (lrow & 15));
+  const int vvo = lrow * vrb + 16 * (pos ^ ((lrow & 3) << 2));
+  auto issue = [&](int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int r0 = 64 * c + 4 * NW * j;                       // wave-uniform
+      unsigned char* kd = lds + slot * SLOTB + (4 * wave + 4 * NW * j) * ROWB;      // the DMA adds lane * 16
+      dma16(rk, kd, kvo, r0 * krb);
+      dma16(rv, kd + IMGB, vvo, r0 * vrb);
+    }
+  };
+  const int chunks = (a.P + 63) >> 6;
+  issue(0, 0);
+
+  // Q rows as B operands: lane (query qc, dims 16ks + 8hi ..)
+  u32x4 qf[KS];
+  {
+    int row = row0 + qc;
+    row = row < a.N ? row : a.N - 1;
+    const uint16_t* qp = a.q + static_cast<int64_t>(row) * a.q_rs + static_cast<int64_t>(h) * a.q_hs + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+  }
+
+  f32x16 oacc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[ot][i] = 0.0f;
+  float mrun = NEG, lsum = 0.0f;
+
+  // fragment addresses (bytes; slot, key tile and k-step offsets are immediates of the reads)
+  const uint32_t lbase = bma::lds_addr(lds);
+  uint32_t ka[KS], va[OT];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) ka[ks] = lbase + qc * ROWB + 16 * ((2 * ks + hi) ^ (qc & 15));
+  {
+    const int gp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+      va[ot] = lbase + IMGB + (4 * hi + q4) * ROWB + 16 * ((4 * ot + 2 * (gp & 1) + (p4 >> 1)) ^ (q4 << 2)) + 8 * (p4 & 1);
+  }
+
+  auto compute = [&](auto slot_c, int c) {
+    constexpr int SO = decltype(slot_c)::value * SLOTB;
+    // ---- S^T = K Q^T: groups of four K fragments, one group in flight while the other is multiplied -------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[0][i] = 0.0f; s[1][i] = 0.0f; }
+    u32x4 kf[2][4];
+    u32x2 vf[3][4];
+    auto kread = [&](auto off, u32x4(&buf)[4], int ks0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) buf[j] = row_read<decltype(off)::value>(ka[ks0 + j]);
+    };
+    auto vread = [&](auto nn, u32x2(&buf)[4]) {            // group n: output tile n >> 1, key tile n & 1
+      constexpr int n = decltype(nn)::value;
+      constexpr int RO = SO + (32 * (n & 1)) * ROWB;
+      buf[0] = tr_read<RO>(va[n >> 1]);
+      buf[1] = tr_read<RO + 8 * ROWB>(va[n >> 1]);
+      buf[2] = tr_read<RO + 16 * ROWB>(va[n >> 1]);
+      buf[3] = tr_read<RO + 24 * ROWB>(va[n >> 1]);
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    kread(std::integral_constant<int, SO>{}, kf[0], 0);
+    kread(std::integral_constant<int, SO>{}, kf[1], 4);
+    wait_rows<4, 4>(kf[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[0][j], qf[j], s[0]);
+    kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[0], 0);
+    wait_rows<4, 4>(kf[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[1][j], qf[4 + j], s[0]);
+    kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[1], 4);
+    wait_rows<4, 4>(kf[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[0][j], qf[j], s[1]);
+    vread(std::integral_constant<int, 0>{}, vf[0]);
+    vread(std::integral_constant<int, 1>{}, vf[1]);
+    wait_rows<8, 4>(kf[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[1][j], qf[4 + j], s[1]);
+
+    // ---- online softmax: a query's 64 scores are in this lane and lane ^ 32 ------------------------------------------
+    if (64 * c + 64 > a.P) {                                   // only the last chunk has keys to mask (wave-uniform)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (64 * c + 32 * kt + 8 * (i >> 2) + 4 * hi + (i & 3) >= a.P) s[kt][i] = NEG;
+    }
+    float cmax = vmax3(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) cmax = vmax3(cmax, s[0][i], s[0][i + 1]);
+    cmax = vmax3(cmax, s[0][15], s[1][0]);
+#pragma unroll
+    for (int i = 1; i < 15; i += 2) cmax = vmax3(cmax, s[1][i], s[1][i + 1]);
+    cmax = vmax(cmax, s[1][15]);
+    cmax = pair_max(cmax);
+    const float mnew = vmax(mrun, cmax);                       // raw units; finite from the first chunk on (P >= 1)
+    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * a.scale_log2e);
+    const float mneg = -mnew * a.scale_log2e;
+    float rs = 0.0f;
+    u32x4 pf[4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], a.scale_log2e, mneg));
+        rs += s[kt][i];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[2 * kt + s2].x = bma::pack16<DT>(s[kt][8 * s2 + 0], s[kt][8 * s2 + 1]);
+        pf[2 * kt + s2].y = bma::pack16<DT>(s[kt][8 * s2 + 2], s[kt][8 * s2 + 3]);
+        pf[2 * kt + s2].z = bma::pack16<DT>(s[kt][8 * s2 + 4], s[kt][8 * s2 + 5]);
+        pf[2 * kt + s2].w = bma::pack16<DT>(s[kt][8 * s2 + 6], s[kt][8 * s2 + 7]);
+      }
+    }
+    lsum = lsum * alpha + rs;
+    mrun = mnew;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {     // a maximum moved somewhere in the wave
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[ot][i] *= alpha;
+    }
+    // ---- O^T += V^T P^T: groups of four transposing reads = the two k-steps of (output tile, key tile) ---------------
+    vread(std::integral_constant<int, 2>{}, vf[2]);
+    auto pv = [&](auto nn) {
+      constexpr int n = decltype(nn)::value;
+      u32x2(&f)[4] = vf[n % 3];
+      if constexpr (n < 6) wait4x2<8>(f);
+      else if constexpr (n == 6) wait4x2<4>(f);
+      else wait4x2<0>(f);
+      u32x4 v0, v1;
+      v0.x = f[0].x; v0.y = f[0].y; v0.z = f[1].x; v0.w = f[1].y;
+      v1.x = f[2].x; v1.y = f[2].y; v1.z = f[3].x; v1.w = f[3].y;
+      oacc[n >> 1] = pmfma32<DT>(v0, pf[2 * (n & 1)], oacc[n >> 1]);
+      oacc[n >> 1] = pmfma32<DT>(v1, pf[2 * (n & 1) + 1], oacc[n >> 1]);
+      if constexpr (n + 3 < 8) vread(std::integral_constant<int, n + 3>{}, f);
+    };
+    pv(std::integral_constant<int, 0>{}); pv(std::integral_constant<int, 1>{}); pv(std::integral_constant<int, 2>{});
+    pv(std::integral_constant<int, 3>{}); pv(std::integral_constant<int, 4>{}); pv(std::integral_constant<int, 5>{});
+    pv(std::integral_constant<int, 6>{}); pv(std::integral_constant<int, 7>{});
+  };
+
+  // The Q rows are waited for HERE, where the compiler can see it: its own wait-count bookkeeping does not know the
+  // waits of the loop (inline asm), and a register load still pending at a loop header in its books costs an
+  // s_waitcnt vmcnt(0) -- the ring drained -- in front of every chunk (ragged_attn_long_kernel learnt this).
+  wait_vm<0>();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
+  for (int c = 0; c < chunks; c += 2) {
+    if (c) wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                          // everybody's pieces of chunk c landed; the other slot is free
+    if (c + 1 < chunks) issue(c + 1, 1);
+    compute(std::integral_constant<int, 0>{}, c);
+    if (c + 1 >= chunks) break;
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (c + 2 < chunks) issue(c + 2, 0);
+    compute(std::integral_constant<int, 1>{}, c + 1);
+  }
+
+  // ---- epilogue: normalise, store o1 (16 bytes per lane) and the natural-log LSE ---------------------------------------
+  const float l = pair_sum(lsum);
+  const int row = row0 + qc;
+  const float inv = 1.0f / l;
+  if (row < a.N && hi == 0)
+    a.lse[static_cast<int64_t>(h) * a.N + row] = (mrun * a.scale_log2e + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+  uint16_t* op = a.out + (static_cast<int64_t>(row) * a.H + h) * DH + 8 * hi;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      // column groups k = 2pr (registers 8pr..8pr+3) and k+1 (8pr+4..8pr+7): lane half 0 holds dims 8k..8k+3, half 1 dims 8k+4..8k+7
+      uint32_t ax = bma::pack16<DT>(oacc[ot][8 * pr + 0] * inv, oacc[ot][8 * pr + 1] * inv);
+      uint32_t ay = bma::pack16<DT>(oacc[ot][8 * pr + 2] * inv, oacc[ot][8 * pr + 3] * inv);
+      uint32_t bx = bma::pack16<DT>(oacc[ot][8 * pr + 4] * inv, oacc[ot][8 * pr + 5] * inv);
+      uint32_t by = bma::pack16<DT>(oacc[ot][8 * pr + 6] * inv, oacc[ot][8 * pr + 7] * inv);
+      const u32x2 sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+      const u32x2 sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      u32x4 ow;
+      ow.x = sx.x; ow.y = sy.x; ow.z = sx.y; ow.w = sy.y;
+      if (row < a.N) *reinterpret_cast<u32x4*>(op + 32 * ot + 16 * pr) = ow;
+    }
+}
+
+// which kernel takes a launch: 0 = by shape (128-wide heads and a prefix of two chunks or more: the 32x32x16 kernel on
+// four waves), 1 = the 16x16x32 kernel always, 4 / 8 = the 32x32x16 kernel on that many waves (measurement, tests)
+int g_plan = 0;
+
+template <int DT>
+int launch(PArgs& a, int Dh, hipStream_t st) {
+  int nw = 0;
+  if (Dh == 128 && g_plan != 1) nw = g_plan == 8 ? 8 : (g_plan == 4 || a.P > 64) ? 4 : 0;
+  if (nw) {
+    // the descriptors of the chunk stream carry 32-bit byte counts and offsets
+    if ((static_cast<int64_t>(a.P) * a.pk_rs + Dh) * 2 > 0x7fffffffLL || (static_cast<int64_t>(a.P) * a.pv_rs + Dh) * 2 > 0x7fffffffLL)
+      nw = 0;
+  }
+  const int rows_per_wg = nw ? 32 * nw : kRowsPerWg;
+  a.row_blocks = (a.N + rows_per_wg - 1) / rows_per_wg;
   const int64_t blocks = static_cast<int64_t>(a.row_blocks) * a.H;
-  (void)hx;
+  if (blocks > 0x7fffffffLL) return BMA_ELIMIT;
   const dim3 grid(static_cast<unsigned>(blocks));
-  if (Dh == 64) hipLaunchKernelGGL((prefix_attn_kernel<DT, 64>), grid, dim3(64 * kWaves), 0, st, a);
+  if (nw == 8) hipLaunchKernelGGL((prefix_attn32_kernel<DT, 8>), grid, dim3(512), 0, st, a);
+  else if (nw == 4) hipLaunchKernelGGL((prefix_attn32_kernel<DT, 4>), grid, dim3(256), 0, st, a);
+  else if (Dh == 64) hipLaunchKernelGGL((prefix_attn_kernel<DT, 64>), grid, dim3(64 * kWaves), 0, st, a);
   else hipLaunchKernelGGL((prefix_attn_kernel<DT, 128>), grid, dim3(64 * kWaves), 0, st, a);
   return BMA_OK;
 }
@@ -391,9 +702,8 @@ extern "C" int bma_prefix_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   a.out = static_cast<uint16_t*>(out); a.lse = lse;
   a.q_rs = q_rs; a.q_hs = q_hs; a.pk_rs = pk_rs; a.pk_hs = pk_hs; a.pv_rs = pv_rs; a.pv_hs = pv_hs;
   a.N = static_cast<int>(N); a.H = H; a.Hk = Hk; a.P = P;
-  a.row_blocks = static_cast<int>((N + kRowsPerWg - 1) / kRowsPerWg);
+  a.row_blocks = 0;                                            // set by launch() for the kernel it picks
   a.scale_log2e = scale * 1.4426950408889634f;
-  if (static_cast<int64_t>(a.row_blocks) * H > 0x7fffffffLL) return BMA_ELIMIT;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // "bytes" of the profiler slot: q read + o written (the work itself is 4*N*P*Dh*H flops)
   BMA_PROF_BEGIN(BMA_K_PREFIX_ATTN, st, 2.0 * static_cast<double>(N) * H * Dh * 2);
@@ -402,4 +712,8 @@ extern "C" int bma_prefix_attention(const void* q, int64_t q_rs, int64_t q_hs, c
   if (rc != BMA_OK) return rc;
   BMA_LAUNCH_CHECK();
   return BMA_OK;
+}
+
+extern "C" void bma_prefix_attention_set_plan(int kernel) {
+  g_plan = (kernel == 1 || kernel == 4 || kernel == 8) ? kernel : 0;
 }

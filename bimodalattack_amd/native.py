@@ -25,7 +25,7 @@ LIB_PATH = os.environ.get("BMA_LIB", os.path.join(_HERE, "lib", "libbma_hip.so")
 BMA_F32, BMA_BF16, BMA_F16 = 0, 1, 2
 BMA_SEG_SHARED, BMA_SEG_PERCAND, BMA_SEG_GATHER = 0, 1, 2
 BMA_MAX_SEGS = 8
-ABI_VERSION = 111
+ABI_VERSION = 112
 
 
 class BmaSegment(Structure):
@@ -113,6 +113,7 @@ PROTOTYPES = {
                                          c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p]),
     "bma_causal_attention_set_plan": (None, [c_int64]),
+    "bma_prefix_attention_set_plan": (None, [c_int]),
     "bma_causal_attention_gqa": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64,
                                          c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bma_causal_attention_bwd_gqa": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,

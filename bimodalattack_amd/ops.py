@@ -849,6 +849,8 @@ def _rows_heads(t: torch.Tensor):
 
 if _os.environ.get("BMA_CA_FWD_TQ2_MIN") is not None:        # experiment knob: the library itself reads no environment
     lib.bma_causal_attention_set_plan(int(_os.environ["BMA_CA_FWD_TQ2_MIN"]))
+if _os.environ.get("BMA_PREFIX_ATTN_PLAN") is not None:      # 0 by shape / 1 the 16x16x32 kernel / 4, 8: the 32x32x16 kernel on that many waves
+    lib.bma_prefix_attention_set_plan(int(_os.environ["BMA_PREFIX_ATTN_PLAN"]))
 
 
 def causal_attention_ok(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> bool:

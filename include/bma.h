@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BMA_VERSION 111 /* 0.1.11: bma_causal_attention_gqa(+_bwd_gqa) (grouped-query heads, 256-wide heads: Gemma-3's decoder at batch 1); 0.1.10: bma_add_layernorm(+_bwd) (CLIP's residual add + LayerNorm pairs in one launch each way); 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
+#define BMA_VERSION 112 /* 0.1.12: bma_prefix_attention_set_plan (128-wide heads on the 32x32x16 kernel: 64-key chunks by LDS-DMA); 0.1.11: bma_causal_attention_gqa(+_bwd_gqa) (grouped-query heads, 256-wide heads: Gemma-3's decoder at batch 1); 0.1.10: bma_add_layernorm(+_bwd) (CLIP's residual add + LayerNorm pairs in one launch each way); 0.1.9: bma_gemm_nt_next (cross-product weight prefetch), bma_gemm_nt_set_plan flags bit 3 (fenced split-K hand-off); 0.1.8: bma_causal_attention(+_bwd) (one long sequence at batch 1); 0.1.7: bma_gemm_mid (the 599-644-row products of the pass with the image in the prompt); 0.1.6: bma_b1_attention(+_bwd); bma_gemm_nt_plan / _set_plan (slab height chosen with the split count); 0.1.5: bma_quick_gelu(+_bwd); 0.1.4: bma_qknorm_rope2; 0.1.3: bma_allgather_f32; 0.1.2: bma_add_rmsnorm(+_bwd), bma_rope2, bma_splice_rows, bma_gemm_nt; 0.1.1: bma_mask_topk takes a workspace; bma_ragged_attention takes blocks of any length, 256-wide heads */
 
 /* element types of model-dtype tensors */
 enum { BMA_F32 = 0, BMA_BF16 = 1, BMA_F16 = 2 };
@@ -390,6 +390,12 @@ int bma_prefix_attention(const void* q, int64_t q_row_stride, int64_t q_head_str
                          int64_t pk_row_stride, int64_t pk_head_stride, const void* pv, int64_t pv_row_stride,
                          int64_t pv_head_stride, int P, int64_t N, int H, int Hk, int Dh, int dtype, float scale,
                          void* out, float* lse, void* stream);
+/* Which kernel takes a launch -- 0: by shape (128-wide heads and a prefix of more than 64 keys: v_mfma_f32_32x32x16, 64-key
+ *   chunks L2 -> LDS by LDS-DMA, four waves of 32 rows; anything else: the 16x16x32 kernel), 1: the 16x16x32 kernel always,
+ *   4 / 8: the 32x32x16 kernel on workgroups of that many waves.  Measurement and tests; process-wide, not thread-safe
+ *   against concurrent launches.  Replaces nothing in the reference (bimodal_attack.py:1150-1163 recomputes the prefix per
+ *   candidate). */
+void bma_prefix_attention_set_plan(int kernel);
 
 /* bma_ragged_attention: the attention of a ragged scoring forward in one launch (bf16 / f16, MFMA).
  *   Candidate i (0 <= i < B2) owns rows start[i] .. start[i]+len[i]-1 of the row list: its tokens at
