@@ -508,51 +508,65 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
       va[ot] = lbase + IMGB + (4 * hi + q4) * ROWB + 16 * ((4 * ot + 2 * (gp & 1) + (p4 >> 1)) ^ (q4 << 2)) + 8 * (p4 & 1);
   }
 
-  auto compute = [&](auto slot_c, int c) {
+  // HALF: the chunk's second 32 keys all lie past the prefix (the last chunk of a prefix with P % 64 <= 32): their
+  // products, exponentials and k-steps are skipped, not masked (P = 599: 23 keys in the tenth chunk)
+  auto compute = [&](auto slot_c, auto half_c, int c) {
     constexpr int SO = decltype(slot_c)::value * SLOTB;
-    // ---- S^T = K Q^T: groups of four K fragments, one group in flight while the other is multiplied -------------------
-    f32x16 s[2];
+    constexpr bool HALF = decltype(half_c)::value;
+    constexpr int NKT = HALF ? 1 : 2;                      // key tiles multiplied
+    constexpr int NG = HALF ? 4 : 8;                       // groups of transposing reads
+    // ---- S^T = K Q^T: groups of four K fragments, requested ahead of the products that take them ---------------------
+    f32x16 s[NKT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s[0][i] = 0.0f; s[1][i] = 0.0f; }
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = 0.0f;
     u32x4 kf[2][4];
     u32x2 vf[3][4];
     auto kread = [&](auto off, u32x4(&buf)[4], int ks0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) buf[j] = row_read<decltype(off)::value>(ka[ks0 + j]);
     };
-    auto vread = [&](auto nn, u32x2(&buf)[4]) {            // group n: output tile n >> 1, key tile n & 1
+    auto vread = [&](auto nn, u32x2(&buf)[4]) {            // group n: output tile n >> 1, key tile n & 1 (HALF: tile n, key tile 0)
       constexpr int n = decltype(nn)::value;
-      constexpr int RO = SO + (32 * (n & 1)) * ROWB;
-      buf[0] = tr_read<RO>(va[n >> 1]);
-      buf[1] = tr_read<RO + 8 * ROWB>(va[n >> 1]);
-      buf[2] = tr_read<RO + 16 * ROWB>(va[n >> 1]);
-      buf[3] = tr_read<RO + 24 * ROWB>(va[n >> 1]);
+      constexpr int ot = HALF ? n : n >> 1;
+      constexpr int RO = SO + (HALF ? 0 : 32 * (n & 1)) * ROWB;
+      buf[0] = tr_read<RO>(va[ot]);
+      buf[1] = tr_read<RO + 8 * ROWB>(va[ot]);
+      buf[2] = tr_read<RO + 16 * ROWB>(va[ot]);
+      buf[3] = tr_read<RO + 24 * ROWB>(va[ot]);
     };
-    using I = std::integral_constant<int, 0>;
-    (void)sizeof(I);
     kread(std::integral_constant<int, SO>{}, kf[0], 0);
     kread(std::integral_constant<int, SO>{}, kf[1], 4);
     wait_rows<4, 4>(kf[0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[0][j], qf[j], s[0]);
-    kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[0], 0);
-    wait_rows<4, 4>(kf[1]);
+    if constexpr (!HALF) {
+      kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[0], 0);
+      wait_rows<4, 4>(kf[1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[1][j], qf[4 + j], s[0]);
-    kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[1], 4);
-    wait_rows<4, 4>(kf[0]);
+      for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[1][j], qf[4 + j], s[0]);
+      kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[1], 4);
+      wait_rows<4, 4>(kf[0]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[0][j], qf[j], s[1]);
-    vread(std::integral_constant<int, 0>{}, vf[0]);
-    vread(std::integral_constant<int, 1>{}, vf[1]);
-    wait_rows<8, 4>(kf[1]);
+      for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[0][j], qf[j], s[1]);
+      vread(std::integral_constant<int, 0>{}, vf[0]);
+      vread(std::integral_constant<int, 1>{}, vf[1]);
+      wait_rows<8, 4>(kf[1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[1][j], qf[4 + j], s[1]);
+      for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[1][j], qf[4 + j], s[1]);
+    } else {
+      vread(std::integral_constant<int, 0>{}, vf[0]);
+      vread(std::integral_constant<int, 1>{}, vf[1]);
+      wait_rows<8, 4>(kf[1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[1][j], qf[4 + j], s[0]);
+    }
 
-    // ---- online softmax: a query's 64 scores are in this lane and lane ^ 32 ------------------------------------------
-    if (64 * c + 64 > a.P) {                                   // only the last chunk has keys to mask (wave-uniform)
+    // ---- online softmax: a query's scores are in this lane and lane ^ 32 ----------------------------------------------
+    if (64 * c + 32 * NKT > a.P) {                             // only the last chunk has keys to mask (wave-uniform)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           if (64 * c + 32 * kt + 8 * (i >> 2) + 4 * hi + (i & 3) >= a.P) s[kt][i] = NEG;
@@ -560,18 +574,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
     float cmax = vmax3(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
     for (int i = 3; i < 15; i += 2) cmax = vmax3(cmax, s[0][i], s[0][i + 1]);
-    cmax = vmax3(cmax, s[0][15], s[1][0]);
+    if constexpr (!HALF) {
+      cmax = vmax3(cmax, s[0][15], s[1][0]);
 #pragma unroll
-    for (int i = 1; i < 15; i += 2) cmax = vmax3(cmax, s[1][i], s[1][i + 1]);
-    cmax = vmax(cmax, s[1][15]);
+      for (int i = 1; i < 15; i += 2) cmax = vmax3(cmax, s[1][i], s[1][i + 1]);
+      cmax = vmax(cmax, s[1][15]);
+    } else {
+      cmax = vmax(cmax, s[0][15]);
+    }
     cmax = pair_max(cmax);
     const float mnew = vmax(mrun, cmax);                       // raw units; finite from the first chunk on (P >= 1)
     const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * a.scale_log2e);
     const float mneg = -mnew * a.scale_log2e;
     float rs = 0.0f;
-    u32x4 pf[4];
+    u32x4 pf[2 * NKT];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], a.scale_log2e, mneg));
@@ -597,20 +615,24 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
     vread(std::integral_constant<int, 2>{}, vf[2]);
     auto pv = [&](auto nn) {
       constexpr int n = decltype(nn)::value;
+      constexpr int ot = HALF ? n : n >> 1, kt = HALF ? 0 : n & 1;
       u32x2(&f)[4] = vf[n % 3];
-      if constexpr (n < 6) wait4x2<8>(f);
-      else if constexpr (n == 6) wait4x2<4>(f);
+      if constexpr (n + 2 < NG) wait4x2<8>(f);
+      else if constexpr (n + 1 < NG) wait4x2<4>(f);
       else wait4x2<0>(f);
       u32x4 v0, v1;
       v0.x = f[0].x; v0.y = f[0].y; v0.z = f[1].x; v0.w = f[1].y;
       v1.x = f[2].x; v1.y = f[2].y; v1.z = f[3].x; v1.w = f[3].y;
-      oacc[n >> 1] = pmfma32<DT>(v0, pf[2 * (n & 1)], oacc[n >> 1]);
-      oacc[n >> 1] = pmfma32<DT>(v1, pf[2 * (n & 1) + 1], oacc[n >> 1]);
-      if constexpr (n + 3 < 8) vread(std::integral_constant<int, n + 3>{}, f);
+      oacc[ot] = pmfma32<DT>(v0, pf[2 * kt], oacc[ot]);
+      oacc[ot] = pmfma32<DT>(v1, pf[2 * kt + 1], oacc[ot]);
+      if constexpr (n + 3 < NG) vread(std::integral_constant<int, n + 3>{}, f);
     };
     pv(std::integral_constant<int, 0>{}); pv(std::integral_constant<int, 1>{}); pv(std::integral_constant<int, 2>{});
-    pv(std::integral_constant<int, 3>{}); pv(std::integral_constant<int, 4>{}); pv(std::integral_constant<int, 5>{});
-    pv(std::integral_constant<int, 6>{}); pv(std::integral_constant<int, 7>{});
+    pv(std::integral_constant<int, 3>{});
+    if constexpr (!HALF) {
+      pv(std::integral_constant<int, 4>{}); pv(std::integral_constant<int, 5>{}); pv(std::integral_constant<int, 6>{});
+      pv(std::integral_constant<int, 7>{});
+    }
   };
 
   // The Q rows are waited for HERE, where the compiler can see it: its own wait-count bookkeeping does not know the
@@ -619,16 +641,21 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
   wait_vm<0>();
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
+  const bool tail_half = a.P - 64 * (chunks - 1) <= 32;      // the last chunk holds 32 keys or fewer
+  auto step = [&](auto slot_c, int c) {
+    if (c + 1 == chunks && tail_half) compute(slot_c, std::true_type{}, c);
+    else compute(slot_c, std::false_type{}, c);
+  };
   for (int c = 0; c < chunks; c += 2) {
     if (c) wait_vm<0>();
     __builtin_amdgcn_s_barrier();                          // everybody's pieces of chunk c landed; the other slot is free
     if (c + 1 < chunks) issue(c + 1, 1);
-    compute(std::integral_constant<int, 0>{}, c);
+    step(std::integral_constant<int, 0>{}, c);
     if (c + 1 >= chunks) break;
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (c + 2 < chunks) issue(c + 2, 0);
-    compute(std::integral_constant<int, 1>{}, c + 1);
+    step(std::integral_constant<int, 1>{}, c + 1);
   }
 
   // ---- epilogue: normalise, store o1 (16 bytes per lane) and the natural-log LSE ---------------------------------------
