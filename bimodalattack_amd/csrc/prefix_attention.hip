@@ -425,16 +425,23 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* l
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
+#ifndef BMA_PA32_DEFER
+#define BMA_PA32_DEFER 4
+#endif
+// measurement builds only (wrong results): 1 = no maximum / exponentials (the scores are packed as they are), 2 = no LDS-DMA
+// inside the loop, 4 = no waits / barriers inside the loop
+#ifndef BMA_PA32_ABL
+#define BMA_PA32_ABL 0
+#endif
 template <int DT, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PArgs a) {
   constexpr int DH = 128;
   constexpr int KS = DH / 16;          // k-steps of the QK product
   constexpr int OT = DH / 32;          // 32-dim tiles of the output
   constexpr int ROWB = 2 * DH;         // bytes of an LDS row
-  constexpr int IMGB = 64 * ROWB;      // one 64-key image
-  constexpr int SLOTB = 2 * IMGB;      // K image + V image
-  constexpr int PPW = 16 / NW;         // 1-KiB pieces per wave, image and chunk
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * SLOTB];
+  constexpr int TILEB = 32 * ROWB;     // one 32-key tile
+  constexpr int PPT = 8 / NW;          // 1-KiB pieces per wave and tile
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[8 * TILEB];      // K tiles t & 3 | V tiles t & 3
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qc = lane & 31, hi = lane >> 5;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
   const int row0 = rb * (32 * NW) + 32 * wave;            // first row of this wave
   const float NEG = -__builtin_inff();
 
-  // ---- the chunk stream: descriptors over this head's prefix rows, per-lane offsets computed once -----------------
+  // ---- the key/value stream: descriptors over this head's prefix rows, per-lane offsets computed once ----------------
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(a.pk + static_cast<int64_t>(hk) * a.pk_hs), 0,
       static_cast<int>((static_cast<int64_t>(a.P - 1) * a.pk_rs + DH) * 2), 0x00020000);
@@ -464,20 +471,23 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
       const_cast<uint16_t*>(a.pv + static_cast<int64_t>(hk) * a.pv_hs), 0,
       static_cast<int>((static_cast<int64_t>(a.P - 1) * a.pv_rs + DH) * 2), 0x00020000);
   const int krb = static_cast<int>(a.pk_rs) * 2, vrb = static_cast<int>(a.pv_rs) * 2;      // bytes per key row
-  const int lrow = 4 * wave + (lane >> 4), pos = lane & 15;     // piece j of this wave: key rows 4*NW*j + lrow
+  const int lrow = 4 * wave + (lane >> 4), pos = lane & 15;     // piece j of this wave: rows 4*NW*j + lrow of the tile
   const int kvo = lrow * krb + 16 * (pos ^ (lrow & 15));
   const int vvo = lrow * vrb + 16 * (pos ^ ((lrow & 3) << 2));
-  auto issue = [&](int c, int slot) {
+  const int tiles = (a.P + 31) >> 5;
+  auto issue_k = [&](int t) {                                   // key tile t into K slot t & 3 (wave-uniform destination)
+    if (t >= tiles) return;
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-      const int r0 = 64 * c + 4 * NW * j;                       // wave-uniform
-      unsigned char* kd = lds + slot * SLOTB + (4 * wave + 4 * NW * j) * ROWB;      // the DMA adds lane * 16
-      dma16(rk, kd, kvo, r0 * krb);
-      dma16(rv, kd + IMGB, vvo, r0 * vrb);
-    }
+    for (int j = 0; j < PPT; ++j)
+      dma16(rk, lds + (t & 3) * TILEB + (4 * wave + 4 * NW * j) * ROWB, kvo, (32 * t + 4 * NW * j) * krb);
   };
-  const int chunks = (a.P + 63) >> 6;
-  issue(0, 0);
+  auto issue_v = [&](int t) {
+    if (t >= tiles) return;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      dma16(rv, lds + (4 + (t & 3)) * TILEB + (4 * wave + 4 * NW * j) * ROWB, vvo, (32 * t + 4 * NW * j) * vrb);
+  };
+  issue_k(0); issue_v(0); issue_k(1); issue_k(2); issue_v(1); issue_k(3); issue_v(2);
 
   // Q rows as B operands: lane (query qc, dims 16ks + 8hi ..)
   u32x4 qf[KS];
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
     for (int i = 0; i < 16; ++i) oacc[ot][i] = 0.0f;
   float mrun = NEG, lsum = 0.0f;
 
-  // fragment addresses (bytes; slot, key tile and k-step offsets are immediates of the reads)
+  // fragment addresses (bytes) in slot 0; k-step offsets are immediates of the reads, the slot advances by one tile per step
   const uint32_t lbase = bma::lds_addr(lds);
   uint32_t ka[KS], va[OT];
 #pragma unroll
@@ -505,157 +515,175 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void prefix_attn32_kernel(const PA
     const int gp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
-      va[ot] = lbase + IMGB + (4 * hi + q4) * ROWB + 16 * ((4 * ot + 2 * (gp & 1) + (p4 >> 1)) ^ (q4 << 2)) + 8 * (p4 & 1);
+      va[ot] = lbase + 4 * TILEB + (4 * hi + q4) * ROWB + 16 * ((4 * ot + 2 * (gp & 1) + (p4 >> 1)) ^ (q4 << 2)) + 8 * (p4 & 1);
   }
+  int kslot = 0, vslot = 0;                                      // wave-uniform: slot the addresses point at
+  auto next_k = [&]() {
+    const int d = kslot == 3 ? -3 * TILEB : TILEB;
+    kslot = (kslot + 1) & 3;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] += d;
+  };
+  auto next_v = [&]() {
+    const int d = vslot == 3 ? -3 * TILEB : TILEB;
+    vslot = (vslot + 1) & 3;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) va[ot] += d;
+  };
+  auto kread = [&](u32x4(&buf)[4], int ks0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) buf[j] = row_read<0>(ka[ks0 + j]);
+  };
 
-  // HALF: the chunk's second 32 keys all lie past the prefix (the last chunk of a prefix with P % 64 <= 32): their
-  // products, exponentials and k-steps are skipped, not masked (P = 599: 23 keys in the tenth chunk)
-  auto compute = [&](auto slot_c, auto half_c, int c) {
-    constexpr int SO = decltype(slot_c)::value * SLOTB;
-    constexpr bool HALF = decltype(half_c)::value;
-    constexpr int NKT = HALF ? 1 : 2;                      // key tiles multiplied
-    constexpr int NG = HALF ? 4 : 8;                       // groups of transposing reads
-    // ---- S^T = K Q^T: groups of four K fragments, requested ahead of the products that take them ---------------------
-    f32x16 s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kt][i] = 0.0f;
+  // One step = one 32-key tile t: its softmax (scores sc, formed in the step before) runs on the vector ALU while the matrix
+  // pipe forms tile t+1's scores sn = K Q^T -- the two are independent, so the wave's MFMAs execute in the shadow of its own
+  // exponentials instead of waiting in line behind them (the first form of this kernel ran QK, softmax and PV of a 64-key
+  // chunk one after the other: profiles/r6_prefix_attn32_pmc_first_form.txt, 38 % of the wave cycles stalled at issue, 24 %
+  // in waits) -- then O^T += V^T P^T of tile t.
+  auto step = [&](auto next_c, int t, f32x16& sc, f32x16& sn) {
+    constexpr bool NEXT = decltype(next_c)::value;
     u32x4 kf[2][4];
-    u32x2 vf[3][4];
-    auto kread = [&](auto off, u32x4(&buf)[4], int ks0) {
+    u32x2 vf[4][4];
+    if constexpr (NEXT) {
+      kread(kf[0], 0);
+      kread(kf[1], 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) buf[j] = row_read<decltype(off)::value>(ka[ks0 + j]);
-    };
-    auto vread = [&](auto nn, u32x2(&buf)[4]) {            // group n: output tile n >> 1, key tile n & 1 (HALF: tile n, key tile 0)
-      constexpr int n = decltype(nn)::value;
-      constexpr int ot = HALF ? n : n >> 1;
-      constexpr int RO = SO + (HALF ? 0 : 32 * (n & 1)) * ROWB;
-      buf[0] = tr_read<RO>(va[ot]);
-      buf[1] = tr_read<RO + 8 * ROWB>(va[ot]);
-      buf[2] = tr_read<RO + 16 * ROWB>(va[ot]);
-      buf[3] = tr_read<RO + 24 * ROWB>(va[ot]);
-    };
-    kread(std::integral_constant<int, SO>{}, kf[0], 0);
-    kread(std::integral_constant<int, SO>{}, kf[1], 4);
-    wait_rows<4, 4>(kf[0]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[0][j], qf[j], s[0]);
-    if constexpr (!HALF) {
-      kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[0], 0);
-      wait_rows<4, 4>(kf[1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[1][j], qf[4 + j], s[0]);
-      kread(std::integral_constant<int, SO + 32 * ROWB>{}, kf[1], 4);
-      wait_rows<4, 4>(kf[0]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[0][j], qf[j], s[1]);
-      vread(std::integral_constant<int, 0>{}, vf[0]);
-      vread(std::integral_constant<int, 1>{}, vf[1]);
-      wait_rows<8, 4>(kf[1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[1] = pmfma32<DT>(kf[1][j], qf[4 + j], s[1]);
-    } else {
-      vread(std::integral_constant<int, 0>{}, vf[0]);
-      vread(std::integral_constant<int, 1>{}, vf[1]);
-      wait_rows<8, 4>(kf[1]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[0] = pmfma32<DT>(kf[1][j], qf[4 + j], s[0]);
+      for (int i = 0; i < 16; ++i) sn[i] = 0.0f;
     }
-
-    // ---- online softmax: a query's scores are in this lane and lane ^ 32 ----------------------------------------------
-    if (64 * c + 32 * NKT > a.P) {                             // only the last chunk has keys to mask (wave-uniform)
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+    // ---- maximum of tile t's scores: a query's 32 scores are in this lane and lane ^ 32 ---------------------------------
+    if constexpr (!NEXT) {                                     // only the last tile can have keys to mask
+      if (32 * t + 32 > a.P) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (64 * c + 32 * kt + 8 * (i >> 2) + 4 * hi + (i & 3) >= a.P) s[kt][i] = NEG;
+          if (32 * t + 8 * (i >> 2) + 4 * hi + (i & 3) >= a.P) sc[i] = NEG;
+      }
     }
-    float cmax = vmax3(s[0][0], s[0][1], s[0][2]);
+    float cmax = vmax3(sc[0], sc[1], sc[2]);
+    if (!(BMA_PA32_ABL & 1)) {
 #pragma unroll
-    for (int i = 3; i < 15; i += 2) cmax = vmax3(cmax, s[0][i], s[0][i + 1]);
-    if constexpr (!HALF) {
-      cmax = vmax3(cmax, s[0][15], s[1][0]);
-#pragma unroll
-      for (int i = 1; i < 15; i += 2) cmax = vmax3(cmax, s[1][i], s[1][i + 1]);
-      cmax = vmax(cmax, s[1][15]);
-    } else {
-      cmax = vmax(cmax, s[0][15]);
+      for (int i = 3; i < 15; i += 2) cmax = vmax3(cmax, sc[i], sc[i + 1]);
+      cmax = vmax(cmax, sc[15]);
     }
-    cmax = pair_max(cmax);
-    const float mnew = vmax(mrun, cmax);                       // raw units; finite from the first chunk on (P >= 1)
+    if constexpr (NEXT) {
+      wait_rows<4, 4>(kf[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sn = pmfma32<DT>(kf[0][j], qf[j], sn);
+    }
+    if (!(BMA_PA32_ABL & 1)) cmax = pair_max(cmax);
+    // the running maximum moves only when a score exceeds it by more than BMA_PA32_DEFER (log2 units after scaling): the
+    // probabilities are then at most 2^DEFER instead of 1 -- the same relative rounding in the 16-bit type -- and the 64
+    // accumulator registers are rescaled only in those steps (0: the textbook update)
+    const float mtop = vmax(mrun, cmax);
+    const float mnew = BMA_PA32_DEFER == 0 ? mtop : ((cmax - mrun) * a.scale_log2e > static_cast<float>(BMA_PA32_DEFER) ? mtop : mrun);
     const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * a.scale_log2e);
     const float mneg = -mnew * a.scale_log2e;
     float rs = 0.0f;
-    u32x4 pf[2 * NKT];
+    u32x4 pf[2];
+    auto exps = [&](int s2) {                                  // eight scores -> one k-step of P
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[kt][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][i], a.scale_log2e, mneg));
-        rs += s[kt][i];
+      for (int i = 8 * s2; i < 8 * s2 + 8; ++i) {
+        if (!(BMA_PA32_ABL & 1)) sc[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], a.scale_log2e, mneg));
+        if (!(BMA_PA32_ABL & 1) || i == 8 * s2) rs += sc[i];
       }
+      pf[s2].x = bma::pack16<DT>(sc[8 * s2 + 0], sc[8 * s2 + 1]);
+      pf[s2].y = bma::pack16<DT>(sc[8 * s2 + 2], sc[8 * s2 + 3]);
+      pf[s2].z = bma::pack16<DT>(sc[8 * s2 + 4], sc[8 * s2 + 5]);
+      pf[s2].w = bma::pack16<DT>(sc[8 * s2 + 6], sc[8 * s2 + 7]);
+    };
+    exps(0);
+    if constexpr (NEXT) {
+      wait_rows<0, 4>(kf[1]);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        pf[2 * kt + s2].x = bma::pack16<DT>(s[kt][8 * s2 + 0], s[kt][8 * s2 + 1]);
-        pf[2 * kt + s2].y = bma::pack16<DT>(s[kt][8 * s2 + 2], s[kt][8 * s2 + 3]);
-        pf[2 * kt + s2].z = bma::pack16<DT>(s[kt][8 * s2 + 4], s[kt][8 * s2 + 5]);
-        pf[2 * kt + s2].w = bma::pack16<DT>(s[kt][8 * s2 + 6], s[kt][8 * s2 + 7]);
-      }
+      for (int j = 0; j < 4; ++j) sn = pmfma32<DT>(kf[1][j], qf[4 + j], sn);
+    }
+    exps(1);
+    // V^T fragments of tile t: group ot = the two k-steps of output tile ot (four transposing reads)
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      vf[ot][0] = tr_read<0>(va[ot]);
+      vf[ot][1] = tr_read<8 * ROWB>(va[ot]);
+      vf[ot][2] = tr_read<16 * ROWB>(va[ot]);
+      vf[ot][3] = tr_read<24 * ROWB>(va[ot]);
     }
     lsum = lsum * alpha + rs;
     mrun = mnew;
+    // (the probabilities are "used" here so that the compiler cannot sink the exponentials below the branch, behind the
+    // products they are meant to run beside)
+    asm volatile("" ::"v"(pf[0].x), "v"(pf[0].y), "v"(pf[0].z), "v"(pf[0].w), "v"(pf[1].x), "v"(pf[1].y), "v"(pf[1].z), "v"(pf[1].w), "v"(lsum));
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {     // a maximum moved somewhere in the wave
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[ot][i] *= alpha;
     }
-    // ---- O^T += V^T P^T: groups of four transposing reads = the two k-steps of (output tile, key tile) ---------------
-    vread(std::integral_constant<int, 2>{}, vf[2]);
-    auto pv = [&](auto nn) {
-      constexpr int n = decltype(nn)::value;
-      constexpr int ot = HALF ? n : n >> 1, kt = HALF ? 0 : n & 1;
-      u32x2(&f)[4] = vf[n % 3];
-      if constexpr (n + 2 < NG) wait4x2<8>(f);
-      else if constexpr (n + 1 < NG) wait4x2<4>(f);
-      else wait4x2<0>(f);
+    // ---- O^T += V^T P^T ---------------------------------------------------------------------------------------------------
+    auto pv = [&](auto oo) {
+      constexpr int ot = decltype(oo)::value;
+      wait4x2<4 * (OT - 1 - ot)>(vf[ot]);
       u32x4 v0, v1;
-      v0.x = f[0].x; v0.y = f[0].y; v0.z = f[1].x; v0.w = f[1].y;
-      v1.x = f[2].x; v1.y = f[2].y; v1.z = f[3].x; v1.w = f[3].y;
-      oacc[ot] = pmfma32<DT>(v0, pf[2 * kt], oacc[ot]);
-      oacc[ot] = pmfma32<DT>(v1, pf[2 * kt + 1], oacc[ot]);
-      if constexpr (n + 3 < NG) vread(std::integral_constant<int, n + 3>{}, f);
+      v0.x = vf[ot][0].x; v0.y = vf[ot][0].y; v0.z = vf[ot][1].x; v0.w = vf[ot][1].y;
+      v1.x = vf[ot][2].x; v1.y = vf[ot][2].y; v1.z = vf[ot][3].x; v1.w = vf[ot][3].y;
+      oacc[ot] = pmfma32<DT>(v0, pf[0], oacc[ot]);
+      oacc[ot] = pmfma32<DT>(v1, pf[1], oacc[ot]);
     };
     pv(std::integral_constant<int, 0>{}); pv(std::integral_constant<int, 1>{}); pv(std::integral_constant<int, 2>{});
     pv(std::integral_constant<int, 3>{});
-    if constexpr (!HALF) {
-      pv(std::integral_constant<int, 4>{}); pv(std::integral_constant<int, 5>{}); pv(std::integral_constant<int, 6>{});
-      pv(std::integral_constant<int, 7>{});
-    }
+    if constexpr (NEXT) next_k();
+    next_v();
   };
 
   // The Q rows are waited for HERE, where the compiler can see it: its own wait-count bookkeeping does not know the
   // waits of the loop (inline asm), and a register load still pending at a loop header in its books costs an
-  // s_waitcnt vmcnt(0) -- the ring drained -- in front of every chunk (ragged_attn_long_kernel learnt this).
+  // s_waitcnt vmcnt(0) -- the ring drained -- in front of every step (ragged_attn_long_kernel learnt this).
   wait_vm<0>();
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks].x), "v"(qf[ks].y), "v"(qf[ks].z), "v"(qf[ks].w));
-  const bool tail_half = a.P - 64 * (chunks - 1) <= 32;      // the last chunk holds 32 keys or fewer
-  auto step = [&](auto slot_c, int c) {
-    if (c + 1 == chunks && tail_half) compute(slot_c, std::true_type{}, c);
-    else compute(slot_c, std::false_type{}, c);
+  __builtin_amdgcn_s_barrier();                            // K tiles 0-3 and V tiles 0-2 landed
+  f32x16 sa, sb;
+  {                                                        // tile 0's scores, nothing to overlap them with
+    u32x4 kf[2][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sa[i] = 0.0f;
+    kread(kf[0], 0);
+    kread(kf[1], 4);
+    wait_rows<4, 4>(kf[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sa = pmfma32<DT>(kf[0][j], qf[j], sa);
+    wait_rows<0, 4>(kf[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sa = pmfma32<DT>(kf[1][j], qf[4 + j], sa);
+    next_k();
+  }
+  // Barriers sit in front of the odd steps.  The one in front of step t (t odd): everybody is through step t-1, so K tiles
+  // <= t and V tiles <= t-1 are multiplied and their slots free: K tiles t+3, t+4 and V tiles t+2, t+3 can be requested from
+  // there on; steps t and t+1 read K tiles t+1, t+2 and V tiles t, t+1 -- requested behind the barrier before, landed at this
+  // one (every wave drains its own requests in front of a barrier).
+  auto sync = [&](int t) {                                 // in front of odd step t
+    if (!(BMA_PA32_ABL & 4)) {
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!(BMA_PA32_ABL & 2)) { issue_k(t + 3); issue_v(t + 2); }
   };
-  for (int c = 0; c < chunks; c += 2) {
-    if (c) wait_vm<0>();
-    __builtin_amdgcn_s_barrier();                          // everybody's pieces of chunk c landed; the other slot is free
-    if (c + 1 < chunks) issue(c + 1, 1);
-    step(std::integral_constant<int, 0>{}, c);
-    if (c + 1 >= chunks) break;
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (c + 2 < chunks) issue(c + 2, 0);
-    step(std::integral_constant<int, 1>{}, c + 1);
+  // the other half of a barrier's requests, made a step later (they are first read two steps on, behind the NEXT barrier,
+  // whose wait covers them): four DMA instructions per wave at a time instead of eight
+  auto late = [&](int t) {                                 // in front of even step t >= 2
+    if (!(BMA_PA32_ABL & 2)) { issue_k(t + 3); issue_v(t + 2); }
+  };
+  int t = 0;
+  for (; t + 2 < tiles; t += 2) {                          // both steps have a tile behind them; the scores end up in sa again
+    if (t) late(t);
+    step(std::true_type{}, t, sa, sb);
+    sync(t + 1);
+    step(std::true_type{}, t + 1, sb, sa);
+  }
+  if (t + 2 == tiles) {
+    if (t) late(t);
+    step(std::true_type{}, t, sa, sb);
+    sync(t + 1);
+    step(std::false_type{}, t + 1, sb, sa);
+  } else {
+    step(std::false_type{}, t, sa, sb);
   }
 
   // ---- epilogue: normalise, store o1 (16 bytes per lane) and the natural-log LSE ---------------------------------------
