@@ -361,28 +361,34 @@ __global__ __launch_bounds__(64 * kWaves, BMA_PA_OCC) void prefix_attn_kernel(co
 // =====================================================================================================================
 // prefix_attn32_kernel (round 6): the same product for 128-wide heads, rebuilt around what the SQ
 // counters of the kernel above said (profiles/r5_prefix_attn_pmc.txt: MFMA pipe 31 % busy, 41 % of the wave cycles in
-// instruction waits, ~190 vector-class instructions per 32 keys and wave):
+// instruction waits, ~190 vector-class instructions per 32 keys and wave).  230 -> 197 us at 17152 x 599 x 32 x 128 on one
+// box, 0.29 -> 0.34 of the MFMA peak (profiles/r6_prefix_attn32.txt; the steps that got there and the ones that did not).
 //
-//   products    v_mfma_f32_32x32x16: S^T[64 keys][32 queries] = K Q^T in 16 instructions per 64-key chunk, O^T[128][32] +=
-//               V^T P^T in 16 -- half the MFMA count of the 16x16x32 form for the same LDS bytes per flop (a wave owns
-//               32 rows either way), and a query's 64 scores sit in TWO lanes (l, l ^ 32): the row maximum is 31 v_max +
-//               one v_permlane32_swap instead of 2 x (7 v_max + two swap levels)
+//   products    v_mfma_f32_32x32x16: S^T[32 keys][32 queries] = K Q^T in 8 instructions per 32-key tile, O^T[128][32] +=
+//               V^T P^T in 8 -- half the MFMA count of the 16x16x32 form for the same LDS bytes per flop (a wave owns 32
+//               rows either way), and a query's 32 scores sit in TWO lanes (l, l ^ 32): the row maximum is 8 v_max3 + one
+//               v_permlane32_swap instead of 7 v_max + two swap levels per 16-row tile
 //   P operand   the exponentiated S^T accumulator, packed pairwise, IS the B operand of the second product: registers
-//               8s..8s+7 of key tile kt are k-step (kt, s), whose slot 8h + j is key 32kt + 16s + 8(j>>2) + 4h + (j&3)
-//               (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"); the V^T fragments are
-//               read in that same key order (two ds_read_b64_tr_b16 per fragment: keys +4h..+4h+3 and +8+4h..), so
-//               nothing moves between lanes
-//   staging     64 keys per chunk, K and V images of 64 x 256 B, two slots; a chunk travels L2 -> LDS by LDS-DMA
-//               (buffer_load_dwordx4 ... lds, 1 KiB = 4 key rows per wave instruction; rows past the prefix read as
-//               zeros through the descriptor's bounds check, no clamping) while the chunk before it is multiplied:
-//               no staging registers, no ds_write; one barrier per chunk
+//               8s..8s+7 are k-step s, whose slot 8h + j is key 16s + 8(j>>2) + 4h + (j&3) (cdna_hip_programming.md
+//               section 3, "An accumulator tile as the next MFMA's operand"); the V^T fragments are read in that same key
+//               order (two ds_read_b64_tr_b16 per fragment: keys +4h..+4h+3 and +8+4h..), so nothing moves between lanes
+//   pipeline    one step = one tile t: tile t+1's scores are formed on the matrix pipe WHILE tile t's maximum, exponentials
+//               and packing run on the vector ALU (independent: the instruction stream alternates one MFMA with ~7 vector
+//               instructions), then O^T += V^T P^T of tile t; the two score accumulators swap names every step
+//   staging     K and V rings of four 32-key tiles each (64 KB: two workgroups per CU); a tile travels L2 -> LDS by LDS-DMA
+//               (buffer_load_dwordx4 ... lds, 1 KiB = 4 key rows per wave instruction; rows past the prefix read as zeros
+//               through the descriptor's bounds check, no clamping) two to three steps ahead of its use: no staging
+//               registers, no ds_write; ONE barrier per two steps
 //   LDS images  16-byte pieces permuted on the DMA's SOURCE side: K piece c of row r at position c ^ (r & 15) (ds_read_b128
 //               of 16 rows x one piece per lane group: 16 distinct positions), V piece c at c ^ ((r & 3) << 2) (a
 //               transposing read takes 4 rows x 64 B per half wave: four distinct 64-byte quarters); both conflict-free
-//               by the bank rule of MI355X_MICROARCH.md (checked with a script before the first run)
+//               by the bank rule of MI355X_MICROARCH.md (checked with a script before the first run; SQ_LDS_BANK_CONFLICT 0)
 //   LDS reads   inline asm with hand-counted lgkmcnt (bma_lds.h: the compiler cannot tell a read from the DMA's writes
-//               and would drain the ring in front of each): groups of four, a group in flight while the one before it
-//               is multiplied; the first V^T groups are requested before the softmax
+//               and would drain the ring in front of each)
+//   maximum     the running maximum of a query moves only when a tile's maximum exceeds it by more than 2^BMA_PA32_DEFER
+//               (after scaling): probabilities are then at most 2^4 instead of 1 -- the same relative rounding in the 16-bit
+//               type -- and the 64 accumulator registers are rescaled only in the steps where some lane's maximum moved
+//               (guide T13; measured against float64: 5.3e-3 -> 6.0e-3 of the row scale in bf16, bound 1.2e-2)
 //   epilogue    v_permlane32_swap pairs the two half-waves' 8-byte column groups into 16-byte stores (guide T21)
 //
 // Per launch the same 4*N*P*Dh*H flops; K/V pulled through L2 -> LDS once per 32*NW rows.

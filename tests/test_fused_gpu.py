@@ -810,6 +810,87 @@ def test_block_attention_at_gemma_size_properties():
     assert worst <= 3 * 2.0 ** -8, worst
 
 
+@pytest.mark.parametrize("plan", [1, 4, 8])
+def test_prefix_attention_kernels_tails_and_grouped_heads(plan):
+    """Both prefix kernels (bma_prefix_attention_set_plan: 1 = 16x16x32 products with 32-key chunks through registers,
+    4 / 8 = 32x32x16 products with 32-key tiles by LDS-DMA on workgroups of 4 / 8 waves) against float64 attention on the
+    same bf16 operands, within 3 bf16 roundings of every row's own scale: prefix lengths around the tile and ring sizes
+    (one tile, a tile and one key, the four-tile ring and one more, a last tile of 1 / 23 / 31 / 32 keys), row counts off the
+    workgroup sizes, grouped heads, strided key rows ((P, Hk, Dh) memory), values with a different scale per key so that
+    a permuted key order inside a k-step would show."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    dt, Dh = torch.bfloat16, 128
+    scale = Dh ** -0.5
+    try:
+        lib.bma_prefix_attention_set_plan(plan)
+        for N, P, H, Hk in [(130, 1, 4, 2), (257, 32, 8, 8), (200, 33, 8, 4), (300, 64, 2, 2), (131, 65, 8, 8), (400, 96, 4, 4),
+                            (129, 127, 8, 2), (500, 128, 8, 8), (260, 129, 16, 16), (300, 160, 8, 8), (64, 161, 3, 3),
+                            (1000, 599, 8, 8), (333, 640, 4, 4), (150, 1025, 8, 4)]:
+            g = torch.Generator(device=DEV).manual_seed(7 * N + P)
+            q = torch.randn((1, N, H, Dh), generator=g, device=DEV).to(dt).transpose(1, 2)
+            pk, pv = (torch.randn((1, P, Hk, Dh), generator=g, device=DEV).to(dt).transpose(1, 2) for _ in range(2))
+            pv = (pv.float() * torch.linspace(0.5, 2.0, P, device=DEV)[None, None, :, None]).to(dt)
+            o, lse = ops.prefix_attention(q, pk, pv, scale)
+            rep = H // Hk
+            s_ = (q[0].double() @ pk[0].double().repeat_interleave(rep, 0).transpose(-1, -2)) * scale
+            want = (torch.softmax(s_, -1) @ pv[0].double().repeat_interleave(rep, 0)).transpose(0, 1)
+            assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+            worst = _row_scale_err(o, want)
+            assert worst <= 3 * 2.0 ** -8, (plan, N, P, H, Hk, worst)
+            np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(s_, -1).cpu().numpy(), rtol=2e-3, atol=2e-3)
+    finally:
+        lib.bma_prefix_attention_set_plan(0)
+
+
+@pytest.mark.parametrize("plan", [1, 4])
+def test_prefix_attention_running_maximum_under_adversarial_scores(plan):
+    """The 32x32x16 kernel moves a query's running maximum only when a tile's maximum exceeds it by more than 2^4 after
+    scaling (BMA_PA32_DEFER) and rescales its accumulators only then; random scores take the deferring path on almost every
+    tile, so both paths are driven on purpose here (cdna_hip_programming.md T13: a passing check on bounded random data
+    says nothing about the rare branch): scores that climb along the keys by a little per tile (deferred several times, then
+    moved), by a lot per tile (moved every tile), that fall (never moved after the first tile), one late outlier key, and
+    rows whose climbs differ inside one wave (some lanes move, others defer: the rescale is per lane, the skip per wave).
+    Against float64 on the same bf16 operands; the 16x16x32 kernel (plan 1) takes the same data as the yardstick."""
+    from bimodalattack_amd import ops
+    from bimodalattack_amd.native import lib
+    dt, Dh, N, P, H = torch.bfloat16, 128, 256, 599, 4
+    scale = Dh ** -0.5
+    g = torch.Generator(device=DEV).manual_seed(3)
+    unit = torch.zeros(Dh, device=DEV)
+    unit[0] = 1.0
+    base_k = torch.randn((P, H, Dh), generator=g, device=DEV) * 0.05
+    base_k[..., 0] = 0.0
+    pv = torch.randn((1, P, H, Dh), generator=g, device=DEV).to(dt).transpose(1, 2)
+    pos = torch.arange(P, device=DEV, dtype=torch.float32)
+    ramps = {                                                         # score contribution of key j through dim 0, in log2 units
+        "slow climb": 0.05 * pos,                                      # +1.6 per tile: deferred twice, then moved
+        "fast climb": 0.4 * pos,                                       # +12.8 per tile: moved every tile
+        "falling": -0.3 * pos,
+        "late outlier": torch.where(pos == 570, torch.tensor(40.0, device=DEV), torch.zeros_like(pos)),
+        "steps of 3.9 and 4.1": torch.floor(pos / 32) * torch.where(torch.floor(pos / 32) % 2 == 0, 3.9, 4.1),
+    }
+    try:
+        lib.bma_prefix_attention_set_plan(plan)
+        for name, ramp in ramps.items():
+            k = base_k.clone()
+            k[..., 0] = (ramp / (scale * 1.4426950408889634))[:, None]      # q[0] = 1 below: score = ramp in log2 units
+            pk = k.unsqueeze(0).to(dt).transpose(1, 2)
+            q = torch.randn((1, N, H, Dh), generator=g, device=DEV) * 0.5
+            q[..., 0] = 1.0
+            q[0, 1::2, :, 0] = 0.25                                       # odd rows climb a quarter as fast: lanes of one wave differ
+            q = q.to(dt).transpose(1, 2)
+            o, lse = ops.prefix_attention(q, pk, pv, scale)
+            s_ = (q[0].double() @ pk[0].double().transpose(-1, -2)) * scale
+            want = (torch.softmax(s_, -1) @ pv[0].double()).transpose(0, 1)
+            assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all(), name
+            worst = _row_scale_err(o, want)
+            assert worst <= 3 * 2.0 ** -8, (plan, name, worst)
+            np.testing.assert_allclose(lse.cpu().numpy(), torch.logsumexp(s_, -1).cpu().numpy(), rtol=2e-3, atol=2e-3, err_msg=name)
+    finally:
+        lib.bma_prefix_attention_set_plan(0)
+
+
 def test_prefix_attention_at_joint_size_properties():
     """bma_prefix_attention at BASELINE configs[3]'s full size (17152 scoring rows against the 599 shared prefix keys,
     32 heads of 128): a row's result does not depend on which other rows are in the launch (bit for bit), linearity

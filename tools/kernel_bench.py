@@ -162,10 +162,19 @@ def cases():
         w = (torch.randn((N, K), generator=g, device=DEV) * 0.02).to(bf)
         return lambda: torch.nn.functional.linear(x, w)
 
-    def prefix_attn(N, P, H, Dh):
+    def prefix_attn(N, P, H, Dh, plan=0):
+        # plan: bma_prefix_attention_set_plan -- 0 by shape (128-wide heads: the 32x32x16 kernel), 1 the 16x16x32 kernel
+        from bimodalattack_amd.native import lib
         q = torch.randn((1, N, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2)
         pk, pv = (torch.randn((1, P, H, Dh), generator=g, device=DEV).to(bf).transpose(1, 2) for _ in range(2))
-        return lambda: ops.prefix_attention(q, pk, pv, Dh ** -0.5)
+
+        def run():
+            lib.bma_prefix_attention_set_plan(plan)
+            try:
+                return ops.prefix_attention(q, pk, pv, Dh ** -0.5)
+            finally:
+                lib.bma_prefix_attention_set_plan(0)
+        return run
 
     def prefix_attn_lib(N, P, H, Dh):
         # the library kernel the hand-written one replaces (aten efficient attention, no mask, with LSE)
@@ -263,6 +272,7 @@ def cases():
         "ragged_attn/c4_B512_L45_P0_H32_Dh128": ("ragged_attn", lambda: block_attn(512, 45, 0, 32, 32, 128)),
         # joint scoring: every computed row against the 599 shared prefix keys (168 GFLOP per launch)
         "prefix_attn/c4_N17152_P599_H32_Dh128": ("prefix_attn", lambda: prefix_attn(17152, 599, 32, 128)),
+        "prefix_attn/c4_16x16x32_kernel_N17152_P599_H32_Dh128": ("prefix_attn", lambda: prefix_attn(17152, 599, 32, 128, plan=1)),
         "libattn/c4_17152x599x32x128": (None, lambda: prefix_attn_lib(17152, 599, 32, 128)),
         "gather_rows/c3r_21164_of_17152x4096": ("gather_rows", lambda: gather(17152, 481 * 44, 4096)),
         "rmsnorm/c3_22528x4096": ("rmsnorm", lambda: rmsnorm(22528, 4096)),

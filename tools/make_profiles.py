@@ -70,7 +70,7 @@ CASES = [
     ("ragged_attn/c3r_sw512_P21_L44_H32_Dh128", "ragged_attn", "ragged_attn_kernel<1, 3, 128>/threads92160", "17152 rows, 480 candidates x 32 heads, 21 prefix keys (C3 ragged)"),
     ("ragged_attn/gemma_B164_L303_P20_H8_Hk4_Dh256", "ragged_attn", "ragged_attn_long_kernel<1, 256, 2, 1, 4>/threads131072", "Gemma-3 joint blocks: 164 x 303 tokens, 8 heads on 4, 256 wide, 20 prefix keys (persistent long-block kernel)"),
     ("ragged_attn/c4_B512_L45_P0_H32_Dh128", "ragged_attn", "ragged_attn_kernel<1, 3, 128>/threads98304", "C4 padded blocks 512 x 45, no prefix"),
-    ("prefix_attn/c4_N17152_P599_H32_Dh128", "prefix_attn", "prefix_attn_kernel<1, 128>/threads1097728", "joint scoring: 17152 rows x 599 shared prefix keys x 32 heads x 128 (168 GFLOP)"),
+    ("prefix_attn/c4_N17152_P599_H32_Dh128", "prefix_attn", "prefix_attn32_kernel<1, 4>/threads1097728", "joint scoring: 17152 rows x 599 shared prefix keys x 32 heads x 128 (168 GFLOP; the 32x32x16 kernel)"),
     ("attn_merge/c3r_N17152_B481_L44", "attn_merge", "attn_merge_kernel<1>/threads4390912", "17152 rows vs padded 481 x 44, H=32 Dh=128 bf16 (library-attention route)"),
     ("gather_rows/c3r_21164_of_17152x4096", "gather_rows", "gather_rows_kernel/threads5417984", "21164 padded slots from 17152 rows of 8 KiB (library-attention route)"),
     ("ce_rows/llava_B512_T20_V32064", "ce_rows", "ce_rows_kernel<1, true, false>/threads2621440", "B=512 T=20 V=32064 bf16 (C3/C4 scoring, one chunk)"),

@@ -25,7 +25,7 @@ from collections import defaultdict
 KERNELS = (r"\b(ce_rows_kernel|ce_dlogits_kernel|ce_fold_kernel|splice_kernel|mask_topk_kernel|"
            r"linf_step_vec4|linf_step_scalar|sample_scatter_kernel|rand_positions_kernel|rmsnorm_kernel|"
            r"swiglu_kernel|qknorm_rope2_kernel|rope2_kernel|rope_kernel|attn_merge_kernel|gather_rows_kernel|rmsnorm_short_kernel|ragged_attn_kernel|ragged_attn_long_kernel|"
-           r"topk_slice_kernel|topk_merge_kernel|prefix_attn_kernel|add_rmsnorm_kernel|splice_rows_kernel|gemm_nt_kernel|gemm_mid_kernel|gemm_mid_reduce_kernel|causal_fwd_kernel|causal_dq_kernel|causal_dkv_kernel|(?:Custom_)?Cijk_\w+)\b(<[^>]*>)?")
+           r"topk_slice_kernel|topk_merge_kernel|prefix_attn32_kernel|prefix_attn_kernel|add_rmsnorm_kernel|splice_rows_kernel|gemm_nt_kernel|gemm_mid_kernel|gemm_mid_reduce_kernel|causal_fwd_kernel|causal_dq_kernel|causal_dkv_kernel|(?:Custom_)?Cijk_\w+)\b(<[^>]*>)?")
 
 
 def is_marker(name: str) -> bool:
