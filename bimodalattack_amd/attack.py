@@ -217,6 +217,52 @@ def _transformers_version() -> str:
         return "transformers ?"
 
 
+class _RunState:
+    """What one run() carries from step to step (BimodalAttack._run)."""
+
+    def __init__(self):
+        self.buffer = None                     # AttackBuffer
+        self.optim_ids: Optional[Tensor] = None
+        self.image: Optional[Tensor] = None
+        self.image_original: Optional[Tensor] = None
+        self.pending = None                    # a gradient pass computed / queued for the NEXT step: (gradients, seconds, span)
+        self.fuse_pgd = False
+        self.trace = None
+        self.writer = None
+        self.losses: List[float] = []
+        self.strings: List[str] = []
+        self.suffixes: List[str] = []
+        self.outputs: List[str] = []
+        self.t_grad: List[float] = []
+        self.t_samp: List[float] = []
+        self.t_loss: List[float] = []
+        self.t_pgd: List[float] = []
+        self.t_total: List[float] = []
+
+
+class _StepState:
+    """What the phases of ONE step hand each other (BimodalAttack._step_*)."""
+
+    def __init__(self, i: int):
+        self.i = i
+        self.st: Optional[dict] = None         # this step's trace record (EngineOptions.trace), or None
+        self.span = None                       # gradient_ahead: stream events of the pass queued in the step before
+        self.g_tok = self.g_img = None
+        self.grad_time = self.pgd_time = self.samp_time = 0.0
+        self.pgd_span = None
+        self.image_synced = False
+        self.flying = None                     # (gradient span, host seconds of the sampling call, PGD span) while the pass may still run
+        self.virtual = None                    # early_plan: host stand-ins of this step's candidates, known before they exist
+        self.sampled_all = self.job = None
+        self.t0 = 0.0                          # start of the scoring phase
+        self.prefetch_s = 0.0
+        self.t_read = None                     # when the host had this step's outcome (gradient_ahead: the stream is still busy then)
+        self.ids_host = None
+        self.sampled = None
+        self.n = 0
+        self.current_loss = None
+
+
 class BimodalAttack:
     def __init__(self, model, tokenizer, processor, config: BimodalAttackConfig, normalize=None,
                  options: Optional[EngineOptions] = None):
@@ -1192,9 +1238,12 @@ class BimodalAttack:
             torch.utils.deterministic.fill_uninitialized_memory = fill_flag
 
     def _run(self, messages, goal, target, image) -> BimodalAttackResult:
+        """The loop of the reference's run() (:441-794), one call per phase: _step_gradients (A), _step_pgd (B, C),
+        _step_sampling (D, device part), _step_scoring (D) and _step_close (times, buffer, logs).  What a run carries
+        from step to step lives in a _RunState, what a step's phases hand each other in a _StepState."""
         from transformers import set_seed
 
-        cfg, tok, mt = self.config, self.tokenizer, self.hf.model_type
+        cfg = self.config
         self.initial_prompt = goal
         os.makedirs(cfg.images_folder, exist_ok=True)
         if cfg.seed is not None:
@@ -1216,31 +1265,22 @@ class BimodalAttack:
         self._warned_nonfinite = False
         ops.set_graph_owner(id(self))            # (captured graphs replayed from here on are this attack's: ops.note_graph_replay)
         self._prepare_prompt(messages, target)
-        buffer = self.init_buffer(image)
-        optim_ids = buffer.get_best_ids()
-        self._warm_gemms(optim_ids.shape[1])
-
-        losses: List[float] = []
-        strings: List[str] = []
-        suffixes: List[str] = []
-        outputs: List[str] = []
-        t_grad: List[float] = []
-        t_samp: List[float] = []
-        t_loss: List[float] = []
-        t_pgd: List[float] = []
-        t_total: List[float] = []
-        trace = self.opt.trace
-        writer = _PngWriter() if (cfg.pgd_attack and self.opt.save_images and self.shard.rank == 0) else None
+        rs = _RunState()
+        rs.buffer = self.init_buffer(image)
+        rs.optim_ids = rs.buffer.get_best_ids()
+        self._warm_gemms(rs.optim_ids.shape[1])
+        rs.image = image
+        rs.trace = self.opt.trace
+        rs.writer = _PngWriter() if (cfg.pgd_attack and self.opt.save_images and self.shard.rank == 0) else None
 
         if cfg.pgd_attack:
             logger.warning(f"Using alpha: {cfg.alpha}, eps: {cfg.eps}")
             image.requires_grad = True            # the caller's tensor, as the reference (:425)
-            image_original = image.clone()
+            rs.image_original = image.clone()
 
         try:
             hook = self.opt.step_hook
             n_done = 0
-            pending = None
             self._early, self._parent_host = None, None      # nothing of an earlier run (an early stop leaves unused draws)
             # PGD-only: nothing is sampled, so the loss of the updated image can come out of the
             # next step's gradient pass (fuse_pgd_only); early_stop needs the argmax test of a
@@ -1249,343 +1289,365 @@ class BimodalAttack:
             # with: it always uses the llava segment order and the unscaled table (:968, :981-991), the
             # re-score the model's own order and embedding scale (:1142, :1150-1163) -- Gemma-3 differs
             # in both, so it keeps the separate re-score
-            fuse_pgd = bool(self.opt.fuse_pgd_only and cfg.pgd_attack and not cfg.gcg_attack and not cfg.early_stop
-                            and segment_order("gcg_pgd", mt) == segment_order("gcg_pgd", "llava")
-                            and self.hf.emb_scale == 1.0)
+            mt = self.hf.model_type
+            rs.fuse_pgd = bool(self.opt.fuse_pgd_only and cfg.pgd_attack and not cfg.gcg_attack and not cfg.early_stop
+                               and segment_order("gcg_pgd", mt) == segment_order("gcg_pgd", "llava")
+                               and self.hf.emb_scale == 1.0)
             for i in range(cfg.num_steps):
                 if hook is not None:
                     hook(i)
                 self._stamp("step")
                 n_done = i + 1
-                st: Optional[dict] = {} if trace is not None else None
-                if st is not None:
-                    trace.append(st)
-                    st.update(optim_ids_in=optim_ids.cpu().numpy(), n_grad=0, grad_tok=[], grad_img=[], losses=[],
-                              collectives=self.shard.n_collectives)     # (data-path collectives issued so far: tests)
-
-                # ---- phase A: gradients --------------------------------------------------
-                def note(g):
-                    if st is not None:
-                        st["n_grad"] += 1
-                        if g[0] is not None:
-                            st["grad_tok"].append(g[0][0].float().cpu().numpy())
-                        if g[1] is not None:
-                            st["grad_img"].append(g[1].cpu().numpy())
-
-                def grad_pass(record: bool = True, tokens_only: bool = False):
-                    t0 = self._sync()
-                    g = self.compute_gradient(optim_ids, image if cfg.pgd_attack else None, tokens_only)
-                    dt = self._sync() - t0
-                    t_grad.append(dt)
-                    if record:
-                        note(g)
-                    return g, dt
-
-                span = None
-                if pending is not None:
-                    # PGD-only: computed while scoring the previous step.  gradient_ahead: queued behind the previous
-                    # step's scoring forward and possibly still running; `span` holds its stream events
-                    (g_tok, g_img, _), grad_time, span = pending
-                    note((g_tok, g_img))
-                    pending = None
-                else:
-                    (g_tok, g_img, _), grad_time = grad_pass()
-
-                # ---- phase B: PGD update; phase C: second gradient pass -------------------
-                pgd_time = 0.0
-                image_synced = False
-                pgd_span = None
-                if cfg.pgd_attack:
-                    if span is not None:           # gradient_ahead: timed on the stream, read after the step
-                        pgd_span = _Span()
-                        image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
-                        pgd_span.stop()
-                    else:
-                        t0 = self._sync()
-                        image = self.perform_pgd_step(image, cfg.eps, cfg.alpha, g_img, image_original)
-                        pgd_time = self._sync() - t0
-                        t_pgd.append(pgd_time)
-                    if st is not None:
-                        st["image_after_pgd"] = image.detach().cpu().numpy()
-                    if cfg.gcg_attack and not cfg.joint_eval:
-                        # several GPUs: rank 0's image overwrites everybody's HERE, before its first consumer -- the
-                        # pass below caches what it derives from the image by tensor identity (_GradPrefix), so an
-                        # in-place overwrite behind it (the packed broadcast of the sampling phase) would leave the
-                        # winner re-score and the next token gradient on the pre-sync pixels
-                        self.shard.sync_state(image)
-                        image_synced = True
-                        # only the token gradient of this pass is used (the image has just been stepped)
-                        (g_tok, g_img, _), grad_time = grad_pass(tokens_only=True)
-
-                # ---- phase D: sampling (device part; the filter runs on the host during scoring) --
-                samp_time = 0.0
-                flying = None
-                virtual = None          # early_plan: host stand-ins of this step's candidates, known before they exist
-                if span is not None:
-                    # the gradient pass was queued ahead and may still be running: the sampling kernels go in behind it
-                    # and the host carries on to the scoring call -- the first thing to wait for the stream is the copy
-                    # of the sampled ids its plan needs (none at all with early_plan).  The gradient pass is timed by stream
-                    # events, read after the step.
-                    early = self._early if (self._early is not None and self._early["step"] == i) else None
-                    t_s = time.perf_counter()
-                    sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok, image if cfg.pgd_attack else None)
-                    # (the sampling kernels' own ~0.3 ms of GPU time are booked with the scoring phase: event pairs
-                    # around them, recorded while the gradient graph was still running, read 3-18 ms too long)
-                    flying = (span, time.perf_counter() - t_s, pgd_span)
-                    self._stamp("sampled")
-                    if early is not None and self._parent_host is not None:
-                        virtual = self._virtual_ids(early, self._parent_host)
-                    self._stamp("virtual")
-                else:
-                    t0 = self._sync()
-                    sampled_all, job = self.candidate_sampling(i, optim_ids, g_tok,
-                                                               image if (cfg.pgd_attack and not image_synced) else None)
-                    if cfg.gcg_attack:
-                        samp_time = self._sync() - t0
-                if self._filter_first_now():
-                    # a tokenizer that rejects a real share of the candidates: filter first, score the survivors only.  (In
-                    # joint mode the image features and the prefix pass -- which need no ids -- are queued in front of the
-                    # wait, so the GPU has that much to do while the host runs the round trip.)
-                    if cfg.pgd_attack and cfg.joint_eval and self._gp_enabled() and self._gp not in (None, False):
-                        with torch.no_grad():
-                            self.scoring_features(image)       # (cached: the scoring call below gets the same tensors back)
-                    sampled_all, job, filt_s = self._filter_now(sampled_all, job)
-                    self.filter_first_steps.append(i)
-                    virtual = None              # the plan made from the draws counted candidates that are gone now
-                    if flying is not None:
-                        flying = (flying[0], flying[1] + filt_s, flying[2])
-                    else:
-                        samp_time += filt_s
-                if cfg.gcg_attack:
-                    if st is not None:
-                        st["sampled"] = self._last["sampled"].cpu().numpy()
-                        st["topk_idx"] = self._last["topk_idx"].cpu().numpy()
-                        st["pos"] = self._last["pos"].cpu().numpy()
-                        st["rank"] = self._last["rank"].cpu().numpy()
-
-                # ---- phase D: scoring -----------------------------------------------------
-                t0 = time.perf_counter() if flying is not None else self._sync()
-                with torch.no_grad():
-                    def survivors(loss_all: Tensor, defer_hit: bool = False):
-                        """Apply the retokenisation filter, computed on the host while the GPU
-                        scored, to the losses: the reference's filtered vector, in order.  `defer_hit`: the
-                        early-stop verdict is handed back as a device tensor instead of being read here."""
-                        self._stamp("enqueued")
-                        keep = job.result()
-                        self._stamp("filtered")
-                        if getattr(job, "enabled", False):
-                            self._keep_rates.append(len(keep) / max(1, loss_all.shape[0]))
-                        if len(keep) == loss_all.shape[0]:
-                            idx = None
-                            out = loss_all, sampled_all
-                        else:
-                            idx = self._upload(np.asarray(keep, dtype=np.int64))
-                            out = loss_all[idx], sampled_all[idx]
-                        hit = None
-                        if cfg.early_stop and self._match is not None:
-                            hit = self._match if idx is None else self._match[idx]
-                            if not defer_hit and bool(hit.any().item()):
-                                self.stop_flag = True
-                        if st is not None:
-                            if cfg.filter_ids:
-                                st["filtered"] = out[1].cpu().numpy()
-                            st["losses"].append(out[0].float().cpu().numpy())
-                        return (*out, hit) if defer_hit else out
-
-                    def settle(loss: Tensor, sampled: Tensor, hit: Optional[Tensor], img: Optional[Tensor]):
-                        """gradient_ahead: the outcome stays on the device -- argmin -> winner -> the NEXT step's
-                        gradient pass, queued behind the scoring forward -- and the host gets ONE packed read-back
-                        (index, loss, early-stop verdict, the winner's ids), marked by an event in FRONT of that pass:
-                        whatever the host does from the read to the next sampling launch, the GPU is not waiting for
-                        it.  Returns (winner, host values, host clock at the read, the queued pass or None)."""
-                        at = loss.argmin().reshape(1)
-                        winner = sampled.index_select(0, at)
-                        f64 = torch.float64
-                        read = self._read_later(torch.cat([
-                            at.to(f64), loss.index_select(0, at).to(f64),
-                            (hit.any().reshape(1) if hit is not None else at.new_zeros(1)).to(f64),
-                            winner.reshape(-1).to(f64)]))
-                        queued = None
-                        rng_before = None
-                        if i + 1 < cfg.num_steps:
-                            # the draws of step i+1 come out of the global generator HERE, ahead of whatever else step i
-                            # still takes from it in the reference's order -- debug_output's generate() under a sampling
-                            # generation_config (:745-777) -- so that mode keeps the plain order; and a step that turns
-                            # out to stop the run (early_stop) gives its draws back, as if they had never been made
-                            if self.opt.early_plan and cfg.gcg_attack and not cfg.debug_output:
-                                if cfg.early_stop:
-                                    rng_before = self._rng_state()
-                                self._draw_ahead(i + 1, winner.shape[1])
-                            sp = _Span()
-                            with torch.enable_grad():
-                                g_next = self.compute_gradient(winner, img)
-                            queued = (g_next, None, sp.stop())
-                        self._stamp("queued_next")
-                        host = read()
-                        self._stamp("read")
-                        if rng_before is not None and host[2] != 0.0:
-                            self._rng_state(rng_before)
-                            self._early = None
-                        return winner, host, time.perf_counter(), queued
-
-                    ahead_ok = bool(self.opt.gradient_ahead and not (self.opt.tp_gradient and self.shard.enabled))
-                    prefetch_s = 0.0
-                    t_read = None           # when the host had this step's outcome (gradient_ahead: the stream is still busy then)
-                    ids_host = None
-                    parent = optim_ids if cfg.gcg_attack else None      # what the candidates were sampled from
-                    if fuse_pgd:
-                        # the forward of the NEXT gradient pass scores the image just updated.  Behind the LAST step there is
-                        # no next pass: the same (captured) pass still scores the final image -- its backward is wasted, 28 ms at
-                        # configs[1]'s size, where the eager scoring forward it replaces met the library with first-sight shapes
-                        # and took 195 ms, once per attack (profiles/r6_full_pgd100.json) -- and its time is scoring time
-                        with torch.enable_grad():
-                            pending = (*grad_pass(record=False), None)
-                        prefetch_s = pending[1] if i + 1 < cfg.num_steps else 0.0
-                        full = pending[0][2].reshape(1)
-                        if i + 1 >= cfg.num_steps:
-                            pending = None
-                            t_grad.pop()                  # (booked as scoring time: the result keeps one gradient time per step)
-                        if self.opt.loss_in_model_dtype:
-                            full = full.to(self.model.dtype)
-                        current_loss = full.item()
-                        best_idx, sampled, winner = 0, sampled_all, sampled_all[0:1].contiguous()
-                        if st is not None:
-                            st["losses"].append(full.float().cpu().numpy())
-                    elif (cfg.pgd_attack and cfg.gcg_attack and cfg.joint_eval and ahead_ok and self.opt.joint_winner_from_batch
-                          and segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt)
-                          and segment_order("pgd", mt, single=True) == self._GRAD_ORDER):
-                        # (image-in-front layouts only.  Gemma-3's joint step, suffix in front, was measured 10 % SLOWER
-                        # this way -- 491.8 -> 539.8 ms, same kernels and launch counts, the library GEMMs of its padded
-                        # scoring chunks each 10-16 % longer with the whole forward queued far ahead -- and keeps the
-                        # plain order)
-                        # joint mode with the winner's loss taken from the batch (see below): nothing but the outcome's
-                        # read-back needs the host, and the next gradient pass -- the tail rows against the prefix this
-                        # scoring call records -- needs the winner and the image, both on the device
-                        feats = self.scoring_features(image)
-                        loss, sampled, hit = survivors(self.score_candidates(
-                            sampled_all, segment_order("pgd", mt, single=True), feats, parent=parent, virtual=virtual),
-                            defer_hit=True)
-                        winner, host, t_read, pending = settle(loss, sampled, hit, image)
-                        if st is not None:
-                            st["losses"].append(np.asarray([host[1]], dtype=np.float32))
-                    elif cfg.pgd_attack:
-                        feats = self.scoring_features(image)
-                        if cfg.joint_eval:
-                            loss, sampled = survivors(self.score_candidates(
-                                sampled_all, segment_order("pgd", mt, single=True), feats, parent=parent))
-                        elif cfg.gcg_attack:
-                            loss, sampled = survivors(self.score_candidates(
-                                sampled_all, segment_order("gcg", mt, single=True), None, parent=parent))
-                        else:
-                            loss, sampled = None, sampled_all
-                        best_idx = int(loss.argmin().item()) if loss is not None else 0
-                        winner = sampled[best_idx:best_idx + 1].contiguous()
-                        # re-score the winner with the image (:605-612); on every rank, unsharded.  With
-                        # joint_eval the candidates WERE scored with the image, in the very segment order of
-                        # the re-score: the winner's row of that batch is the same function of the same
-                        # inputs, so it is taken instead of a second forward (joint_winner_from_batch).
-                        if cfg.joint_eval and loss is not None and self.opt.joint_winner_from_batch and \
-                                segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt):
-                            full = loss[best_idx].reshape(1).clone()
-                        else:
-                            full = self.rescore_winner(winner, segment_order("gcg_pgd", mt), feats)
-                            if cfg.early_stop and self._match is not None:
-                                hit = self._match.reshape(-1)[:1].to(torch.float32)
-                                if self.shard.enabled:
-                                    # every rank re-scored the winner itself: rank 0's verdict decides, or ranks
-                                    # could leave the loop at different steps
-                                    both = torch.cat([full.reshape(-1)[:1].to(torch.float32), hit])
-                                    self.shard.broadcast_(both)
-                                    full, hit = both[:1].to(full.dtype), both[1:]
-                                if bool(hit.any().item()):
-                                    self.stop_flag = True
-                        current_loss = full.item()
-                        if st is not None:
-                            st["losses"].append(full.float().cpu().numpy())
-                    elif ahead_ok:
-                        loss, sampled, hit = survivors(self.score_candidates(
-                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent,
-                            virtual=virtual), defer_hit=True)
-                        winner, host, t_read, pending = settle(loss, sampled, hit, None)
-                    else:
-                        loss, sampled = survivors(self.score_candidates(
-                            sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent))
-                        best_idx = int(loss.argmin().item())
-                        current_loss = loss[best_idx].item()
-                        winner = sampled[best_idx:best_idx + 1].contiguous()
-                    if t_read is not None:
-                        best_idx, current_loss = int(host[0]), float(host[1])
-                        if host[2] != 0.0:
-                            self.stop_flag = True
-                        ids_host = [int(v) for v in host[3:]]
-                        self._parent_host = ids_host
-                        if flying is not None:
-                            # the phases tile the step: what is left of the period between two read-backs after the
-                            # gradient pass, the PGD update and the sampling kernels is the scoring phase (host
-                            # planning included)
-                            grad_time, samp_time = flying[0].seconds(), flying[1]
-                            t_grad.append(grad_time)
-                            if flying[2] is not None:
-                                pgd_time = flying[2].seconds()
-                                t_pgd.append(pgd_time)
-                            t0 = min(t_read, self._t_read + grad_time + pgd_time + samp_time)
-                        self._t_read = t_read
-                    n = sampled.shape[0]
-                    optim_ids = winner                      # greedy: accepted even when worse (:613, :638)
-                    if current_loss != current_loss or current_loss in (float("inf"), float("-inf")):
-                        # the reference would carry a NaN on silently (argmin then picks arbitrary winners and
-                        # sign(NaN) poisons the image for good); so does the engine -- but it says so, once per run
-                        if not getattr(self, "_warned_nonfinite", False):
-                            self._warned_nonfinite = True
-                            logger.warning(f"[Iteration {i}] non-finite loss ({current_loss}): the run continues as the reference's "
-                                           "would, but its results from here on are meaningless")
-                    losses.append(current_loss)
-                    strings.append(tok.batch_decode(optim_ids if ids_host is None else [ids_host])[0])
-                    if buffer.size == 0 or current_loss < buffer.get_highest_loss():
-                        buffer.add(current_loss, optim_ids)
-                    self.n_scored.append(n)
-                    if st is not None:
-                        st.update(best_idx=best_idx, current_loss=current_loss, n_scored=n)
-                # a prefetched gradient pass is booked as gradient time
-                loss_time = max((self._sync() if t_read is None else t_read) - t0 - prefetch_s, 0.0)
-                if cfg.gcg_attack:
-                    # the reference books the filter under "sampling"; here it ran beside the forward, so what it
-                    # cost this section is the time result() was blocked on it
-                    # (gradient_ahead: result() is reached while the stream is still on its way to the ids' copy --
-                    # that wait is the gradient pass's, already booked; the round trip's own duration counts)
-                    filt = job.seconds if flying is not None else job.waited
-                    samp_time += filt
-                    loss_time = max(loss_time - filt, 0.0)
-                    t_samp.append(samp_time)
-                t_loss.append(loss_time)
-                logger.info(f"[Iteration {i}] Current loss: {current_loss:.4f} | Best loss: {buffer.get_lowest_loss():.4f} | ")
-
-                if writer is not None:
-                    writer.submit(image, os.path.join(cfg.images_folder, f"{i}.png"))
-                if cfg.debug_output and i % 10 == 0:
-                    outputs.append(self._debug_generate(sampled, image if cfg.pgd_attack else None, n))
-                else:
-                    outputs.append("")
-                suffixes.append(strings[-1])           # the reference decodes the same ids a second time (:782)
-                buffer.log_buffer(tok)
-                if self.stop_flag:
-                    logger.info("Early stopping due to finding a perfect match.")
+                sp = _StepState(i)
+                if rs.trace is not None:
+                    sp.st = {}
+                    rs.trace.append(sp.st)
+                    sp.st.update(optim_ids_in=rs.optim_ids.cpu().numpy(), n_grad=0, grad_tok=[], grad_img=[], losses=[],
+                                 collectives=self.shard.n_collectives)     # (data-path collectives issued so far: tests)
+                self._step_gradients(rs, sp)
+                self._step_pgd(rs, sp)
+                self._step_sampling(rs, sp)
+                self._step_scoring(rs, sp)
+                if self._step_close(rs, sp):
                     break
-                t_total.append(grad_time + samp_time + pgd_time + loss_time)
             if hook is not None:
                 hook(n_done)
-            if trace:
-                trace[-1]["collectives_end"] = self.shard.n_collectives
+            if rs.trace:
+                rs.trace[-1]["collectives_end"] = self.shard.n_collectives
         finally:
-            if writer is not None:
-                writer.close()
+            if rs.writer is not None:
+                rs.writer.close()
 
-        self.final_image = image
-        k = losses.index(min(losses))
+        self.final_image = rs.image
+        k = rs.losses.index(min(rs.losses))
         return BimodalAttackResult(
-            best_loss=losses[k], best_string=strings[k], losses=losses, strings=strings,
-            adversarial_suffixes=suffixes, model_outputs=outputs, gradient_times=t_grad, sampling_times=t_samp,
-            loss_times=t_loss, pgd_times=t_pgd, total_times=t_total)
+            best_loss=rs.losses[k], best_string=rs.strings[k], losses=rs.losses, strings=rs.strings,
+            adversarial_suffixes=rs.suffixes, model_outputs=rs.outputs, gradient_times=rs.t_grad, sampling_times=rs.t_samp,
+            loss_times=rs.t_loss, pgd_times=rs.t_pgd, total_times=rs.t_total)
+
+    # ---- phase A: gradients ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _note_gradient(sp: "_StepState", g) -> None:
+        st = sp.st
+        if st is not None:
+            st["n_grad"] += 1
+            if g[0] is not None:
+                st["grad_tok"].append(g[0][0].float().cpu().numpy())
+            if g[1] is not None:
+                st["grad_img"].append(g[1].cpu().numpy())
+
+    def _grad_pass(self, rs: "_RunState", sp: "_StepState", record: bool = True, tokens_only: bool = False):
+        t0 = self._sync()
+        g = self.compute_gradient(rs.optim_ids, rs.image if self.config.pgd_attack else None, tokens_only)
+        dt = self._sync() - t0
+        rs.t_grad.append(dt)
+        if record:
+            self._note_gradient(sp, g)
+        return g, dt
+
+    def _step_gradients(self, rs: "_RunState", sp: "_StepState") -> None:
+        if rs.pending is not None:
+            # PGD-only: computed while scoring the previous step.  gradient_ahead: queued behind the previous
+            # step's scoring forward and possibly still running; `span` holds its stream events
+            (sp.g_tok, sp.g_img, _), sp.grad_time, sp.span = rs.pending
+            self._note_gradient(sp, (sp.g_tok, sp.g_img))
+            rs.pending = None
+        else:
+            (sp.g_tok, sp.g_img, _), sp.grad_time = self._grad_pass(rs, sp)
+
+    # ---- phase B: PGD update; phase C: second gradient pass ------------------------------------------------------------
+    def _step_pgd(self, rs: "_RunState", sp: "_StepState") -> None:
+        cfg = self.config
+        if not cfg.pgd_attack:
+            return
+        if sp.span is not None:           # gradient_ahead: timed on the stream, read after the step
+            sp.pgd_span = _Span()
+            rs.image = self.perform_pgd_step(rs.image, cfg.eps, cfg.alpha, sp.g_img, rs.image_original)
+            sp.pgd_span.stop()
+        else:
+            t0 = self._sync()
+            rs.image = self.perform_pgd_step(rs.image, cfg.eps, cfg.alpha, sp.g_img, rs.image_original)
+            sp.pgd_time = self._sync() - t0
+            rs.t_pgd.append(sp.pgd_time)
+        if sp.st is not None:
+            sp.st["image_after_pgd"] = rs.image.detach().cpu().numpy()
+        if cfg.gcg_attack and not cfg.joint_eval:
+            # several GPUs: rank 0's image overwrites everybody's HERE, before its first consumer -- the
+            # pass below caches what it derives from the image by tensor identity (_GradPrefix), so an
+            # in-place overwrite behind it (the packed broadcast of the sampling phase) would leave the
+            # winner re-score and the next token gradient on the pre-sync pixels
+            self.shard.sync_state(rs.image)
+            sp.image_synced = True
+            # only the token gradient of this pass is used (the image has just been stepped)
+            (sp.g_tok, sp.g_img, _), sp.grad_time = self._grad_pass(rs, sp, tokens_only=True)
+
+    # ---- phase D: sampling (device part; the filter runs on the host during scoring) -----------------------------------
+    def _step_sampling(self, rs: "_RunState", sp: "_StepState") -> None:
+        cfg, i = self.config, sp.i
+        image = rs.image
+        if sp.span is not None:
+            # the gradient pass was queued ahead and may still be running: the sampling kernels go in behind it
+            # and the host carries on to the scoring call -- the first thing to wait for the stream is the copy
+            # of the sampled ids its plan needs (none at all with early_plan).  The gradient pass is timed by stream
+            # events, read after the step.
+            early = self._early if (self._early is not None and self._early["step"] == i) else None
+            t_s = time.perf_counter()
+            sp.sampled_all, sp.job = self.candidate_sampling(i, rs.optim_ids, sp.g_tok, image if cfg.pgd_attack else None)
+            # (the sampling kernels' own ~0.3 ms of GPU time are booked with the scoring phase: event pairs
+            # around them, recorded while the gradient graph was still running, read 3-18 ms too long)
+            sp.flying = (sp.span, time.perf_counter() - t_s, sp.pgd_span)
+            self._stamp("sampled")
+            if early is not None and self._parent_host is not None:
+                sp.virtual = self._virtual_ids(early, self._parent_host)
+            self._stamp("virtual")
+        else:
+            t0 = self._sync()
+            sp.sampled_all, sp.job = self.candidate_sampling(i, rs.optim_ids, sp.g_tok,
+                                                             image if (cfg.pgd_attack and not sp.image_synced) else None)
+            if cfg.gcg_attack:
+                sp.samp_time = self._sync() - t0
+        if self._filter_first_now():
+            # a tokenizer that rejects a real share of the candidates: filter first, score the survivors only.  (In
+            # joint mode the image features and the prefix pass -- which need no ids -- are queued in front of the
+            # wait, so the GPU has that much to do while the host runs the round trip.)
+            if cfg.pgd_attack and cfg.joint_eval and self._gp_enabled() and self._gp not in (None, False):
+                with torch.no_grad():
+                    self.scoring_features(image)       # (cached: the scoring call below gets the same tensors back)
+            sp.sampled_all, sp.job, filt_s = self._filter_now(sp.sampled_all, sp.job)
+            self.filter_first_steps.append(i)
+            sp.virtual = None              # the plan made from the draws counted candidates that are gone now
+            if sp.flying is not None:
+                sp.flying = (sp.flying[0], sp.flying[1] + filt_s, sp.flying[2])
+            else:
+                sp.samp_time += filt_s
+        if cfg.gcg_attack:
+            st = sp.st
+            if st is not None:
+                st["sampled"] = self._last["sampled"].cpu().numpy()
+                st["topk_idx"] = self._last["topk_idx"].cpu().numpy()
+                st["pos"] = self._last["pos"].cpu().numpy()
+                st["rank"] = self._last["rank"].cpu().numpy()
+
+    # ---- phase D: scoring ----------------------------------------------------------------------------------------------
+    def _survivors(self, sp: "_StepState", loss_all: Tensor, defer_hit: bool = False):
+        """Apply the retokenisation filter, computed on the host while the GPU
+        scored, to the losses: the reference's filtered vector, in order.  `defer_hit`: the
+        early-stop verdict is handed back as a device tensor instead of being read here."""
+        cfg, st, job, sampled_all = self.config, sp.st, sp.job, sp.sampled_all
+        self._stamp("enqueued")
+        keep = job.result()
+        self._stamp("filtered")
+        if getattr(job, "enabled", False):
+            self._keep_rates.append(len(keep) / max(1, loss_all.shape[0]))
+        if len(keep) == loss_all.shape[0]:
+            idx = None
+            out = loss_all, sampled_all
+        else:
+            idx = self._upload(np.asarray(keep, dtype=np.int64))
+            out = loss_all[idx], sampled_all[idx]
+        hit = None
+        if cfg.early_stop and self._match is not None:
+            hit = self._match if idx is None else self._match[idx]
+            if not defer_hit and bool(hit.any().item()):
+                self.stop_flag = True
+        if st is not None:
+            if cfg.filter_ids:
+                st["filtered"] = out[1].cpu().numpy()
+            st["losses"].append(out[0].float().cpu().numpy())
+        return (*out, hit) if defer_hit else out
+
+    def _settle(self, sp: "_StepState", loss: Tensor, sampled: Tensor, hit: Optional[Tensor], img: Optional[Tensor]):
+        """gradient_ahead: the outcome stays on the device -- argmin -> winner -> the NEXT step's
+        gradient pass, queued behind the scoring forward -- and the host gets ONE packed read-back
+        (index, loss, early-stop verdict, the winner's ids), marked by an event in FRONT of that pass:
+        whatever the host does from the read to the next sampling launch, the GPU is not waiting for
+        it.  Returns (winner, host values, host clock at the read, the queued pass or None)."""
+        cfg, i = self.config, sp.i
+        at = loss.argmin().reshape(1)
+        winner = sampled.index_select(0, at)
+        f64 = torch.float64
+        read = self._read_later(torch.cat([
+            at.to(f64), loss.index_select(0, at).to(f64),
+            (hit.any().reshape(1) if hit is not None else at.new_zeros(1)).to(f64),
+            winner.reshape(-1).to(f64)]))
+        queued = None
+        rng_before = None
+        if i + 1 < cfg.num_steps:
+            # the draws of step i+1 come out of the global generator HERE, ahead of whatever else step i
+            # still takes from it in the reference's order -- debug_output's generate() under a sampling
+            # generation_config (:745-777) -- so that mode keeps the plain order; and a step that turns
+            # out to stop the run (early_stop) gives its draws back, as if they had never been made
+            if self.opt.early_plan and cfg.gcg_attack and not cfg.debug_output:
+                if cfg.early_stop:
+                    rng_before = self._rng_state()
+                self._draw_ahead(i + 1, winner.shape[1])
+            span = _Span()
+            with torch.enable_grad():
+                g_next = self.compute_gradient(winner, img)
+            queued = (g_next, None, span.stop())
+        self._stamp("queued_next")
+        host = read()
+        self._stamp("read")
+        if rng_before is not None and host[2] != 0.0:
+            self._rng_state(rng_before)
+            self._early = None
+        return winner, host, time.perf_counter(), queued
+
+    def _step_scoring(self, rs: "_RunState", sp: "_StepState") -> None:
+        cfg, mt, i, st = self.config, self.hf.model_type, sp.i, sp.st
+        image, sampled_all, virtual = rs.image, sp.sampled_all, sp.virtual
+        sp.t0 = time.perf_counter() if sp.flying is not None else self._sync()
+        with torch.no_grad():
+            ahead_ok = bool(self.opt.gradient_ahead and not (self.opt.tp_gradient and self.shard.enabled))
+            host = None
+            best_idx = 0
+            current_loss = None
+            parent = rs.optim_ids if cfg.gcg_attack else None      # what the candidates were sampled from
+            if rs.fuse_pgd:
+                # the forward of the NEXT gradient pass scores the image just updated.  Behind the LAST step there is
+                # no next pass: the same (captured) pass still scores the final image -- its backward is wasted, 28 ms at
+                # configs[1]'s size, where the eager scoring forward it replaces met the library with first-sight shapes
+                # and took 195 ms, once per attack (profiles/r6_full_pgd100.json) -- and its time is scoring time
+                with torch.enable_grad():
+                    rs.pending = (*self._grad_pass(rs, sp, record=False), None)
+                sp.prefetch_s = rs.pending[1] if i + 1 < cfg.num_steps else 0.0
+                full = rs.pending[0][2].reshape(1)
+                if i + 1 >= cfg.num_steps:
+                    rs.pending = None
+                    rs.t_grad.pop()                  # (booked as scoring time: the result keeps one gradient time per step)
+                if self.opt.loss_in_model_dtype:
+                    full = full.to(self.model.dtype)
+                current_loss = full.item()
+                best_idx, sampled, winner = 0, sampled_all, sampled_all[0:1].contiguous()
+                if st is not None:
+                    st["losses"].append(full.float().cpu().numpy())
+            elif (cfg.pgd_attack and cfg.gcg_attack and cfg.joint_eval and ahead_ok and self.opt.joint_winner_from_batch
+                  and segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt)
+                  and segment_order("pgd", mt, single=True) == self._GRAD_ORDER):
+                # (image-in-front layouts only.  Gemma-3's joint step, suffix in front, was measured 10 % SLOWER
+                # this way -- 491.8 -> 539.8 ms, same kernels and launch counts, the library GEMMs of its padded
+                # scoring chunks each 10-16 % longer with the whole forward queued far ahead -- and keeps the
+                # plain order)
+                # joint mode with the winner's loss taken from the batch (see below): nothing but the outcome's
+                # read-back needs the host, and the next gradient pass -- the tail rows against the prefix this
+                # scoring call records -- needs the winner and the image, both on the device
+                feats = self.scoring_features(image)
+                loss, sampled, hit = self._survivors(sp, self.score_candidates(
+                    sampled_all, segment_order("pgd", mt, single=True), feats, parent=parent, virtual=virtual),
+                    defer_hit=True)
+                winner, host, sp.t_read, rs.pending = self._settle(sp, loss, sampled, hit, image)
+                if st is not None:
+                    st["losses"].append(np.asarray([host[1]], dtype=np.float32))
+            elif cfg.pgd_attack:
+                feats = self.scoring_features(image)
+                if cfg.joint_eval:
+                    loss, sampled = self._survivors(sp, self.score_candidates(
+                        sampled_all, segment_order("pgd", mt, single=True), feats, parent=parent))
+                elif cfg.gcg_attack:
+                    loss, sampled = self._survivors(sp, self.score_candidates(
+                        sampled_all, segment_order("gcg", mt, single=True), None, parent=parent))
+                else:
+                    loss, sampled = None, sampled_all
+                best_idx = int(loss.argmin().item()) if loss is not None else 0
+                winner = sampled[best_idx:best_idx + 1].contiguous()
+                # re-score the winner with the image (:605-612); on every rank, unsharded.  With
+                # joint_eval the candidates WERE scored with the image, in the very segment order of
+                # the re-score: the winner's row of that batch is the same function of the same
+                # inputs, so it is taken instead of a second forward (joint_winner_from_batch).
+                if cfg.joint_eval and loss is not None and self.opt.joint_winner_from_batch and \
+                        segment_order("pgd", mt, single=True) == segment_order("gcg_pgd", mt):
+                    full = loss[best_idx].reshape(1).clone()
+                else:
+                    full = self.rescore_winner(winner, segment_order("gcg_pgd", mt), feats)
+                    if cfg.early_stop and self._match is not None:
+                        hit = self._match.reshape(-1)[:1].to(torch.float32)
+                        if self.shard.enabled:
+                            # every rank re-scored the winner itself: rank 0's verdict decides, or ranks
+                            # could leave the loop at different steps
+                            both = torch.cat([full.reshape(-1)[:1].to(torch.float32), hit])
+                            self.shard.broadcast_(both)
+                            full, hit = both[:1].to(full.dtype), both[1:]
+                        if bool(hit.any().item()):
+                            self.stop_flag = True
+                current_loss = full.item()
+                if st is not None:
+                    st["losses"].append(full.float().cpu().numpy())
+            elif ahead_ok:
+                loss, sampled, hit = self._survivors(sp, self.score_candidates(
+                    sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent,
+                    virtual=virtual), defer_hit=True)
+                winner, host, sp.t_read, rs.pending = self._settle(sp, loss, sampled, hit, None)
+            else:
+                loss, sampled = self._survivors(sp, self.score_candidates(
+                    sampled_all, segment_order("gcg", mt, no_joint_eval=True), None, parent=parent))
+                best_idx = int(loss.argmin().item())
+                current_loss = loss[best_idx].item()
+                winner = sampled[best_idx:best_idx + 1].contiguous()
+            if sp.t_read is not None:
+                best_idx, current_loss = int(host[0]), float(host[1])
+                if host[2] != 0.0:
+                    self.stop_flag = True
+                sp.ids_host = [int(v) for v in host[3:]]
+                self._parent_host = sp.ids_host
+                if sp.flying is not None:
+                    # the phases tile the step: what is left of the period between two read-backs after the
+                    # gradient pass, the PGD update and the sampling kernels is the scoring phase (host
+                    # planning included)
+                    sp.grad_time, sp.samp_time = sp.flying[0].seconds(), sp.flying[1]
+                    rs.t_grad.append(sp.grad_time)
+                    if sp.flying[2] is not None:
+                        sp.pgd_time = sp.flying[2].seconds()
+                        rs.t_pgd.append(sp.pgd_time)
+                    sp.t0 = min(sp.t_read, self._t_read + sp.grad_time + sp.pgd_time + sp.samp_time)
+                self._t_read = sp.t_read
+            sp.sampled, sp.n = sampled, sampled.shape[0]
+            rs.optim_ids = winner                      # greedy: accepted even when worse (:613, :638)
+            if current_loss != current_loss or current_loss in (float("inf"), float("-inf")):
+                # the reference would carry a NaN on silently (argmin then picks arbitrary winners and
+                # sign(NaN) poisons the image for good); so does the engine -- but it says so, once per run
+                if not getattr(self, "_warned_nonfinite", False):
+                    self._warned_nonfinite = True
+                    logger.warning(f"[Iteration {i}] non-finite loss ({current_loss}): the run continues as the reference's "
+                                   "would, but its results from here on are meaningless")
+            sp.current_loss = current_loss
+            rs.losses.append(current_loss)
+            rs.strings.append(self.tokenizer.batch_decode(rs.optim_ids if sp.ids_host is None else [sp.ids_host])[0])
+            if rs.buffer.size == 0 or current_loss < rs.buffer.get_highest_loss():
+                rs.buffer.add(current_loss, rs.optim_ids)
+            self.n_scored.append(sp.n)
+            if st is not None:
+                st.update(best_idx=best_idx, current_loss=current_loss, n_scored=sp.n)
+
+    # ---- the step's times, outputs and logs; True when the run stops here -------------------------------------------------
+    def _step_close(self, rs: "_RunState", sp: "_StepState") -> bool:
+        cfg, i = self.config, sp.i
+        # a prefetched gradient pass is booked as gradient time
+        loss_time = max((self._sync() if sp.t_read is None else sp.t_read) - sp.t0 - sp.prefetch_s, 0.0)
+        if cfg.gcg_attack:
+            # the reference books the filter under "sampling"; here it ran beside the forward, so what it
+            # cost this section is the time result() was blocked on it
+            # (gradient_ahead: result() is reached while the stream is still on its way to the ids' copy --
+            # that wait is the gradient pass's, already booked; the round trip's own duration counts)
+            filt = sp.job.seconds if sp.flying is not None else sp.job.waited
+            sp.samp_time += filt
+            loss_time = max(loss_time - filt, 0.0)
+            rs.t_samp.append(sp.samp_time)
+        rs.t_loss.append(loss_time)
+        logger.info(f"[Iteration {i}] Current loss: {sp.current_loss:.4f} | Best loss: {rs.buffer.get_lowest_loss():.4f} | ")
+
+        if rs.writer is not None:
+            rs.writer.submit(rs.image, os.path.join(cfg.images_folder, f"{i}.png"))
+        if cfg.debug_output and i % 10 == 0:
+            rs.outputs.append(self._debug_generate(sp.sampled, rs.image if cfg.pgd_attack else None, sp.n))
+        else:
+            rs.outputs.append("")
+        rs.suffixes.append(rs.strings[-1])           # the reference decodes the same ids a second time (:782)
+        rs.buffer.log_buffer(self.tokenizer)
+        if self.stop_flag:
+            logger.info("Early stopping due to finding a perfect match.")
+            return True
+        rs.t_total.append(sp.grad_time + sp.samp_time + sp.pgd_time + loss_time)
+        return False
 
     # ------------------------------------------------------------ debug output
     def _debug_generate(self, sampled: Tensor, image: Optional[Tensor], n: int) -> str:
