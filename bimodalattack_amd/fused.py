@@ -50,6 +50,26 @@ def _eps_of(m):
 
 
 SKINNY_ROWS = 1024     # rows up to which the gradient pass takes its input gradients through transposed weight copies
+# A no-grad product whose row count sits just above a whole number of 256 x 256 tile rounds of the library's kernel on this
+# chip's CUs runs as TWO calls -- the whole rounds, then the rest: 16896 x 4096 is 66 x 16 = 1056 tiles = 4.1 rounds on 256
+# CUs and takes five (o_proj 416 us, down_proj 1072 us), 16384 rows + 512 rows take 388 / 1000 us (profiles/r6_round_split.txt;
+# q/k/v and gate/up, whose rounds do not end on a row-tile boundary, gain nothing and are left alone).  BMA_ROUND_SPLIT=0: off.
+ROUND_SPLIT = _os.environ.get("BMA_ROUND_SPLIT", "1") not in ("0", "false", "False")
+_CUS = {}
+
+
+def round_cut(rows: int, n_out: int, cus: int) -> int:
+    """Row count of the first of two calls for a rows x n_out product on `cus` compute units, 0 = one call: the whole tile
+    rounds of 256 x 256 tiles, when a round ends on a row-tile boundary and what is left is at most 5/16 of a round."""
+    col_tiles = (n_out + 255) // 256
+    if col_tiles <= 0 or (cus * 256) % col_tiles:
+        return 0
+    per_round = cus * 256 // col_tiles                  # rows of one round
+    if per_round % 256:
+        return 0
+    cut = rows // per_round * per_round
+    rest = rows - cut
+    return cut if cut > 0 and 0 < rest <= per_round * 5 // 16 else 0
 
 # Derived weight copies (transposed, concatenated q/k/v, interleaved gate/up) belong to the MODEL, not to one attack
 # object: a second attack on the same model (the next prompt of an experiment, bench.py's other workloads) finds them
@@ -481,6 +501,19 @@ class FusedInference:
         copy of the (constant) weight so that it, too, streams weight rows along the reduction."""
         def forward(x):
             w = m.weight
+            if ROUND_SPLIT and not self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16) \
+                    and x.is_contiguous() and self.tp is None:
+                cus = _CUS.get(x.device)
+                if cus is None:
+                    cus = _CUS[x.device] = torch.cuda.get_device_properties(x.device).multi_processor_count
+                rows = x.numel() // x.shape[-1]
+                cut = round_cut(rows, w.shape[0], cus)
+                if cut:
+                    x2 = x.view(rows, x.shape[-1])
+                    out = x2.new_empty((rows, w.shape[0]))
+                    torch.mm(x2[:cut], w.t(), out=out[:cut])
+                    torch.mm(x2[cut:], w.t(), out=out[cut:])
+                    return out.view(*x.shape[:-1], w.shape[0])
             if not (self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                     and x.numel() // x.shape[-1] <= SKINNY_ROWS):
                 return orig(x)
