@@ -59,25 +59,19 @@ _CUS = {}
 
 
 def round_cut(rows: int, n_out: int, cus: int) -> int:
-    """Row count of the first of two calls for a rows x n_out product on `cus` compute units, 0 = one call: the whole tile
-    rounds of 256 x 256 tiles, when a round ends on a row-tile boundary and what is left is at most 5/16 of a round."""
+    """Row count of the first of two calls for a rows x n_out product on `cus` compute units, 0 = one call.  In 256 x 256
+    tiles, n_out is C tile columns; cus tiles make a round, and rounds end on a row-tile boundary every cus / gcd(cus, C) row
+    tiles (16 for C = 16 or 48, 128 for C = 86).  The cut is the last such boundary, taken when what is left behind it is at
+    most 5/16 of a round's tiles (measured: at 6/16 the second call costs what the saved part-round did)."""
+    from math import gcd
     col_tiles = (n_out + 255) // 256
-    if col_tiles <= 0 or (cus * 256) % col_tiles:
+    row_tiles = (rows + 255) // 256
+    if col_tiles <= 0 or cus <= 0:
         return 0
-    per_round = cus * 256 // col_tiles                  # rows of one round
-    if per_round % 256:
-        return 0
-    cut = rows // per_round * per_round
-    rest = rows - cut
-    return cut if cut > 0 and 0 < rest <= per_round * 5 // 16 else 0
-
-# Derived weight copies (transposed, concatenated q/k/v, interleaved gate/up) belong to the MODEL, not to one attack
-# object: a second attack on the same model (the next prompt of an experiment, bench.py's other workloads) finds them
-# instead of building another 30 GB.  Every copy remembers the (data_ptr, _version) of the tensors it was made from
-# and is rebuilt when a caller has changed the weights in between (``_CopyCache.get``).
-import weakref
-
-_COPY_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+    period = cus // gcd(cus, col_tiles)
+    cut_tiles = row_tiles // period * period
+    rest_tiles = (row_tiles - cut_tiles) * col_tiles
+    return cut_tiles * 256 if cut_tiles > 0 and 0 < rest_tiles <= cus * 5 // 16 else 0
 
 
 class _CopyCache:

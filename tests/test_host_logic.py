@@ -864,14 +864,18 @@ def test_bench_line_guard_prints_the_held_line_only_when_its_parent_dies():
 
 
 def test_round_cut_splits_only_just_above_whole_tile_rounds():
-    """fused.round_cut: a rows x N product is cut into (whole 256 x 256 tile rounds, rest) only when a round ends on a row-tile
-    boundary (N / 256 divides CUs * 256 into a multiple of 256 rows) and the rest is at most 5/16 of a round."""
+    """fused.round_cut: a rows x N product is cut into (whole 256 x 256 tile rounds, rest) at the last row-tile boundary on
+    which a round ends, when the rest is at most 5/16 of a round's tiles."""
     from bimodalattack_amd.fused import round_cut
     assert round_cut(16896, 4096, 256) == 16384 and round_cut(17152, 4096, 256) == 16384 and round_cut(17664, 4096, 256) == 16384
     assert round_cut(16384, 4096, 256) == 0              # whole rounds already
     assert round_cut(18432, 4096, 256) == 0              # half a round left: one call
+    assert round_cut(17920, 4096, 256) == 0              # 6 row tiles x 16 = 96 tiles > 80
     assert round_cut(3000, 4096, 256) == 0               # less than one round
     assert round_cut(8704, 4096, 256) == 8192 and round_cut(4352, 4096, 256) == 4096      # rank 0's rows of 2 / 4 ranks
-    assert round_cut(16896, 12288, 256) == 0 and round_cut(16896, 22016, 256) == 0        # 48 / 86 tile columns: rounds end mid-tile
-    assert round_cut(16896, 2560, 256) == 0              # Gemma-3's width: 10 tile columns
+    assert round_cut(16896, 12288, 256) == 0             # 48 tile columns: 2 row tiles behind the boundary are 96 tiles
+    assert round_cut(16640, 12288, 256) == 16384 and round_cut(4352, 12288, 256) == 4096  # one row tile behind it: 48 tiles
+    assert round_cut(16896, 22016, 256) == 0             # 86 tile columns: rounds end every 128 row tiles
+    assert round_cut(48480, 2560, 256) == 0 and round_cut(48480, 20480, 256) == 0         # Gemma-3's products: too much left
     assert round_cut(16896, 4096, 304) == 0 and round_cut(4200, 8192, 256) == 4096
+    assert round_cut(16500, 4096, 256) == 16384          # a row count off the tile grid: the cut is on it
