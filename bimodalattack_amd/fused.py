@@ -74,6 +74,14 @@ def round_cut(rows: int, n_out: int, cus: int) -> int:
     return cut_tiles * 256 if cut_tiles > 0 and 0 < rest_tiles <= cus * 5 // 16 else 0
 
 
+# Derived weight copies (transposed, concatenated q/k/v, interleaved gate/up) belong to the MODEL, not to one attack
+# object: a second attack on the same model (the next prompt of an experiment, bench.py's other workloads) finds them
+# instead of building another 30 GB.  Every copy remembers the (data_ptr, _version) of the tensors it was made from
+# and is rebuilt when a caller has changed the weights in between (``_CopyCache.get``).
+import weakref
+
+_COPY_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
 class _CopyCache:
     def __init__(self):
         self.d = {}

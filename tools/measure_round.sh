@@ -32,7 +32,9 @@ timeout -k 10 300 python bench.py --workload pgd_gcg --no-cpu-baseline --extra-w
 for n in 2 4 8; do
   BMA_EMULATE_WORLD=$n timeout -k 10 300 python bench.py --no-cpu-baseline --detail "$D/bench_em${n}_detail.json" > "$D/bench_em$n.json" 2> /dev/null; echo "em$n-rc=$?"
 done
-BMA_EMULATE_WORLD=8 timeout -k 10 300 python bench.py --workload joint --no-cpu-baseline --detail "$D/bench_joint_em8_detail.json" > "$D/bench_joint_em8.json" 2> /dev/null; echo "joint-em8-rc=$?"
+for n in 2 4 8; do
+  BMA_EMULATE_WORLD=$n timeout -k 10 300 python bench.py --workload joint --no-cpu-baseline --detail "$D/bench_joint_em${n}_detail.json" > "$D/bench_joint_em$n.json" 2> /dev/null; echo "joint-em$n-rc=$?"
+done
 timeout -k 10 300 python bench.py --workload opt125m --detail "$D/bench_opt125m_detail.json" > "$D/bench_opt125m.json" 2> "$D/bench_opt125m.err"; echo "opt125m-rc=$?"
 timeout -k 10 200 python tools/gemm_bench.py --rows 65,44 --json "$D/gemm_bench.json" 2>&1 | grep -v amdgpu.ids > "$D/gemm_bench.txt"; echo "gemm-bench-rc=$?"
 timeout -k 10 200 python tools/gemm_bench.py --chain --rows 65,44 --json "$D/gemm_chain.json" 2>&1 | grep -v amdgpu.ids > "$D/gemm_chain.txt"; echo "gemm-chain-rc=$?"
