@@ -33,7 +33,7 @@ for w in ("gcg", "joint", "pgd", "gemma_joint"):  # the batch-1 gradient pass al
                     f.write("# " + (last[0] if last else "") + "\n")
 for extra in ("bench_driver_detail.json", "bench_gcg_under_rocprof_detail.json", "bench_joint_under_rocprof_detail.json",
               "bench_pgd_under_rocprof_detail.json", "bench_gemma_joint_under_rocprof_detail.json", "bench_em8_detail.json",
-              "bench_joint_em8_detail.json", "bench_opt125m_detail.json", "bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
+              "bench_joint_em8_detail.json", "bench_opt125m_detail.json", "bench_em2.json", "bench_em4.json", "bench_em8.json", "bench_joint_em2.json", "bench_joint_em4.json", "bench_joint_em8.json", "bench_opt125m.json", "bench_pgd.json", "bench_pgd_gcg.json", "bench_joint.json",
               "bench_gemma_joint.json", "bench_default.json", "bench_driver.json", "gemm_bench.json", "gemm_bench.txt", "gemm_mid_bench.json", "gemm_mid_bench.txt", "gemm_chain.json", "gemm_chain.txt", "kernel_bench.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copyfile(os.path.join(src, extra), os.path.join(out, f"{tag}_{extra}"))
