@@ -232,6 +232,66 @@ def test_fused_context_patches_and_restores(kind, dtype):
     assert not any("forward" in m.__dict__ for m in model.modules())
 
 
+def test_products_just_above_whole_tile_rounds_run_as_two_calls():
+    """fused.round_cut / ROUND_SPLIT: inside the fused context a no-grad o_proj / down_proj product whose row count sits just above a
+    whole number of 256 x 256 tile rounds (4352 rows x 4096 columns on this chip's CUs: 17 x 16 = 272 tiles) is issued as two library
+    calls into row slices of ONE output -- the same rows, so the same numbers up to the rounding of whichever solution serves each
+    call (fp32 accumulation, one rounding to bf16) -- and a product that does not qualify, a recording autograd, or the switch turned
+    off leave the module's own forward in charge."""
+    from bimodalattack_amd import fused as F_
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+
+    class Block(torch.nn.Module):               # what FusedInference looks for: a block with bias-free projections
+        def __init__(self):
+            super().__init__()
+            self.q_proj = torch.nn.Linear(512, 64, bias=False)
+            self.o_proj = torch.nn.Linear(512, 4096, bias=False)
+            self.layer_idx = 0
+
+    g = torch.Generator(device=DEV).manual_seed(2)
+    blk = Block().to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        blk.o_proj.weight.copy_(torch.randn((4096, 512), generator=g, device=DEV) * 0.05)
+    rows = 256 * (cus // 16 + 1)                # one row tile behind the first round boundary (4352 on 256 CUs)
+    assert F_.round_cut(rows, 4096, cus) == rows - 256
+    x = torch.randn((1, rows, 512), generator=g, device=DEV).to(torch.bfloat16)
+    want = torch.nn.functional.linear(x.double(), blk.o_proj.weight.detach().double())
+    calls = []
+    real_mm = torch.mm
+
+    def counting_mm(a, b, out=None):
+        calls.append(tuple(a.shape))
+        return real_mm(a, b, out=out)
+
+    fi = F_.FusedInference(blk, True)
+    try:
+        torch.mm = counting_mm
+        with torch.no_grad(), fi:
+            got = blk.o_proj(x)
+            assert calls == [(rows - 256, 512), (256, 512)], calls
+            calls.clear()
+            small = blk.o_proj(x[:, :rows - 256])               # whole rounds exactly: one call, the module's own
+            assert calls == [] and small.shape == (1, rows - 256, 4096)
+        with fi:
+            xg = x.clone().requires_grad_()
+            y = blk.o_proj(xg)                                  # autograd records: never split
+            assert calls == [] and y.requires_grad
+        old = F_.ROUND_SPLIT
+        F_.ROUND_SPLIT = False
+        try:
+            with torch.no_grad(), fi:
+                off = blk.o_proj(x)
+            assert calls == []
+        finally:
+            F_.ROUND_SPLIT = old
+    finally:
+        torch.mm = real_mm
+    assert got.shape == (1, rows, 4096) and got.dtype == torch.bfloat16
+    for t in (got, off):
+        err = (t.double() - want).abs() / want.abs().clamp_min(1.0)
+        assert float(err.max()) <= 2.0 ** -8, float(err.max())      # one bf16 rounding of an fp32-accumulated sum
+
+
 # ------------------------------------------------------------------ shared-prefix attention
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 def test_attn_merge_and_shared_prefix_equal_full_attention(dtype):
