@@ -316,6 +316,7 @@ class BimodalAttack:
         self.fused = FusedInference(model, self.opt.fused_elementwise, copies, copies, copies, self.opt.fuse_add_norm, FUSE_QK_ROPE,
                                     own and ops.OWN_KERNELS["b1_attention"], own and ops.OWN_KERNELS["causal_attention"])
         self.tuned_gemms = gemm_tuning.enable(self.opt.gemm_tuning, model.device)
+        self.fused.round_split = bool(self.tuned_gemms)      # (fused.round_cut's arithmetic is the tuned solutions' tile shape)
         self.hf.fused = self.fused
         logger.info(f"Fused forward admitted: {self.fused.admitted}; refused: {self.fused.refused}")
         # A fast path refused because the installed transformers' SOURCE no longer reads like what it was checked against (or is

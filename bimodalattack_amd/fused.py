@@ -82,6 +82,7 @@ import weakref
 
 _COPY_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
+
 class _CopyCache:
     def __init__(self):
         self.d = {}
@@ -314,6 +315,9 @@ class FusedInference:
         self.tp = None
         self._tp_roles = {}
         self.gemm_probe = None                       # measurement hook for products no nn.Linear module owns
+        # products just above a whole number of tile rounds as two library calls (round_cut): measured with the shipped GEMM
+        # selection, whose picks for these shapes ARE 256 x 256-tile kernels -- the engine turns it off when that table is not in use
+        self.round_split = True
         cache = _COPY_CACHES.get(model)
         if cache is None:
             cache = _COPY_CACHES[model] = _CopyCache()
@@ -503,7 +507,7 @@ class FusedInference:
         copy of the (constant) weight so that it, too, streams weight rows along the reduction."""
         def forward(x):
             w = m.weight
-            if ROUND_SPLIT and not self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16) \
+            if ROUND_SPLIT and self.round_split and not self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16) \
                     and x.is_contiguous() and self.tp is None:
                 cus = _CUS.get(x.device)
                 if cus is None:
