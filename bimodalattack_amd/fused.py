@@ -74,6 +74,52 @@ def round_cut(rows: int, n_out: int, cus: int) -> int:
     return cut_tiles * 256 if cut_tiles > 0 and 0 < rest_tiles <= cus * 5 // 16 else 0
 
 
+def col_cut(rows: int, n_out: int, cus: int) -> int:
+    """Column count of the first of two calls, 0 = one call: the most tile columns that still fill WHOLE rounds, when the
+    product has at most six of them and what is left is at most 5/16 of a round's tiles -- rank 0's gate/up product of
+    eight GPUs (2112-2304 rows: 9 x 86 = 774 tiles = 3.02 rounds, run as four): 85 tile columns, then one (323-338 -> 301-304
+    us, profiles/r6_round_split.txt).  With many rounds the saved one is worth less than a product 256 columns wide costs
+    (16896 rows: 2028 -> 2039 us), with more left behind the cut the second call costs more than the round (2432 rows, 100
+    tiles: 340 -> 493 us)."""
+    col_tiles = (n_out + 255) // 256
+    row_tiles = (rows + 255) // 256
+    if col_tiles <= 1 or rows < 1536 or cus <= 0:          # (a few hundred rows: the library's picks are not 256-row tiles)
+        return 0
+    rounds = row_tiles * col_tiles // cus                 # whole rounds
+    if not 1 <= rounds <= 6 or row_tiles * col_tiles == rounds * cus:
+        return 0
+    cut = rounds * cus // row_tiles                       # tile columns of the first call
+    rest_tiles = row_tiles * (col_tiles - cut)
+    return cut * 256 if 0 < cut < col_tiles and 0 < rest_tiles <= cus * 5 // 16 else 0
+
+
+def two_calls(x: torch.Tensor, w: torch.Tensor):
+    """x @ w.T for a no-grad 16-bit product as two library calls into slices of one output when round_cut / col_cut say
+    so; None = the caller's own single call."""
+    if not (ROUND_SPLIT and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
+            and x.is_contiguous() and w.is_contiguous() and x.dim() >= 2):
+        return None
+    cus = _CUS.get(x.device)
+    if cus is None:
+        cus = _CUS[x.device] = torch.cuda.get_device_properties(x.device).multi_processor_count
+    rows, n_out = x.numel() // x.shape[-1], w.shape[0]
+    cut = round_cut(rows, n_out, cus)
+    if cut:
+        x2 = x.view(rows, x.shape[-1])
+        out = x2.new_empty((rows, n_out))
+        torch.mm(x2[:cut], w.t(), out=out[:cut])
+        torch.mm(x2[cut:], w.t(), out=out[cut:])
+        return out.view(*x.shape[:-1], n_out)
+    cut = col_cut(rows, n_out, cus)
+    if cut:
+        x2 = x.view(rows, x.shape[-1])
+        out = x2.new_empty((rows, n_out))
+        torch.mm(x2, w[:cut].t(), out=out[:, :cut])
+        torch.mm(x2, w[cut:].t(), out=out[:, cut:])
+        return out.view(*x.shape[:-1], n_out)
+    return None
+
+
 # Derived weight copies (transposed, concatenated q/k/v, interleaved gate/up) belong to the MODEL, not to one attack
 # object: a second attack on the same model (the next prompt of an experiment, bench.py's other workloads) finds them
 # instead of building another 30 GB.  Every copy remembers the (data_ptr, _version) of the tensors it was made from
@@ -502,24 +548,23 @@ class FusedInference:
             return ops.rmsnorm(x, m.weight, eps, gemma)
         return forward
 
+    def _product(self, x, w):
+        """A no-grad x @ w.T: two library calls when the row count sits just above whole tile rounds (two_calls), else one."""
+        if self.round_split and self.tp is None:
+            y = two_calls(x, w)
+            if y is not None:
+                return y
+        return torch.nn.functional.linear(x, w)
+
     def _linear_forward(self, m, orig):
         """Gradient pass with a handful of rows: the backward product goes through a transposed
         copy of the (constant) weight so that it, too, streams weight rows along the reduction."""
         def forward(x):
             w = m.weight
-            if ROUND_SPLIT and self.round_split and not self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16) \
-                    and x.is_contiguous() and self.tp is None:
-                cus = _CUS.get(x.device)
-                if cus is None:
-                    cus = _CUS[x.device] = torch.cuda.get_device_properties(x.device).multi_processor_count
-                rows = x.numel() // x.shape[-1]
-                cut = round_cut(rows, w.shape[0], cus)
-                if cut:
-                    x2 = x.view(rows, x.shape[-1])
-                    out = x2.new_empty((rows, w.shape[0]))
-                    torch.mm(x2[:cut], w.t(), out=out[:cut])
-                    torch.mm(x2[cut:], w.t(), out=out[cut:])
-                    return out.view(*x.shape[:-1], w.shape[0])
+            if self.round_split and self.tp is None and not self._tracking(x):
+                y = two_calls(x, w)
+                if y is not None:
+                    return y
             if not (self._tracking(x) and x.is_cuda and x.dtype == w.dtype and x.dtype in (torch.bfloat16, torch.float16)
                     and x.numel() // x.shape[-1] <= SKINNY_ROWS):
                 return orig(x)
@@ -623,7 +668,7 @@ class FusedInference:
                     with torch.no_grad():
                         wt = self._copies.put(("wqkv_t", id(attn)), w.t().contiguous(), srcs)
                 return ops.FrozenLinearFn.apply(x, w, wt)
-            return torch.nn.functional.linear(x, w)
+            return self._product(x, w)
 
         def first(x):
             slot.clear()
@@ -736,10 +781,10 @@ class FusedInference:
                 probe = self.gemm_probe
                 if probe is not None and probe.on:       # bench.py's HIP-event bracket (profiled steps only)
                     t0 = probe.begin(x)
-                    y = torch.nn.functional.linear(x, w)
+                    y = self._product(x, w)
                     probe.end(t0, "gate_up_proj", x, w.shape[0], w.shape[1])
                 else:
-                    y = torch.nn.functional.linear(x, w)
+                    y = self._product(x, w)
                 return m.down_proj(ops.swiglu_il(y, act))
             g, u = m.gate_proj(x), m.up_proj(x)
             if (g.numel() * g.element_size()) % 16:

@@ -879,3 +879,18 @@ def test_round_cut_splits_only_just_above_whole_tile_rounds():
     assert round_cut(48480, 2560, 256) == 0 and round_cut(48480, 20480, 256) == 0         # Gemma-3's products: too much left
     assert round_cut(16896, 4096, 304) == 0 and round_cut(4200, 8192, 256) == 4096
     assert round_cut(16500, 4096, 256) == 16384          # a row count off the tile grid: the cut is on it
+
+
+def test_col_cut_takes_the_columns_that_fill_whole_rounds():
+    """fused.col_cut: the first call gets the most tile columns that still fill whole rounds when the product has at most six
+    of them and at most 5/16 of a round's tiles are left; never at a few hundred rows."""
+    from bimodalattack_amd.fused import col_cut, round_cut
+    for rows in (2112, 2176, 2240, 2304):                # rank 0's gate/up product of eight GPUs: 9 x 86 tiles = 3.02 rounds
+        assert col_cut(rows, 22016, 256) == 85 * 256 and round_cut(rows, 22016, 256) == 0
+    assert col_cut(2048, 22016, 256) == 0                # 8 x 86 = 688 tiles: 176 behind 64 columns
+    assert col_cut(2432, 22016, 256) == 0                # 10 x 86: 100 tiles behind 76 columns (measured: 340 -> 493 us)
+    assert col_cut(16896, 22016, 256) == 0               # 22 whole rounds: the saved one is not worth a 256-column product
+    assert col_cut(599, 22016, 256) == 0 and col_cut(644, 22016, 256) == 0      # the batch-1 passes
+    assert col_cut(4352, 12288, 256) == 45 * 256         # (the row cut comes first in two_calls: 4096 rows)
+    assert col_cut(4096, 4096, 256) == 0                 # whole rounds exactly
+

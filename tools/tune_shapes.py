@@ -13,6 +13,7 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 
 
 def main():
@@ -20,6 +21,9 @@ def main():
     ap.add_argument("--rows", required=True, help="comma-separated row counts (M)")
     ap.add_argument("--shapes", required=True, help="comma-separated OUTxIN weight shapes")
     ap.add_argument("--ms", default="60", help="tuning time per candidate kernel")
+    ap.add_argument("--two-calls", action="store_true",
+                    help="tune the calls fused.two_calls makes for each shape (row / column slices of one output: their own keys, "
+                         "the leading dimension of a column slice is the whole output's) instead of the one-call product")
     args = ap.parse_args()
     out_dir = os.path.join(REPO, "gpurun_out", "tune")
     os.makedirs(out_dir, exist_ok=True)
@@ -41,7 +45,14 @@ def main():
         w = (torch.randn((n, k), device=dev) * 0.02).to(dt)
         for m in rows:
             x = torch.randn((1, m, k), device=dev).to(dt)
-            torch.nn.functional.linear(x, w)
+            if args.two_calls:
+                from bimodalattack_amd import fused
+                with torch.no_grad():
+                    if fused.two_calls(x, w) is None:
+                        print(f"  {m} x {n} x {k}: one call (nothing to tune here)", flush=True)
+                        continue
+            else:
+                torch.nn.functional.linear(x, w)
             torch.cuda.synchronize()
             print(f"  {m} x {n} x {k} done at {time.perf_counter() - t0:.0f} s", flush=True)
     print(f"TunableOp writes {src} when the process exits; copy it over {dst}", flush=True)
