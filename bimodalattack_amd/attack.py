@@ -217,6 +217,29 @@ def _transformers_version() -> str:
         return "transformers ?"
 
 
+class _Share:
+    """This rank's share of a scoring call (BimodalAttack._share_out)."""
+
+    def __init__(self):
+        self.mine: Optional[Tensor] = None     # the candidates this rank scores (distinct ones when dealt)
+        self.host_mine = self.host_par = self.inv_mine = None   # their ids / the parent's on the host; distinct -> all (the ragged plan)
+        self.pick = None                       # virtual ids: which rows of `sampled` the distinct candidates of `host_mine` are
+        self.dealt = None                      # (order over distinct candidates, device index candidate -> gathered slot, distinct count, first positions)
+        self.want_ragged = False
+        self.world = 1
+        self.emulate = 0
+
+
+class _Scored:
+    """What the forward(s) over a share left behind (BimodalAttack._score_share)."""
+
+    def __init__(self):
+        self.losses = self.match = None
+        self.log: dict = {}
+        self.cache = None
+        self.segs = ()
+
+
 class _RunState:
     """What one run() carries from step to step (BimodalAttack._run)."""
 
@@ -907,27 +930,36 @@ class BimodalAttack:
 
     def _score_candidates(self, sampled: Tensor, order: List[str], feats: Optional[Tensor],
                           allow_prefix: bool = True, parent: Optional[Tensor] = None, virtual=None) -> Tensor:
-        cfg, hf = self.config, self.hf
+        """Losses of all n sampled candidates, in order (:1278-1310): `_share_out` decides which of them this rank scores and
+        plans the ragged forward from one dedup, `_score_share` runs the forward(s) over that share (ragged rows, padded chunks
+        behind a shared prefix, or the HF-cache route; OOM halving), `_collect` puts every rank's losses back in the
+        candidates' order."""
+        sh = self._share_out(sampled, allow_prefix, parent, virtual)
+        sc = self._score_share(sh, sampled, order, feats, allow_prefix, parent)
+        return self._collect(sh, sc, sampled, feats)
+
+    def _share_out(self, sampled: Tensor, allow_prefix: bool, parent: Optional[Tensor], virtual) -> "_Share":
+        """Which candidates this rank scores (`mine`), with the host-side facts the ragged plan needs -- from ONE copy of the
+        ids to the host and ONE exact dedup per step (or from the virtual ids planned while the gradient pass ran)."""
+        hf = self.hf
         n = sampled.shape[0]
-        dealt = None           # (order over distinct candidates, device index candidate -> gathered slot, distinct count, first positions) when dealing
-        emulate = self.emulate_world if (self.emulate_world > 1 and not self.shard.enabled) else 0
-        world = emulate or self.shard.world
+        sh = _Share()
+        sh.emulate = emulate = self.emulate_world if (self.emulate_world > 1 and not self.shard.enabled) else 0
+        sh.world = world = emulate or self.shard.world
         # `plan_ok` depends on options and the model family only -- never on what one rank learnt at run time --
         # because it also decides HOW candidates are partitioned over ranks, which every rank must decide alike
         plan_ok = bool(parent is not None and allow_prefix and self.opt.ragged_suffix and n > 1 and self.opt.prefix_reuse
                        and self.opt.target_rows_only and self.opt.shared_prefix_attention and hf.shared_prefix_configs())
-        want_ragged = bool(plan_ok and hf.ragged_ok is not False and hf.shared_ok is not False)
-        host_mine = host_par = inv_mine = None
-        pick = None            # virtual ids: which rows of `sampled` the distinct candidates of `host_mine` are
+        sh.want_ragged = bool(plan_ok and hf.ragged_ok is not False and hf.shared_ok is not False)
         if plan_ok and virtual is not None:
             # planned while the gradient pass ran, from the draws alone: nothing here waits for the stream
-            host_all, host_par = virtual
+            host_all, sh.host_par = virtual
             uniq, inv, first_at = unique_rows(host_all, return_first=True)
         elif plan_ok:
             # ONE device-to-host copy (ids + parent) and ONE exact dedup per step feed both the partition over
             # ranks and the ragged plan
             both_h = torch.cat([sampled, parent.reshape(1, -1).to(sampled.device)], dim=0).cpu().numpy()
-            host_all, host_par = both_h[:n], both_h[n]
+            host_all, sh.host_par = both_h[:n], both_h[n]
             uniq, inv = unique_rows(host_all)
             first_at = None
         if plan_ok and (self.shard.enabled or emulate) and n > world:
@@ -936,16 +968,16 @@ class BimodalAttack:
             # world-th one -- all ranks then compute (almost) the same number of rows, and the fixed
             # per-rank row budget is the global one divided by the world size instead of a
             # small-sample budget with its own safety margin.
-            diff = uniq != host_par[None, :]
+            diff = uniq != sh.host_par[None, :]
             first = np.where(diff.any(1), diff.argmax(1), uniq.shape[1] - 1)
             by_cost = np.argsort(first, kind="stable")
             take = by_cost[0::world] if emulate else self.shard.deal(by_cost)
-            host_mine = np.ascontiguousarray(uniq[take])
+            sh.host_mine = np.ascontiguousarray(uniq[take])
             if first_at is None:
-                mine = self._upload(host_mine)
+                sh.mine = self._upload(sh.host_mine)
             else:
-                pick = np.ascontiguousarray(first_at[take])
-                mine = sampled.index_select(0, self._upload(pick))
+                sh.pick = np.ascontiguousarray(first_at[take])
+                sh.mine = sampled.index_select(0, self._upload(sh.pick))
             # where each of the n candidates' loss will sit in the gathered buffer: uploaded NOW, while the stream
             # is idle -- behind the forward the same pageable copy would hold the host until the GPU had finished,
             # and the retokenisation filter would run after the forward instead of beside it (dist.dealt_index)
@@ -955,17 +987,24 @@ class BimodalAttack:
                 sel = slot[inv]
             else:
                 sel = self.shard.dealt_index(by_cost, inv)
-            dealt = (by_cost, self._upload(sel), uniq.shape[0], first)
+            sh.dealt = (by_cost, self._upload(sel), uniq.shape[0], first)
         else:
             lo, hi = self.shard.bounds(n)
-            mine = sampled[lo:hi].contiguous()
+            sh.mine = sampled[lo:hi].contiguous()
             if plan_ok:
                 if (lo, hi) == (0, n):
-                    host_mine, inv_mine, pick = uniq, inv, first_at
+                    sh.host_mine, sh.inv_mine, sh.pick = uniq, inv, first_at
                 elif first_at is None:
-                    host_mine, inv_mine = unique_rows(host_all[lo:hi])
+                    sh.host_mine, sh.inv_mine = unique_rows(host_all[lo:hi])
                 else:
-                    host_mine, inv_mine, pick = unique_rows(host_all[lo:hi], return_first=True)
+                    sh.host_mine, sh.inv_mine, sh.pick = unique_rows(host_all[lo:hi], return_first=True)
+        return sh
+
+    def _score_share(self, sh: "_Share", sampled: Tensor, order: List[str], feats: Optional[Tensor], allow_prefix: bool,
+                     parent: Optional[Tensor]) -> "_Scored":
+        """The forward(s) over this rank's candidates: one ragged forward when the plan allows it, else padded chunks."""
+        cfg, hf = self.config, self.hf
+        mine, dealt, pick = sh.mine, sh.dealt, sh.pick
         m = mine.shape[0]
         E = self.embedding_layer.weight
         feats = None if feats is None else feats.to(E.dtype)
@@ -996,7 +1035,7 @@ class BimodalAttack:
 
         losses = torch.empty(m, dtype=torch.float32, device=self.model.device)
         match = torch.zeros(m, dtype=torch.float32, device=self.model.device) if cfg.early_stop else None
-        ragged = bool(shared and want_ragged and host_mine is not None
+        ragged = bool(shared and sh.want_ragged and sh.host_mine is not None
                       and chunk >= m > 1 and tail_names[0] == "optim" and L - self.T >= mine.shape[1] - 1)
         s = 0
         while s < m:
@@ -1009,14 +1048,14 @@ class BimodalAttack:
                         if dealt is not None:
                             # every rank builds the row count of the rank with the most rows (they differ by
                             # a few rows after dealing): one set of GEMM shapes per step on all ranks
-                            n_rows = self._dealt_rows(dealt, world, L, mine.shape[1])
+                            n_rows = self._dealt_rows(dealt, sh.world, L, mine.shape[1])
                         real = None
                         if pick is not None:
                             # the stand-ins planned it; the forward embeds the real ids, gathered on the device
                             # (dealt: `mine` IS that gather; else the first appearances within this rank's slice)
                             real = (mine if dealt is not None else mine.index_select(0, self._upload(pick)),
                                     parent.reshape(1, -1).to(sampled.device))
-                        scored = self._ragged_score(host_mine, host_par, segs, L, P, cache, n_rows, inv_mine, real)
+                        scored = self._ragged_score(sh.host_mine, sh.host_par, segs, L, P, cache, n_rows, sh.inv_mine, real)
                         hf.ragged_ok = True
                     except DeferredNormMissed:
                         raise                          # (a missed deferral costs the deferral, not the ragged path)
@@ -1081,9 +1120,19 @@ class BimodalAttack:
                 ragged = False        # the ragged forward scores all m at once: retry through padded chunks
                 logger.warning(f"Decreasing batch size to: {chunk}")
                 torch.cuda.empty_cache()
-        if dealt is not None:
-            by_cost, sel_t, n_u, _ = dealt
-            if emulate:        # GEMM tuning only: rank 0's shapes of an `emulate`-rank run, the other ranks' shares unscored
+        sc = _Scored()
+        sc.losses, sc.match = losses, match
+        sc.log = dict(m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared), use_prefix=bool(use_prefix))
+        sc.cache, sc.segs = cache, segs
+        return sc
+
+    def _collect(self, sh: "_Share", sc: "_Scored", sampled: Tensor, feats: Optional[Tensor]) -> Tensor:
+        """Every rank's losses (and early-stop hits, left in self._match) back in the order of the n candidates."""
+        n = sampled.shape[0]
+        losses, match = sc.losses, sc.match
+        if sh.dealt is not None:
+            by_cost, sel_t, n_u, _ = sh.dealt
+            if sh.emulate:     # GEMM tuning only: rank 0's shapes of an `emulate`-rank run, the other ranks' shares unscored
                 full = torch.cat([losses.to(torch.float32), losses.new_full((1,), float("inf"), dtype=torch.float32)])[sel_t]
                 self._match = None if match is None else torch.cat([match.to(torch.float32), match.new_zeros((1,), dtype=torch.float32)])[sel_t]
             elif match is None:
@@ -1101,13 +1150,13 @@ class BimodalAttack:
             if feats is not None:
                 extra["feats_bad"] = (~torch.isfinite(feats.float())).sum()
             extra["ids_min"], extra["ids_max"] = sampled.min(), sampled.max()
+            cache = sc.cache
             if cache is not None and hasattr(cache, "k"):
                 extra["prefix_bad"] = sum((~torch.isfinite(t.float())).sum() for t in list(cache.k) + list(cache.v))
-            for k_, t in segs:
+            for k_, t in sc.segs:
                 if t is not None and k_ == "shared":
                     extra["segs_bad"] = extra.get("segs_bad", 0) + (~torch.isfinite(t.float())).sum()
-            self.score_log.append(dict(n=n, m=m, L=L, P=P, chunk=chunk, ragged=bool(ragged), shared=bool(shared), **extra,
-                                           use_prefix=bool(use_prefix), rows=self.score_stats["rows"],
+            self.score_log.append(dict(n=n, **sc.log, **extra, rows=self.score_stats["rows"],
                                            bad=(~torch.isfinite(full.float())).sum(),
                                            first_bad=(~torch.isfinite(full.float())).to(torch.int32).argmax()))
         return full
